@@ -1,0 +1,95 @@
+"""ctypes binding of libcofi_hip.so (the C ABI declared in include/cofi_hip.h).
+
+There is NO fallback: if the shared library is missing or does not load, importing the product
+path raises.  `python -m cofii2p_amd.build` (or `__graft_entry__.build()`) produces the library
+in-tree with hipcc for gfx950.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcofi_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cofi_hip.h")
+
+c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_P, _I, _F, _Z = c_void_p, c_int, c_float, c_size_t
+
+# name -> (restype, argtypes); mirrors include/cofi_hip.h declaration by declaration
+SIGNATURES = {
+    "cofi_abi_version": (_I, []),
+    "cofi_target_arch": (ctypes.c_char_p, []),
+    "cofi_knn_topk": (_I, [_P, _I, _P, _I, _I, _P, _P, _P]),
+    "cofi_nearest_node": (_I, [_P, _I, _P, _I, _P, _P]),
+    "cofi_nearest_node_sel": (_I, [_P, _I, _P, _P, _P, _I, _P, _P]),
+    "cofi_idx64_to_idx32": (_I, [_P, _P, _Z, _P]),
+    "cofi_idx32_to_idx64": (_I, [_P, _P, _Z, _P]),
+    "cofi_row_sum_positive": (_I, [_P, _I, _I, _I, _P, _P]),
+    "cofi_kpconv_aggregate": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _F, _P, _P, _I, _P, _P]),
+    "cofi_neighbor_maxpool": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _P]),
+    "cofi_gather_rows": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _P]),
+    "cofi_gemm_f32_workspace": (_Z, [_I, _I, _I]),
+    "cofi_gemm_f32": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _Z, _P]),
+    "cofi_group_stats_workspace": (_Z, [_I, _I, _I]),
+    "cofi_group_stats": (_I, [_P, _I, _I, _I, _I, _F, _P, _P, _Z, _P]),
+    "cofi_group_norm_apply": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _F, _P, _I, _P]),
+    "cofi_layer_norm": (_I, [_P, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _I, _P]),
+    "cofi_attention_workspace": (_Z, [_I, _I, _I, _I]),
+    "cofi_attention_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
+    "cofi_col_inv_norm": (_I, [_P, _I, _I, _I, _F, _P, _P]),
+    "cofi_pos_sine": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _P, _I, _P]),
+    "cofi_l2norm_rows": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
+    "cofi_transpose": (_I, [_P, _I, _I, _I, _P, _I, _P]),
+    "cofi_l2norm_cols": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P]),
+    "cofi_row_argmin_1m": (_I, [_P, _I, _I, _I, _P, _P]),
+    "cofi_select_matches": (_I, [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P]),
+    "cofi_gather_points_sel": (_I, [_P, _P, _P, _I, _P, _P]),
+    "cofi_extract_patches": (_I, [_P, _I, _I, _I, _P, _I, _F, _P, _I, _P, _P]),
+    "cofi_gather_rows_sel": (_I, [_P, _I, _I, _P, _P, _I, _P, _I, _P]),
+    "cofi_fine_match": (_I, [_P, _P, _I, _I, _P, _I, _F, _P, _I, _P, _P, _P]),
+}
+
+
+def header_symbols():
+    """Every function name declared in include/cofi_hip.h."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cofi_[a-z0-9_]+)\s*\(", text)))
+
+
+class CofiError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises CofiError if it is missing (never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CofiError("libcofi_hip.so not found at %s — build it with `python -m cofii2p_amd.build` "
+                        "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise CofiError("libcofi_hip.so failed to load: %s" % e)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise CofiError("libcofi_hip.so does not export %s (stale build?)" % name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cofi_abi_version() != 1:
+        raise CofiError("ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        kind = {-1: "COFI_EINVAL", -2: "COFI_EWORKSPACE", -3: "COFI_EUNSUPPORTED"}.get(rc, "hipError %d" % rc)
+        raise CofiError("%s failed: %s" % (what, kind))

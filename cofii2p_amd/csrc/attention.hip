@@ -1,0 +1,169 @@
+// Flash-style multi-head attention for the I2P transformer on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+// Reference: model/transformer/linear_attention.py:56-79 (FullAttention) + the token-axis query
+// normalisation of model/transformer/transformer.py:53, folded in as a per-channel scale.
+//
+// Workgroup = 4 waves = one (head, 32-query block).  The four waves take interleaved 32-key blocks
+// (split-KV), each running an online softmax in registers, and merge (m, l, O) through LDS at the
+// end.  The L x S score matrix never exists in memory (the reference materialises it twice).
+//
+// Per 32-key block and wave:
+//   S^T[key, q] = K_blk . Q^T    16 MFMA, A = K straight from L2 (float4 per lane), B = Q registers
+//   online softmax, per lane = per query column (q = lane&31), 16 keys per lane, halves joined by
+//   one __shfl_xor(.., 32)
+//   O^T[d, q] += V_blk^T . P^T   16 MFMA, A = V[key, d = lane&31] (128-B coalesced rows), B = P
+// The MFMA D layout of S^T (lane (q,h) holds keys (r&3)+8(r>>2)+4h) is exactly the B-operand layout
+// the second chain needs once the contraction index is allowed to run in that (permuted) key order,
+// so P never moves between lanes and O^T keeps "one query per lane": the softmax rescale and the
+// final 1/l are plain per-lane multiplies.
+#include "common.h"
+
+namespace {
+
+struct AttnArgs {
+    const float *Q, *K, *V, *qs;
+    float *O;
+    int ldq, ldk, ldv, ldo, L, S, H;
+    float scale_log2e;
+};
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
+    constexpr int D = 32;
+    __shared__ __attribute__((aligned(16))) float s_o[4][32][D + 4];
+    __shared__ float s_m[4][32], s_l[4][32];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.y, q0 = blockIdx.x * 32;
+    const int hc = head * D;
+
+    // Q fragment: lane (q = li, h) holds Q[q][8c+4h+e], pre-multiplied by colscale * scale * log2(e)
+    float qf[16];
+    {
+        const int q = min(q0 + li, a.L - 1);
+        const float *qp = a.Q + (size_t)q * a.ldq + hc + 4 * lh;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 v = *reinterpret_cast<const float4 *>(qp + 8 * c);
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (a.qs) sc = *reinterpret_cast<const float4 *>(a.qs + hc + 4 * lh + 8 * c);
+            qf[4 * c + 0] = (v.x * sc.x) * a.scale_log2e;
+            qf[4 * c + 1] = (v.y * sc.y) * a.scale_log2e;
+            qf[4 * c + 2] = (v.z * sc.z) * a.scale_log2e;
+            qf[4 * c + 3] = (v.w * sc.w) * a.scale_log2e;
+        }
+    }
+
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int nblk = (a.S + 31) >> 5;
+    for (int b = wave; b < nblk; b += 4) {
+        const int k0 = b * 32;
+        // ---- S^T = K . Q^T
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        {
+            const int key = min(k0 + li, a.S - 1);
+            const float *kp = a.K + (size_t)key * a.ldk + hc + 4 * lh;
+            float4 kf[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) kf[c] = *reinterpret_cast<const float4 *>(kp + 8 * c);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].x, qf[4 * c + 0], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].y, qf[4 * c + 1], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].z, qf[4 * c + 2], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].w, qf[4 * c + 3], s, 0, 0, 0);
+            }
+        }
+        // issue the V loads early: lane (d = li, h) needs V[k0 + keyrow(r,h)][d]
+        float vf[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = min(k0 + (r & 3) + 8 * (r >> 2) + 4 * lh, a.S - 1);
+            vf[r] = a.V[(size_t)key * a.ldv + hc + li];
+        }
+        // ---- online softmax (base 2); mask the key tail
+        float bmax = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (key >= a.S) s[r] = -INFINITY;
+            bmax = fmaxf(bmax, s[r]);
+        }
+        bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+        const float m_new = fmaxf(m_run, bmax);
+        const float alpha = fast_exp2(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = fast_exp2(s[r] - m_new);
+            psum += s[r];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= alpha;
+        // ---- O^T += V^T . P^T   (contraction over this block's keys in D-layout order)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], s[r], o, 0, 0, 0);
+    }
+    // join the two halves' row sums (same m in both halves by construction)
+    l_run += __shfl_xor(l_run, 32, 64);
+
+    // ---- merge the four key splits through LDS
+    if (lh == 0) {
+        s_m[wave][li] = m_run;
+        s_l[wave][li] = l_run;
+    }
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+        const int d0 = 8 * rq + 4 * lh;  // lane (q, h) holds O[q][d0 .. d0+3] in regs 4rq .. 4rq+3
+        *reinterpret_cast<float4 *>(&s_o[wave][li][d0]) = make_float4(o[4 * rq], o[4 * rq + 1], o[4 * rq + 2], o[4 * rq + 3]);
+    }
+    __syncthreads();
+    {
+        const int q = threadIdx.x >> 3, d4 = (threadIdx.x & 7) * 4;
+        const float m0 = s_m[0][q], m1 = s_m[1][q], m2 = s_m[2][q], m3 = s_m[3][q];
+        const float mm = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        const float w0 = fast_exp2(m0 - mm), w1 = fast_exp2(m1 - mm), w2 = fast_exp2(m2 - mm), w3 = fast_exp2(m3 - mm);
+        const float l = ((s_l[0][q] * w0 + s_l[1][q] * w1) + s_l[2][q] * w2) + s_l[3][q] * w3;
+        const float4 a0 = *reinterpret_cast<const float4 *>(&s_o[0][q][d4]);
+        const float4 a1 = *reinterpret_cast<const float4 *>(&s_o[1][q][d4]);
+        const float4 a2 = *reinterpret_cast<const float4 *>(&s_o[2][q][d4]);
+        const float4 a3 = *reinterpret_cast<const float4 *>(&s_o[3][q][d4]);
+        const float inv = 1.0f / l;
+        float4 r;
+        r.x = (((a0.x * w0 + a1.x * w1) + a2.x * w2) + a3.x * w3) * inv;
+        r.y = (((a0.y * w0 + a1.y * w1) + a2.y * w2) + a3.y * w3) * inv;
+        r.z = (((a0.z * w0 + a1.z * w1) + a2.z * w2) + a3.z * w3) * inv;
+        r.w = (((a0.w * w0 + a1.w * w1) + a2.w * w2) + a3.w * w3) * inv;
+        if (q0 + q < a.L) *reinterpret_cast<float4 *>(a.O + (size_t)(q0 + q) * a.ldo + hc + d4) = r;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t cofi_attention_workspace(int L, int S, int H, int D) {
+    (void)L; (void)S; (void)H; (void)D;
+    return 0;  // split-KV partials are merged in LDS
+}
+
+extern "C" int cofi_attention_fwd(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, const float *q_colscale,
+                                  float *O, int ldo, int L, int S, int H, int D, float scale, void *ws, size_t ws_bytes,
+                                  cofi_stream_t stream) {
+    (void)ws; (void)ws_bytes;
+    if (!Q || !K || !V || !O || L <= 0 || S <= 0 || H <= 0) return COFI_EINVAL;
+    if (D != 32) return COFI_EUNSUPPORTED;
+    if ((ldq & 3) || (ldk & 3) || (ldo & 3) || ldq < H * D || ldk < H * D || ldv < H * D || ldo < H * D) return COFI_EINVAL;
+    if (((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)O & 15) || (q_colscale && ((uintptr_t)q_colscale & 15)))
+        return COFI_EINVAL;
+    AttnArgs a{Q, K, V, q_colscale, O, ldq, ldk, ldv, ldo, L, S, H, scale * 1.4426950408889634f};
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3(cofi_cdiv(L, 32), H), dim3(256), 0, cofi_s(stream), a);
+    return cofi_launch_status();
+}

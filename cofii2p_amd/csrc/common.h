@@ -1,0 +1,39 @@
+// Shared helpers for the gfx950 kernels of libcofi_hip.so.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cofi_hip.h"
+
+#define COFI_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int cofi_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+static inline hipStream_t cofi_s(cofi_stream_t s) { return (hipStream_t)s; }
+
+static inline int cofi_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// full-wave reductions through DPP-free shuffles (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

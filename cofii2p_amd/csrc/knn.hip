@@ -1,0 +1,233 @@
+// Brute-force k-nearest neighbours with a wavefront-level top-k (k <= 128), bit-exact against
+// oracle/knn_oracle.c.  Reference: model/kpconv/preprocess_data.py:109-143 (`square_distance` +
+// `dist.topk(k, largest=False)`), model/network.py:250-264 (`point2node`).
+//
+// Canonical fp32 arithmetic (file compiled with -ffp-contract=off; the only fused operations are the
+// two explicit fmaf):
+//     dot = fmaf(qz, sz, fmaf(qy, sy, qx*sx));  qq = (qx*qx + qy*qy) + qz*qz;  ss likewise
+//     d   = max(((-2*dot) + qq) + ss, 1e-12f)
+// Order: ascending 64-bit key (float bits of d) << 32 | index  ==  (distance, lowest index first).
+//
+// Workgroup = 16 waves = 16 queries.  Candidates are staged once per workgroup through LDS as
+// (x,y,z,|s|^2) float4 tiles of 1024 points (coalesced 12-B rows -> one ds_read_b128 per lane and
+// step), so L2 is read once per 16 queries.  Each wave streams the tile 64 candidates at a time and
+// keeps its query's best 128 keys sorted across the wave (2 keys per lane).  A candidate enters a
+// 64-entry LDS staging buffer only if it beats the current 128th key (ballot + mbcnt compaction);
+// a full buffer is bitonic-sorted across the wave and bitonic-merged into the list.  After the first
+// few hundred candidates almost nothing passes the threshold, so the stream runs at ~10 VALU
+// instructions per 64 distances.
+#include "common.h"
+
+namespace {
+
+typedef unsigned long long u64;
+constexpr u64 KEY_INF = 0x7f8000007fffffffull;  // (+inf, INT_MAX)
+constexpr int TILE = 1024;
+
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl_xor(lo, m, 64);
+    hi = __shfl_xor(hi, m, 64);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl(lo, src, 64);
+    hi = __shfl(hi, src, 64);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 umin64(u64 a, u64 b) { return a < b ? a : b; }
+__device__ __forceinline__ u64 umax64(u64 a, u64 b) { return a < b ? b : a; }
+
+// ascending bitonic sort of one key per lane
+__device__ __forceinline__ u64 wave_sort(u64 v, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const u64 p = shfl_xor_u64(v, j);
+            const bool up = (lane & k) == 0;
+            const bool lower = (lane & j) == 0;
+            v = (lower == up) ? umin64(v, p) : umax64(v, p);
+        }
+    }
+    return v;
+}
+// sorts a bitonic sequence held one key per lane into ascending order
+__device__ __forceinline__ u64 wave_bitonic_merge(u64 v, int lane) {
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+        const u64 p = shfl_xor_u64(v, j);
+        v = ((lane & j) == 0) ? umin64(v, p) : umax64(v, p);
+    }
+    return v;
+}
+
+__device__ __forceinline__ float canon_sqnorm(float x, float y, float z) { return (x * x + y * y) + z * z; }
+__device__ __forceinline__ float canon_dist(float qx, float qy, float qz, float qq, float4 s) {
+    const float dot = fmaf(qz, s.z, fmaf(qy, s.y, qx * s.x));
+    const float d = ((-2.0f * dot) + qq) + s.w;
+    return d < 1e-12f ? 1e-12f : d;
+}
+
+__global__ __launch_bounds__(1024) void knn_topk_kernel(const float *support, int S, const float *query, int Q, int k,
+                                                        int32_t *out_idx, float *out_dist) {
+    __shared__ float4 tile[TILE];
+    __shared__ u64 stage[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 16 + wave;
+    const bool active = q < Q;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (active) {
+        qx = query[3 * (size_t)q];
+        qy = query[3 * (size_t)q + 1];
+        qz = query[3 * (size_t)q + 2];
+    }
+    const float qq = canon_sqnorm(qx, qy, qz);
+    u64 l0 = KEY_INF, l1 = KEY_INF;  // sorted best-128: rank lane (l0) and 64+lane (l1)
+    u64 tau = KEY_INF;
+    int nstage = 0;  // wave-uniform fill of stage[wave]
+
+    auto flush = [&]() {
+        u64 b = lane < nstage ? stage[wave][lane] : KEY_INF;
+        nstage = 0;
+        b = wave_sort(b, lane);
+        // 64 smallest of (l1 U b): min(l1[i], b[63-i]) is bitonic
+        u64 t = umin64(l1, shfl_u64(b, 63 - lane));
+        t = wave_bitonic_merge(t, lane);
+        // merge sorted l0 with sorted t (128 keys): low/high halves are each bitonic
+        const u64 tr = shfl_u64(t, 63 - lane);
+        const u64 lo = umin64(l0, tr), hi = umax64(l0, tr);
+        l0 = wave_bitonic_merge(lo, lane);
+        l1 = wave_bitonic_merge(hi, lane);
+        tau = shfl_u64(l1, 63);
+    };
+
+    for (int t0 = 0; t0 < S; t0 += TILE) {
+        __syncthreads();
+        {
+            const int c = t0 + threadIdx.x;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < S) {
+                v.x = support[3 * (size_t)c];
+                v.y = support[3 * (size_t)c + 1];
+                v.z = support[3 * (size_t)c + 2];
+                v.w = canon_sqnorm(v.x, v.y, v.z);
+            }
+            tile[threadIdx.x] = v;
+        }
+        __syncthreads();
+        if (!active) continue;
+        const int nt = min(TILE, S - t0);
+        for (int i = 0; i < nt; i += 64) {
+            const int c = i + lane;
+            const float4 sp = tile[c];
+            const float d = canon_dist(qx, qy, qz, qq, sp);
+            const u64 key = ((u64)__float_as_uint(d) << 32) | (unsigned)(t0 + c);
+            const bool pass = (c < nt) && key < tau;
+            const u64 mask = __ballot(pass);
+            if (mask == 0) continue;
+            const int n = __popcll(mask);
+            if (nstage + n > 64) flush();  // wave-uniform branch
+            // a flush lowers tau, but every staged/passing key is still a valid candidate: the list merge
+            // keeps only the 128 smallest, so over-admission is harmless
+            if (pass) {
+                const int pos = nstage + __popcll(mask & ((1ull << lane) - 1ull));
+                stage[wave][pos] = key;
+            }
+            nstage += n;
+        }
+    }
+    if (!active) return;
+    if (nstage > 0) flush();
+    // emit ranks lane and 64+lane
+    if (lane < k) {
+        const int id = (int)(unsigned)(l0 & 0xffffffffu);
+        out_idx[(size_t)q * k + lane] = id == 0x7fffffff ? S : id;
+        if (out_dist) out_dist[(size_t)q * k + lane] = __uint_as_float((unsigned)(l0 >> 32));
+    }
+    if (64 + lane < k) {
+        const int id = (int)(unsigned)(l1 & 0xffffffffu);
+        out_idx[(size_t)q * k + 64 + lane] = id == 0x7fffffff ? S : id;
+        if (out_dist) out_dist[(size_t)q * k + 64 + lane] = __uint_as_float((unsigned)(l1 >> 32));
+    }
+}
+
+// k = 1: nearest support row per query, lowest index on ties.  One wave per query; if sel != NULL
+// the query rows are points[sel[i]] and the row count is read from count_dev on the device.
+__global__ __launch_bounds__(256) void nearest_kernel(const float *nodes, int S, const float *points, const int32_t *sel,
+                                                      const int32_t *count_dev, int Q, int32_t *out_idx) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nq = count_dev ? min(*count_dev, Q) : Q;
+    if (q >= nq) return;
+    const size_t row = sel ? (size_t)sel[q] : (size_t)q;
+    const float qx = points[3 * row], qy = points[3 * row + 1], qz = points[3 * row + 2];
+    const float qq = canon_sqnorm(qx, qy, qz);
+    u64 best = KEY_INF;
+    for (int c = lane; c < S; c += 64) {
+        float4 sp;
+        sp.x = nodes[3 * (size_t)c];
+        sp.y = nodes[3 * (size_t)c + 1];
+        sp.z = nodes[3 * (size_t)c + 2];
+        sp.w = canon_sqnorm(sp.x, sp.y, sp.z);
+        const float d = canon_dist(qx, qy, qz, qq, sp);
+        best = umin64(best, ((u64)__float_as_uint(d) << 32) | (unsigned)c);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = umin64(best, shfl_xor_u64(best, o));
+    if (lane == 0) out_idx[q] = (int)(unsigned)(best & 0xffffffffu);
+}
+
+__global__ void idx64_to_32_kernel(const int64_t *src, int32_t *dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (int32_t)src[i];
+}
+__global__ void idx32_to_64_kernel(const int32_t *src, int64_t *dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (int64_t)src[i];
+}
+
+}  // namespace
+
+extern "C" int cofi_knn_topk(const float *support, int S, const float *query, int Q, int k, int32_t *out_idx, float *out_dist,
+                             cofi_stream_t stream) {
+    if (!support || !query || !out_idx || S <= 0 || Q < 0 || k <= 0 || k > 128) return COFI_EINVAL;
+    if (Q == 0) return 0;
+    hipLaunchKernelGGL(knn_topk_kernel, dim3(cofi_cdiv(Q, 16)), dim3(1024), 0, cofi_s(stream), support, S, query, Q, k, out_idx,
+                       out_dist);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_nearest_node(const float *nodes, int S, const float *points, int Q, int32_t *out_idx, cofi_stream_t stream) {
+    if (!nodes || !points || !out_idx || S <= 0 || Q < 0) return COFI_EINVAL;
+    if (Q == 0) return 0;
+    hipLaunchKernelGGL(nearest_kernel, dim3(cofi_cdiv(Q, 4)), dim3(256), 0, cofi_s(stream), nodes, S, points,
+                       (const int32_t *)nullptr, (const int32_t *)nullptr, Q, out_idx);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_nearest_node_sel(const float *nodes, int S, const float *points_all, const int32_t *sel,
+                                     const int32_t *count_dev, int max_count, int32_t *out_idx, cofi_stream_t stream) {
+    if (!nodes || !points_all || !sel || !count_dev || !out_idx || S <= 0 || max_count < 0) return COFI_EINVAL;
+    if (max_count == 0) return 0;
+    hipLaunchKernelGGL(nearest_kernel, dim3(cofi_cdiv(max_count, 4)), dim3(256), 0, cofi_s(stream), nodes, S, points_all, sel,
+                       count_dev, max_count, out_idx);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_idx64_to_idx32(const int64_t *src, int32_t *dst, size_t n, cofi_stream_t stream) {
+    if (!src || !dst) return COFI_EINVAL;
+    if (n == 0) return 0;
+    int nb = (int)((n + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(idx64_to_32_kernel, dim3(nb), dim3(256), 0, cofi_s(stream), src, dst, n);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_idx32_to_idx64(const int32_t *src, int64_t *dst, size_t n, cofi_stream_t stream) {
+    if (!src || !dst) return COFI_EINVAL;
+    if (n == 0) return 0;
+    int nb = (int)((n + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(idx32_to_64_kernel, dim3(nb), dim3(256), 0, cofi_s(stream), src, dst, n);
+    return cofi_launch_status();
+}

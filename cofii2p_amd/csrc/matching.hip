@@ -1,0 +1,219 @@
+// Coarse super-point -> super-pixel matching and 4x4 patch fine matching with no host round trip.
+// Reference: model/network.py:145-161 (threshold loop), :167-187 (`fine_process`), :206-226
+// (`extract_patch`), evaluation/eval_all.py:99-105 (fine matching in the caller).
+// The match count stays on the device (count_dev); downstream kernels are launched at capacity and
+// read it, so the only host synchronisation of a test-mode forward is the final read of the count.
+#include "common.h"
+
+namespace {
+
+// pix[n] = argmin_p (1 - sim[n,p]), first index on ties (torch.argmin).  One wave per row.
+__global__ __launch_bounds__(256) void row_argmin_1m_kernel(const float *sim, int lds, int N, int P, int32_t *pix) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int lane = threadIdx.x & 63;
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int p = lane; p < P; p += 64) {
+        const float d = 1.0f - sim[(size_t)n * lds + p];
+        if (d < best) { best = d; bi = p; }  // strict: keeps the lowest p of this lane
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) pix[n] = bi;
+}
+
+struct SelArgs {
+    const float *score;
+    const int32_t *pix;
+    int32_t *sel, *count;
+    float *xy;
+    int N, W8, H8, n_thr, min_matches;
+    float thr[64];
+};
+
+// single workgroup: threshold search + ordered compaction (ascending point index)
+__global__ __launch_bounds__(1024) void select_matches_kernel(SelArgs a) {
+    __shared__ int s_cnt[16];
+    __shared__ int s_thr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // pass 1: find the first threshold with enough survivors
+    if (tid == 0) s_thr = -1;
+    __syncthreads();
+    for (int t = 0; t < a.n_thr; ++t) {
+        int c = 0;
+        for (int n = tid; n < a.N; n += 1024) {
+            const int p = a.pix[n];
+            const int x = p % a.W8, y = p / a.W8;
+            const bool ok = a.score[n] >= a.thr[t] && x >= 2 && x <= a.W8 - 2 && y >= 2 && y <= a.H8 - 2;
+            c += ok ? 1 : 0;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (lane == 0) s_cnt[wave] = c;
+        __syncthreads();
+        int tot = 0;
+        for (int w = 0; w < 16; ++w) tot += s_cnt[w];
+        __syncthreads();
+        if (tot >= a.min_matches) {
+            if (tid == 0) s_thr = t;
+            break;  // uniform: every thread computed the same tot
+        }
+    }
+    __syncthreads();
+    const int tsel = s_thr;
+    if (tsel < 0) {
+        if (tid == 0) { a.count[0] = 0; a.count[1] = -1; }
+        return;
+    }
+    const float thr = a.thr[tsel];
+    // pass 2: ordered compaction in chunks of 1024 points
+    int base = 0;
+    for (int n0 = 0; n0 < a.N; n0 += 1024) {
+        const int n = n0 + tid;
+        bool ok = false;
+        int x = 0, y = 0;
+        if (n < a.N) {
+            const int p = a.pix[n];
+            x = p % a.W8; y = p / a.W8;
+            ok = a.score[n] >= thr && x >= 2 && x <= a.W8 - 2 && y >= 2 && y <= a.H8 - 2;
+        }
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) s_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += s_cnt[w];
+        int tot = 0;
+        for (int w = 0; w < 16; ++w) tot += s_cnt[w];
+        if (ok) {
+            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            a.sel[pos] = n;
+            a.xy[pos] = (float)x;
+            a.xy[a.N + pos] = (float)y;
+        }
+        base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) { a.count[0] = base; a.count[1] = tsel; }
+}
+
+__global__ void gather_points_sel_kernel(const float *pts, const int32_t *sel, const int32_t *count_dev, int cap, float *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = min(*count_dev, cap);
+    if (i >= n * 3) return;
+    out[i] = pts[3 * (size_t)sel[i / 3] + (i % 3)];
+}
+
+// patches[i, c, r*4 + w] = fmap[c, 4*y - 2 + r, 4*x - 2 + w]
+__global__ void extract_patches_kernel(const float *fmap, int C, int H2, int W2, const float *xy, int ldxy, float cscale,
+                                       const int32_t *count_dev, int cap, float *patches) {
+    const int i = blockIdx.x;
+    if (i >= min(*count_dev, cap)) return;
+    const int left = (int)floorf(xy[i] * cscale - 2.0f), top = (int)floorf(xy[ldxy + i] * cscale - 2.0f);
+    for (int e = threadIdx.x; e < C * 16; e += blockDim.x) {
+        const int c = e >> 4, r = (e >> 2) & 3, w = e & 3;
+        const int yy = top + r, xx = left + w;
+        float v = 0.f;
+        if (yy >= 0 && yy < H2 && xx >= 0 && xx < W2) v = fmap[((size_t)c * H2 + yy) * W2 + xx];
+        patches[((size_t)i * C + c) * 16 + (r * 4 + w)] = v;
+    }
+}
+
+__global__ void gather_rows_sel_kernel(const float *x, int ldx, int C, const int32_t *row_idx, const int32_t *count_dev, int cap,
+                                       float *out, int ldo) {
+    const int i = blockIdx.x;
+    if (i >= min(*count_dev, cap)) return;
+    const size_t r = (size_t)row_idx[i];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) out[(size_t)i * ldo + c] = x[r * ldx + c];
+}
+
+// one wave per match: 16 cosine similarities (eps 1e-8, torch.cosine_similarity), argmax, fine_xy
+__global__ __launch_bounds__(64) void fine_match_kernel(const float *patches, const float *pcf, int ldp, int C, const float *xy,
+                                                        int ldxy, float cscale, const int32_t *count_dev, int cap, float *fine_xy,
+                                                        int32_t *best) {
+    const int i = blockIdx.x;
+    if (i >= min(*count_dev, cap)) return;
+    const int lane = threadIdx.x;
+    const int pxl = lane & 15, part = lane >> 4;  // 4 lanes groups split the channels of one pixel
+    float dot = 0.f, nn = 0.f, pp = 0.f;
+    for (int c = part; c < C; c += 4) {
+        const float pv = patches[((size_t)i * C + c) * 16 + pxl];
+        const float fv = pcf[(size_t)i * ldp + c];
+        dot += pv * fv;
+        nn += pv * pv;
+        pp += fv * fv;
+    }
+    dot += __shfl_xor(dot, 16, 64); dot += __shfl_xor(dot, 32, 64);
+    nn += __shfl_xor(nn, 16, 64); nn += __shfl_xor(nn, 32, 64);
+    pp += __shfl_xor(pp, 16, 64); pp += __shfl_xor(pp, 32, 64);
+    float sim = dot / (fmaxf(sqrtf(nn), 1e-8f) * fmaxf(sqrtf(pp), 1e-8f));
+    int bi = pxl;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        const float os = __shfl_xor(sim, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (os > sim || (os == sim && oi < bi)) { sim = os; bi = oi; }
+    }
+    if (lane == 0) {
+        best[i] = bi;
+        // eval_all.py:103-105 — x receives idx // 4 and y receives idx % 4 (kept as in the reference)
+        fine_xy[i] = (xy[i] * cscale - 2.0f) + (float)(bi / 4);
+        fine_xy[cap + i] = (xy[ldxy + i] * cscale - 2.0f) + (float)(bi % 4);
+    }
+}
+
+}  // namespace
+
+extern "C" int cofi_row_argmin_1m(const float *sim, int lds, int N, int P, int32_t *pix, cofi_stream_t stream) {
+    if (!sim || !pix || N <= 0 || P <= 0 || lds < P) return COFI_EINVAL;
+    hipLaunchKernelGGL(row_argmin_1m_kernel, dim3(cofi_cdiv(N, 4)), dim3(256), 0, cofi_s(stream), sim, lds, N, P, pix);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_select_matches(const float *score, const int32_t *pix, int N, int W8, int H8, const float *thr_host, int n_thr,
+                                   int min_matches, int32_t *sel, float *coarse_xy, int32_t *count_dev, cofi_stream_t stream) {
+    if (!score || !pix || !thr_host || !sel || !coarse_xy || !count_dev || N <= 0 || W8 <= 4 || H8 <= 4 || n_thr <= 0 || n_thr > 64)
+        return COFI_EINVAL;
+    SelArgs a;
+    a.score = score; a.pix = pix; a.sel = sel; a.count = count_dev; a.xy = coarse_xy;
+    a.N = N; a.W8 = W8; a.H8 = H8; a.n_thr = n_thr; a.min_matches = min_matches;
+    for (int i = 0; i < 64; ++i) a.thr[i] = i < n_thr ? thr_host[i] : 0.f;
+    hipLaunchKernelGGL(select_matches_kernel, dim3(1), dim3(1024), 0, cofi_s(stream), a);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_gather_points_sel(const float *pts, const int32_t *sel, const int32_t *count_dev, int cap, float *out,
+                                      cofi_stream_t stream) {
+    if (!pts || !sel || !count_dev || !out || cap <= 0) return COFI_EINVAL;
+    hipLaunchKernelGGL(gather_points_sel_kernel, dim3(cofi_cdiv(cap * 3, 256)), dim3(256), 0, cofi_s(stream), pts, sel, count_dev, cap,
+                       out);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_extract_patches(const float *fmap, int C, int H2, int W2, const float *coarse_xy, int ldxy, float center_scale,
+                                    const int32_t *count_dev, int cap, float *patches, cofi_stream_t stream) {
+    if (!fmap || !coarse_xy || !count_dev || !patches || C <= 0 || H2 <= 0 || W2 <= 0 || cap <= 0) return COFI_EINVAL;
+    hipLaunchKernelGGL(extract_patches_kernel, dim3(cap), dim3(256), 0, cofi_s(stream), fmap, C, H2, W2, coarse_xy, ldxy, center_scale,
+                       count_dev, cap, patches);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_gather_rows_sel(const float *x, int ldx, int C, const int32_t *row_idx, const int32_t *count_dev, int cap,
+                                    float *out, int ldo, cofi_stream_t stream) {
+    if (!x || !row_idx || !count_dev || !out || C <= 0 || cap <= 0 || ldx < C || ldo < C) return COFI_EINVAL;
+    hipLaunchKernelGGL(gather_rows_sel_kernel, dim3(cap), dim3(64), 0, cofi_s(stream), x, ldx, C, row_idx, count_dev, cap, out, ldo);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_fine_match(const float *patches, const float *pc_feats, int ldp, int C, const float *coarse_xy, int ldxy,
+                               float center_scale, const int32_t *count_dev, int cap, float *fine_xy, int32_t *best,
+                               cofi_stream_t stream) {
+    if (!patches || !pc_feats || !coarse_xy || !count_dev || !fine_xy || !best || C <= 0 || cap <= 0 || ldp < C) return COFI_EINVAL;
+    hipLaunchKernelGGL(fine_match_kernel, dim3(cap), dim3(64), 0, cofi_s(stream), patches, pc_feats, ldp, C, coarse_xy, ldxy,
+                       center_scale, count_dev, cap, fine_xy, best);
+    return cofi_launch_status();
+}

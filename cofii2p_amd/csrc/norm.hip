@@ -1,0 +1,362 @@
+// Normalisation / glue kernels: stack-mode GroupNorm (two-level deterministic statistics),
+// row LayerNorm, column inverse norms (token-axis Q normalisation), L2 normalisation, transposes
+// and the sine position embedding.  All HBM/L2-bound streaming kernels: float4 accesses where the
+// layout allows, one pass over the data per kernel.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------- GroupNorm stats
+// Level 1: block b reduces rows [b*ROWS, (b+1)*ROWS) for every group -> part[b][g] = {sum, sumsq}
+// (fp32 within a thread's <= ROWS*cpg values, fp64 across threads).  Level 2: one block combines
+// the partials in fp64 in a fixed order -> {mean, rstd}.  No atomics: bit-reproducible.
+constexpr int GS_ROWS = 64;
+
+__global__ __launch_bounds__(256) void group_stats_partial_kernel(const float *x, int ldx, int M, int C, int groups, double *part) {
+    // grid: x = row slab of GS_ROWS rows, y = 64-column tile (cpg < 64) or group (cpg >= 64)
+    const int cpg = C / groups;
+    const int r0 = blockIdx.x * GS_ROWS, r1 = min(M, r0 + GS_ROWS);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ double red[4][64][2];
+    if (cpg < 64) {
+        // lanes own columns of this tile; a group is cpg adjacent lanes (cpg is a power of two)
+        const int c = blockIdx.y * 64 + lane;
+        float s = 0.f, q = 0.f;
+        if (c < C)
+            for (int r = r0 + wv; r < r1; r += 4) {
+                const float v = x[(size_t)r * ldx + c];
+                s += v;
+                q += v * v;
+            }
+        double ds = s, dq = q;
+        for (int o = 1; o < cpg; o <<= 1) {
+            ds += __shfl_xor(ds, o, 64);
+            dq += __shfl_xor(dq, o, 64);
+        }
+        red[wv][lane][0] = ds;
+        red[wv][lane][1] = dq;
+        __syncthreads();
+        if (wv == 0 && c < C && (lane % cpg) == 0) {
+            const int g = c / cpg;
+            part[((size_t)blockIdx.x * groups + g) * 2 + 0] = red[0][lane][0] + red[1][lane][0] + red[2][lane][0] + red[3][lane][0];
+            part[((size_t)blockIdx.x * groups + g) * 2 + 1] = red[0][lane][1] + red[1][lane][1] + red[2][lane][1] + red[3][lane][1];
+        }
+    } else {
+        const int g = blockIdx.y;
+        float s = 0.f, q = 0.f;
+        for (int r = r0 + wv; r < r1; r += 4)
+            for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+                const float v = x[(size_t)r * ldx + c];
+                s += v;
+                q += v * v;
+            }
+        const double ds = wave_sum_d((double)s), dq = wave_sum_d((double)q);
+        if (lane == 0) {
+            red[wv][0][0] = ds;
+            red[wv][0][1] = dq;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            part[((size_t)blockIdx.x * groups + g) * 2 + 0] = red[0][0][0] + red[1][0][0] + red[2][0][0] + red[3][0][0];
+            part[((size_t)blockIdx.x * groups + g) * 2 + 1] = red[0][0][1] + red[1][0][1] + red[2][0][1] + red[3][0][1];
+        }
+    }
+}
+
+__global__ void group_stats_final_kernel(const double *part, int nblk, int groups, double count, float eps, float *stats) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += part[((size_t)b * groups + g) * 2 + 0];
+        q += part[((size_t)b * groups + g) * 2 + 1];
+    }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * g + 0] = (float)mean;
+    stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+struct GnApplyArgs {
+    const float *x, *stats, *gamma, *beta, *res, *res_stats, *res_gamma, *res_beta;
+    float *y;
+    int ldx, ldr, ldy, M, C, cpg;
+    float slope;
+};
+
+__global__ __launch_bounds__(256) void group_norm_apply_kernel(GnApplyArgs a) {
+    const int c4n = a.C >> 2;
+    const size_t total = (size_t)a.M * c4n;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(e / c4n), c = (int)(e % c4n) * 4;
+        const float4 xv = *reinterpret_cast<const float4 *>(a.x + (size_t)m * a.ldx + c);
+        float v[4] = {xv.x, xv.y, xv.z, xv.w};
+        float r[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.res) {
+            const float4 rv = *reinterpret_cast<const float4 *>(a.res + (size_t)m * a.ldr + c);
+            r[0] = rv.x; r[1] = rv.y; r[2] = rv.z; r[3] = rv.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = c + i, g = ch / a.cpg;
+            float t = (v[i] - a.stats[2 * g]) * a.stats[2 * g + 1];
+            if (a.gamma) t = t * a.gamma[ch] + a.beta[ch];
+            if (a.res) {
+                float rr = r[i];
+                if (a.res_stats) {
+                    rr = (rr - a.res_stats[2 * g]) * a.res_stats[2 * g + 1];
+                    if (a.res_gamma) rr = rr * a.res_gamma[ch] + a.res_beta[ch];
+                }
+                t += rr;
+            }
+            v[i] = t >= 0.f ? t : t * a.slope;
+        }
+        *reinterpret_cast<float4 *>(a.y + (size_t)m * a.ldy + c) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------- LayerNorm
+// one wave per row, C <= 2048 held in registers (8 float4 per lane)
+__global__ __launch_bounds__(256) void layer_norm_kernel(const float *x, int ldx, int M, int C, const float *gamma,
+                                                         const float *beta, float eps, int relu, const float *res, int ldr,
+                                                         float *y, int ldy) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int lane = threadIdx.x & 63;
+    const int c4n = C >> 2;
+    float4 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 < c4n) {
+            v[i] = reinterpret_cast<const float4 *>(x + (size_t)m * ldx)[c4];
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 < c4n) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 < c4n) {
+            const float4 gm = reinterpret_cast<const float4 *>(gamma)[c4], bt = reinterpret_cast<const float4 *>(beta)[c4];
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * gm.x + bt.x;
+            o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
+            o.z = (v[i].z - mean) * rstd * gm.z + bt.z;
+            o.w = (v[i].w - mean) * rstd * gm.w + bt.w;
+            if (relu) {
+                o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+            }
+            if (res) {
+                const float4 rv = reinterpret_cast<const float4 *>(res + (size_t)m * ldr)[c4];
+                o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+            }
+            reinterpret_cast<float4 *>(y + (size_t)m * ldy)[c4] = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- column inverse norm
+// out[c] = 1 / max(sqrt(sum_m x[m,c]^2), eps).  Block = 32 columns x 8 row phases, fixed-order
+// LDS fold (deterministic).
+__global__ __launch_bounds__(256) void col_inv_norm_kernel(const float *x, int ldx, int M, int C, float eps, float *out) {
+    __shared__ double red[8][32];
+    const int cl = threadIdx.x & 31, rp = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0;
+    if (c < C) {
+        float part = 0.f;
+        int n = 0;
+        for (int m = rp; m < M; m += 8) {
+            const float v = x[(size_t)m * ldx + c];
+            part += v * v;
+            if (++n == 32) { s += (double)part; part = 0.f; n = 0; }
+        }
+        s += (double)part;
+    }
+    red[rp][cl] = s;
+    __syncthreads();
+    if (rp == 0 && c < C) {
+        double t = 0.0;
+        for (int i = 0; i < 8; ++i) t += red[i][cl];
+        out[c] = 1.0f / fmaxf((float)sqrt(t), eps);
+    }
+}
+
+// ---------------------------------------------------------------------------- L2 norm of rows
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float *x, int ldx, int M, int C, float *y, int ldy, int transpose) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int lane = threadIdx.x & 63;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float v = x[(size_t)m * ldx + c];
+        q += v * v;
+    }
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+    for (int c = lane; c < C; c += 64) {
+        const float v = x[(size_t)m * ldx + c] * inv;
+        if (transpose)
+            y[(size_t)c * ldy + m] = v;
+        else
+            y[(size_t)m * ldy + c] = v;
+    }
+}
+
+// (C,P) channel-major map: normalise every pixel's C-vector; lanes = consecutive pixels
+__global__ __launch_bounds__(256) void l2norm_cols_kernel(const float *x, int ldx, int C, int P, float *y_cp, int ldy, float *y_pc,
+                                                          int ldt) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    float q = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float v = x[(size_t)c * ldx + p];
+        q += v * v;
+    }
+    const float inv = 1.0f / fmaxf(sqrtf(q), 1e-12f);
+    for (int c = 0; c < C; ++c) {
+        const float v = x[(size_t)c * ldx + p] * inv;
+        if (y_cp) y_cp[(size_t)c * ldy + p] = v;
+        if (y_pc) y_pc[(size_t)p * ldt + c] = v;
+    }
+}
+
+__global__ void transpose_kernel(const float *x, int ldx, int M, int C, float *y, int ldy) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int m = by + i, c = bx + tx;
+        tile[i][tx] = (m < M && c < C) ? x[(size_t)m * ldx + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = bx + i, m = by + tx;
+        if (c < C && m < M) y[(size_t)c * ldy + m] = tile[tx][i];
+    }
+}
+
+// ---------------------------------------------------------------------------- sine position embedding
+struct PosArgs {
+    const void *coords;
+    float *out;
+    int coords_are_int, T, n_dim, F, d_model, accumulate, ldo;
+    float dim_t[64];
+};
+
+// position_encoding.py:39-50: ang = (x * 2pi) / dim_t[i]; even i -> sin, odd i -> cos; precise
+// sinf/cosf (arguments reach ~500 rad for metre-scale coordinates).
+__global__ void pos_sine_kernel(PosArgs a) {
+    const size_t total = (size_t)a.T * a.d_model;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(e / a.d_model), o = (int)(e % a.d_model);
+        float v = 0.f;
+        if (o < a.n_dim * a.F) {
+            const int d = o / a.F, i = o % a.F;
+            const float x = a.coords_are_int ? (float)reinterpret_cast<const int32_t *>(a.coords)[(size_t)t * a.n_dim + d]
+                                             : reinterpret_cast<const float *>(a.coords)[(size_t)t * a.n_dim + d];
+            const float ang = (x * 6.283185307179586f) / a.dim_t[i];
+            v = (i & 1) ? cosf(ang) : sinf(ang);
+        }
+        float *dst = a.out + (size_t)t * a.ldo + o;
+        *dst = a.accumulate ? (*dst + v) : v;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t cofi_group_stats_workspace(int M, int C, int groups) {
+    if (M <= 0 || groups <= 0) return 0;
+    return (size_t)cofi_cdiv(M, GS_ROWS) * groups * 2 * sizeof(double);
+}
+
+extern "C" int cofi_group_stats(const float *x, int ldx, int M, int C, int groups, float eps, float *stats, void *ws,
+                                size_t ws_bytes, cofi_stream_t stream) {
+    if (!x || !stats || M <= 0 || C <= 0 || groups <= 0 || (C % groups) || ldx < C) return COFI_EINVAL;
+    const int cpg = C / groups;
+    if (cpg < 64 && (cpg & (cpg - 1))) return COFI_EUNSUPPORTED;  // power-of-two group width below one wave
+    if (!ws || ws_bytes < cofi_group_stats_workspace(M, C, groups)) return COFI_EWORKSPACE;
+    const int nblk = cofi_cdiv(M, GS_ROWS);
+    hipStream_t s = cofi_s(stream);
+    hipLaunchKernelGGL(group_stats_partial_kernel, dim3(nblk, cpg < 64 ? cofi_cdiv(C, 64) : groups), dim3(256), 0, s, x, ldx, M, C,
+                       groups, (double *)ws);
+    hipLaunchKernelGGL(group_stats_final_kernel, dim3(cofi_cdiv(groups, 64)), dim3(64), 0, s, (const double *)ws, nblk, groups,
+                       (double)M * cpg, eps, stats);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_group_norm_apply(const float *x, int ldx, int M, int C, int groups, const float *stats, const float *gamma,
+                                     const float *beta, const float *res, int ldr, const float *res_stats,
+                                     const float *res_gamma, const float *res_beta, float slope, float *y, int ldy,
+                                     cofi_stream_t stream) {
+    if (!x || !stats || !y || M <= 0 || C <= 0 || groups <= 0 || (C % groups) || (C & 3) || (ldx & 3) || (ldy & 3)) return COFI_EINVAL;
+    if ((gamma == nullptr) != (beta == nullptr) || (res_gamma == nullptr) != (res_beta == nullptr)) return COFI_EINVAL;
+    if (res && (ldr & 3)) return COFI_EINVAL;
+    GnApplyArgs a{x, stats, gamma, beta, res, res_stats, res_gamma, res_beta, y, ldx, ldr, ldy, M, C, C / groups, slope};
+    size_t total = (size_t)M * (C >> 2);
+    int nb = (int)((total + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(group_norm_apply_kernel, dim3(nb), dim3(256), 0, cofi_s(stream), a);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_layer_norm(const float *x, int ldx, int M, int C, const float *gamma, const float *beta, float eps, int relu,
+                               const float *res, int ldr, float *y, int ldy, cofi_stream_t stream) {
+    if (!x || !y || !gamma || !beta || M <= 0 || C <= 0 || C > 2048 || (C & 3) || (ldx & 3) || (ldy & 3) || (res && (ldr & 3)))
+        return COFI_EINVAL;
+    hipLaunchKernelGGL(layer_norm_kernel, dim3(cofi_cdiv(M, 4)), dim3(256), 0, cofi_s(stream), x, ldx, M, C, gamma, beta, eps, relu,
+                       res, ldr, y, ldy);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_col_inv_norm(const float *x, int ldx, int M, int C, float eps, float *out, cofi_stream_t stream) {
+    if (!x || !out || M <= 0 || C <= 0 || ldx < C) return COFI_EINVAL;
+    hipLaunchKernelGGL(col_inv_norm_kernel, dim3(cofi_cdiv(C, 32)), dim3(256), 0, cofi_s(stream), x, ldx, M, C, eps, out);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_l2norm_rows(const float *x, int ldx, int M, int C, float *y, int ldy, int transpose, cofi_stream_t stream) {
+    if (!x || !y || M <= 0 || C <= 0 || ldx < C || (transpose ? ldy < M : ldy < C)) return COFI_EINVAL;
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cofi_cdiv(M, 4)), dim3(256), 0, cofi_s(stream), x, ldx, M, C, y, ldy, transpose);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_l2norm_cols(const float *x, int ldx, int C, int P, float *y_cp, int ldy, float *y_pc, int ldt,
+                                cofi_stream_t stream) {
+    if (!x || C <= 0 || P <= 0 || ldx < P || (y_cp && ldy < P) || (y_pc && ldt < C)) return COFI_EINVAL;
+    hipLaunchKernelGGL(l2norm_cols_kernel, dim3(cofi_cdiv(P, 64)), dim3(64), 0, cofi_s(stream), x, ldx, C, P, y_cp, ldy, y_pc, ldt);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_transpose(const float *x, int ldx, int M, int C, float *y, int ldy, cofi_stream_t stream) {
+    if (!x || !y || M <= 0 || C <= 0 || ldx < C || ldy < M) return COFI_EINVAL;
+    hipLaunchKernelGGL(transpose_kernel, dim3(cofi_cdiv(C, 32), cofi_cdiv(M, 32)), dim3(256), 0, cofi_s(stream), x, ldx, M, C, y, ldy);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_pos_sine(const void *coords, int coords_are_int, int T, int n_dim, const float *dim_t_host, int F, int d_model,
+                             int accumulate, float *out, int ldo, cofi_stream_t stream) {
+    if (!coords || !dim_t_host || !out || T <= 0 || n_dim <= 0 || F <= 0 || F > 64 || n_dim * F > d_model || ldo < d_model)
+        return COFI_EINVAL;
+    PosArgs a;
+    a.coords = coords; a.out = out; a.coords_are_int = coords_are_int; a.T = T; a.n_dim = n_dim; a.F = F; a.d_model = d_model;
+    a.accumulate = accumulate; a.ldo = ldo;
+    for (int i = 0; i < 64; ++i) a.dim_t[i] = i < F ? dim_t_host[i] : 1.0f;
+    size_t total = (size_t)T * d_model;
+    int nb = (int)((total + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(pos_sine_kernel, dim3(nb), dim3(256), 0, cofi_s(stream), a);
+    return cofi_launch_status();
+}

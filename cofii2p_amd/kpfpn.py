@@ -1,0 +1,102 @@
+"""KPConv-FPN point encoder assembled from the HIP kernels
+(reference: model/kpconv/kp_backbone.py:79-128, modules.py:115-240, kpconv.py:79-122)."""
+from typing import Dict, List
+
+import torch
+
+from . import ops
+from .spec import DECODERS, ENCODER, GN_GROUPS, KPBlock
+
+LRELU = 0.1
+
+
+def pack_encoder(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """KPConv weights (15,Cin,Cout) -> (Cout, 15*Cin) so that part 2 of the operator
+    (kpconv.py:107-110: sum_k agg[:,k,:] @ W[k]) is ONE K-contiguous GEMM; the rest is used in place."""
+    out = {}
+    for k, v in sd.items():
+        if not k.startswith("pc_encoder."):
+            continue
+        if k.endswith("KPConv.weights"):
+            out[k] = v.permute(2, 0, 1).reshape(v.shape[2], -1).contiguous()
+        else:
+            out[k] = v.contiguous()
+    return out
+
+
+def _kpconv(P, p: str, feats, q_pts, s_pts, idx, sigma: float):
+    agg, cnt = ops.kpconv_aggregate(feats, q_pts, s_pts, idx, P[p + "KPConv.kernel_points"], sigma)
+    return ops.gemm(agg, P[p + "KPConv.weights"], bias=P[p + "KPConv.bias"], rowdiv=cnt)
+
+
+def _unary_raw(P, p: str, x):
+    y = ops.gemm(x, P[p + "mlp.weight"], bias=P[p + "mlp.bias"])
+    return y, ops.group_stats(y, GN_GROUPS)
+
+
+def _unary(P, p: str, x, slope: float, out=None):
+    y, st = _unary_raw(P, p, x)
+    return ops.group_norm_apply(y, st, P[p + "norm.norm.weight"], P[p + "norm.norm.bias"], slope=slope, out=out)
+
+
+def run_block(P, blk: KPBlock, feats, q_pts, s_pts, idx, out=None):
+    p = "pc_encoder.%s." % blk.name
+    if blk.kind == "conv":  # modules.py:155-159
+        y = _kpconv(P, p, feats, q_pts, s_pts, idx, blk.sigma)
+        return ops.group_norm_apply(y, ops.group_stats(y, GN_GROUPS), P[p + "norm.norm.weight"], P[p + "norm.norm.bias"], slope=LRELU,
+                                    out=out)
+    # modules.py:222-240
+    x = _unary(P, p + "unary1.", feats, LRELU) if blk.cin != blk.mid else feats
+    y = _kpconv(P, p, x, q_pts, s_pts, idx, blk.sigma)
+    x = ops.group_norm_apply(y, ops.group_stats(y, GN_GROUPS), P[p + "norm_conv.norm.weight"], P[p + "norm_conv.norm.bias"], slope=LRELU)
+    y2, st2 = _unary_raw(P, p + "unary2.", x)
+    sc = ops.neighbor_maxpool(feats, idx) if blk.strided else feats
+    g2, b2 = P[p + "unary2.norm.norm.weight"], P[p + "unary2.norm.norm.bias"]
+    if blk.has_shortcut_unary:
+        ys, sts = _unary_raw(P, p + "unary_shortcut.", sc)
+        return ops.group_norm_apply(y2, st2, g2, b2, slope=LRELU, res=ys, res_stats=sts,
+                                    res_gamma=P[p + "unary_shortcut.norm.norm.weight"],
+                                    res_beta=P[p + "unary_shortcut.norm.norm.bias"], out=out)
+    return ops.group_norm_apply(y2, st2, g2, b2, slope=LRELU, res=sc, out=out)
+
+
+def run_fpn(P, points: List[torch.Tensor], neighbors, subsampling, upsampling, feats, taps=None):
+    """Returns [latent_s2 (N1,64), latent_s3 (N2,512), latent_s4 (N3,1024), feats_s5 (N4,2048)].
+    The last block of stages 1..3 writes directly into the right part of the decoder's concat
+    buffer (kp_backbone.py:112,117,122 torch.cat)."""
+    dev = feats.device
+    dec_in = {name: cin for name, cin, _, _ in DECODERS}
+    # concat buffers: [upsampled deeper latent | stage features]
+    cat = {3: torch.empty((points[3].shape[0], dec_in["decoder4"]), dtype=torch.float32, device=dev),
+           2: torch.empty((points[2].shape[0], dec_in["decoder3"]), dtype=torch.float32, device=dev),
+           1: torch.empty((points[1].shape[0], dec_in["decoder2"]), dtype=torch.float32, device=dev)}
+    stage_width = {1: 256, 2: 512, 3: 1024}
+    last_of_stage = {}
+    for blk in ENCODER:
+        last_of_stage[blk.stage] = blk.name
+    x = feats
+    stage_out = {}
+    for blk in ENCODER:
+        st = blk.stage
+        if blk.strided:
+            q, s, idx = points[st], points[st - 1], subsampling[st - 1]
+        else:
+            q, s, idx = points[st], points[st], neighbors[st]
+        out = None
+        if st in cat and last_of_stage[st] == blk.name:
+            w = stage_width[st]
+            out = cat[st][:, cat[st].shape[1] - w:]
+        x = run_block(P, blk, x, q, s, idx, out=out)
+        stage_out[st] = x
+        if taps is not None:
+            taps[blk.name] = x
+    s5 = stage_out[4]
+    ops.gather_rows(s5, upsampling[3], out=cat[3][:, :2048])
+    l4 = _unary(P, "pc_encoder.decoder4.", cat[3], LRELU)
+    ops.gather_rows(l4, upsampling[2], out=cat[2][:, :1024])
+    l3 = _unary(P, "pc_encoder.decoder3.", cat[2], LRELU)
+    ops.gather_rows(l3, upsampling[1], out=cat[1][:, :512])
+    l2 = ops.gemm(cat[1], P["pc_encoder.decoder2.mlp.weight"], bias=P["pc_encoder.decoder2.mlp.bias"])
+    if taps is not None:
+        taps.update(decoder4=l4, decoder3=l3, decoder2=l2)
+    return [l2, l3, l4, s5]

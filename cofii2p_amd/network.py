@@ -1,0 +1,276 @@
+"""Drop-in mirror of the reference's `model/network.py` module surface on MI355X.
+
+`CoFiI2P(opt)` has the reference's constructor, `forward` signature, 8-tuple return and state_dict
+layout (model/network.py:14-164; 430 tensors, strict-loadable: evaluation/eval_all.py:49), so it
+drops into `evaluation/eval_all.py` / `train.py`-style callers under PyTorch-ROCm.  Underneath,
+forward enqueues hand-written gfx950 kernels through the C ABI of libcofi_hip.so
+(include/cofi_hip.h).  Inference only (`torch.no_grad()` semantics): there is no autograd and no
+CPU path — the module raises if the HIP library is missing or a tensor is not on the GPU.
+"""
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, image, kpfpn, ops, transformer
+from .spec import D_MODEL, LAYER_KINDS, N_HEAD, N_LAYERS, is_buffer, state_dict_spec
+
+__all__ = ["CoFiI2P", "CoFiI2P_wrapper", "fine_process", "extract_patch", "point2node", "square_distance", "fine_matching",
+           "score_thresholds"]
+
+
+class _Node(nn.Module):
+    """Anonymous container: the parameter tree is generated from spec.state_dict_spec()."""
+
+
+def _attach(root: nn.Module, name: str, shape, dtype: str):
+    parts = name.split(".")
+    node = root
+    for p in parts[:-1]:
+        if p not in node._modules:
+            node.add_module(p, _Node())
+        node = node._modules[p]
+    t = torch.zeros(shape, dtype=torch.int64 if dtype == "int64" else torch.float32)
+    if is_buffer(name):
+        node.register_buffer(parts[-1], t)
+    else:
+        node.register_parameter(parts[-1], nn.Parameter(t, requires_grad=False))
+
+
+def score_thresholds(n: int = 64) -> np.ndarray:
+    """network.py:147-151: ``thrs = 0.9`` then ``thrs -= 0.02`` in python floats; the comparison with
+    the fp32 score tensor happens in fp32, hence the cast."""
+    out, t = [], 0.9
+    for _ in range(n):
+        out.append(t)
+        t -= 0.02
+    return np.asarray(out, dtype=np.float64).astype(np.float32)
+
+
+class CoFiI2P(nn.Module):
+    """See module docstring.  ``opt`` needs ``img_H, img_W, img_fine_resolution_scale, norm``
+    (data/options.py:17-19,51); only ``norm == 'gn'`` (the shipped configuration) is implemented."""
+
+    def __init__(self, opt, init: str = "synthetic"):
+        super().__init__()
+        self.opt = opt
+        if getattr(opt, "norm", "gn") != "gn":
+            raise NotImplementedError("only opt.norm == 'gn' (data/options.py:51) is implemented")
+        self.pe_H = int(opt.img_H / 8)
+        self.pe_W = int(opt.img_W / 8)
+        self.H_fine_res = int(round(opt.img_H / opt.img_fine_resolution_scale))
+        self.W_fine_res = int(round(opt.img_W / opt.img_fine_resolution_scale))
+        for name, (shape, dtype) in state_dict_spec().items():
+            _attach(self, name, shape, dtype)
+        if init == "synthetic":
+            from .spec import synth_state_dict
+
+            self.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict().items()}, strict=True)
+        self._packed: Optional[Dict[str, torch.Tensor]] = None
+        self._packed_key = None
+        self.compute_unused_image_maps = True  # layer3/layer4/avg-pool of the ResNet (network.py:87-89)
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
+        self.eval()
+
+    # ------------------------------------------------------------------ weights
+    def _invalidate(self):
+        self._packed = None
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def _pack(self, device) -> Dict[str, torch.Tensor]:
+        if self._packed is not None and self._packed_key == device:
+            return self._packed
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        for k, v in sd.items():
+            if v.device != device:
+                raise _lib.CofiError("parameter %s is on %s but the inputs are on %s (call .cuda())" % (k, v.device, device))
+        P: Dict[str, torch.Tensor] = {}
+        P.update(kpfpn.pack_encoder(sd))
+        P.update(image.pack_image(sd))
+        for k, v in sd.items():
+            if k.startswith("pc_feature_layer."):
+                P[k] = v.contiguous()
+        for head in ("pc_score_layer", "img_score_layer"):
+            for i in (0, 3, 6):
+                w = sd["%s.%d.weight" % (head, i)]
+                P["%s.%d.weight" % (head, i)] = w.reshape(w.shape[0], w.shape[1]).contiguous()
+        # the last score GEMM has K = 64 -> fine (K % 4 == 0)
+        self._layers = [transformer.pack_layer(sd, "transformer.layers.%d." % l) for l in range(N_LAYERS)]
+        self._packed, self._packed_key = P, device
+        return P
+
+    # ------------------------------------------------------------------ forward pieces
+    @staticmethod
+    def _as_idx32(t: torch.Tensor) -> torch.Tensor:
+        return ops.idx_to_int32(t) if t.dtype != torch.int32 else t.contiguous()
+
+    def _score_head(self, P, head: str, tokens: torch.Tensor) -> torch.Tensor:
+        """network.py:42-43 on token-major data: 1x1 conv = GEMM, InstanceNorm over positions =
+        per-column normalisation (group width 1), ReLU = slope 0."""
+        y = ops.gemm(tokens, P[head + ".0.weight"])
+        y = ops.group_norm(y, y.shape[1], slope=0.0)
+        y = ops.gemm(y, P[head + ".3.weight"])
+        y = ops.group_norm(y, y.shape[1], slope=0.0)
+        return ops.gemm(y, P[head + ".6.weight"], act=ops.ACT_SIGMOID)  # (T,1)
+
+    def _pc_feature_mlp(self, P, x: torch.Tensor) -> torch.Tensor:
+        """network.py:29."""
+        p = "pc_feature_layer."
+        y = ops.layer_norm(ops.gemm(x, P[p + "0.weight"]), P[p + "1.weight"], P[p + "1.bias"], relu=True)
+        y = ops.layer_norm(ops.gemm(y, P[p + "3.weight"]), P[p + "4.weight"], P[p + "4.bias"], relu=True)
+        return ops.gemm(y, P[p + "6.weight"])
+
+    @torch.no_grad()
+    def forward(self, pc_data_dict, img, fine_center_kpt_coors, fine_xy, fine_pc_inline_index, mode, taps=None):
+        """model/network.py:74-164.  ``fine_xy`` is unused (as in the reference)."""
+        if mode not in ("train", "val", "test"):
+            raise ValueError("mode must be 'train', 'val' or 'test'")
+        if not img.is_cuda:
+            raise _lib.CofiError("CoFiI2P.forward needs CUDA (HIP) tensors: there is no CPU path")
+        _lib.load()
+        dev = img.device
+        P = self._pack(dev)
+        points = [p.contiguous() for p in pc_data_dict["points"]]
+        neighbors = [self._as_idx32(t) for t in pc_data_dict["neighbors"]]
+        subsampling = [self._as_idx32(t) for t in pc_data_dict["subsampling"]]
+        upsampling = [self._as_idx32(t) for t in pc_data_dict["upsampling"]]
+        feats = pc_data_dict["feats"].contiguous()
+
+        # ---- encoders
+        pc_set = kpfpn.run_fpn(P, points, neighbors, subsampling, upsampling, feats, taps=taps)
+        img_set = image.resnet34(P, img, full=self.compute_unused_image_maps)
+        s2, s4, s8 = img_set[0], img_set[1], img_set[2]
+        _, C, H8, W8 = s8.shape
+        N4 = points[-1].shape[0]
+        T_img = H8 * W8
+
+        # ---- descriptors + position embedding -> token streams (network.py:83-110)
+        fine_pc = ops.l2norm_rows(pc_set[0])  # (N1,64)
+        ts = transformer.TokenStreams(T_img, N4, D_MODEL, dev)
+        s8n, _ = ops.l2norm_cols(s8[0].reshape(C, T_img), tokens_out=ts.img[0][:, :D_MODEL])
+        gy, gx = torch.meshgrid(torch.arange(H8, device=dev, dtype=torch.int32), torch.arange(W8, device=dev, dtype=torch.int32),
+                                indexing="ij")
+        grid = torch.stack([gy, gx], -1).reshape(T_img, 2).contiguous()
+        ops.pos_sine(grid, ts.img[0], accumulate=True)
+        ops.l2norm_rows(self._pc_feature_mlp(P, pc_set[-1]), out=ts.pc[0][:, :D_MODEL])
+        ops.pos_sine(points[-1], ts.pc[0], accumulate=True)
+        if taps is not None:
+            taps["tok_img"], taps["tok_pc"] = ts.img_tokens().clone(), ts.pc_tokens().clone()
+
+        # ---- transformer (network.py:113-115)
+        tok_img, tok_pc = transformer.run_transformer(self._layers, LAYER_KINDS, ts, N_HEAD)
+
+        # ---- scores + coarse descriptors (network.py:123-126)
+        pc_score = self._score_head(P, "pc_score_layer", tok_pc)  # (N4,1)
+        img_score = self._score_head(P, "img_score_layer", tok_img)  # (T,1)
+        pc_desc_tok = ops.l2norm_rows(tok_pc)  # (N4,128) token-major copy for the similarity GEMM
+        img_desc_tok = ops.l2norm_rows(tok_img)
+        pc_desc = ops.transpose(pc_desc_tok)  # (128,N4)
+        img_desc = ops.transpose(img_desc_tok).reshape(1, C, H8, W8)
+
+        # ---- fine image descriptors (network.py:129-130)
+        up4 = image.upsample_stage(P, "img_upsample_1", s8n.reshape(1, C, H8, W8), s4)
+        up2_raw = image.upsample_stage(P, "img_upsample_2", up4, s2)
+        C2, H2, W2 = up2_raw.shape[1:]
+        up2, _ = ops.l2norm_cols(up2_raw[0].reshape(C2, H2 * W2), want_tokens=False)
+        up2 = up2.reshape(C2, H2, W2)
+        if taps is not None:
+            taps.update(up2=up2, fine_pc=fine_pc, tok_img_out=tok_img, tok_pc_out=tok_pc)
+
+        coarse_img_score = img_score.reshape(1, 1, H8, W8)
+        coarse_pc_score = pc_score.reshape(1, 1, N4)
+        if mode in ("train", "val"):
+            K = fine_center_kpt_coors.shape[1]
+            cnt = torch.tensor([K, 0], dtype=torch.int32, device=dev)
+            ctr = fine_center_kpt_coors.to(torch.float32).contiguous()
+            patches = ops.extract_patches(up2, ctr, cnt, K, 1.0).reshape(K, C2, 4, 4)
+            idx = self._as_idx32(fine_pc_inline_index.reshape(-1))
+            fine_pc_feat = ops.gather_rows(fine_pc, idx)
+            return img_desc, pc_desc, coarse_img_score, coarse_pc_score, patches, fine_pc_feat, None, None
+
+        # ---- test mode: coarse matching + patch extraction, one host sync (the match count)
+        sim = ops.gemm(pc_desc_tok, img_desc_tok)  # (N4, T): <pc, pixel>
+        pix = ops.row_argmin_1m(sim)
+        sel, xy, cnt = ops.select_matches(pc_score.reshape(-1), pix, W8, H8, score_thresholds(), 4)
+        coarse_pts = ops.gather_points_sel(points[-1], sel, cnt)
+        node = ops.nearest_node_sel(points[1], points[-1], sel, cnt)
+        patches = ops.extract_patches(up2, xy, cnt, N4, 4.0)
+        fine_pc_feat = ops.gather_rows_sel(fine_pc, node, cnt, N4)
+        n, thr_i = (int(v) for v in cnt.cpu())  # the only device->host synchronisation of forward
+        if thr_i < 0:
+            raise RuntimeError("fewer than 4 coarse matches at every threshold (network.py:148 would loop forever)")
+        fine_center_xy = xy[:, :n] * 4
+        self.last_match = {"sel": sel[:n], "coarse_xy": xy[:, :n], "count_dev": cnt, "patches_cap": patches, "fine_pc_cap": fine_pc_feat,
+                           "xy_cap": xy, "threshold": float(score_thresholds()[thr_i])}
+        return (img_desc, pc_desc, coarse_img_score, coarse_pc_score, patches[:n], fine_pc_feat[:n], fine_center_xy, coarse_pts[:n])
+
+
+def fine_matching(fine_img_feature_patch, fine_pc_inline_feature, fine_center_xy):
+    """The fine point/pixel matching the reference performs in its callers
+    (evaluation/eval_all.py:99-105, train.py:272-278): returns (fine_xy (2,n), predict_index (n,))."""
+    n = fine_img_feature_patch.shape[0]
+    patches = fine_img_feature_patch.reshape(n, fine_img_feature_patch.shape[1], 16).contiguous()
+    cnt = torch.tensor([n, 0], dtype=torch.int32, device=patches.device)
+    xy = fine_center_xy.to(torch.float32).contiguous()
+    fxy, best = ops.fine_match(patches, fine_pc_inline_feature.contiguous(), xy, cnt, 1.0)
+    return fxy, best.to(torch.int64)
+
+
+# ---------------------------------------------------------------- free functions of model/network.py
+def square_distance(src, tgt, normalize: bool = False):
+    """network.py:228-247 on (B,N,3)/(B,M,3) CUDA tensors (GEMM kernel + canonical expansion)."""
+    if normalize:
+        raise NotImplementedError("normalize=True is never used by the reference's callers")
+    out = []
+    for b in range(src.shape[0]):
+        s, t = src[b].contiguous(), tgt[b].contiguous()
+        s4 = torch.zeros((s.shape[0], 4), device=s.device)
+        t4 = torch.zeros((t.shape[0], 4), device=t.device)
+        s4[:, :3], t4[:, :3] = s, t
+        d = ops.gemm(s4, t4) * -2.0
+        d += (s * s).sum(-1)[:, None]
+        d += (t * t).sum(-1)[None, :]
+        out.append(d.clamp_min(1e-12))
+    return torch.stack(out)
+
+
+def point2node(nodes, points):
+    """network.py:250-264 -> (N,) int64 index of the nearest node (lowest index on ties)."""
+    return ops.nearest_node(nodes.contiguous(), points.contiguous()).to(torch.int64)
+
+
+def fine_process(coarse_pc_score, coarse_pc_feature, coarse_img_feature, thrs: float = 0.9):
+    """network.py:167-187: returns (coarse_xy (2,n), pc_inline_index (n,) int64)."""
+    C, H8, W8 = coarse_img_feature.shape[1:]
+    pc_tok = ops.transpose(coarse_pc_feature.contiguous())
+    img_tok = ops.transpose(coarse_img_feature.reshape(C, H8 * W8).contiguous())
+    pix = ops.row_argmin_1m(ops.gemm(pc_tok, img_tok))
+    sel, xy, cnt = ops.select_matches(coarse_pc_score.reshape(-1).contiguous(), pix, W8, H8, np.asarray([thrs], dtype=np.float32), 0)
+    n = int(cnt[0])
+    return xy[:, :n], sel[:n].to(torch.int64)
+
+
+def extract_patch(feature_map, center_points, size: int = 4):
+    """network.py:206-226: (B,C,H,W), (2,n) -> (n,B,C,4,4)."""
+    if size != 4:
+        raise NotImplementedError("the reference asserts 4x4 patches (network.py:222)")
+    n = center_points.shape[1]
+    cnt = torch.tensor([n, 0], dtype=torch.int32, device=feature_map.device)
+    out = [ops.extract_patches(feature_map[b].contiguous(), center_points.to(torch.float32).contiguous(), cnt, n, 1.0)
+           .reshape(n, feature_map.shape[1], 4, 4) for b in range(feature_map.shape[0])]
+    return torch.stack(out, 1)
+
+
+class CoFiI2P_wrapper(nn.Module):
+    """network.py:267-274."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.cofii2p = CoFiI2P(opt)
+
+    def forward(self, inputs):
+        return self.cofii2p.forward(*inputs)

@@ -1,0 +1,367 @@
+"""Tensor-level host wrappers over the C ABI (torch is used for device memory + the stream only).
+
+Every function takes torch CUDA tensors, validates layout, and enqueues the HIP kernels of
+libcofi_hip.so on the CURRENT torch stream.  Row-major 2-D tensors may be column slices of a wider
+buffer: the leading dimension is `stride(0)`, `stride(1)` must be 1.
+"""
+import ctypes
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _mat(t: torch.Tensor, name: str, dtype=torch.float32):
+    if not t.is_cuda:
+        raise _lib.CofiError("%s must be a CUDA (HIP) tensor — there is no CPU path" % name)
+    if t.dtype != dtype or t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise _lib.CofiError("%s: expected row-major 2-D %s, got %s %s stride %s" % (name, dtype, t.dtype, tuple(t.shape), t.stride()))
+    return t
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def _vec(t: Optional[torch.Tensor], name: str, n: int, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != dtype or t.numel() != n or not t.is_contiguous():
+        raise _lib.CofiError("%s: expected contiguous CUDA %s of %d elements" % (name, dtype, n))
+    return t
+
+
+class Workspace:
+    """Grow-only device scratch, one per (device, purpose).  All kernels are stream ordered on the
+    current stream, so reuse across consecutive calls is safe."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes: int, device) -> Optional[torch.Tensor]:
+        if nbytes == 0:
+            return None
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        return self.buf
+
+
+_WS_GEMM = Workspace()
+_WS_STATS = Workspace()
+
+
+# ------------------------------------------------------------------------------------------ dense
+def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, bias=None, rowdiv=None, act: int = ACT_NONE):
+    """out[m,n] = act( (a @ w.T)[m,n] / rowdiv[m] + bias[n] );  a (M,K), w (N,K)."""
+    lib = _lib.load()
+    _mat(a, "a"), _mat(w, "w")
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise _lib.CofiError("gemm: K mismatch %s vs %s" % (tuple(a.shape), tuple(w.shape)))
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _mat(out, "out")
+    _vec(bias, "bias", N), _vec(rowdiv, "rowdiv", M)
+    nbytes = lib.cofi_gemm_f32_workspace(M, N, K)
+    ws = _WS_GEMM.get(nbytes, a.device)
+    rc = lib.cofi_gemm_f32(_p(a), _ld(a), _p(w), _ld(w), _p(out), _ld(out), M, N, K, _p(bias), _p(rowdiv), act, _p(ws),
+                           0 if ws is None else ws.numel(), _stream())
+    _lib.check(rc, "cofi_gemm_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ KPConv
+def row_sum_positive(feats: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _mat(feats, "feats")
+    out = torch.empty((feats.shape[0],), dtype=torch.uint8, device=feats.device)
+    _lib.check(lib.cofi_row_sum_positive(_p(feats), _ld(feats), feats.shape[0], feats.shape[1], _p(out), _stream()), "cofi_row_sum_positive")
+    return out
+
+
+def kpconv_aggregate(feats, q_pts, s_pts, idx, kernel_points, sigma: float, row_pos=None):
+    """-> agg (M, 15*C), cnt (M,) float.  idx int32 (M,H)."""
+    lib = _lib.load()
+    _mat(feats, "feats"), _mat(idx, "idx", torch.int32)
+    if not (q_pts.is_contiguous() and s_pts.is_contiguous() and kernel_points.is_contiguous() and idx.is_contiguous()):
+        raise _lib.CofiError("kpconv_aggregate: points / idx / kernel_points must be contiguous")
+    N, C = feats.shape
+    M, H = idx.shape
+    if s_pts.shape != (N, 3) or q_pts.shape != (M, 3) or kernel_points.shape != (15, 3):
+        raise _lib.CofiError("kpconv_aggregate: shape mismatch")
+    if row_pos is None:
+        row_pos = row_sum_positive(feats)
+    agg = torch.empty((M, 15 * C), dtype=torch.float32, device=feats.device)
+    cnt = torch.empty((M,), dtype=torch.float32, device=feats.device)
+    rc = lib.cofi_kpconv_aggregate(_p(feats), _ld(feats), N, C, _p(q_pts), _p(s_pts), _p(idx), M, H, _p(kernel_points), float(sigma),
+                                   _p(row_pos), _p(agg), 15 * C, _p(cnt), _stream())
+    _lib.check(rc, "cofi_kpconv_aggregate")
+    return agg, cnt
+
+
+def neighbor_maxpool(x, idx, out=None):
+    lib = _lib.load()
+    _mat(x, "x"), _mat(idx, "idx", torch.int32)
+    M, H = idx.shape
+    if out is None:
+        out = torch.empty((M, x.shape[1]), dtype=torch.float32, device=x.device)
+    _lib.check(lib.cofi_neighbor_maxpool(_p(x), _ld(x), x.shape[0], x.shape[1], _p(idx), M, H, _p(out), _ld(out), _stream()),
+               "cofi_neighbor_maxpool")
+    return out
+
+
+def gather_rows(x, idx, out=None):
+    """out[m] = x[idx[m, 0]] (zero row for idx == N).  idx (M,) or (M,H) int32."""
+    lib = _lib.load()
+    _mat(x, "x")
+    if idx.dtype != torch.int32 or not idx.is_cuda:
+        raise _lib.CofiError("gather_rows: idx must be CUDA int32")
+    M = idx.shape[0]
+    stride = idx.stride(0) if idx.dim() == 2 else 1
+    if out is None:
+        out = torch.empty((M, x.shape[1]), dtype=torch.float32, device=x.device)
+    _lib.check(lib.cofi_gather_rows(_p(x), _ld(x), x.shape[0], x.shape[1], _p(idx), stride, M, _p(out), _ld(out), _stream()),
+               "cofi_gather_rows")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ norms
+def group_stats(x, groups: int, eps: float = 1e-5):
+    lib = _lib.load()
+    _mat(x, "x")
+    M, C = x.shape
+    stats = torch.empty((groups, 2), dtype=torch.float32, device=x.device)
+    ws = _WS_STATS.get(lib.cofi_group_stats_workspace(M, C, groups), x.device)
+    _lib.check(lib.cofi_group_stats(_p(x), _ld(x), M, C, groups, eps, _p(stats), _p(ws), ws.numel(), _stream()), "cofi_group_stats")
+    return stats
+
+
+def group_norm_apply(x, stats, gamma=None, beta=None, slope: float = 1.0, res=None, res_stats=None, res_gamma=None, res_beta=None,
+                     out=None):
+    lib = _lib.load()
+    _mat(x, "x")
+    M, C = x.shape
+    groups = stats.shape[0]
+    if out is None:
+        out = torch.empty((M, C), dtype=torch.float32, device=x.device)
+    rc = lib.cofi_group_norm_apply(_p(x), _ld(x), M, C, groups, _p(stats), _p(gamma), _p(beta), _p(res), 0 if res is None else _ld(res),
+                                   _p(res_stats), _p(res_gamma), _p(res_beta), float(slope), _p(out), _ld(out), _stream())
+    _lib.check(rc, "cofi_group_norm_apply")
+    return out
+
+
+def group_norm(x, groups, gamma=None, beta=None, slope=1.0, eps=1e-5, out=None):
+    return group_norm_apply(x, group_stats(x, groups, eps), gamma, beta, slope, out=out)
+
+
+def layer_norm(x, gamma, beta, relu: bool = False, res=None, out=None, eps: float = 1e-5):
+    lib = _lib.load()
+    _mat(x, "x")
+    M, C = x.shape
+    if out is None:
+        out = torch.empty((M, C), dtype=torch.float32, device=x.device)
+    rc = lib.cofi_layer_norm(_p(x), _ld(x), M, C, _p(gamma), _p(beta), eps, int(relu), _p(res), 0 if res is None else _ld(res), _p(out),
+                             _ld(out), _stream())
+    _lib.check(rc, "cofi_layer_norm")
+    return out
+
+
+def col_inv_norm(x, eps: float = 1e-12):
+    lib = _lib.load()
+    _mat(x, "x")
+    out = torch.empty((x.shape[1],), dtype=torch.float32, device=x.device)
+    _lib.check(lib.cofi_col_inv_norm(_p(x), _ld(x), x.shape[0], x.shape[1], eps, _p(out), _stream()), "cofi_col_inv_norm")
+    return out
+
+
+def l2norm_rows(x, out=None, transpose: bool = False):
+    lib = _lib.load()
+    _mat(x, "x")
+    M, C = x.shape
+    if out is None:
+        out = torch.empty((C, M) if transpose else (M, C), dtype=torch.float32, device=x.device)
+    _lib.check(lib.cofi_l2norm_rows(_p(x), _ld(x), M, C, _p(out), _ld(out), int(transpose), _stream()), "cofi_l2norm_rows")
+    return out
+
+
+def l2norm_cols(x_cp, want_map: bool = True, want_tokens: bool = True, tokens_out=None):
+    """x (C,P) channel-major -> (normalised (C,P) map, token-major (P,C) copy)."""
+    lib = _lib.load()
+    _mat(x_cp, "x")
+    C, P = x_cp.shape
+    y_cp = torch.empty((C, P), dtype=torch.float32, device=x_cp.device) if want_map else None
+    y_pc = tokens_out if tokens_out is not None else (torch.empty((P, C), dtype=torch.float32, device=x_cp.device) if want_tokens else None)
+    rc = lib.cofi_l2norm_cols(_p(x_cp), _ld(x_cp), C, P, _p(y_cp), 0 if y_cp is None else _ld(y_cp), _p(y_pc),
+                              0 if y_pc is None else _ld(y_pc), _stream())
+    _lib.check(rc, "cofi_l2norm_cols")
+    return y_cp, y_pc
+
+
+def transpose(x, out=None):
+    lib = _lib.load()
+    _mat(x, "x")
+    M, C = x.shape
+    if out is None:
+        out = torch.empty((C, M), dtype=torch.float32, device=x.device)
+    _lib.check(lib.cofi_transpose(_p(x), _ld(x), M, C, _p(out), _ld(out), _stream()), "cofi_transpose")
+    return out
+
+
+def sine_frequencies(n_dim: int, d_model: int = 128, temperature: float = 10000.0) -> np.ndarray:
+    """position_encoding.py:39-40 evaluated with the same fp32 torch ops (host constant table)."""
+    f = d_model // n_dim // 2 * 2
+    i = torch.arange(f, dtype=torch.float32)
+    return (temperature ** (2 * torch.div(i, 2, rounding_mode="trunc") / f)).numpy().astype(np.float32)
+
+
+def pos_sine(coords, out, accumulate: bool, d_model: int = 128):
+    """out (T, >=d_model) (+)= PositionEmbeddingCoordsSine(coords).  coords float32 (T,n) or int32 grid."""
+    lib = _lib.load()
+    if not coords.is_cuda or not coords.is_contiguous() or coords.dtype not in (torch.float32, torch.int32):
+        raise _lib.CofiError("pos_sine: coords must be contiguous CUDA float32/int32")
+    T, n_dim = coords.shape
+    dim_t = sine_frequencies(n_dim, d_model)
+    rc = lib.cofi_pos_sine(_p(coords), int(coords.dtype == torch.int32), T, n_dim, dim_t.ctypes.data_as(ctypes.c_void_p), len(dim_t),
+                           d_model, int(accumulate), _p(out), _ld(out), _stream())
+    _lib.check(rc, "cofi_pos_sine")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attention(q, k, v, q_colscale=None, nhead: int = 4, out=None):
+    lib = _lib.load()
+    _mat(q, "q"), _mat(k, "k"), _mat(v, "v")
+    L, HD = q.shape
+    S = k.shape[0]
+    D = HD // nhead
+    if out is None:
+        out = torch.empty((L, HD), dtype=torch.float32, device=q.device)
+    rc = lib.cofi_attention_fwd(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(q_colscale), _p(out), _ld(out), L, S, nhead, D,
+                                1.0 / math.sqrt(D), None, 0, _stream())
+    _lib.check(rc, "cofi_attention_fwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ KNN / indices
+def knn(support, query, k: int, return_dist: bool = False):
+    lib = _lib.load()
+    for t, n in ((support, "support"), (query, "query")):
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.shape[1] != 3 or not t.is_contiguous():
+            raise _lib.CofiError("knn: %s must be contiguous CUDA float32 (n,3)" % n)
+    Q = query.shape[0]
+    idx = torch.empty((Q, k), dtype=torch.int32, device=query.device)
+    dist = torch.empty((Q, k), dtype=torch.float32, device=query.device) if return_dist else None
+    _lib.check(lib.cofi_knn_topk(_p(support), support.shape[0], _p(query), Q, k, _p(idx), _p(dist), _stream()), "cofi_knn_topk")
+    return (idx, dist) if return_dist else idx
+
+
+def nearest_node(nodes, points):
+    lib = _lib.load()
+    out = torch.empty((points.shape[0],), dtype=torch.int32, device=points.device)
+    _lib.check(lib.cofi_nearest_node(_p(nodes.contiguous()), nodes.shape[0], _p(points.contiguous()), points.shape[0], _p(out), _stream()),
+               "cofi_nearest_node")
+    return out
+
+
+def idx_to_int32(idx64: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    if idx64.dtype == torch.int32:
+        return idx64
+    if idx64.dtype != torch.int64 or not idx64.is_cuda:
+        raise _lib.CofiError("idx_to_int32: expected CUDA int64")
+    src = idx64.contiguous()
+    out = torch.empty(src.shape, dtype=torch.int32, device=src.device)
+    _lib.check(lib.cofi_idx64_to_idx32(_p(src), _p(out), src.numel(), _stream()), "cofi_idx64_to_idx32")
+    return out
+
+
+def idx_to_int64(idx32: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    src = idx32.contiguous()
+    out = torch.empty(src.shape, dtype=torch.int64, device=src.device)
+    _lib.check(lib.cofi_idx32_to_idx64(_p(src), _p(out), src.numel(), _stream()), "cofi_idx32_to_idx64")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ matching
+def row_argmin_1m(sim):
+    lib = _lib.load()
+    _mat(sim, "sim")
+    out = torch.empty((sim.shape[0],), dtype=torch.int32, device=sim.device)
+    _lib.check(lib.cofi_row_argmin_1m(_p(sim), _ld(sim), sim.shape[0], sim.shape[1], _p(out), _stream()), "cofi_row_argmin_1m")
+    return out
+
+
+def select_matches(score, pix, W8: int, H8: int, thresholds: np.ndarray, min_matches: int = 4):
+    """-> sel (N,) int32, coarse_xy (2,N) float32, count_dev (2,) int32 [n, threshold index]."""
+    lib = _lib.load()
+    N = score.numel()
+    sel = torch.empty((N,), dtype=torch.int32, device=score.device)
+    xy = torch.empty((2, N), dtype=torch.float32, device=score.device)
+    cnt = torch.empty((2,), dtype=torch.int32, device=score.device)
+    thr = np.ascontiguousarray(thresholds, dtype=np.float32)
+    rc = lib.cofi_select_matches(_p(score), _p(pix), N, W8, H8, thr.ctypes.data_as(ctypes.c_void_p), len(thr), min_matches, _p(sel),
+                                 _p(xy), _p(cnt), _stream())
+    _lib.check(rc, "cofi_select_matches")
+    return sel, xy, cnt
+
+
+def gather_points_sel(pts, sel, cnt):
+    lib = _lib.load()
+    cap = sel.numel()
+    out = torch.empty((cap, 3), dtype=torch.float32, device=pts.device)
+    _lib.check(lib.cofi_gather_points_sel(_p(pts), _p(sel), _p(cnt), cap, _p(out), _stream()), "cofi_gather_points_sel")
+    return out
+
+
+def nearest_node_sel(nodes, points_all, sel, cnt):
+    lib = _lib.load()
+    cap = sel.numel()
+    out = torch.empty((cap,), dtype=torch.int32, device=nodes.device)
+    rc = lib.cofi_nearest_node_sel(_p(nodes), nodes.shape[0], _p(points_all), _p(sel), _p(cnt), cap, _p(out), _stream())
+    _lib.check(rc, "cofi_nearest_node_sel")
+    return out
+
+
+def extract_patches(fmap_chw, xy, cnt, cap: int, center_scale: float):
+    lib = _lib.load()
+    C, H2, W2 = fmap_chw.shape
+    out = torch.empty((cap, C, 16), dtype=torch.float32, device=fmap_chw.device)
+    rc = lib.cofi_extract_patches(_p(fmap_chw), C, H2, W2, _p(xy), xy.stride(0), float(center_scale), _p(cnt), cap, _p(out), _stream())
+    _lib.check(rc, "cofi_extract_patches")
+    return out
+
+
+def gather_rows_sel(x, row_idx, cnt, cap: int):
+    lib = _lib.load()
+    _mat(x, "x")
+    out = torch.empty((cap, x.shape[1]), dtype=torch.float32, device=x.device)
+    _lib.check(lib.cofi_gather_rows_sel(_p(x), _ld(x), x.shape[1], _p(row_idx), _p(cnt), cap, _p(out), _ld(out), _stream()),
+               "cofi_gather_rows_sel")
+    return out
+
+
+def fine_match(patches, pc_feats, xy, cnt, center_scale: float):
+    """patches (cap,C,16), pc_feats (cap,C), xy (2,ld) -> fine_xy (2,cap), best (cap,) int32."""
+    lib = _lib.load()
+    cap, C, _ = patches.shape
+    fine_xy = torch.empty((2, cap), dtype=torch.float32, device=patches.device)
+    best = torch.empty((cap,), dtype=torch.int32, device=patches.device)
+    rc = lib.cofi_fine_match(_p(patches), _p(pc_feats), _ld(pc_feats), C, _p(xy), xy.stride(0), float(center_scale), _p(cnt), cap,
+                             _p(fine_xy), _p(best), _stream())
+    _lib.check(rc, "cofi_fine_match")
+    return fine_xy, best

@@ -1,0 +1,42 @@
+"""Point-cloud pyramid on the GPU: the HIP KNN kernel in the role of the reference's DataLoader-side
+`precompute_point_cloud_stack_mode` (model/kpconv/preprocess_data.py:36-107; its importable torch twin
+`precompute_point_cloud_cuda`, :145-203)."""
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .spec import NUM_NEIGHBORS
+
+
+def build_pyramid(points: torch.Tensor, subsample: List[torch.Tensor], k: int = NUM_NEIGHBORS, int64: bool = False) -> Dict:
+    """points (N,3) CUDA fp32; subsample[i] = indices (CUDA int64/int32) into stage i selecting stage
+    i+1 (the reference draws them with np.random.choice WITH replacement, preprocess_data.py:58).
+    Returns the reference's dict layout: neighbors[i] (N_i,k) into stage i, subsampling[i] (N_{i+1},k)
+    into stage i, upsampling[i] (N_i,k) into stage i+1 — int32 (device native) or int64."""
+    pts = [points.contiguous()]
+    for sel in subsample:
+        pts.append(pts[-1][sel.long()].contiguous())
+    neighbors, subsampling, upsampling = [], [], []
+    for i in range(len(pts)):
+        neighbors.append(ops.knn(pts[i], pts[i], k))
+        if i < len(pts) - 1:
+            subsampling.append(ops.knn(pts[i], pts[i + 1], k))
+            upsampling.append(ops.knn(pts[i + 1], pts[i], k))
+    conv = ops.idx_to_int64 if int64 else (lambda t: t)
+    return {"points": pts, "lengths": [int(p.shape[0]) for p in pts], "neighbors": [conv(t) for t in neighbors],
+            "subsampling": [conv(t) for t in subsampling], "upsampling": [conv(t) for t in upsampling]}
+
+
+def precompute_point_cloud_stack_mode(points, intensity, normals, lengths, num_stages, device="cuda", rng: Optional[np.random.RandomState] = None):
+    """Signature of preprocess_data.py:36.  points (3,N) numpy; intensity / normals are carried by the
+    caller (kitti.py:293) and ignored here, exactly as in the reference."""
+    rng = np.random if rng is None else rng
+    n = points.shape[1]
+    sub = []
+    for _ in range(num_stages - 1):
+        sub.append(torch.from_numpy(rng.choice(np.arange(n), size=n // 2)).to(device))
+        n //= 2
+    p = torch.from_numpy(np.ascontiguousarray(points.T)).float().to(device)
+    return build_pyramid(p, sub, int64=True)

@@ -1,0 +1,96 @@
+"""I2P transformer assembled from the HIP kernels (reference: model/transformer/transformer.py).
+
+Token streams live in the LEFT half of (L, 2C) buffers so that the reference's
+``torch.cat([x, message], dim=2)`` (transformer.py:61) is free: LayerNorm1 writes the message
+straight into the right half and the 256-wide MLP GEMM reads the whole row.
+"""
+from typing import Dict
+
+import torch
+
+from . import ops
+
+
+def pack_layer(sd: Dict[str, torch.Tensor], p: str) -> Dict[str, torch.Tensor]:
+    """Fused projection weights of one LoFTREncoderLayer: [Wq;Wk;Wv] (3C,C) for self layers,
+    [Wk;Wv] for cross layers; everything else is used in place (nn.Linear layout == GEMM layout)."""
+    wq, wk, wv = sd[p + "q_proj.weight"], sd[p + "k_proj.weight"], sd[p + "v_proj.weight"]
+    return {
+        "q_proj.weight": wq.contiguous(),
+        "kv.weight": torch.cat([wk, wv], 0).contiguous(),
+        "qkv.weight": torch.cat([wq, wk, wv], 0).contiguous(),
+        "merge.weight": sd[p + "merge.weight"].contiguous(),
+        "mlp.0.weight": sd[p + "mlp.0.weight"].contiguous(),
+        "mlp.2.weight": sd[p + "mlp.2.weight"].contiguous(),
+        "norm1.weight": sd[p + "norm1.weight"].contiguous(), "norm1.bias": sd[p + "norm1.bias"].contiguous(),
+        "norm2.weight": sd[p + "norm2.weight"].contiguous(), "norm2.bias": sd[p + "norm2.bias"].contiguous(),
+    }
+
+
+def _layer(w, xcat: torch.Tensor, src: torch.Tensor, out: torch.Tensor, self_attn: bool, nhead: int = 4):
+    """xcat (L,2C): x in [:, :C]; src (S,C) view; out (L,C) view receiving x + message.
+    transformer.py:43-64."""
+    C = xcat.shape[1] // 2
+    x = xcat[:, :C]
+    if self_attn:
+        qkv = ops.gemm(x, w["qkv.weight"])
+        q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    else:
+        q = ops.gemm(x, w["q_proj.weight"])
+        kv = ops.gemm(src, w["kv.weight"])
+        k, v = kv[:, :C], kv[:, C:]
+    qscale = ops.col_inv_norm(q)  # F.normalize over the token axis (transformer.py:53)
+    msg = ops.attention(q, k, v, q_colscale=qscale, nhead=nhead)
+    merged = ops.gemm(msg, w["merge.weight"])
+    ops.layer_norm(merged, w["norm1.weight"], w["norm1.bias"], out=xcat[:, C:])
+    h = ops.gemm(xcat, w["mlp.0.weight"], act=ops.ACT_RELU)
+    h = ops.gemm(h, w["mlp.2.weight"])
+    ops.layer_norm(h, w["norm2.weight"], w["norm2.bias"], res=x, out=out)
+    return out
+
+
+def loftr_layer(w, x: torch.Tensor, src: torch.Tensor, nhead: int = 4) -> torch.Tensor:
+    """Stand-alone layer on plain (L,C)/(S,C) tensors (tests); `w` holds raw reference-named weights
+    or a packed dict."""
+    if "kv.weight" not in w:
+        w = pack_layer(w, "")
+    L, C = x.shape
+    xcat = torch.empty((L, 2 * C), dtype=torch.float32, device=x.device)
+    xcat[:, :C].copy_(x)
+    out = torch.empty((L, C), dtype=torch.float32, device=x.device)
+    return _layer(w, xcat, src, out, self_attn=False, nhead=nhead)
+
+
+class TokenStreams:
+    """Ping-pong (L,2C) buffers for the image and point streams."""
+
+    def __init__(self, L_img: int, L_pc: int, C: int, device):
+        self.C = C
+        self.img = [torch.empty((L_img, 2 * C), dtype=torch.float32, device=device) for _ in range(2)]
+        self.pc = [torch.empty((L_pc, 2 * C), dtype=torch.float32, device=device) for _ in range(2)]
+        self.cur_img = 0
+        self.cur_pc = 0
+
+    def img_tokens(self):
+        return self.img[self.cur_img][:, : self.C]
+
+    def pc_tokens(self):
+        return self.pc[self.cur_pc][:, : self.C]
+
+
+def run_transformer(layers, kinds, ts: TokenStreams, nhead: int = 4):
+    """transformer.py:85-104.  Self layers share weights between the streams; in a cross layer the
+    point stream attends to the ALREADY UPDATED image stream (:99-100)."""
+    C = ts.C
+    for w, kind in zip(layers, kinds):
+        xi, xp = ts.img[ts.cur_img], ts.pc[ts.cur_pc]
+        oi, op = ts.img[ts.cur_img ^ 1], ts.pc[ts.cur_pc ^ 1]
+        if kind == "self":
+            _layer(w, xi, xi[:, :C], oi[:, :C], True, nhead)
+            _layer(w, xp, xp[:, :C], op[:, :C], True, nhead)
+        else:
+            _layer(w, xi, xp[:, :C], oi[:, :C], False, nhead)
+            _layer(w, xp, oi[:, :C], op[:, :C], False, nhead)
+        ts.cur_img ^= 1
+        ts.cur_pc ^= 1
+    return ts.img_tokens(), ts.pc_tokens()

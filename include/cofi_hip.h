@@ -1,0 +1,197 @@
+/*
+ * cofi_hip.h — C ABI of libcofi_hip.so: the MI355X (gfx950) kernels behind CoFiI2P's
+ * coarse-to-fine correspondence forward path.
+ *
+ * The reference (WHU-USI3DV/CoFiI2P) is pure Python/PyTorch and has NO FFI/plugin layer
+ * (SURVEY.md §8b); the drop-in boundary is its nn.Module surface (model/network.py:14-164).
+ * This header is the kernel-level boundary underneath that surface: each entry point replaces
+ * one stock-op sequence of the reference, cited as `file:line` (paths relative to the reference
+ * root).  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'd / torch CUDA tensor .data_ptr()) unless the
+ *     parameter name ends in `_host`;
+ *   - all matrices are row-major fp32 with an explicit leading dimension `ld*` in ELEMENTS;
+ *   - neighbour/index tables are int32 on the device (`cofi_idx64_to_idx32` converts the
+ *     reference's int64 tables once per frame);
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it, allocates
+ *     nothing, keeps no global state and is re-entrant;
+ *   - scratch memory is passed in (`ws`, `ws_bytes`), sized by the matching `*_workspace` query;
+ *   - return value: 0 on success, a positive hipError_t from the launch, or a negative
+ *     COFI_E* code for argument errors (nothing is launched in that case).
+ */
+#ifndef COFI_HIP_H
+#define COFI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COFI_ABI_VERSION 1
+
+#define COFI_EINVAL (-1)      /* bad shape / alignment / null pointer */
+#define COFI_EWORKSPACE (-2)  /* workspace too small */
+#define COFI_EUNSUPPORTED (-3)
+
+typedef void *cofi_stream_t;
+
+/* activation codes of the GEMM epilogue */
+#define COFI_ACT_NONE 0
+#define COFI_ACT_RELU 1
+#define COFI_ACT_SIGMOID 2
+
+int cofi_abi_version(void);
+/* name of the code object's target, "gfx950" */
+const char *cofi_target_arch(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  brute-force KNN with wavefront top-k.
+ * Replaces model/kpconv/preprocess_data.py:109-143 (`square_distance` + `knn`, i.e.
+ * dist.topk(k, largest=False)) and model/network.py:250-264 (`point2node`, k = 1).
+ * support (S,3), query (Q,3) fp32 contiguous.  out_idx (Q,k) int32, ascending by
+ * (distance, index): ties are broken by the LOWEST support index (torch.topk leaves them
+ * unspecified).  Distance arithmetic is the canonical fp32 sequence documented in
+ * oracle/knn_oracle.c.  If S < k the tail of a row is padded with the shadow index S.
+ * out_dist (Q,k) may be NULL.  k <= 128.
+ */
+int cofi_knn_topk(const float *support, int S, const float *query, int Q, int k, int32_t *out_idx, float *out_dist,
+                  cofi_stream_t stream);
+int cofi_nearest_node(const float *nodes, int S, const float *points, int Q, int32_t *out_idx, cofi_stream_t stream);
+/* like cofi_nearest_node, but the query rows are points_all[sel[i]] for i < *count_dev (count read
+ * on the device: no host sync).  Used by the test-mode matching chain (network.py:152-153). */
+int cofi_nearest_node_sel(const float *nodes, int S, const float *points_all, const int32_t *sel, const int32_t *count_dev,
+                          int max_count, int32_t *out_idx, cofi_stream_t stream);
+
+/* int64 -> int32 index tables (values must fit; the shadow index N is preserved) */
+int cofi_idx64_to_idx32(const int64_t *src, int32_t *dst, size_t n, cofi_stream_t stream);
+int cofi_idx32_to_idx64(const int32_t *src, int64_t *dst, size_t n, cofi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2  KPConv, part 1: kernel-point influence + neighbour aggregation (MFMA 16x16x4 f32).
+ * Replaces model/kpconv/kpconv.py:91-105:
+ *   w[m,h,k] = max(0, 1 - |(s_pts[idx[m,h]] - q_pts[m]) - kp[k]| / sigma)
+ *   agg[m, k*C + c] = sum_h w[m,h,k] * feats[idx[m,h], c]
+ * and kpconv.py:113-115: cnt[m] = max(1, #{h : row_pos[idx[m,h]] != 0}) (as float), where
+ * row_pos[n] = (sum_c feats[n,c] > 0) comes from cofi_row_sum_positive.
+ * idx (M,H) int32; idx == N is the shadow neighbour (far point, zero feature).  H % 4 == 0.
+ * agg is (M, 15*C) with leading dimension ld_agg; part 2 is cofi_gemm_f32 with `rowdiv = cnt`.
+ */
+int cofi_row_sum_positive(const float *feats, int ld, int N, int C, uint8_t *row_pos, cofi_stream_t stream);
+int cofi_kpconv_aggregate(const float *feats, int ldf, int N, int C, const float *q_pts, const float *s_pts, const int32_t *idx,
+                          int M, int H, const float *kernel_points /* (15,3) */, float sigma, const uint8_t *row_pos,
+                          float *agg, int ld_agg, float *cnt, cofi_stream_t stream);
+
+/* K3 / K4  neighbour max-pool and nearest up-sample.
+ * Replace model/kpconv/functional.py:53-66 (`maxpool`) and :5-21 (`nearest_upsample`): a zero
+ * pad row stands behind index N. */
+int cofi_neighbor_maxpool(const float *x, int ldx, int N, int C, const int32_t *idx, int M, int H, float *out, int ldo,
+                          cofi_stream_t stream);
+int cofi_gather_rows(const float *x, int ldx, int N, int C, const int32_t *idx, int idx_stride, int M, float *out, int ldo,
+                     cofi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense contraction on fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 products/accumulation.
+ *   C[m,n] = act( (sum_k A[m,k] * W[n,k]) / rowdiv[m] + bias[n] )
+ * A (M,K) lda; W (N,K) ldw — torch.nn.Linear's own layout, so weights are used in place
+ * (model/kpconv/modules.py:76 `nn.Linear`, model/transformer/transformer.py:27-37,
+ * model/network.py:29,42-43; KPConv weights (15,Cin,Cout) are packed once to (Cout, 15*Cin),
+ * kpconv.py:107-110).  K % 4 == 0, lda % 4 == 0, ldw % 4 == 0, 16-byte aligned bases.
+ * bias / rowdiv may be NULL.  Deep-K problems are split over K into `ws` and reduced in a fixed
+ * order (deterministic, no float atomics).
+ */
+size_t cofi_gemm_f32_workspace(int M, int N, int K);
+int cofi_gemm_f32(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K, const float *bias,
+                  const float *rowdiv, int act, void *ws, size_t ws_bytes, cofi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K5  stack-mode GroupNorm (+ LeakyReLU / residual).
+ * Replaces model/kpconv/modules.py:32-49 (nn.GroupNorm over ALL rows of the frame x C/groups
+ * channels, eps 1e-5, biased variance) and, with groups == C and gamma == NULL, the
+ * InstanceNorm1d/2d of the score heads (model/network.py:42-43).
+ * cofi_group_stats writes stats (groups,2) = {mean, rstd}; deterministic two-level reduction,
+ * combined in fp64.  ws: cofi_group_stats_workspace(M, C, groups) bytes.
+ * cofi_group_norm_apply:
+ *   y = leaky( gn(x; stats, gamma, beta) + R , slope )   with
+ *   R = 0                              if res == NULL
+ *   R = res                            if res != NULL and res_stats == NULL
+ *   R = gn(res; res_stats, rg, rb)     otherwise        (modules.py:222-240 residual tail)
+ * slope = 1 is the identity, 0 is ReLU, 0.1 the reference's LeakyReLU.
+ */
+size_t cofi_group_stats_workspace(int M, int C, int groups);
+int cofi_group_stats(const float *x, int ldx, int M, int C, int groups, float eps, float *stats, void *ws, size_t ws_bytes,
+                     cofi_stream_t stream);
+int cofi_group_norm_apply(const float *x, int ldx, int M, int C, int groups, const float *stats, const float *gamma,
+                          const float *beta, const float *res, int ldr, const float *res_stats, const float *res_gamma,
+                          const float *res_beta, float slope, float *y, int ldy, cofi_stream_t stream);
+
+/* Row LayerNorm: y = act(LN(x) * gamma + beta) (+ res).  Replaces nn.LayerNorm at
+ * model/transformer/transformer.py:40-41,58,62 and model/network.py:29.  C <= 2048, C % 4 == 0. */
+int cofi_layer_norm(const float *x, int ldx, int M, int C, const float *gamma, const float *beta, float eps, int relu,
+                    const float *res, int ldr, float *y, int ldy, cofi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K6  flash-style multi-head attention on fp32 MFMA, never materialising the LxS score matrix.
+ * Replaces model/transformer/linear_attention.py:56-79 (`FullAttention.forward`) together with
+ * the per-channel query scaling of model/transformer/transformer.py:53
+ * (F.normalize over the TOKEN axis): q'[l,c] = q[l,c] * q_colscale[c].
+ *   O[l, h*D + d] = sum_s softmax_s( scale * <q'[l,h,:], k[s,h,:]> ) * v[s,h,d]
+ * Q (L, H*D) ldq; K,V (S, H*D) ldk/ldv; O (L, H*D) ldo.  D == 32.  q_colscale (H*D) may be NULL.
+ * cofi_col_inv_norm: out[c] = 1 / max(sqrt(sum_m x[m,c]^2), eps)  (F.normalize, eps 1e-12).
+ */
+size_t cofi_attention_workspace(int L, int S, int H, int D);
+int cofi_attention_fwd(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, const float *q_colscale,
+                       float *O, int ldo, int L, int S, int H, int D, float scale, void *ws, size_t ws_bytes,
+                       cofi_stream_t stream);
+int cofi_col_inv_norm(const float *x, int ldx, int M, int C, float eps, float *out, cofi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K8 / glue.
+ * cofi_pos_sine: model/transformer/position_encoding.py:29-50.  coords (T, n_dim) fp32 (or int32 grid
+ * coordinates when coords_are_int), dim_t_host = the F frequencies (host array, F <= 64);
+ * out[t, :] (+)= embedding, zero padded to d_model.  accumulate != 0 adds into `out`.
+ * cofi_l2norm_rows: F.normalize(x, dim=1) of row-major rows (model/network.py:83-84,125-126):
+ *   y[m,:] = x[m,:] / max(|x[m,:]|, 1e-12); if transpose != 0, y is written as (C, M) with ldy.
+ * cofi_transpose: out (C,M) <- in (M,C).
+ */
+int cofi_pos_sine(const void *coords, int coords_are_int, int T, int n_dim, const float *dim_t_host, int F, int d_model,
+                  int accumulate, float *out, int ldo, cofi_stream_t stream);
+int cofi_l2norm_rows(const float *x, int ldx, int M, int C, float *y, int ldy, int transpose, cofi_stream_t stream);
+int cofi_transpose(const float *x, int ldx, int M, int C, float *y, int ldy, cofi_stream_t stream);
+/* channel-major (C, P) map -> L2-normalised over C; writes the normalised map (C,P) and/or the
+ * token-major (P, C) copy (model/network.py:90,110).  Either output may be NULL. */
+int cofi_l2norm_cols(const float *x, int ldx, int C, int P, float *y_cp, int ldy, float *y_pc, int ldt, cofi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K10-K12  coarse + fine matching without host round trips (model/network.py:145-161,167-226,
+ * evaluation/eval_all.py:99-105).
+ * cofi_row_argmin_1m: pix[n] = argmin_p (1 - sim[n,p]) with the lowest index on ties
+ *   (network.py:176-180); sim (N,P) comes from cofi_gemm_f32 on the two descriptor sets.
+ * cofi_select_matches: tries thresholds thr_host[0..n_thr) in order until at least `min_matches`
+ *   super-points satisfy score >= thr AND 2 <= x <= W8-2 AND 2 <= y <= H8-2 (network.py:147-151,184;
+ *   x = pix % W8, y = pix / W8).  Writes (ascending point index) sel (cap N), coarse_xy (2, N) with
+ *   leading dimension N, count_dev[0] = n, count_dev[1] = index of the threshold used (or -1).
+ * cofi_extract_patches: 4x4 windows [4*xy - 2, 4*xy + 2) of the (C,H2,W2) map -> (n, C, 16)
+ *   (network.py:206-226,156-158).
+ * cofi_fine_match: cosine similarity of the 16 patch pixels against the point descriptor, argmax
+ *   (first index on ties), fine_xy = 4*xy - 2 + (idx / 4, idx % 4)  [sic: x gets idx/4]
+ *   (eval_all.py:99-105).  fine_xy (2, cap) with leading dimension `cap`.
+ */
+int cofi_row_argmin_1m(const float *sim, int lds, int N, int P, int32_t *pix, cofi_stream_t stream);
+int cofi_select_matches(const float *score, const int32_t *pix, int N, int W8, int H8, const float *thr_host, int n_thr,
+                        int min_matches, int32_t *sel, float *coarse_xy, int32_t *count_dev, cofi_stream_t stream);
+int cofi_gather_points_sel(const float *pts, const int32_t *sel, const int32_t *count_dev, int cap, float *out,
+                           cofi_stream_t stream);
+int cofi_extract_patches(const float *fmap, int C, int H2, int W2, const float *coarse_xy, int ldxy, float center_scale,
+                         const int32_t *count_dev, int cap, float *patches, cofi_stream_t stream);
+int cofi_gather_rows_sel(const float *x, int ldx, int C, const int32_t *row_idx, const int32_t *count_dev, int cap, float *out,
+                         int ldo, cofi_stream_t stream);
+int cofi_fine_match(const float *patches, const float *pc_feats, int ldp, int C, const float *coarse_xy, int ldxy,
+                    float center_scale, const int32_t *count_dev, int cap, float *fine_xy, int32_t *best, cofi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COFI_HIP_H */

@@ -1,0 +1,124 @@
+"""End-to-end parity of CoFiI2P.forward on the GPU against (i) the reference's recorded outputs
+(tests/golden/frame_*.npz) and (ii) the CPU oracle's intermediate taps.  Tolerance: 1e-3 absolute on
+L2-normalised descriptors / sigmoid scores (BASELINE.json north_star), exact on integer outputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import cofi_oracle as O  # noqa: E402
+from common import check_input_hashes, frame_inputs, load_golden, synth_sd  # noqa: E402
+
+DEV = "cuda:0"
+TOL = 1e-3
+
+
+class Opt:
+    img_H, img_W, img_fine_resolution_scale, norm = 160, 512, 32, "gn"
+
+
+@pytest.fixture(scope="module")
+def model():
+    from cofii2p_amd.network import CoFiI2P
+
+    return CoFiI2P(Opt()).to(DEV)
+
+
+def to_dev(data):
+    out = {}
+    for k, v in data.items():
+        if isinstance(v, list):
+            out[k] = [t.to(DEV) if torch.is_tensor(t) else t for t in v]
+        else:
+            out[k] = v.to(DEV)
+    return out
+
+
+def maxdiff(a, b):
+    return float((a.detach().cpu().float() - torch.as_tensor(b).float()).abs().max())
+
+
+@pytest.mark.parametrize("mode", ["val", "test"])
+def test_tiny_frame_vs_reference(model, mode):
+    gold = load_golden("frame_tiny.npz")
+    fr, data = frame_inputs(int(gold["frame_id"]), int(gold["num_points"]), int(gold["pyr_seed"]))
+    check_input_hashes(gold, fr, data)
+    img = torch.from_numpy(fr.img)[None].to(DEV)
+    taps = {}
+    res = model(to_dev(data), img, torch.from_numpy(gold["val_kpt"]).to(DEV), None, torch.from_numpy(gold["val_inl"]).to(DEV), mode, taps=taps)
+    # intermediate drift against the oracle (fp32 both sides)
+    otaps = {}
+    with torch.no_grad():
+        O.forward(synth_sd(), data, torch.from_numpy(fr.img)[None], torch.from_numpy(gold["val_kpt"]), torch.from_numpy(gold["val_inl"]), mode, taps=otaps)
+    for name in ("encoder1_1", "encoder1_2", "encoder2_1", "encoder3_3", "encoder5_3"):
+        d = maxdiff(taps[name], otaps[name])
+        scale = float(otaps[name].abs().max())
+        assert d <= 2e-4 * max(1.0, scale), (name, d, scale)
+    assert maxdiff(taps["tok_img"], otaps["tok_img"]) < 1e-4
+    assert maxdiff(taps["tok_pc"], otaps["tok_pc"]) < 1e-4
+    names = ("img_desc", "pc_desc", "img_score", "pc_score", "patches", "fine_pc", "center_xy", "coarse_pts")
+    for n, t in zip(names, res):
+        key = "%s_%s" % (mode, n)
+        if t is None:
+            assert key not in gold.files
+            continue
+        assert tuple(t.shape) == gold[key].shape, (key, tuple(t.shape), gold[key].shape)
+        assert maxdiff(t, gold[key]) <= TOL, (key, maxdiff(t, gold[key]))
+
+
+def test_kitti_frame_vs_reference(model):
+    gold = load_golden("frame_kitti.npz")
+    fr, data = frame_inputs(int(gold["frame_id"]), int(gold["num_points"]), int(gold["pyr_seed"]))
+    check_input_hashes(gold, fr, data)
+    res = model(to_dev(data), torch.from_numpy(fr.img)[None].to(DEV), None, None, None, "test")
+    names = ("img_desc", "pc_desc", "img_score", "pc_score", "patches", "fine_pc", "center_xy", "coarse_pts")
+    for n, t in zip(names[:4], res[:4]):
+        assert maxdiff(t, gold["test_" + n]) <= TOL, (n, maxdiff(t, gold["test_" + n]))
+    # matches: identical selection unless a score sits within 1e-5 of the threshold
+    ref_xy, got_xy = gold["test_center_xy"], res[6].cpu().numpy()
+    assert got_xy.shape == ref_xy.shape, (got_xy.shape, ref_xy.shape)
+    assert np.array_equal(res[7].cpu().numpy(), gold["test_coarse_pts"])
+    same = (got_xy == ref_xy).all(0)
+    assert same.mean() > 0.98, same.mean()  # an argmin may flip only on a near-tie of two pixels
+    assert maxdiff(res[5], gold["test_fine_pc"]) <= TOL
+    assert float(np.abs(res[4].cpu().numpy()[same] - gold["test_patches"][same]).max()) <= TOL
+    # fine matching in the caller (eval_all.py:99-105) through the HIP kernel vs the oracle
+    from cofii2p_amd.network import fine_matching
+
+    fxy, best = fine_matching(res[4], res[5], res[6])
+    oxy, obest = O.fine_match(res[4].cpu(), res[5].cpu(), res[6].cpu())
+    agree = (best.cpu() == obest).float().mean()
+    assert agree > 0.98
+    assert np.array_equal(fxy.cpu().numpy()[:, (best.cpu() == obest).numpy()], oxy.numpy()[:, (best.cpu() == obest).numpy()])
+
+
+def test_gpu_pyramid_bit_exact_and_int64_contract(model):
+    """KNN pyramid built by the HIP kernel == tie-defined C oracle; forward accepts int64 tables."""
+    from cofii2p_amd.preprocess import build_pyramid
+    from cofii2p_amd.synth import make_frame, subsample_indices
+
+    fr = make_frame(5, 4096)
+    sub = subsample_indices(4096, 5, seed=3)
+    pyr = build_pyramid(torch.from_numpy(fr.points).to(DEV), [torch.from_numpy(s).to(DEV) for s in sub], int64=True)
+    import knn_c
+
+    pts = [fr.points]
+    for s in sub:
+        pts.append(pts[-1][s])
+    for i in range(5):
+        assert np.array_equal(pyr["neighbors"][i].cpu().numpy(), knn_c.knn(pts[i], pts[i], 128))
+        if i < 4:
+            assert np.array_equal(pyr["subsampling"][i].cpu().numpy(), knn_c.knn(pts[i], pts[i + 1], 128))
+            assert np.array_equal(pyr["upsampling"][i].cpu().numpy(), knn_c.knn(pts[i + 1], pts[i], 128))
+    pyr["feats"] = torch.from_numpy(fr.feats).to(DEV)
+    out = model(pyr, torch.from_numpy(fr.img)[None].to(DEV), None, None, None, "test")
+    assert out[4].shape[0] >= 4 and out[4].shape[1:] == (64, 16)
+
+
+def test_product_refuses_cpu_tensors(model):
+    from cofii2p_amd._lib import CofiError
+
+    with pytest.raises(CofiError):
+        model({"points": [], "neighbors": [], "subsampling": [], "upsampling": [], "feats": torch.zeros(1, 4)}, torch.zeros(1, 3, 160, 512),
+              None, None, None, "test")

@@ -1,0 +1,100 @@
+"""CPU-side checks of the product: C-ABI library loads and exports every declared symbol, module
+surface / state_dict layout, host logic.  No compute kernels are called (no GPU here)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from common import GOLD
+
+
+def test_library_exports_every_declared_symbol():
+    from cofii2p_amd import _lib, build
+
+    build.build()
+    lib = _lib.load()
+    declared = _lib.header_symbols()
+    assert len(declared) >= 30
+    assert set(declared) == set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.cofi_abi_version() == 1 and lib.cofi_target_arch() == b"gfx950"
+    # pure host-side queries are callable without a GPU
+    assert lib.cofi_gemm_f32_workspace(1280, 512, 7680) > 0
+    assert lib.cofi_gemm_f32_workspace(20480, 128, 64) == 0
+    assert lib.cofi_group_stats_workspace(1280, 2048, 32) == 20 * 32 * 2 * 8
+
+
+def test_code_object_targets_gfx950_only():
+    from cofii2p_amd import _lib
+
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"gfx942" not in blob and b"gfx90a" not in blob
+
+
+def test_state_dict_layout_matches_reference_dump():
+    from cofii2p_amd.network import CoFiI2P
+
+    class Opt:
+        img_H, img_W, img_fine_resolution_scale, norm = 160, 512, 32, "gn"
+
+    m = CoFiI2P(Opt())
+    ref = json.load(open(os.path.join(GOLD, "state_dict_spec.json")))
+    sd = m.state_dict()
+    assert [k for k, _, _ in ref] == list(sd.keys())
+    for k, shape, dtype in ref:
+        assert list(sd[k].shape) == shape and str(sd[k].dtype) == "torch." + dtype, k
+    assert sum(p.numel() for p in m.parameters()) == 51588744
+    # strict loading of a foreign checkpoint with the reference's keys, and pack invalidation
+    other = {k: torch.zeros_like(v) for k, v in sd.items()}
+    m._packed = {"stale": None}
+    m.load_state_dict(other, strict=True)
+    assert m._packed is None
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({k: v for k, v in list(other.items())[:-1]}, strict=True)
+
+
+def test_forward_has_no_cpu_path():
+    from cofii2p_amd._lib import CofiError
+    from cofii2p_amd.network import CoFiI2P
+
+    class Opt:
+        img_H, img_W, img_fine_resolution_scale, norm = 160, 512, 32, "gn"
+
+    with pytest.raises(CofiError):
+        CoFiI2P(Opt())({"points": [], "neighbors": [], "subsampling": [], "upsampling": [], "feats": torch.zeros(1, 4)},
+                       torch.zeros(1, 3, 160, 512), None, None, None, "test")
+
+
+def test_threshold_sequence_and_frequencies():
+    import cofi_oracle as O
+    from cofii2p_amd import ops
+    from cofii2p_amd.network import score_thresholds
+
+    t = score_thresholds()
+    assert t.dtype == np.float32 and t[0] == np.float32(0.9) and len(t) == 64
+    assert np.array_equal(t, np.asarray(O.score_thresholds(), dtype=np.float64).astype(np.float32))
+    f = ops.sine_frequencies(3)
+    assert f.shape == (42,) and f[0] == 1.0 and f[1] == 1.0
+    assert ops.sine_frequencies(2).shape == (64,)
+
+
+def test_synthetic_frame_is_deterministic_and_lattice_like():
+    from cofii2p_amd.synth import make_frame, subsample_indices
+
+    a, b = make_frame(3, 2048), make_frame(3, 2048)
+    assert np.array_equal(a.points, b.points) and np.array_equal(a.img, b.img) and a.points.shape == (2048, 3)
+    assert a.feats.shape == (2048, 4) and np.allclose(np.linalg.norm(a.feats[:, 1:], axis=1), 1, atol=1e-5)
+    s = subsample_indices(2048, 5, 1)
+    assert [len(x) for x in s] == [1024, 512, 256, 128]
+
+
+def test_spec_tables():
+    from cofii2p_amd import spec
+
+    assert [b.mid for b in spec.ENCODER][:3] == [64, 32, 32]
+    assert abs(spec.ENCODER[-1].sigma - 3.2) < 1e-6 and spec.stage_sizes(20480) == [20480, 10240, 5120, 2560, 1280]
+    kp = spec.synth_state_dict()["pc_encoder.encoder3_2.KPConv.kernel_points"]
+    assert kp.shape == (15, 3) and np.allclose(kp[0], 0) and abs(np.linalg.norm(kp[1]) - 0.66 * 0.425 * 4) < 1e-5

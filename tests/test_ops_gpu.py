@@ -1,0 +1,242 @@
+"""Parity of every HIP kernel (through the C ABI) against the CPU oracle / golden vectors.
+Needs a real MI355X:  python -m pytest tests -m gpu"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import cofi_oracle as O  # noqa: E402
+import knn_c  # noqa: E402
+from common import load_golden  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from cofii2p_amd import ops as _ops
+
+    assert torch.cuda.is_available()
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def mg():
+    return load_golden("micro_ops.npz")
+
+
+def G(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def close(a, b, tol=1e-4):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (128, 128, 128), (1280, 512, 7680), (77, 33, 60), (1280, 1, 64), (2560, 1024, 3072),
+                                   (20480, 32, 64), (300, 200, 36), (5, 7, 4)])
+def test_gemm(ops, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    rd = torch.randint(1, 9, (M,), generator=g).float()
+    ref = (a.double() @ w.double().t())
+    close(ops.gemm(G(a), G(w)), ref.float(), 2e-4)
+    close(ops.gemm(G(a), G(w), bias=G(bias), rowdiv=G(rd), act=ops.ACT_RELU), torch.relu(ref / rd[:, None].double() + bias.double()).float(), 2e-4)
+    close(ops.gemm(G(a), G(w), bias=G(bias), act=ops.ACT_SIGMOID), torch.sigmoid(ref + bias.double()).float(), 2e-4)
+
+
+def test_gemm_strided_views(ops):
+    g = torch.Generator().manual_seed(5)
+    buf = torch.randn(200, 256, generator=g)
+    w = torch.randn(96, 128, generator=g) * 0.1
+    a = G(buf)
+    out = torch.zeros(200, 160, device=DEV)
+    ops.gemm(a[:, 128:], G(w), out=out[:, 32:128])
+    close(out[:, 32:128], buf[:, 128:] @ w.t(), 2e-4)
+    assert float(out[:, :32].abs().max()) == 0.0 and float(out[:, 128:].abs().max()) == 0.0
+
+
+def test_kpconv_micro_golden(ops, mg):
+    idx = G(mg["kp_idx"], torch.int32)
+    agg, cnt = ops.kpconv_aggregate(G(mg["kp_feats"]), G(mg["kp_q_pts"]), G(mg["kp_s_pts"]), idx, G(mg["kp_kernel_points"]), 0.2)
+    w = torch.from_numpy(mg["kp_weights"])  # (15,Cin,Cout) -> (Cout, 15*Cin)
+    wp = w.permute(2, 0, 1).reshape(w.shape[2], -1).contiguous()
+    out = ops.gemm(agg, G(wp), bias=G(mg["kp_bias"]), rowdiv=cnt)
+    close(out, mg["kp_out"], 2e-5)
+
+
+@pytest.mark.parametrize("N,M,H,C,Co", [(500, 300, 128, 32, 32), (2000, 1000, 128, 4, 64), (700, 350, 128, 128, 128), (400, 200, 64, 512, 64)])
+def test_kpconv_random(ops, N, M, H, C, Co):
+    g = np.random.default_rng(N + C)
+    s_pts = torch.from_numpy(g.uniform(-1, 1, (N, 3)).astype(np.float32))
+    q_pts = s_pts[g.integers(0, N, M)] + 0.01
+    idx = O.knn_torch(s_pts, q_pts, H)
+    idx[::11, -5:] = N
+    feats = torch.from_numpy(g.standard_normal((N, C)).astype(np.float32))
+    feats[::9] = 0
+    kp = torch.from_numpy((g.uniform(-0.3, 0.3, (15, 3))).astype(np.float32))
+    w = torch.from_numpy((g.standard_normal((15, C, Co)) * 0.1).astype(np.float32))
+    b = torch.from_numpy(g.standard_normal(Co).astype(np.float32))
+    ref = O.kpconv(feats, q_pts, s_pts, idx, kp, w, b, 0.35)
+    agg, cnt = ops.kpconv_aggregate(G(feats), G(q_pts), G(s_pts), G(idx, torch.int32), G(kp), 0.35)
+    out = ops.gemm(agg, G(w.permute(2, 0, 1).reshape(Co, -1).contiguous()), bias=G(b), rowdiv=cnt)
+    close(out, ref, 1e-4)
+
+
+def test_pool_gather(ops, mg):
+    idx = G(mg["kp_idx"], torch.int32)
+    x = G(mg["pool_x"])
+    assert torch.equal(ops.neighbor_maxpool(x, idx).cpu(), torch.from_numpy(mg["pool_out"]))
+    assert torch.equal(ops.gather_rows(x, idx).cpu(), torch.from_numpy(mg["up_out"]))
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1000, 200, generator=g)
+    idx = torch.randint(0, 1001, (333, 128), generator=g)
+    assert torch.equal(ops.neighbor_maxpool(G(x), G(idx, torch.int32)).cpu(), O.neighbor_maxpool(x, idx))
+    assert torch.equal(ops.gather_rows(G(x), G(idx, torch.int32)).cpu(), O.nearest_upsample(x, idx))
+
+
+@pytest.mark.parametrize("M,C,groups", [(77, 64, 32), (1000, 32, 32), (333, 2048, 32), (1280, 128, 128), (130, 256, 32)])
+def test_group_norm(ops, M, C, groups):
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g) * 2 + 0.7
+    ga, be = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    ref = O.group_norm_rows(x, ga, be, groups)
+    close(ops.group_norm(G(x), groups, G(ga), G(be)), ref, 2e-5)
+    close(ops.group_norm(G(x), groups, G(ga), G(be), slope=0.1), O.leaky(ref), 2e-5)
+    r = torch.randn(M, C, generator=g)
+    st = ops.group_stats(G(x), groups)
+    close(ops.group_norm_apply(G(x), st, G(ga), G(be), slope=0.1, res=G(r)), O.leaky(ref + r), 2e-5)
+    rst = ops.group_stats(G(r), groups)
+    close(ops.group_norm_apply(G(x), st, G(ga), G(be), slope=0.1, res=G(r), res_stats=rst, res_gamma=G(be), res_beta=G(ga)),
+          O.leaky(ref + O.group_norm_rows(r, be, ga, groups)), 2e-5)
+    # gamma-less, group width 1: the InstanceNorm + ReLU of the score heads
+    if groups == C:
+        var, mean = torch.var_mean(x, dim=0, unbiased=False, keepdim=True)
+        close(ops.group_norm(G(x), groups, slope=0.0), torch.relu((x - mean) * torch.rsqrt(var + 1e-5)), 2e-5)
+
+
+def test_group_norm_golden(ops, mg):
+    close(ops.group_norm(G(mg["gn_x"]), 32, G(mg["gn_w"]), G(mg["gn_b"])), mg["gn_out"], 2e-5)
+    y = ops.gemm(G(mg["un_x"]), G(mg["un_w"]), bias=G(mg["un_b"]))
+    close(ops.group_norm(y, 32, G(mg["un_gw"]), G(mg["un_gb"]), slope=0.1), mg["un_out"], 2e-5)
+
+
+@pytest.mark.parametrize("M,C", [(50, 128), (1280, 1024), (7, 512), (300, 256)])
+def test_layer_norm(ops, M, C):
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(M, C, generator=g) * 3 + 1
+    ga, be, r = torch.randn(C, generator=g), torch.randn(C, generator=g), torch.randn(M, C, generator=g)
+    ref = torch.nn.functional.layer_norm(x, (C,), ga, be)
+    close(ops.layer_norm(G(x), G(ga), G(be)), ref, 2e-5)
+    close(ops.layer_norm(G(x), G(ga), G(be), relu=True), torch.relu(ref), 2e-5)
+    close(ops.layer_norm(G(x), G(ga), G(be), res=G(r)), ref + r, 2e-5)
+
+
+def test_attention_golden(ops, mg):
+    q, k, v = (torch.from_numpy(mg[n]).reshape(-1, 128) for n in ("att_q", "att_k", "att_v"))
+    close(ops.attention(G(q), G(k), G(v)), mg["att_out"].reshape(-1, 128), 2e-5)
+
+
+@pytest.mark.parametrize("L,S", [(1280, 1280), (1280, 128), (100, 1000), (33, 5), (2560, 640)])
+def test_attention_random(ops, L, S):
+    g = torch.Generator().manual_seed(L + S)
+    q, k, v = torch.randn(L, 128, generator=g), torch.randn(S, 128, generator=g) * 2, torch.randn(S, 128, generator=g)
+    cs = torch.rand(128, generator=g) + 0.5
+    ref = O.full_attention((q * cs).view(L, 4, 32), k.view(S, 4, 32), v.view(S, 4, 32)).reshape(L, 128)
+    close(ops.attention(G(q), G(k), G(v), q_colscale=G(cs)), ref, 5e-5)
+
+
+def test_attention_forced_rescale(ops):
+    """a key block arriving late with a much larger score forces the online-softmax rescale branch"""
+    L, S = 64, 256
+    g = torch.Generator().manual_seed(0)
+    q, k, v = torch.randn(L, 128, generator=g), torch.randn(S, 128, generator=g) * 0.1, torch.randn(S, 128, generator=g)
+    k[200] = q[5] * 4.0
+    k[37] = q[9] * 6.0
+    ref = O.full_attention(q.view(L, 4, 32), k.view(S, 4, 32), v.view(S, 4, 32)).reshape(L, 128)
+    close(ops.attention(G(q), G(k), G(v)), ref, 5e-5)
+
+
+def test_loftr_layer_golden(ops, mg):
+    """the whole encoder layer assembled from kernels, against the reference layer output"""
+    from cofii2p_amd.transformer import loftr_layer
+
+    w = {k[len("lay_w_"):]: G(mg[k]) for k in mg.files if k.startswith("lay_w_")}
+    out = loftr_layer(w, G(mg["lay_x"]), G(mg["lay_src"]))
+    close(out, mg["lay_out"], 5e-5)
+
+
+def test_small_glue(ops, mg):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1280, 128, generator=g)
+    close(ops.col_inv_norm(G(x)), 1.0 / x.norm(dim=0).clamp_min(1e-12), 1e-5)
+    close(ops.l2norm_rows(G(x)), torch.nn.functional.normalize(x, dim=1), 1e-6)
+    close(ops.l2norm_rows(G(x), transpose=True), torch.nn.functional.normalize(x, dim=1).t(), 1e-6)
+    close(ops.transpose(G(x)), x.t(), 0)
+    m = torch.randn(128, 20 * 64, generator=g)
+    y_cp, y_pc = ops.l2norm_cols(G(m))
+    close(y_cp, torch.nn.functional.normalize(m, dim=0), 1e-6)
+    close(y_pc, torch.nn.functional.normalize(m, dim=0).t(), 1e-6)
+    out = torch.zeros(1280, 128, device=DEV)
+    ops.pos_sine(G(mg["pe_grid"], torch.int32), out, accumulate=False)
+    close(out, mg["pe_grid_out"], 1e-5)
+    out = torch.ones(200, 128, device=DEV)
+    ops.pos_sine(G(mg["pe_xyz"]), out, accumulate=True)
+    close(out, mg["pe_xyz_out"] + 1.0, 2e-4)  # fp32 sin/cos of arguments up to ~500 rad
+
+
+@pytest.mark.parametrize("S,Q,k", [(4096, 512, 128), (1000, 1000, 128), (2048, 300, 16), (10, 4, 16), (5000, 77, 1), (20480, 256, 128)])
+def test_knn_bit_exact(ops, S, Q, k):
+    from cofii2p_amd.synth import make_frame
+
+    fr = make_frame(7, max(S, 64))
+    sup = fr.points[:S].copy()
+    if S >= 1000:
+        sup[S // 2:] = sup[np.random.RandomState(0).choice(S // 2, S - S // 2)]  # exact duplicates -> ties
+    qry = np.concatenate([sup[: Q // 2], sup[:Q - Q // 2] + np.float32(0.03)])
+    ic, dc = knn_c.knn(sup, qry, k, True)
+    ig, dg = ops.knn(G(sup), G(qry), k, return_dist=True)
+    assert np.array_equal(ig.cpu().numpy().astype(np.int64), ic)
+    assert np.array_equal(dg.cpu().numpy(), dc)
+    assert np.array_equal(ops.nearest_node(G(sup), G(qry)).cpu().numpy().astype(np.int64), knn_c.nearest(sup, qry))
+
+
+def test_idx_convert(ops):
+    a = torch.randint(0, 20481, (1000, 128))
+    assert torch.equal(ops.idx_to_int64(ops.idx_to_int32(G(a))).cpu(), a)
+
+
+def test_matching_chain(ops, mg):
+    pc, img, score = torch.from_numpy(mg["fp_pc"]), torch.from_numpy(mg["fp_img"]), torch.from_numpy(mg["fp_score"]).flatten()
+    N = pc.shape[1]
+    sim = ops.gemm(G(pc.t().contiguous()), G(img[0].reshape(128, -1).t().contiguous()))
+    pix = ops.row_argmin_1m(sim)
+    thr = np.array(O.score_thresholds(), dtype=np.float32)
+    sel, xy, cnt = ops.select_matches(G(score), pix, 64, 20, thr)
+    n = int(cnt[0])
+    assert n == len(mg["fp_sel"]) and int(cnt[1]) == 0
+    assert np.array_equal(sel[:n].cpu().numpy(), mg["fp_sel"])
+    assert np.array_equal(xy[:, :n].cpu().numpy(), mg["fp_xy"])
+    # threshold fallback: require more matches than the first threshold yields
+    sel2, xy2, cnt2 = ops.select_matches(G(score), pix, 64, 20, thr, min_matches=n + 1)
+    assert int(cnt2[0]) > n and int(cnt2[1]) > 0
+    xy_ref, sel_ref = O.fine_process(score, pc, img[0], float(thr[int(cnt2[1])]))
+    assert np.array_equal(sel2[: int(cnt2[0])].cpu().numpy(), sel_ref.numpy())
+    # point2node
+    assert np.array_equal(ops.nearest_node(G(mg["p2n_nodes"]), G(mg["p2n_pts"])).cpu().numpy(), mg["p2n_out"])
+    # patches: val-style centres at scale 1
+    ctr = G(mg["ep_ctr"])
+    c12 = torch.tensor([12, 0], dtype=torch.int32, device=DEV)
+    pat = ops.extract_patches(G(mg["ep_fmap"]), ctr, c12, 12, 1.0)
+    close(pat.reshape(12, 8, 4, 4), mg["ep_out"], 0)
+    fxy, best = ops.fine_match(G(mg["fm_patches"]), G(mg["fm_pc"]), ctr, c12, 1.0)
+    assert np.array_equal(best.cpu().numpy(), mg["fm_pred"])
+    assert np.array_equal(fxy.cpu().numpy(), mg["fm_xy"])
