@@ -1,0 +1,266 @@
+#!/usr/bin/env python
+"""I2P frames/s of the CoFiI2P forward hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (torchrun for N > 1; frames shard across ranks, no data-path collective:
+"scaling": "weak").  A step = ONE KITTI-shaped synthetic frame (160x512 image, 20 480 points, KNN-128
+pyramid already resident in HBM) through `CoFiI2P.forward(mode='test')` + the caller-side fine
+matching (evaluation/eval_all.py:99-105), fp32, batch 1 — BASELINE.json configs[1].
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+timed live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle = a port of the
+reference's forward, timed on a bounded sample on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
+HBM_PEAK_GBS = 8000.0
+
+
+class Opt:
+    img_H, img_W, img_fine_resolution_scale, norm = 160, 512, 32, "gn"
+
+
+def make_inputs(model_dev, frame_ids, num_points):
+    from cofii2p_amd.preprocess import build_pyramid
+    from cofii2p_amd.synth import make_frame, subsample_indices
+
+    frames = []
+    for fid in frame_ids:
+        fr = make_frame(fid, num_points=num_points, img_hw=(Opt.img_H, Opt.img_W))
+        sub = [torch.from_numpy(s).to(model_dev) for s in subsample_indices(num_points, 5, seed=1000 + fid)]
+        pyr = build_pyramid(torch.from_numpy(fr.points).to(model_dev), sub)  # int32 tables, device resident
+        pyr["feats"] = torch.from_numpy(fr.feats).to(model_dev)
+        frames.append((pyr, torch.from_numpy(fr.img)[None].to(model_dev), fr))
+    return frames
+
+
+def one_step(model, frame):
+    """forward(mode='test') computes the coarse matches, the 4x4 patches AND (in the same hipGraph) the
+    caller-side fine matching of eval_all.py:99-105; the returned tuple is the reference's 8-tuple."""
+    pyr, img, _ = frame
+    out = model(pyr, img, None, None, None, "test")
+    return out, model.last_match["fine_xy"]
+
+
+class KernelTimer:
+    """Per-entry-point kernel time of one frame, measured with HIP events on the launch stream.
+
+    Pass 1 (eager) records every C-ABI call of one forward with its live argument tensors and its
+    algorithmic work.  Pass 2 replays, per entry point, exactly those launches back-to-back inside one
+    hipGraph and times the replay with events: no CPU launch gaps, the same shapes/data as the frame."""
+
+    NAMES = ("gemm", "kpconv_aggregate", "attention", "neighbor_maxpool", "group_stats", "group_norm_apply", "layer_norm", "l2norm_rows",
+             "gather_rows", "row_sum_positive", "col_inv_norm")
+
+    def __init__(self):
+        self.calls = {}
+
+    @staticmethod
+    def work(name, a, k):
+        if name == "gemm":
+            M, K = a[0].shape
+            N = a[1].shape[0]
+            return 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)
+        if name == "kpconv_aggregate":
+            feats, idx = a[0], a[3]
+            M, H = idx.shape
+            C = feats.shape[1]
+            # algorithmic bytes: every source row once + index table + output (the gather itself must come from cache)
+            return 2.0 * M * H * 15 * C, 4.0 * (feats.shape[0] * C + M * H + M * 15 * C)
+        if name == "attention":
+            L, HD = a[0].shape
+            S = a[1].shape[0]
+            return 4.0 * L * S * HD, 4.0 * (2 * L * HD + 2 * S * HD)
+        if name == "neighbor_maxpool":
+            x, idx = a[0], a[1]
+            return 0.0, 4.0 * (x.numel() + idx.numel() + idx.shape[0] * x.shape[1])
+        return 0.0, 8.0 * a[0].numel()
+
+    def record(self, model, frame):
+        from cofii2p_amd import ops
+
+        orig = {}
+        for name in self.NAMES:
+            fn = getattr(ops, name)
+            orig[name] = fn
+
+            def rec(*a, _n=name, _f=fn, **k):
+                kk = {x: y for x, y in k.items() if x != "out"}  # replay into fresh outputs
+                self.calls.setdefault(_n, []).append((_f, a, kk, self.work(_n, a, k)))
+                return _f(*a, **k)
+
+            setattr(ops, name, rec)
+        try:
+            one_step(model, frame)
+        finally:
+            for name, fn in orig.items():
+                setattr(ops, name, fn)
+        torch.cuda.synchronize()
+
+    def measure(self, reps=5):
+        out = {}
+        for name, calls in self.calls.items():
+            def run():
+                for fn, a, k, _ in calls:
+                    fn(*a, **k)
+            run()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                run()
+            g.replay()
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(reps):
+                g.replay()
+            e.record()
+            torch.cuda.synchronize()
+            sec = s.elapsed_time(e) * 1e-3 / reps
+            out[name] = {"seconds_per_frame": sec, "flops_per_frame": sum(c[3][0] for c in calls), "bytes_per_frame": sum(c[3][1] for c in calls),
+                         "launches_per_frame": len(calls)}
+            del g
+        return out
+
+
+def cpu_baseline(frame, n_frames=2):
+    """The CPU oracle (port of the reference forward, validated against reference-generated golden
+    vectors) on the host cores, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cofi_oracle as O
+
+    from cofii2p_amd.spec import synth_state_dict
+
+    pyr, img, fr = frame
+    data = {k: ([t.cpu().long() if t.dtype in (torch.int32, torch.int64) else t.cpu() for t in v] if isinstance(v, list) and torch.is_tensor(v[0])
+                else (v.cpu() if torch.is_tensor(v) else v)) for k, v in pyr.items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth_state_dict().items()}
+    best = None
+    ncpu = os.cpu_count() or 8
+    with torch.no_grad():
+        for threads in sorted({min(8, ncpu), min(32, ncpu)}):
+            torch.set_num_threads(threads)
+            O.forward(sd, data, img.cpu(), None, None, "test")  # warm-up
+            t0 = time.time()
+            for _ in range(n_frames):
+                res = O.forward(sd, data, img.cpu(), None, None, "test")
+                O.fine_match(res[4], res[5], res[6])
+            fps = n_frames / (time.time() - t0)
+            if best is None or fps > best[0]:
+                best = (fps, threads)
+    return {"value": best[0], "unit": "frames/s", "cores": best[1], "kind": "port",
+            "sample": "%d KITTI-shaped frames (forward test mode + fine match) through oracle/cofi_oracle.py, torch-CPU fp32, KNN pyramid "
+                      "precomputed; best of 8 / 32 torch threads on a %d-core host" % (n_frames, ncpu)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--points", type=int, default=20480)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the hipGraph")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from cofii2p_amd.network import CoFiI2P
+    from cofii2p_amd.parallel import shard_frames
+
+    model = CoFiI2P(Opt()).to(dev)
+    if not args.eager:
+        model.enable_graphs()
+    n_distinct = 4
+    my_ids = shard_frames(list(range(n_distinct * world)), rank, world)
+    frames = make_inputs(dev, my_ids, args.points)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    nmatch = 0
+    for i in range(args.warmup):
+        out, _ = one_step(model, frames[i % len(frames)])
+        nmatch = out[4].shape[0]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(model, frames[i % len(frames)])
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    result = {
+        "metric": "I2P frames/sec (160x512 img, 20480 pts)", "value": world * args.steps / dt, "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "launch": "eager" if args.eager else "hipGraph replay",
+        "config": {"workload": "KITTI-shape synthetic frame (160x512 image, %d points, KNN-128 pyramid resident in HBM), batch 1, "
+                               "CoFiI2P.forward(mode='test') + fine matching, one frame per step per GPU" % args.points,
+                   "matches_per_frame": int(nmatch), "parallelism": "frame-parallel x%d" % world},
+    }
+
+    if rank == 0 and not args.no_kernel_timing:
+        model.enable_graphs(False)
+        kt = KernelTimer()
+        kt.record(model, frames[0])
+        per = kt.measure()
+        del kt
+        dom = max(per, key=lambda n: per[n]["seconds_per_frame"])
+        d = per[dom]
+        if d["flops_per_frame"] > 0:
+            ach = d["flops_per_frame"] / d["seconds_per_frame"] / 1e12
+            result["roofline"] = {"kernel": "cofi_" + dom, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                  "frac": ach / FP32_MFMA_PEAK_TF, "traffic": None,
+                                  "launches_per_frame": d["launches_per_frame"], "avg_launch_us": 1e6 * d["seconds_per_frame"] / d["launches_per_frame"]}
+        else:
+            ach = d["bytes_per_frame"] / d["seconds_per_frame"] / 1e9
+            result["roofline"] = {"kernel": "cofi_" + dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": ach / HBM_PEAK_GBS, "traffic": None}
+        a = per.get("attention")
+        if a:
+            ach = a["flops_per_frame"] / a["seconds_per_frame"] / 1e12
+            result["roofline_attention"] = {"kernel": "cofi_attention_fwd", "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF,
+                                            "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TF,
+                                            "avg_launch_us": 1e6 * a["seconds_per_frame"] / a["launches_per_frame"]}
+        result["kernel_ms_per_frame"] = {n: round(1e3 * v["seconds_per_frame"], 4) for n, v in sorted(per.items(), key=lambda kv: -kv[1]["seconds_per_frame"])}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(frames[0])
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,19 +24,25 @@ struct KpArgs {
     float sigma;
 };
 
-template <int NACC>
+// VEC = contiguous channels one lane loads per neighbour (1, 2 or 4 -> dword / dwordx2 / dwordx4), NCH =
+// channel chunks of 16*VEC per pass.  MFMA column j of accumulator (ch, a) is channel
+// c0 + ch*16*VEC + VEC*j + a: a permutation of the channel axis that turns the B-operand gather into
+// 16 lanes x 4*VEC contiguous bytes per neighbour row.
+template <int VEC, int NCH>
 __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= a.M) return;
     const int j = lane & 15, g = lane >> 4;
-    const int c0 = blockIdx.y * (16 * NACC);
+    const int c0 = blockIdx.y * (16 * VEC * NCH);
     const float qx = a.q_pts[3 * m], qy = a.q_pts[3 * m + 1], qz = a.q_pts[3 * m + 2];
     const bool kvalid = j < 15;
     const float kx = kvalid ? a.kp[3 * j] : 0.f, ky = kvalid ? a.kp[3 * j + 1] : 0.f, kz = kvalid ? a.kp[3 * j + 2] : 0.f;
-    f32x4 acc[NACC];
+    f32x4 acc[NCH][VEC];
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[ch][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int npos = 0;
     const int32_t *irow = a.idx + (size_t)m * a.H;
     const int steps = a.H >> 2;
@@ -44,34 +50,58 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
         const int id = irow[4 * s + g];
         const bool valid = (unsigned)id < (unsigned)a.N;
         float w = 0.f;
-        float f[NACC];
+        float f[NCH][VEC];
 #pragma unroll
-        for (int i = 0; i < NACC; ++i) f[i] = 0.f;
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) f[ch][v] = 0.f;
         if (valid) {
             const float *sp = a.s_pts + 3 * (size_t)id;
             // kpconv.py:93-99: ((s - q) - kp)^2 summed, sqrt, 1 - d/sigma, clamp at 0
             const float dx = (sp[0] - qx) - kx, dy = (sp[1] - qy) - ky, dz = (sp[2] - qz) - kz;
             const float sq = (dx * dx + dy * dy) + dz * dz;
             w = kvalid ? fmaxf(1.0f - sqrtf(sq) / a.sigma, 0.0f) : 0.0f;
-            const float *fr = a.feats + (size_t)id * a.ldf + c0 + j;
+            const float *fr = a.feats + (size_t)id * a.ldf + c0 + VEC * j;
 #pragma unroll
-            for (int i = 0; i < NACC; ++i)
-                if (c0 + 16 * i + j < a.C) f[i] = fr[16 * i];
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int c = c0 + ch * 16 * VEC + VEC * j;
+                if (c < a.C) {  // C % VEC == 0 is checked on the host
+                    if constexpr (VEC == 4) {
+                        const float4 t = *reinterpret_cast<const float4 *>(fr + ch * 64);
+                        f[ch][0] = t.x; f[ch][1] = t.y; f[ch][2] = t.z; f[ch][3] = t.w;
+                    } else if constexpr (VEC == 2) {
+                        const float2 t = *reinterpret_cast<const float2 *>(fr + ch * 32);
+                        f[ch][0] = t.x; f[ch][1] = t.y;
+                    } else {
+                        f[ch][0] = fr[ch * 16];
+                    }
+                }
+            }
             if (j == 0 && blockIdx.y == 0) npos += a.row_pos[id];
         }
 #pragma unroll
-        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, f[i], acc[i], 0, 0, 0);
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[ch][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, f[ch][v], acc[ch][v], 0, 0, 0);
     }
-    // D layout 16x16: row (kernel point) = 4*g + r, col (channel) = j
+    // D layout 16x16: row (kernel point) = 4*g + r, col = j  ->  channels c .. c+VEC-1 contiguous
     float *orow = a.agg + (size_t)m * a.ld_agg;
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) {
-        const int c = c0 + 16 * i + j;
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c = c0 + ch * 16 * VEC + VEC * j;
         if (c < a.C) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = 4 * g + r;
-                if (k < 15) orow[(size_t)k * a.C + c] = acc[i][r];
+                if (k < 15) {
+                    float *dst = orow + (size_t)k * a.C + c;
+                    if constexpr (VEC == 4)
+                        *reinterpret_cast<float4 *>(dst) = make_float4(acc[ch][0][r], acc[ch][1][r], acc[ch][2][r], acc[ch][3][r]);
+                    else if constexpr (VEC == 2)
+                        *reinterpret_cast<float2 *>(dst) = make_float2(acc[ch][0][r], acc[ch][1][r]);
+                    else
+                        dst[0] = acc[ch][0][r];
+                }
             }
         }
     }
@@ -93,27 +123,34 @@ __global__ void row_sum_positive_kernel(const float *feats, int ld, int N, int C
     if (lane == 0) row_pos[n] = s > 0.0f ? 1 : 0;
 }
 
-// out[m,c] = max_h x[idx[m,h], c], zero row behind idx == N.  Block: 64 channels x 4 row groups;
-// consecutive lanes read consecutive channels (256 B per neighbour row).
+// out[m,c] = max_h x[idx[m,h], c], zero row behind idx == N.  One wave per (query, 32-channel chunk):
+// lane (g = l>>3, c4 = l&7) reads float4 #c4 of the chunk for neighbours h = 8i+g, so one load instruction
+// fetches 8 neighbour rows x 128 contiguous bytes; the 8 lane groups are folded with 3 xor-shuffles.
+// Chunks are the slow grid axis: all queries of one chunk run together and its source slice
+// (N x 128 B <= 2.6 MB) stays resident in every XCD's 4 MB L2.
 __global__ __launch_bounds__(256) void neighbor_maxpool_kernel(const float *x, int ldx, int N, int C, const int32_t *idx, int M,
                                                                int H, float *out, int ldo) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int m = blockIdx.x * 4 + wv;
-    const int c = blockIdx.y * 64 + lane;
     if (m >= M) return;
+    const int g = lane >> 3, c = blockIdx.y * 32 + (lane & 7) * 4;
     const int32_t *irow = idx + (size_t)m * H;
-    float best = -INFINITY;
-    for (int h0 = 0; h0 < H; h0 += 64) {
-        const int myid = (h0 + lane < H) ? irow[h0 + lane] : -1;
-        const int cnt = min(64, H - h0);
-        for (int h = 0; h < cnt; ++h) {
-            const int id = __shfl(myid, h, 64);
-            float v = 0.0f;
-            if ((unsigned)id < (unsigned)N && c < C) v = x[(size_t)id * ldx + c];
-            best = fmaxf(best, v);
-        }
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    const bool cin = c < C;
+    for (int h = g; h < H; h += 8) {
+        const int id = irow[h];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)id < (unsigned)N && cin) v = *reinterpret_cast<const float4 *>(x + (size_t)id * ldx + c);
+        best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
     }
-    if (c < C) out[(size_t)m * ldo + c] = best;
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+        best.x = fmaxf(best.x, __shfl_xor(best.x, o, 64));
+        best.y = fmaxf(best.y, __shfl_xor(best.y, o, 64));
+        best.z = fmaxf(best.z, __shfl_xor(best.z, o, 64));
+        best.w = fmaxf(best.w, __shfl_xor(best.w, o, 64));
+    }
+    if (g == 0 && cin) *reinterpret_cast<float4 *>(out + (size_t)m * ldo + c) = best;
 }
 
 // out[m,:] = x[idx[m*idx_stride], :] (zero row for idx == N)
@@ -151,22 +188,25 @@ extern "C" int cofi_kpconv_aggregate(const float *feats, int ldf, int N, int C, 
     KpArgs a{feats, q_pts, s_pts, kernel_points, idx, row_pos, agg, cnt, ldf, N, C, M, H, ld_agg, sigma};
     hipStream_t s = cofi_s(stream);
     const int mb = cofi_cdiv(M, 4);
-    if (C <= 16)
-        hipLaunchKernelGGL((kpconv_aggregate_kernel<1>), dim3(mb, 1), dim3(256), 0, s, a);
-    else if (C <= 32)
-        hipLaunchKernelGGL((kpconv_aggregate_kernel<2>), dim3(mb, 1), dim3(256), 0, s, a);
-    else if (C <= 64)
-        hipLaunchKernelGGL((kpconv_aggregate_kernel<4>), dim3(mb, 1), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((kpconv_aggregate_kernel<8>), dim3(mb, cofi_cdiv(C, 128)), dim3(256), 0, s, a);
+    if ((C & 3) == 0 && (ldf & 3) == 0 && C >= 64) {
+        if (C % 128 == 0)
+            hipLaunchKernelGGL((kpconv_aggregate_kernel<4, 2>), dim3(mb, C / 128), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((kpconv_aggregate_kernel<4, 1>), dim3(mb, cofi_cdiv(C, 64)), dim3(256), 0, s, a);
+    } else if ((C & 1) == 0 && (ldf & 1) == 0 && C >= 32) {
+        hipLaunchKernelGGL((kpconv_aggregate_kernel<2, 1>), dim3(mb, cofi_cdiv(C, 32)), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((kpconv_aggregate_kernel<1, 1>), dim3(mb, cofi_cdiv(C, 16)), dim3(256), 0, s, a);
+    }
     return cofi_launch_status();
 }
 
 extern "C" int cofi_neighbor_maxpool(const float *x, int ldx, int N, int C, const int32_t *idx, int M, int H, float *out, int ldo,
                                      cofi_stream_t stream) {
     if (!x || !idx || !out || N <= 0 || C <= 0 || M < 0 || H <= 0 || ldx < C || ldo < C) return COFI_EINVAL;
+    if ((C & 3) || (ldx & 3) || (ldo & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return COFI_EINVAL;
     if (M == 0) return 0;
-    hipLaunchKernelGGL(neighbor_maxpool_kernel, dim3(cofi_cdiv(M, 4), cofi_cdiv(C, 64)), dim3(256), 0, cofi_s(stream), x, ldx, N,
+    hipLaunchKernelGGL(neighbor_maxpool_kernel, dim3(cofi_cdiv(M, 4), cofi_cdiv(C, 32)), dim3(256), 0, cofi_s(stream), x, ldx, N,
                        C, idx, M, H, out, ldo);
     return cofi_launch_status();
 }

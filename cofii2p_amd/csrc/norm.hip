@@ -63,19 +63,26 @@ __global__ __launch_bounds__(256) void group_stats_partial_kernel(const float *x
     }
 }
 
-__global__ void group_stats_final_kernel(const double *part, int nblk, int groups, double count, float eps, float *stats) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per group: lanes stride over the row-slab partials, fp64 butterfly (fixed order)
+__global__ __launch_bounds__(256) void group_stats_final_kernel(const double *part, int nblk, int groups, double count, float eps,
+                                                                float *stats) {
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= groups) return;
+    const int lane = threadIdx.x & 63;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = lane; b < nblk; b += 64) {
         s += part[((size_t)b * groups + g) * 2 + 0];
         q += part[((size_t)b * groups + g) * 2 + 1];
     }
-    const double mean = s / count;
-    double var = q / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[2 * g + 0] = (float)mean;
-    stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if (lane == 0) {
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[2 * g + 0] = (float)mean;
+        stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 struct GnApplyArgs {
@@ -169,29 +176,25 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float *x, int ldx
 }
 
 // ---------------------------------------------------------------------------- column inverse norm
-// out[c] = 1 / max(sqrt(sum_m x[m,c]^2), eps).  Block = 32 columns x 8 row phases, fixed-order
-// LDS fold (deterministic).
+// out[c] = 1 / max(sqrt(sum_m x[m,c]^2), eps).  Block = 16 columns (one float4 per 4 lanes) x 64 row
+// phases; fp32 per thread, fp64 fixed-order LDS fold (deterministic).
 __global__ __launch_bounds__(256) void col_inv_norm_kernel(const float *x, int ldx, int M, int C, float eps, float *out) {
-    __shared__ double red[8][32];
-    const int cl = threadIdx.x & 31, rp = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double s = 0.0;
+    __shared__ double red[64][16];
+    const int cq = threadIdx.x & 3, rp = threadIdx.x >> 2;  // 4 lanes x float4 = 16 columns; 64 row phases
+    const int c = blockIdx.x * 16 + cq * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < C) {
-        float part = 0.f;
-        int n = 0;
-        for (int m = rp; m < M; m += 8) {
-            const float v = x[(size_t)m * ldx + c];
-            part += v * v;
-            if (++n == 32) { s += (double)part; part = 0.f; n = 0; }
+        for (int m = rp; m < M; m += 64) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + (size_t)m * ldx + c);
+            acc.x += v.x * v.x; acc.y += v.y * v.y; acc.z += v.z * v.z; acc.w += v.w * v.w;
         }
-        s += (double)part;
     }
-    red[rp][cl] = s;
+    red[rp][cq * 4 + 0] = acc.x; red[rp][cq * 4 + 1] = acc.y; red[rp][cq * 4 + 2] = acc.z; red[rp][cq * 4 + 3] = acc.w;
     __syncthreads();
-    if (rp == 0 && c < C) {
+    if (threadIdx.x < 16 && blockIdx.x * 16 + threadIdx.x < C) {
         double t = 0.0;
-        for (int i = 0; i < 8; ++i) t += red[i][cl];
-        out[c] = 1.0f / fmaxf((float)sqrt(t), eps);
+        for (int i = 0; i < 64; ++i) t += red[i][threadIdx.x];
+        out[blockIdx.x * 16 + threadIdx.x] = 1.0f / fmaxf((float)sqrt(t), eps);
     }
 }
 
@@ -292,7 +295,7 @@ extern "C" int cofi_group_stats(const float *x, int ldx, int M, int C, int group
     hipStream_t s = cofi_s(stream);
     hipLaunchKernelGGL(group_stats_partial_kernel, dim3(nblk, cpg < 64 ? cofi_cdiv(C, 64) : groups), dim3(256), 0, s, x, ldx, M, C,
                        groups, (double *)ws);
-    hipLaunchKernelGGL(group_stats_final_kernel, dim3(cofi_cdiv(groups, 64)), dim3(64), 0, s, (const double *)ws, nblk, groups,
+    hipLaunchKernelGGL(group_stats_final_kernel, dim3(cofi_cdiv(groups, 4)), dim3(256), 0, s, (const double *)ws, nblk, groups,
                        (double)M * cpg, eps, stats);
     return cofi_launch_status();
 }
@@ -322,8 +325,8 @@ extern "C" int cofi_layer_norm(const float *x, int ldx, int M, int C, const floa
 }
 
 extern "C" int cofi_col_inv_norm(const float *x, int ldx, int M, int C, float eps, float *out, cofi_stream_t stream) {
-    if (!x || !out || M <= 0 || C <= 0 || ldx < C) return COFI_EINVAL;
-    hipLaunchKernelGGL(col_inv_norm_kernel, dim3(cofi_cdiv(C, 32)), dim3(256), 0, cofi_s(stream), x, ldx, M, C, eps, out);
+    if (!x || !out || M <= 0 || C <= 0 || ldx < C || (C & 3) || (ldx & 3) || ((uintptr_t)x & 15)) return COFI_EINVAL;
+    hipLaunchKernelGGL(col_inv_norm_kernel, dim3(cofi_cdiv(C, 16)), dim3(256), 0, cofi_s(stream), x, ldx, M, C, eps, out);
     return cofi_launch_status();
 }
 

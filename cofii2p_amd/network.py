@@ -70,15 +70,19 @@ class CoFiI2P(nn.Module):
         self._packed: Optional[Dict[str, torch.Tensor]] = None
         self._packed_key = None
         self.compute_unused_image_maps = True  # layer3/layer4/avg-pool of the ResNet (network.py:87-89)
+        self._use_graphs = False
+        self._graphs = {}
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
         self.eval()
 
     # ------------------------------------------------------------------ weights
     def _invalidate(self):
         self._packed = None
+        self._graphs = {}
 
     def _apply(self, fn, *a, **k):
         self._packed = None
+        self._graphs = {}
         return super()._apply(fn, *a, **k)
 
     def _pack(self, device) -> Dict[str, torch.Tensor]:
@@ -124,23 +128,12 @@ class CoFiI2P(nn.Module):
         y = ops.layer_norm(ops.gemm(y, P[p + "3.weight"]), P[p + "4.weight"], P[p + "4.bias"], relu=True)
         return ops.gemm(y, P[p + "6.weight"])
 
-    @torch.no_grad()
-    def forward(self, pc_data_dict, img, fine_center_kpt_coors, fine_xy, fine_pc_inline_index, mode, taps=None):
-        """model/network.py:74-164.  ``fine_xy`` is unused (as in the reference)."""
-        if mode not in ("train", "val", "test"):
-            raise ValueError("mode must be 'train', 'val' or 'test'")
-        if not img.is_cuda:
-            raise _lib.CofiError("CoFiI2P.forward needs CUDA (HIP) tensors: there is no CPU path")
-        _lib.load()
+    # ------------------------------------------------------------------ device-side forward (no host sync)
+    def _run_device(self, P, points, neighbors, subsampling, upsampling, feats, img, mode, fine_center_kpt_coors,
+                    fine_pc_inline_index, taps=None):
+        """Everything of network.py:74-161 that runs on the device.  Test-mode outputs are sized at
+        capacity (N4 rows) with the match count left in device memory: capturable in a hipGraph."""
         dev = img.device
-        P = self._pack(dev)
-        points = [p.contiguous() for p in pc_data_dict["points"]]
-        neighbors = [self._as_idx32(t) for t in pc_data_dict["neighbors"]]
-        subsampling = [self._as_idx32(t) for t in pc_data_dict["subsampling"]]
-        upsampling = [self._as_idx32(t) for t in pc_data_dict["upsampling"]]
-        feats = pc_data_dict["feats"].contiguous()
-
-        # ---- encoders
         pc_set = kpfpn.run_fpn(P, points, neighbors, subsampling, upsampling, feats, taps=taps)
         img_set = image.resnet34(P, img, full=self.compute_unused_image_maps)
         s2, s4, s8 = img_set[0], img_set[1], img_set[2]
@@ -181,32 +174,104 @@ class CoFiI2P(nn.Module):
         if taps is not None:
             taps.update(up2=up2, fine_pc=fine_pc, tok_img_out=tok_img, tok_pc_out=tok_pc)
 
-        coarse_img_score = img_score.reshape(1, 1, H8, W8)
-        coarse_pc_score = pc_score.reshape(1, 1, N4)
+        out = {"img_desc": img_desc, "pc_desc": pc_desc, "img_score": img_score.reshape(1, 1, H8, W8),
+               "pc_score": pc_score.reshape(1, 1, N4)}
         if mode in ("train", "val"):
             K = fine_center_kpt_coors.shape[1]
-            cnt = torch.tensor([K, 0], dtype=torch.int32, device=dev)
+            cnt = torch.zeros((2,), dtype=torch.int32, device=dev)
+            cnt[0] = K
             ctr = fine_center_kpt_coors.to(torch.float32).contiguous()
-            patches = ops.extract_patches(up2, ctr, cnt, K, 1.0).reshape(K, C2, 4, 4)
-            idx = self._as_idx32(fine_pc_inline_index.reshape(-1))
-            fine_pc_feat = ops.gather_rows(fine_pc, idx)
-            return img_desc, pc_desc, coarse_img_score, coarse_pc_score, patches, fine_pc_feat, None, None
-
-        # ---- test mode: coarse matching + patch extraction, one host sync (the match count)
+            out["patches"] = ops.extract_patches(up2, ctr, cnt, K, 1.0).reshape(K, C2, 4, 4)
+            out["fine_pc"] = ops.gather_rows(fine_pc, self._as_idx32(fine_pc_inline_index.reshape(-1)))
+            return out
+        # ---- test mode: coarse matching + patch extraction (network.py:145-161), count stays on the device
         sim = ops.gemm(pc_desc_tok, img_desc_tok)  # (N4, T): <pc, pixel>
         pix = ops.row_argmin_1m(sim)
         sel, xy, cnt = ops.select_matches(pc_score.reshape(-1), pix, W8, H8, score_thresholds(), 4)
-        coarse_pts = ops.gather_points_sel(points[-1], sel, cnt)
+        out["coarse_pts"] = ops.gather_points_sel(points[-1], sel, cnt)
         node = ops.nearest_node_sel(points[1], points[-1], sel, cnt)
-        patches = ops.extract_patches(up2, xy, cnt, N4, 4.0)
-        fine_pc_feat = ops.gather_rows_sel(fine_pc, node, cnt, N4)
-        n, thr_i = (int(v) for v in cnt.cpu())  # the only device->host synchronisation of forward
+        out["patches"] = ops.extract_patches(up2, xy, cnt, N4, 4.0)
+        out["fine_pc"] = ops.gather_rows_sel(fine_pc, node, cnt, N4)
+        out["fine_xy"], out["fine_best"] = ops.fine_match(out["patches"], out["fine_pc"], xy, cnt, 4.0)  # eval_all.py:99-105
+        out.update(sel=sel, coarse_xy=xy, count=cnt)
+        return out
+
+    # ------------------------------------------------------------------ hipGraph replay
+    def enable_graphs(self, flag: bool = True):
+        """Capture the device-side forward in a hipGraph per input signature and replay it: ~450 kernel
+        launches per frame become one graph launch (the eager path is CPU-launch bound at batch 1).
+        Inputs are staged into static buffers; returned tensors are views of static outputs that the NEXT
+        forward overwrites (clone them to keep them)."""
+        self._use_graphs = bool(flag)
+        if not flag:
+            self._graphs = {}
+        return self
+
+    def _graph_forward(self, P, points, neighbors, subsampling, upsampling, feats, img, mode, kpt, inl):
+        def sig(t):
+            return None if t is None else (tuple(t.shape), str(t.dtype))
+
+        tensors = list(points) + list(neighbors) + list(subsampling) + list(upsampling) + [feats, img, kpt, inl]
+        key = (mode, str(img.device)) + tuple(sig(t) for t in tensors)
+        ent = self._graphs.get(key)
+        if ent is None:
+            static = [None if t is None else torch.empty_like(t) for t in tensors]
+            for s_, t in zip(static, tensors):
+                if t is not None:
+                    s_.copy_(t)
+            n = [len(points), len(neighbors), len(subsampling), len(upsampling)]
+            o = [0, n[0], n[0] + n[1], n[0] + n[1] + n[2], sum(n)]
+            args = (static[o[0]:o[1]], static[o[1]:o[2]], static[o[2]:o[3]], static[o[3]:o[4]], static[o[4]], static[o[4] + 1], mode,
+                    static[o[4] + 2], static[o[4] + 3])
+            side = torch.cuda.Stream(device=img.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):  # warm-up: packs weights, grows every workspace outside the capture
+                    self._run_device(P, *args)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = self._run_device(P, *args)
+            ent = (graph, static, outs)
+            self._graphs[key] = ent
+        graph, static, outs = ent
+        for s_, t in zip(static, tensors):
+            if t is not None:
+                s_.copy_(t, non_blocking=True)
+        graph.replay()
+        return outs
+
+    @torch.no_grad()
+    def forward(self, pc_data_dict, img, fine_center_kpt_coors, fine_xy, fine_pc_inline_index, mode, taps=None):
+        """model/network.py:74-164.  ``fine_xy`` is unused (as in the reference)."""
+        if mode not in ("train", "val", "test"):
+            raise ValueError("mode must be 'train', 'val' or 'test'")
+        if not img.is_cuda:
+            raise _lib.CofiError("CoFiI2P.forward needs CUDA (HIP) tensors: there is no CPU path")
+        _lib.load()
+        dev = img.device
+        P = self._pack(dev)
+        points = [p.contiguous() for p in pc_data_dict["points"]]
+        neighbors = [self._as_idx32(t) for t in pc_data_dict["neighbors"]]
+        subsampling = [self._as_idx32(t) for t in pc_data_dict["subsampling"]]
+        upsampling = [self._as_idx32(t) for t in pc_data_dict["upsampling"]]
+        feats = pc_data_dict["feats"].contiguous()
+        if getattr(self, "_use_graphs", False) and taps is None:
+            o = self._graph_forward(P, points, neighbors, subsampling, upsampling, feats, img.contiguous(), mode, fine_center_kpt_coors,
+                                    fine_pc_inline_index)
+        else:
+            o = self._run_device(P, points, neighbors, subsampling, upsampling, feats, img, mode, fine_center_kpt_coors,
+                                 fine_pc_inline_index, taps=taps)
+        if mode in ("train", "val"):
+            return o["img_desc"], o["pc_desc"], o["img_score"], o["pc_score"], o["patches"], o["fine_pc"], None, None
+        n, thr_i = (int(v) for v in o["count"].cpu())  # the only device->host synchronisation of forward
         if thr_i < 0:
             raise RuntimeError("fewer than 4 coarse matches at every threshold (network.py:148 would loop forever)")
-        fine_center_xy = xy[:, :n] * 4
-        self.last_match = {"sel": sel[:n], "coarse_xy": xy[:, :n], "count_dev": cnt, "patches_cap": patches, "fine_pc_cap": fine_pc_feat,
-                           "xy_cap": xy, "threshold": float(score_thresholds()[thr_i])}
-        return (img_desc, pc_desc, coarse_img_score, coarse_pc_score, patches[:n], fine_pc_feat[:n], fine_center_xy, coarse_pts[:n])
+        self.last_match = {"n": n, "sel": o["sel"][:n], "coarse_xy": o["coarse_xy"][:, :n], "count_dev": o["count"],
+                           "fine_xy": o["fine_xy"][:, :n], "fine_best": o["fine_best"][:n], "threshold": float(score_thresholds()[thr_i])}
+        return (o["img_desc"], o["pc_desc"], o["img_score"], o["pc_score"], o["patches"][:n], o["fine_pc"][:n], o["coarse_xy"][:, :n] * 4,
+                o["coarse_pts"][:n])
 
 
 def fine_matching(fine_img_feature_patch, fine_pc_inline_feature, fine_center_xy):

@@ -122,3 +122,33 @@ def test_product_refuses_cpu_tensors(model):
     with pytest.raises(CofiError):
         model({"points": [], "neighbors": [], "subsampling": [], "upsampling": [], "feats": torch.zeros(1, 4)}, torch.zeros(1, 3, 160, 512),
               None, None, None, "test")
+
+
+def test_hipgraph_replay_equals_eager(model):
+    """the captured graph replays the same kernels on the same data; also on a second frame that reuses the
+    captured graph.  (The MIOpen convolutions of the image branch are not run-to-run bit-reproducible, so
+    floats are compared at 2e-5; everything written by this repository's kernels is bit-stable.)"""
+    from cofii2p_amd.preprocess import build_pyramid
+    from cofii2p_amd.synth import make_frame, subsample_indices
+
+    outs = {}
+    for fid in (11, 12):
+        fr = make_frame(fid, 4096)
+        sub = [torch.from_numpy(s).to(DEV) for s in subsample_indices(4096, 5, seed=fid)]
+        pyr = build_pyramid(torch.from_numpy(fr.points).to(DEV), sub)
+        pyr["feats"] = torch.from_numpy(fr.feats).to(DEV)
+        img = torch.from_numpy(fr.img)[None].to(DEV)
+        model.enable_graphs(False)
+        eager = [t.clone() for t in model(pyr, img, None, None, None, "test")]
+        efx = model.last_match["fine_xy"].clone()
+        model.enable_graphs(True)
+        graph = [t.clone() for t in model(pyr, img, None, None, None, "test")]
+        gfx = model.last_match["fine_xy"].clone()
+        for a, b in zip(eager[:4], graph[:4]):
+            assert maxdiff(a, b.cpu()) < 2e-5
+        assert eager[6].shape == graph[6].shape and (eager[6] == graph[6]).float().mean() > 0.98
+        assert efx.shape == gfx.shape
+        outs[fid] = graph
+    assert len(model._graphs) == 1  # one capture served both frames
+    assert not torch.equal(outs[11][1], outs[12][1])
+    model.enable_graphs(False)

@@ -1,0 +1,59 @@
+"""world_size-2 gloo test of the frame sharding + result gather (the N>1 path of bench.py /
+eval-style drivers); runs on CPU."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+from cofii2p_amd.parallel import gather_frame_results, shard_frames
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ids = shard_frames(list(range(total)), rank, world)
+    vals = torch.tensor([[float(i) * 2.0, float(i) + 0.5, float(rank)] for i in ids], dtype=torch.float32).reshape(len(ids), 3)
+    out = gather_frame_results(ids, vals, total)
+    q.put((rank, out.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_is_a_partition():
+    for world in (1, 2, 3, 8):
+        shards = [shard_frames(list(range(21)), r, world) for r in range(world)]
+        assert sorted(sum(shards, [])) == list(range(21))
+        assert max(map(len, shards)) - min(map(len, shards)) <= 1
+
+
+def test_gather_two_ranks_ragged():
+    total, world = 7, 2  # ragged: 4 + 3 frames
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    expect = torch.tensor([[i * 2.0, i + 0.5, float(i % world)] for i in range(total)])
+    for r in range(world):
+        assert torch.equal(got[r], expect)
+
+
+def test_gather_without_process_group():
+    out = gather_frame_results([2, 0], torch.tensor([[1.0], [3.0]]), 3)
+    assert out.flatten().tolist() == [3.0, 0.0, 1.0]

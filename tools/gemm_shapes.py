@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Per-shape timing of every cofi_gemm_f32 launch of one KITTI frame (GPU tool, not a test).
+    python tools/gemm_shapes.py [--points 20480]"""
+import argparse
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bench
+
+
+def time_graph(fn, reps=20):
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    g.replay()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e-3 / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=20480)
+    ap.add_argument("--kernel", default="gemm")
+    args = ap.parse_args()
+    from cofii2p_amd.network import CoFiI2P
+
+    dev = torch.device("cuda", 0)
+    model = CoFiI2P(bench.Opt()).to(dev)
+    frames = bench.make_inputs(dev, [0], args.points)
+    bench.one_step(model, frames[0])
+    kt = bench.KernelTimer()
+    kt.record(model, frames[0])
+    rows = {}
+    for fn, a, k, (fl, by) in kt.calls[args.kernel]:
+        if args.kernel == "gemm":
+            key = (a[0].shape[0], a[1].shape[0], a[0].shape[1], "bias" if k.get("bias") is not None else "", "div" if k.get("rowdiv") is not None else "")
+        else:
+            key = tuple(tuple(t.shape) for t in a if torch.is_tensor(t))[:4]
+        t = time_graph(lambda: fn(*a, **k))
+        r = rows.setdefault(key, [0, 0.0, fl, by])
+        r[0] += 1
+        r[1] += t
+    tot = sum(r[1] for r in rows.values())
+    print("%-46s %5s %9s %9s %8s" % ("shape", "calls", "us/call", "TF/s", "% time"))
+    for key, r in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+        print("%-46s %5d %9.2f %9.2f %8.1f" % (str(key), r[0], 1e6 * r[1] / r[0], r[2] / (r[1] / r[0]) / 1e12, 100 * r[1] / tot))
+    print("total %.1f us per frame" % (1e6 * tot))
+
+
+if __name__ == "__main__":
+    main()
