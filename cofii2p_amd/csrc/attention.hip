@@ -2,7 +2,7 @@
 // Reference: model/transformer/linear_attention.py:56-79 (FullAttention) + the token-axis query
 // normalisation of model/transformer/transformer.py:53, folded in as a per-channel scale.
 //
-// Workgroup = 4 waves = one (head, 32-query block).  The four waves take interleaved 32-key blocks
+// Workgroup = 8 waves = one (head, 32-query block).  The eight waves take interleaved 32-key blocks
 // (split-KV), each running an online softmax in registers, and merge (m, l, O) through LDS at the
 // end.  The L x S score matrix never exists in memory (the reference materialises it twice).
 //
@@ -28,10 +28,12 @@ struct AttnArgs {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-__global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
+constexpr int NW = 8;  // waves per workgroup = key splits
+
+__global__ __launch_bounds__(64 * NW) void attention_fwd_kernel(AttnArgs a) {
     constexpr int D = 32;
-    __shared__ __attribute__((aligned(16))) float s_o[4][32][D + 4];
-    __shared__ float s_m[4][32], s_l[4][32];
+    __shared__ __attribute__((aligned(16))) float s_o[NW][32][D + 4];
+    __shared__ float s_m[NW][32], s_l[NW][32];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -61,41 +63,42 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
     float m_run = -1e30f, l_run = 0.f;
 
     const int nblk = (a.S + 31) >> 5;
-    for (int b = wave; b < nblk; b += 4) {
-        const int k0 = b * 32;
-        // ---- S^T = K . Q^T
+    auto load_k = [&](int b, float4(&kf)[4]) {
+        const int key = min(b * 32 + li, a.S - 1);
+        const float *kp = a.K + (size_t)key * a.ldk + hc + 4 * lh;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) kf[c] = *reinterpret_cast<const float4 *>(kp + 8 * c);
+    };
+    auto load_v = [&](int b, float(&vf)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {  // lane (d = li, h) needs V[k0 + keyrow(r,h)][d]
+            const int kr = min(b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, a.S - 1);
+            vf[r] = a.V[(size_t)kr * a.ldv + hc + li];
+        }
+    };
+    auto qk = [&](const float4(&kf)[4]) {  // S^T = K . Q^T, 16 chained MFMAs
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        {
-            const int key = min(k0 + li, a.S - 1);
-            const float *kp = a.K + (size_t)key * a.ldk + hc + 4 * lh;
-            float4 kf[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) kf[c] = *reinterpret_cast<const float4 *>(kp + 8 * c);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].x, qf[4 * c + 0], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].y, qf[4 * c + 1], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].z, qf[4 * c + 2], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].w, qf[4 * c + 3], s, 0, 0, 0);
-            }
+        for (int c = 0; c < 4; ++c) {
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].x, qf[4 * c + 0], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].y, qf[4 * c + 1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].z, qf[4 * c + 2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].w, qf[4 * c + 3], s, 0, 0, 0);
         }
-        // issue the V loads early: lane (d = li, h) needs V[k0 + keyrow(r,h)][d]
-        float vf[16];
+        return s;
+    };
+    auto softmax = [&](int b, f32x16 &s) {  // online softmax (base 2); returns P in s, rescales o
+        const int k0 = b * 32;
+        if (k0 + 32 > a.S) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = min(k0 + (r & 3) + 8 * (r >> 2) + 4 * lh, a.S - 1);
-            vf[r] = a.V[(size_t)key * a.ldv + hc + li];
+            for (int r = 0; r < 16; ++r)
+                if (k0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= a.S) s[r] = -INFINITY;
         }
-        // ---- online softmax (base 2); mask the key tail
         float bmax = -1e30f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (key >= a.S) s[r] = -INFINITY;
-            bmax = fmaxf(bmax, s[r]);
-        }
+        for (int r = 0; r < 16; ++r) bmax = fmaxf(bmax, s[r]);
         bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
         const float m_new = fmaxf(m_run, bmax);
         const float alpha = fast_exp2(m_run - m_new);
@@ -109,14 +112,45 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
         m_run = m_new;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] *= alpha;
-        // ---- O^T += V^T . P^T   (contraction over this block's keys in D-layout order)
+    };
+    auto pv = [&](const f32x16 &p, const float(&vf)[16]) {  // O^T += V^T . P^T in D-layout key order
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], s[r], o, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], p[r], o, 0, 0, 0);
+    };
+
+    // Software pipeline over this wave's key blocks b, b+NW, ...: the loop body is ONE basic block in which
+    // the next block's QK^T MFMA chain is issued before the current block's softmax (VALU/transcendental
+    // work runs under matrix-core time), V of the next block and K of the block after it are in flight.
+    {
+        int b = wave;
+        if (b < nblk) {
+            float4 kC[4], kN[4], kN2[4];
+            float vC[16], vN[16];
+            load_k(b, kC);
+            load_v(b, vC);
+            load_k(min(b + NW, nblk - 1), kN);
+            f32x16 sC = qk(kC);
+            while (b + NW < nblk) {
+                load_v(b + NW, vN);
+                load_k(min(b + 2 * NW, nblk - 1), kN2);
+                f32x16 sN = qk(kN);
+                softmax(b, sC);
+                pv(sC, vC);
+                sC = sN;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vC[r] = vN[r];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) kN[c] = kN2[c];
+                b += NW;
+            }
+            softmax(b, sC);
+            pv(sC, vC);
+        }
     }
     // join the two halves' row sums (same m in both halves by construction)
     l_run += __shfl_xor(l_run, 32, 64);
 
-    // ---- merge the four key splits through LDS
+    // ---- merge the NW key splits through LDS
     if (lh == 0) {
         s_m[wave][li] = m_run;
         s_l[wave][li] = l_run;
@@ -127,22 +161,22 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
         *reinterpret_cast<float4 *>(&s_o[wave][li][d0]) = make_float4(o[4 * rq], o[4 * rq + 1], o[4 * rq + 2], o[4 * rq + 3]);
     }
     __syncthreads();
-    {
+    if (threadIdx.x < 256) {
         const int q = threadIdx.x >> 3, d4 = (threadIdx.x & 7) * 4;
-        const float m0 = s_m[0][q], m1 = s_m[1][q], m2 = s_m[2][q], m3 = s_m[3][q];
-        const float mm = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-        const float w0 = fast_exp2(m0 - mm), w1 = fast_exp2(m1 - mm), w2 = fast_exp2(m2 - mm), w3 = fast_exp2(m3 - mm);
-        const float l = ((s_l[0][q] * w0 + s_l[1][q] * w1) + s_l[2][q] * w2) + s_l[3][q] * w3;
-        const float4 a0 = *reinterpret_cast<const float4 *>(&s_o[0][q][d4]);
-        const float4 a1 = *reinterpret_cast<const float4 *>(&s_o[1][q][d4]);
-        const float4 a2 = *reinterpret_cast<const float4 *>(&s_o[2][q][d4]);
-        const float4 a3 = *reinterpret_cast<const float4 *>(&s_o[3][q][d4]);
+        float mm = s_m[0][q];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) mm = fmaxf(mm, s_m[w][q]);
+        float l = 0.f;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {  // fixed order: deterministic
+            const float sc = fast_exp2(s_m[w][q] - mm);
+            l += s_l[w][q] * sc;
+            const float4 t = *reinterpret_cast<const float4 *>(&s_o[w][q][d4]);
+            r.x += t.x * sc; r.y += t.y * sc; r.z += t.z * sc; r.w += t.w * sc;
+        }
         const float inv = 1.0f / l;
-        float4 r;
-        r.x = (((a0.x * w0 + a1.x * w1) + a2.x * w2) + a3.x * w3) * inv;
-        r.y = (((a0.y * w0 + a1.y * w1) + a2.y * w2) + a3.y * w3) * inv;
-        r.z = (((a0.z * w0 + a1.z * w1) + a2.z * w2) + a3.z * w3) * inv;
-        r.w = (((a0.w * w0 + a1.w * w1) + a2.w * w2) + a3.w * w3) * inv;
+        r.x *= inv; r.y *= inv; r.z *= inv; r.w *= inv;
         if (q0 + q < a.L) *reinterpret_cast<float4 *>(a.O + (size_t)(q0 + q) * a.ldo + hc + d4) = r;
     }
 }
@@ -164,6 +198,6 @@ extern "C" int cofi_attention_fwd(const float *Q, int ldq, const float *K, int l
     if (((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)O & 15) || (q_colscale && ((uintptr_t)q_colscale & 15)))
         return COFI_EINVAL;
     AttnArgs a{Q, K, V, q_colscale, O, ldq, ldk, ldv, ldo, L, S, H, scale * 1.4426950408889634f};
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3(cofi_cdiv(L, 32), H), dim3(256), 0, cofi_s(stream), a);
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3(cofi_cdiv(L, 32), H), dim3(64 * NW), 0, cofi_s(stream), a);
     return cofi_launch_status();
 }

@@ -1,7 +1,10 @@
-// Dense fp32 contraction on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF/s chip peak).
-//   C[m,n] = act( (sum_k A[m,k] * W[n,k]) / rowdiv[m] + bias[n] )
-// Both operands are K-contiguous ("NT"): activations row-major, weights in nn.Linear's (N,K)
-// layout — no packing of the reference's Linear weights is needed.
+// Dense fp32 contraction on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF/s chip peak) with fused epilogues.
+//   C[m,n] = act( (sum_k A[m,k] * W[n,k]) / rowdiv[m] + bias[n] )                (plain)
+//   C[m,:] = relu?( LayerNorm_n( ... ) * gamma + beta ) + res[m,:]               (fused LayerNorm, N <= 128)
+//   colpart[slab, n] = { sum_m C[m,n], sum_m C[m,n]^2 } over the rows of a slab   (fused column statistics:
+//        feeds stack-mode GroupNorm / InstanceNorm / the token-axis Q normalisation without another pass)
+// Both operands are K-contiguous ("NT"): activations row-major, weights in nn.Linear's (N,K) layout — no
+// packing of the reference's Linear weights is needed.
 //
 // Tile: BM x BN x 32 per workgroup of 4 waves (2x2), each wave TM x TN MFMA tiles of 32x32.
 // LDS image: rows of 32 k-values padded to 36 floats.  A lane reads its MFMA operands as ONE
@@ -11,8 +14,12 @@
 // about.  Row stride 36 dwords makes the b128 reads (16-lane groups, bank = dword mod 64) and the
 // b128 staging writes (8-lane groups, bank mod 32) conflict free (MI355X_MICROARCH §LDS).
 //
+// Epilogue: the accumulator tile goes through LDS once (the operand buffers are dead by then), so rows
+// are written back as whole 128-B+ segments by consecutive lanes and the row / column reductions of the
+// fused epilogues are plain shuffles over row-major data.
+//
 // Deep-K / small-MN problems are split over K (gridDim.z) into a workspace and reduced in fixed
-// order by splitk_epilogue_kernel: deterministic, no float atomics.
+// order by splitk_epilogue_kernel (same row-wise epilogue): deterministic, no float atomics.
 #include "common.h"
 
 namespace {
@@ -25,7 +32,11 @@ struct GemmArgs {
     float *C;
     const float *bias, *rowdiv;
     float *ws;
-    int lda, ldw, ldc, M, N, K, act, ksplit, kchunk;
+    float *colpart;                    // optional (nslab, N, 2)
+    const float *ln_gamma, *ln_beta;   // optional fused LayerNorm over the N columns of a row
+    const float *res;                  // optional residual added after the LayerNorm
+    int lda, ldw, ldc, ldr, M, N, K, act, ksplit, kchunk, ln_relu;
+    float ln_eps;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -34,12 +45,132 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+// Row-wise epilogue over a ROWS x BN tile held row-major in LDS (`tile`, leading dimension TLD) or summed
+// from split-K partials.  Thread (tr, tc): row phase tr, float4 column chunk tc.  256 threads.
+template <int ROWS, int BN, bool FROM_WS>
+__device__ __forceinline__ void rowwise_epilogue(const GemmArgs &g, const float *tile, int TLD, int m0, int n0, int slab, float *red) {
+    constexpr int TPR = BN / 4;        // threads per row
+    constexpr int RPP = 256 / TPR;     // rows per pass
+    const int tc = threadIdx.x % TPR, tr = threadIdx.x / TPR;
+    const int col = n0 + 4 * tc;
+    const bool vec_ok = ((g.N & 3) == 0) && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
+    float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (col + e < g.N) bias4[e] = g.bias[col + e];
+    }
+    for (int r0 = 0; r0 < ROWS; r0 += RPP) {
+        const int rl = r0 + tr, row = m0 + rl;
+        const bool rin = row < g.M;
+        float v[4];
+        if constexpr (FROM_WS) {
+            v[0] = v[1] = v[2] = v[3] = 0.f;
+            if (rin) {
+                const size_t total = (size_t)g.M * g.N;
+                for (int z = 0; z < g.ksplit; ++z) {
+                    const float *p = g.ws + (size_t)z * total + (size_t)row * g.N + col;
+                    if ((g.N & 3) == 0 && col < g.N) {
+                        const float4 t = *reinterpret_cast<const float4 *>(p);
+                        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (col + e < g.N) v[e] += p[e];
+                    }
+                }
+            }
+        } else {
+            const float4 t = *reinterpret_cast<const float4 *>(tile + rl * TLD + 4 * tc);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        }
+        const float rd = (g.rowdiv && rin) ? g.rowdiv[row] : 1.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = v[e];
+            if (g.rowdiv) x = x / rd;
+            x += bias4[e];
+            v[e] = x;
+        }
+        if (g.ln_gamma) {
+            // LayerNorm over the N (<= BN) columns of this row: the TPR threads of a row are adjacent lanes
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += (col + e < g.N) ? v[e] : 0.f;
+#pragma unroll
+            for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o, 64);
+            const float mean = s / (float)g.N;
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[e] - mean;
+                q += (col + e < g.N) ? d * d : 0.f;
+            }
+#pragma unroll
+            for (int o = 1; o < TPR; o <<= 1) q += __shfl_xor(q, o, 64);
+            const float rstd = 1.0f / sqrtf(q / (float)g.N + g.ln_eps);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (col + e < g.N) {
+                    float x = (v[e] - mean) * rstd * g.ln_gamma[col + e] + g.ln_beta[col + e];
+                    if (g.ln_relu) x = fmaxf(x, 0.f);
+                    if (g.res && rin) x += g.res[(size_t)row * g.ldr + col + e];
+                    v[e] = x;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], g.act);
+        }
+        if (rin) {
+            if (g.colpart) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    cs[e] += v[e];
+                    cq[e] += v[e] * v[e];
+                }
+            }
+            float *dst = g.C + (size_t)row * g.ldc + col;
+            if (vec_ok && col + 3 < g.N) {
+                *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < g.N) dst[e] = v[e];
+            }
+        }
+    }
+    if (g.colpart) {
+        // fold the RPP row phases in a fixed order (deterministic): red is (RPP, BN, 2) floats
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[(tr * BN + 4 * tc + e) * 2 + 0] = cs[e];
+            red[(tr * BN + 4 * tc + e) * 2 + 1] = cq[e];
+        }
+        __syncthreads();
+        if (threadIdx.x < BN && n0 + (int)threadIdx.x < g.N) {
+            float s = 0.f, q = 0.f;
+            for (int p = 0; p < RPP; ++p) {
+                s += red[(p * BN + threadIdx.x) * 2 + 0];
+                q += red[(p * BN + threadIdx.x) * 2 + 1];
+            }
+            float *o = g.colpart + ((size_t)slab * g.N + n0 + threadIdx.x) * 2;
+            o[0] = s;
+            o[1] = q;
+        }
+    }
+}
+
 template <int BM, int BN, int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 waves");
     constexpr int A_LD4 = BM / 32;  // float4 loads per thread for the A tile
     constexpr int W_LD4 = BN / 32;
-    __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDS_LD];
+    constexpr int TLD = BN + 4;     // epilogue tile leading dimension
+    static_assert(BM * TLD <= 2 * (BM + BN) * LDS_LD && (256 / (BN / 4)) * BN * 2 <= BM * TLD, "epilogue tile must fit in the operand buffers");
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -66,7 +197,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         }
     };
     auto sstore = [&](int buf) {
-        float *as = lds[buf], *bs = lds[buf] + BM * LDS_LD;
+        float *as = lds + buf * (BM + BN) * LDS_LD, *bs = as + BM * LDS_LD;
 #pragma unroll
         for (int j = 0; j < A_LD4; ++j) *reinterpret_cast<float4 *>(as + (lrow + 32 * j) * LDS_LD + lk) = ra[j];
 #pragma unroll
@@ -91,8 +222,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         if (t + 1 < ntiles) gload(t + 1);
-        const float *as = lds[buf] + (wm * 32 * TM + li) * LDS_LD + 4 * lh;
-        const float *bs = lds[buf] + BM * LDS_LD + (wn * 32 * TN + li) * LDS_LD + 4 * lh;
+        const float *as = lds + buf * (BM + BN) * LDS_LD + (wm * 32 * TM + li) * LDS_LD + 4 * lh;
+        const float *bs = lds + buf * (BM + BN) * LDS_LD + BM * LDS_LD + (wn * 32 * TN + li) * LDS_LD + 4 * lh;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float4 fa[TM], fb[TN];
@@ -114,39 +245,42 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    // epilogue.  D layout of 32x32 MFMA: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
+    if (g.ksplit > 1) {
+        // raw partial sums straight from the D layout: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * 32 * TN + j * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < g.M && col < g.N) g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+    // accumulators -> row-major LDS tile (the operand buffers are dead: the loop ended on a barrier)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * 32 * TN + j * 32 + li;
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < g.M && col < g.N) {
-                    float v = acc[i][j][r];
-                    if (g.ksplit > 1) {
-                        g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = v;
-                    } else {
-                        if (g.rowdiv) v = v / g.rowdiv[row];
-                        if (g.bias) v += g.bias[col];
-                        g.C[(size_t)row * g.ldc + col] = apply_act(v, g.act);
-                    }
-                }
+                const int rl = wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                lds[rl * TLD + wn * 32 * TN + j * 32 + li] = acc[i][j][r];
             }
-        }
+    __syncthreads();
+    rowwise_epilogue<BM, BN, false>(g, lds, TLD, m0, n0, blockIdx.y, lds);  // `red` aliases the tile: it is written after a barrier
 }
 
-__global__ void splitk_epilogue_kernel(GemmArgs g) {
-    const size_t total = (size_t)g.M * g.N;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int row = (int)(e / g.N), col = (int)(e % g.N);
-        float v = 0.0f;
-        for (int z = 0; z < g.ksplit; ++z) v += g.ws[(size_t)z * total + e];
-        if (g.rowdiv) v = v / g.rowdiv[row];
-        if (g.bias) v += g.bias[col];
-        g.C[(size_t)row * g.ldc + col] = apply_act(v, g.act);
-    }
+// split-K tail: SK_ROWS x 128-column tiles (small, so that even M = 1280 gives >= 80 workgroups per 128
+// columns), same row-wise epilogue reading the partial sums; a tile spans whole rows when N <= 128, which is
+// what the fused LayerNorm needs
+constexpr int SK_ROWS = 16;
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs g) {
+    __shared__ float red[8 * 128 * 2];
+    rowwise_epilogue<SK_ROWS, 128, true>(g, nullptr, 0, blockIdx.y * SK_ROWS, blockIdx.x * 128, blockIdx.y, red);
 }
 
 struct Plan {
@@ -154,8 +288,8 @@ struct Plan {
 };
 
 // Heuristic: largest tile that still gives >= ~1 workgroup per CU, then split K until the chip
-// (256 CUs) is covered about twice, keeping >= 4 k-tiles (128 values) per split.
-Plan make_plan(int M, int N, int K) {
+// (256 CUs) is covered about twice, keeping >= 2 k-tiles (64 values) per split.
+Plan make_plan(int M, int N, int K, bool fused_ln) {
     Plan p;
     auto blocks = [&](int bm, int bn) { return (long)cofi_cdiv(M, bm) * cofi_cdiv(N, bn); };
     if (N > 64 && M > 64 && blocks(128, 128) >= 200) {
@@ -173,7 +307,7 @@ Plan make_plan(int M, int N, int K) {
     int ks = 1;
     if (nb < 384) {
         ks = (int)((512 + nb - 1) / nb);
-        int maxks = ktiles / 4;
+        int maxks = ktiles / 2;
         if (maxks < 1) maxks = 1;
         if (ks > maxks) ks = maxks;
         if (ks > 32) ks = 32;
@@ -181,40 +315,74 @@ Plan make_plan(int M, int N, int K) {
     int tiles_per = cofi_cdiv(ktiles, ks);
     p.kchunk = tiles_per * BK;
     p.ksplit = cofi_cdiv(K, p.kchunk);
+    if (fused_ln && p.ksplit == 1 && p.bn < N) {  // un-split: one tile must span the whole row (N <= 128)
+        p.bm = 64;
+        p.bn = 128;
+    }
     return p;
 }
 
-}  // namespace
-
-extern "C" size_t cofi_gemm_f32_workspace(int M, int N, int K) {
-    if (M <= 0 || N <= 0 || K <= 0) return 0;
-    Plan p = make_plan(M, N, K);
-    return p.ksplit > 1 ? (size_t)p.ksplit * M * N * sizeof(float) : 0;
-}
-
-extern "C" int cofi_gemm_f32(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K,
-                             const float *bias, const float *rowdiv, int act, void *ws, size_t ws_bytes, cofi_stream_t stream) {
-    if (!A || !W || !C || M < 0 || N <= 0 || K <= 0) return COFI_EINVAL;
-    if (M == 0) return 0;
-    if ((K & 3) || (lda & 3) || (ldw & 3) || lda < K || ldw < K || ldc < N) return COFI_EINVAL;
-    if (((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return COFI_EINVAL;
-    if (act < 0 || act > 2) return COFI_EINVAL;
-    Plan p = make_plan(M, N, K);
-    if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
-    GemmArgs g{A, W, C, bias, rowdiv, (float *)ws, lda, ldw, ldc, M, N, K, act, p.ksplit, p.kchunk};
-    dim3 grid(cofi_cdiv(N, p.bn), cofi_cdiv(M, p.bm), p.ksplit);
-    hipStream_t s = cofi_s(stream);
+int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
+    GemmArgs g = g0;
+    g.ksplit = p.ksplit;
+    g.kchunk = p.kchunk;
+    dim3 grid(cofi_cdiv(g.N, p.bn), cofi_cdiv(g.M, p.bm), p.ksplit);
     if (p.bm == 128 && p.bn == 128)
         hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, g);
     else if (p.bm == 64 && p.bn == 128)
         hipLaunchKernelGGL((gemm_kernel<64, 128, 1, 2>), grid, dim3(256), 0, s, g);
     else
         hipLaunchKernelGGL((gemm_kernel<64, 64, 1, 1>), grid, dim3(256), 0, s, g);
-    if (p.ksplit > 1) {
-        size_t total = (size_t)M * N;
-        int nb = (int)((total + 255) / 256);
-        if (nb > 2048) nb = 2048;
-        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(nb), dim3(256), 0, s, g);
-    }
+    if (p.ksplit > 1) hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(cofi_cdiv(g.N, 128), cofi_cdiv(g.M, SK_ROWS)), dim3(256), 0, s, g);
     return cofi_launch_status();
+}
+
+int check_common(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K) {
+    if (!A || !W || !C || M < 0 || N <= 0 || K <= 0) return COFI_EINVAL;
+    if ((K & 3) || (lda & 3) || (ldw & 3) || lda < K || ldw < K || ldc < N) return COFI_EINVAL;
+    if (((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return COFI_EINVAL;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t cofi_gemm_f32_workspace(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    Plan p = make_plan(M, N, K, false);
+    return p.ksplit > 1 ? (size_t)p.ksplit * M * N * sizeof(float) : 0;
+}
+
+extern "C" int cofi_gemm_f32_stat_slabs(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    Plan p = make_plan(M, N, K, false);
+    return cofi_cdiv(M, p.ksplit > 1 ? SK_ROWS : p.bm);
+}
+
+extern "C" int cofi_gemm_f32(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K,
+                             const float *bias, const float *rowdiv, int act, void *ws, size_t ws_bytes, cofi_stream_t stream) {
+    return cofi_gemm_f32_colstats(A, lda, W, ldw, C, ldc, M, N, K, bias, rowdiv, act, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int cofi_gemm_f32_colstats(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K,
+                                      const float *bias, const float *rowdiv, int act, float *colpart, void *ws, size_t ws_bytes,
+                                      cofi_stream_t stream) {
+    if (int rc = check_common(A, lda, W, ldw, C, ldc, M, N, K)) return rc;
+    if (M == 0) return 0;
+    if (act < 0 || act > 2) return COFI_EINVAL;
+    Plan p = make_plan(M, N, K, false);
+    if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
+    GemmArgs g{A, W, C, bias, rowdiv, (float *)ws, colpart, nullptr, nullptr, nullptr, lda, ldw, ldc, 0, M, N, K, act, 1, 0, 0, 0.f};
+    return launch(g, p, cofi_s(stream));
+}
+
+extern "C" int cofi_gemm_f32_layernorm(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K,
+                                       const float *bias, const float *gamma, const float *beta, float eps, int relu, const float *res,
+                                       int ldr, void *ws, size_t ws_bytes, cofi_stream_t stream) {
+    if (int rc = check_common(A, lda, W, ldw, C, ldc, M, N, K)) return rc;
+    if (!gamma || !beta || N > 128 || (res && ldr < N)) return COFI_EINVAL;
+    if (M == 0) return 0;
+    Plan p = make_plan(M, N, K, true);
+    if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
+    GemmArgs g{A, W, C, bias, nullptr, (float *)ws, nullptr, gamma, beta, res, lda, ldw, ldc, ldr, M, N, K, 0, 1, 0, relu, eps};
+    return launch(g, p, cofi_s(stream));
 }

@@ -29,6 +29,14 @@ struct KpArgs {
 // c0 + ch*16*VEC + VEC*j + a: a permutation of the channel axis that turns the B-operand gather into
 // 16 lanes x 4*VEC contiguous bytes per neighbour row.
 template <int VEC, int NCH>
+struct KpStep {  // operands of one 4-neighbour step, loaded one step ahead of their use
+    float px, py, pz;
+    float f[NCH][VEC];
+    int pos;
+    bool valid;
+};
+
+template <int VEC, int NCH>
 __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -46,43 +54,64 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
     int npos = 0;
     const int32_t *irow = a.idx + (size_t)m * a.H;
     const int steps = a.H >> 2;
-    for (int s = 0; s < steps; ++s) {
-        const int id = irow[4 * s + g];
-        const bool valid = (unsigned)id < (unsigned)a.N;
-        float w = 0.f;
-        float f[NCH][VEC];
+    // per-lane channel offsets, clamped so that every load is unconditional (branch-free inner loop);
+    // out-of-range channels / shadow neighbours are zeroed by select, not skipped
+    int coff[NCH];
+    bool cok[NCH];
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) f[ch][v] = 0.f;
-        if (valid) {
-            const float *sp = a.s_pts + 3 * (size_t)id;
-            // kpconv.py:93-99: ((s - q) - kp)^2 summed, sqrt, 1 - d/sigma, clamp at 0
-            const float dx = (sp[0] - qx) - kx, dy = (sp[1] - qy) - ky, dz = (sp[2] - qz) - kz;
-            const float sq = (dx * dx + dy * dy) + dz * dz;
-            w = kvalid ? fmaxf(1.0f - sqrtf(sq) / a.sigma, 0.0f) : 0.0f;
-            const float *fr = a.feats + (size_t)id * a.ldf + c0 + VEC * j;
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c = c0 + ch * 16 * VEC + VEC * j;
+        cok[ch] = c < a.C;
+        coff[ch] = cok[ch] ? c : 0;
+    }
+
+    // The neighbour row is read once, coalesced (lane l holds idx[4*s0 + l]); step t takes idx[4t+g] from the
+    // owning lane by shuffle.  Loads of step t+1 are issued before the MFMAs of step t.
+    for (int s0 = 0; s0 < steps; s0 += 16) {
+        const int h0 = 4 * s0 + lane;
+        const int myidx = h0 < a.H ? irow[h0] : a.N;
+        auto issue = [&](int t, KpStep<VEC, NCH> &r) {
+            const int id = __shfl(myidx, 4 * t + g, 64);
+            r.valid = (unsigned)id < (unsigned)a.N;
+            const int idc = r.valid ? id : 0;
+            const float *sp = a.s_pts + 3 * (size_t)idc;
+            r.px = sp[0]; r.py = sp[1]; r.pz = sp[2];
+            const float *fr = a.feats + (size_t)idc * a.ldf;
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
-                const int c = c0 + ch * 16 * VEC + VEC * j;
-                if (c < a.C) {  // C % VEC == 0 is checked on the host
-                    if constexpr (VEC == 4) {
-                        const float4 t = *reinterpret_cast<const float4 *>(fr + ch * 64);
-                        f[ch][0] = t.x; f[ch][1] = t.y; f[ch][2] = t.z; f[ch][3] = t.w;
-                    } else if constexpr (VEC == 2) {
-                        const float2 t = *reinterpret_cast<const float2 *>(fr + ch * 32);
-                        f[ch][0] = t.x; f[ch][1] = t.y;
-                    } else {
-                        f[ch][0] = fr[ch * 16];
-                    }
+                if constexpr (VEC == 4) {
+                    const float4 tt = *reinterpret_cast<const float4 *>(fr + coff[ch]);
+                    r.f[ch][0] = tt.x; r.f[ch][1] = tt.y; r.f[ch][2] = tt.z; r.f[ch][3] = tt.w;
+                } else if constexpr (VEC == 2) {
+                    const float2 tt = *reinterpret_cast<const float2 *>(fr + coff[ch]);
+                    r.f[ch][0] = tt.x; r.f[ch][1] = tt.y;
+                } else {
+                    r.f[ch][0] = fr[coff[ch]];
                 }
             }
-            if (j == 0 && blockIdx.y == 0) npos += a.row_pos[id];
+            r.pos = a.row_pos[idc];
+        };
+        auto consume = [&](const KpStep<VEC, NCH> &r) {
+            // kpconv.py:93-99: ((s - q) - kp)^2 summed, sqrt, 1 - d/sigma, clamp at 0
+            const float dx = (r.px - qx) - kx, dy = (r.py - qy) - ky, dz = (r.pz - qz) - kz;
+            const float sq = (dx * dx + dy * dy) + dz * dz;
+            const float w = (kvalid && r.valid) ? fmaxf(1.0f - sqrtf(sq) / a.sigma, 0.0f) : 0.0f;
+            npos += (r.valid && j == 0) ? r.pos : 0;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    acc[ch][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, cok[ch] ? r.f[ch][v] : 0.0f, acc[ch][v], 0, 0, 0);
+        };
+        KpStep<VEC, NCH> ra, rb;
+        issue(0, ra);
+#pragma unroll
+        for (int t = 0; t < 16; t += 2) {  // tail steps (H < 64) see the shadow index N and contribute zero
+            issue(t + 1, rb);
+            consume(ra);
+            if (t + 2 < 16) issue(t + 2, ra);
+            consume(rb);
         }
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[ch][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, f[ch][v], acc[ch][v], 0, 0, 0);
     }
     // D layout 16x16: row (kernel point) = 4*g + r, col = j  ->  channels c .. c+VEC-1 contiguous
     float *orow = a.agg + (size_t)m * a.ld_agg;

@@ -85,6 +85,41 @@ __global__ __launch_bounds__(256) void group_stats_final_kernel(const double *pa
     }
 }
 
+// GroupNorm statistics from the GEMM's fused column partials: one wave per group, fp64 fold in a fixed order
+__global__ __launch_bounds__(256) void group_stats_from_colpart_kernel(const float *colpart, int nslab, int C, int groups, double count,
+                                                                        float eps, float *stats) {
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= groups) return;
+    const int lane = threadIdx.x & 63;
+    const int cpg = C / groups;
+    const int total = nslab * cpg;
+    double s = 0.0, q = 0.0;
+    for (int e = lane; e < total; e += 64) {
+        const int b = e / cpg, c = g * cpg + e % cpg;
+        const float2 t = *reinterpret_cast<const float2 *>(colpart + ((size_t)b * C + c) * 2);
+        s += (double)t.x;
+        q += (double)t.y;
+    }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if (lane == 0) {
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[2 * g + 0] = (float)mean;
+        stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// out[c] = 1 / max(sqrt(sum over slabs of colpart[slab, c].sumsq), eps) for the first C of ncols columns
+__global__ void col_inv_norm_from_colpart_kernel(const float *colpart, int nslab, int ncols, int C, float eps, float *out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double q = 0.0;
+    for (int b = 0; b < nslab; ++b) q += (double)colpart[((size_t)b * ncols + c) * 2 + 1];
+    out[c] = 1.0f / fmaxf((float)sqrt(q), eps);
+}
+
 struct GnApplyArgs {
     const float *x, *stats, *gamma, *beta, *res, *res_stats, *res_gamma, *res_beta;
     float *y;
@@ -279,6 +314,22 @@ __global__ void pos_sine_kernel(PosArgs a) {
 }
 
 }  // namespace
+
+extern "C" int cofi_group_stats_from_colpart(const float *colpart, int nslab, int M, int C, int groups, float eps, float *stats,
+                                             cofi_stream_t stream) {
+    if (!colpart || !stats || nslab <= 0 || M <= 0 || C <= 0 || groups <= 0 || (C % groups)) return COFI_EINVAL;
+    hipLaunchKernelGGL(group_stats_from_colpart_kernel, dim3(cofi_cdiv(groups, 4)), dim3(256), 0, cofi_s(stream), colpart, nslab, C, groups,
+                       (double)M * (C / groups), eps, stats);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_col_inv_norm_from_colpart(const float *colpart, int nslab, int ncols, int C, float eps, float *out,
+                                              cofi_stream_t stream) {
+    if (!colpart || !out || nslab <= 0 || C <= 0 || ncols < C) return COFI_EINVAL;
+    hipLaunchKernelGGL(col_inv_norm_from_colpart_kernel, dim3(cofi_cdiv(C, 128)), dim3(128), 0, cofi_s(stream), colpart, nslab, ncols, C,
+                       eps, out);
+    return cofi_launch_status();
+}
 
 extern "C" size_t cofi_group_stats_workspace(int M, int C, int groups) {
     if (M <= 0 || groups <= 0) return 0;

@@ -25,13 +25,16 @@ def pack_encoder(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
 
 
 def _kpconv(P, p: str, feats, q_pts, s_pts, idx, sigma: float):
+    """-> (KPConv output, its GroupNorm statistics).  The statistics come out of the GEMM epilogue (column
+    partials) instead of another pass over the activation."""
     agg, cnt = ops.kpconv_aggregate(feats, q_pts, s_pts, idx, P[p + "KPConv.kernel_points"], sigma)
-    return ops.gemm(agg, P[p + "KPConv.weights"], bias=P[p + "KPConv.bias"], rowdiv=cnt)
+    y, part = ops.gemm_colstats(agg, P[p + "KPConv.weights"], bias=P[p + "KPConv.bias"], rowdiv=cnt)
+    return y, ops.group_stats_from_colpart(part, y.shape[0], GN_GROUPS)
 
 
 def _unary_raw(P, p: str, x):
-    y = ops.gemm(x, P[p + "mlp.weight"], bias=P[p + "mlp.bias"])
-    return y, ops.group_stats(y, GN_GROUPS)
+    y, part = ops.gemm_colstats(x, P[p + "mlp.weight"], bias=P[p + "mlp.bias"])
+    return y, ops.group_stats_from_colpart(part, y.shape[0], GN_GROUPS)
 
 
 def _unary(P, p: str, x, slope: float, out=None):
@@ -39,21 +42,26 @@ def _unary(P, p: str, x, slope: float, out=None):
     return ops.group_norm_apply(y, st, P[p + "norm.norm.weight"], P[p + "norm.norm.bias"], slope=slope, out=out)
 
 
-def run_block(P, blk: KPBlock, feats, q_pts, s_pts, idx, out=None):
+def run_block(P, blk: KPBlock, feats, q_pts, s_pts, idx, out=None, concurrent: bool = True):
     p = "pc_encoder.%s." % blk.name
     if blk.kind == "conv":  # modules.py:155-159
-        y = _kpconv(P, p, feats, q_pts, s_pts, idx, blk.sigma)
-        return ops.group_norm_apply(y, ops.group_stats(y, GN_GROUPS), P[p + "norm.norm.weight"], P[p + "norm.norm.bias"], slope=LRELU,
-                                    out=out)
-    # modules.py:222-240
+        y, st = _kpconv(P, p, feats, q_pts, s_pts, idx, blk.sigma)
+        return ops.group_norm_apply(y, st, P[p + "norm.norm.weight"], P[p + "norm.norm.bias"], slope=LRELU, out=out)
+    # modules.py:222-240.  The shortcut (max-pool / Linear+GN statistics) only meets the main branch in the
+    # final fused normalise+add+LeakyReLU: it runs on a side stream.
+    has_branch = blk.strided or blk.has_shortcut_unary
+    with ops.Branch(feats.device, 1, enabled=concurrent and has_branch) as br:
+        sc = ops.neighbor_maxpool(feats, idx) if blk.strided else feats
+        ys = sts = None
+        if blk.has_shortcut_unary:
+            ys, sts = _unary_raw(P, p + "unary_shortcut.", sc)
     x = _unary(P, p + "unary1.", feats, LRELU) if blk.cin != blk.mid else feats
-    y = _kpconv(P, p, x, q_pts, s_pts, idx, blk.sigma)
-    x = ops.group_norm_apply(y, ops.group_stats(y, GN_GROUPS), P[p + "norm_conv.norm.weight"], P[p + "norm_conv.norm.bias"], slope=LRELU)
+    y, st = _kpconv(P, p, x, q_pts, s_pts, idx, blk.sigma)
+    x = ops.group_norm_apply(y, st, P[p + "norm_conv.norm.weight"], P[p + "norm_conv.norm.bias"], slope=LRELU)
     y2, st2 = _unary_raw(P, p + "unary2.", x)
-    sc = ops.neighbor_maxpool(feats, idx) if blk.strided else feats
+    br.join(sc, ys, sts)
     g2, b2 = P[p + "unary2.norm.norm.weight"], P[p + "unary2.norm.norm.bias"]
     if blk.has_shortcut_unary:
-        ys, sts = _unary_raw(P, p + "unary_shortcut.", sc)
         return ops.group_norm_apply(y2, st2, g2, b2, slope=LRELU, res=ys, res_stats=sts,
                                     res_gamma=P[p + "unary_shortcut.norm.norm.weight"],
                                     res_beta=P[p + "unary_shortcut.norm.norm.bias"], out=out)

@@ -115,10 +115,11 @@ class CoFiI2P(nn.Module):
     def _score_head(self, P, head: str, tokens: torch.Tensor) -> torch.Tensor:
         """network.py:42-43 on token-major data: 1x1 conv = GEMM, InstanceNorm over positions =
         per-column normalisation (group width 1), ReLU = slope 0."""
-        y = ops.gemm(tokens, P[head + ".0.weight"])
-        y = ops.group_norm(y, y.shape[1], slope=0.0)
-        y = ops.gemm(y, P[head + ".3.weight"])
-        y = ops.group_norm(y, y.shape[1], slope=0.0)
+        T = tokens.shape[0]
+        y, part = ops.gemm_colstats(tokens, P[head + ".0.weight"])
+        y = ops.group_norm_apply(y, ops.group_stats_from_colpart(part, T, y.shape[1]), slope=0.0)
+        y, part = ops.gemm_colstats(y, P[head + ".3.weight"])
+        y = ops.group_norm_apply(y, ops.group_stats_from_colpart(part, T, y.shape[1]), slope=0.0)
         return ops.gemm(y, P[head + ".6.weight"], act=ops.ACT_SIGMOID)  # (T,1)
 
     def _pc_feature_mlp(self, P, x: torch.Tensor) -> torch.Tensor:
@@ -134,25 +135,35 @@ class CoFiI2P(nn.Module):
         """Everything of network.py:74-161 that runs on the device.  Test-mode outputs are sized at
         capacity (N4 rows) with the match count left in device memory: capturable in a hipGraph."""
         dev = img.device
-        pc_set = kpfpn.run_fpn(P, points, neighbors, subsampling, upsampling, feats, taps=taps)
-        img_set = image.resnet34(P, img, full=self.compute_unused_image_maps)
-        s2, s4, s8 = img_set[0], img_set[1], img_set[2]
-        _, C, H8, W8 = s8.shape
         N4 = points[-1].shape[0]
-        T_img = H8 * W8
-
-        # ---- descriptors + position embedding -> token streams (network.py:83-110)
-        fine_pc = ops.l2norm_rows(pc_set[0])  # (N1,64)
+        H8, W8 = img.shape[2] // 8, img.shape[3] // 8
+        T_img, C = H8 * W8, D_MODEL
         ts = transformer.TokenStreams(T_img, N4, D_MODEL, dev)
-        s8n, _ = ops.l2norm_cols(s8[0].reshape(C, T_img), tokens_out=ts.img[0][:, :D_MODEL])
-        gy, gx = torch.meshgrid(torch.arange(H8, device=dev, dtype=torch.int32), torch.arange(W8, device=dev, dtype=torch.int32),
-                                indexing="ij")
-        grid = torch.stack([gy, gx], -1).reshape(T_img, 2).contiguous()
-        ops.pos_sine(grid, ts.img[0], accumulate=True)
+        # ---- image branch (network.py:77,90,104-106,110) on a side stream, concurrent with the point encoder
+        with ops.Branch(dev, 0) as br_img:
+            img_set = image.resnet34(P, img, full=self.compute_unused_image_maps)
+            s2, s4, s8 = img_set[0], img_set[1], img_set[2]
+            s8n, _ = ops.l2norm_cols(s8[0].reshape(C, T_img), tokens_out=ts.img[0][:, :D_MODEL])
+            gy, gx = torch.meshgrid(torch.arange(H8, device=dev, dtype=torch.int32), torch.arange(W8, device=dev, dtype=torch.int32),
+                                    indexing="ij")
+            grid = torch.stack([gy, gx], -1).reshape(T_img, 2).contiguous()
+            ops.pos_sine(grid, ts.img[0], accumulate=True)
+        # ---- point branch (network.py:76,83-84,107,111)
+        pc_set = kpfpn.run_fpn(P, points, neighbors, subsampling, upsampling, feats, taps=taps)
+        fine_pc = ops.l2norm_rows(pc_set[0])  # (N1,64)
         ops.l2norm_rows(self._pc_feature_mlp(P, pc_set[-1]), out=ts.pc[0][:, :D_MODEL])
         ops.pos_sine(points[-1], ts.pc[0], accumulate=True)
+        br_img.join(s2, s4, s8n, ts.img[0])
         if taps is not None:
             taps["tok_img"], taps["tok_pc"] = ts.img_tokens().clone(), ts.pc_tokens().clone()
+
+        # ---- fine image descriptors (network.py:129-130): only image data -> side stream, under the transformer
+        with ops.Branch(dev, 0) as br_up:
+            up4 = image.upsample_stage(P, "img_upsample_1", s8n.reshape(1, C, H8, W8), s4)
+            up2_raw = image.upsample_stage(P, "img_upsample_2", up4, s2)
+            C2, H2, W2 = up2_raw.shape[1:]
+            up2, _ = ops.l2norm_cols(up2_raw[0].reshape(C2, H2 * W2), want_tokens=False)
+            up2 = up2.reshape(C2, H2, W2)
 
         # ---- transformer (network.py:113-115)
         tok_img, tok_pc = transformer.run_transformer(self._layers, LAYER_KINDS, ts, N_HEAD)
@@ -164,13 +175,7 @@ class CoFiI2P(nn.Module):
         img_desc_tok = ops.l2norm_rows(tok_img)
         pc_desc = ops.transpose(pc_desc_tok)  # (128,N4)
         img_desc = ops.transpose(img_desc_tok).reshape(1, C, H8, W8)
-
-        # ---- fine image descriptors (network.py:129-130)
-        up4 = image.upsample_stage(P, "img_upsample_1", s8n.reshape(1, C, H8, W8), s4)
-        up2_raw = image.upsample_stage(P, "img_upsample_2", up4, s2)
-        C2, H2, W2 = up2_raw.shape[1:]
-        up2, _ = ops.l2norm_cols(up2_raw[0].reshape(C2, H2 * W2), want_tokens=False)
-        up2 = up2.reshape(C2, H2, W2)
+        br_up.join(up2)
         if taps is not None:
             taps.update(up2=up2, fine_pc=fine_pc, tok_img_out=tok_img, tok_pc_out=tok_pc)
 
@@ -223,15 +228,19 @@ class CoFiI2P(nn.Module):
             o = [0, n[0], n[0] + n[1], n[0] + n[1] + n[2], sum(n)]
             args = (static[o[0]:o[1]], static[o[1]:o[2]], static[o[2]:o[3]], static[o[3]:o[4]], static[o[4]], static[o[4] + 1], mode,
                     static[o[4] + 2], static[o[4] + 3])
-            side = torch.cuda.Stream(device=img.device)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):  # warm-up: packs weights, grows every workspace outside the capture
+            # warm-up AND capture run on one persistent stream, so every per-stream workspace is grown (in the
+            # ordinary allocator pool) before the capture starts and nothing is allocated for it inside
+            if getattr(self, "_capture_stream", None) is None or self._capture_stream.device != img.device:
+                self._capture_stream = torch.cuda.Stream(device=img.device)
+            cap = self._capture_stream
+            cap.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap):
+                for _ in range(2):
                     self._run_device(P, *args)
-            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.current_stream().wait_stream(cap)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=cap):
                 outs = self._run_device(P, *args)
             ent = (graph, static, outs)
             self._graphs[key] = ent

@@ -45,18 +45,65 @@ def _vec(t: Optional[torch.Tensor], name: str, n: int, dtype=torch.float32):
 
 
 class Workspace:
-    """Grow-only device scratch, one per (device, purpose).  All kernels are stream ordered on the
-    current stream, so reuse across consecutive calls is safe."""
+    """Grow-only device scratch, one per (purpose, device, stream).  Kernels are stream ordered, so reuse by
+    consecutive calls on ONE stream is safe; concurrent streams (forked branches of the forward graph) each
+    get their own buffer."""
 
     def __init__(self):
-        self.buf = None
+        self.bufs = {}
 
     def get(self, nbytes: int, device) -> Optional[torch.Tensor]:
         if nbytes == 0:
             return None
-        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-            self.buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
-        return self.buf
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+            self.bufs[key] = buf
+        return buf
+
+
+class Branch:
+    """Fork/join helper: run a branch of the forward on a side HIP stream (captured as a parallel branch
+    when the forward is recorded into a hipGraph).
+
+        with Branch(device, 0) as br:      # side stream waits for everything enqueued so far
+            y = ops.gemm(...)              # enqueued on the side stream
+        ...                                # main stream continues concurrently
+        br.join(y)                         # main stream waits for the branch; y is safe to use
+    """
+
+    _pool = {}
+
+    def __init__(self, device, slot: int = 0, enabled: bool = True):
+        self.enabled = enabled
+        self.device = device
+        if enabled:
+            key = (str(device), slot)
+            if key not in Branch._pool:
+                Branch._pool[key] = torch.cuda.Stream(device=device)
+            self.side = Branch._pool[key]
+
+    def __enter__(self):
+        if self.enabled:
+            self.main = torch.cuda.current_stream(self.device)
+            self.side.wait_stream(self.main)
+            self._ctx = torch.cuda.stream(self.side)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            self._ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        if self.enabled:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_stream(self.side)
+            for t in tensors:
+                if torch.is_tensor(t):
+                    t.record_stream(cur)
 
 
 _WS_GEMM = Workspace()
@@ -81,6 +128,59 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, b
     rc = lib.cofi_gemm_f32(_p(a), _ld(a), _p(w), _ld(w), _p(out), _ld(out), M, N, K, _p(bias), _p(rowdiv), act, _p(ws),
                            0 if ws is None else ws.numel(), _stream())
     _lib.check(rc, "cofi_gemm_f32")
+    return out
+
+
+def gemm_colstats(a, w, out=None, bias=None, rowdiv=None, act: int = ACT_NONE):
+    """gemm() that also returns the fused per-slab column statistics: (out, colpart (nslab,N,2))."""
+    lib = _lib.load()
+    _mat(a, "a"), _mat(w, "w")
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise _lib.CofiError("gemm: K mismatch %s vs %s" % (tuple(a.shape), tuple(w.shape)))
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _mat(out, "out")
+    _vec(bias, "bias", N), _vec(rowdiv, "rowdiv", M)
+    nslab = lib.cofi_gemm_f32_stat_slabs(M, N, K)
+    colpart = torch.empty((nslab, N, 2), dtype=torch.float32, device=a.device)
+    ws = _WS_GEMM.get(lib.cofi_gemm_f32_workspace(M, N, K), a.device)
+    rc = lib.cofi_gemm_f32_colstats(_p(a), _ld(a), _p(w), _ld(w), _p(out), _ld(out), M, N, K, _p(bias), _p(rowdiv), act, _p(colpart),
+                                    _p(ws), 0 if ws is None else ws.numel(), _stream())
+    _lib.check(rc, "cofi_gemm_f32_colstats")
+    return out, colpart
+
+
+def gemm_layernorm(a, w, gamma, beta, bias=None, relu: bool = False, res=None, out=None, eps: float = 1e-5):
+    """out = relu?(LayerNorm(a @ w.T + bias) * gamma + beta) + res, one kernel (N <= 128)."""
+    lib = _lib.load()
+    _mat(a, "a"), _mat(w, "w")
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _mat(out, "out")
+    ws = _WS_GEMM.get(lib.cofi_gemm_f32_workspace(M, N, K), a.device)
+    rc = lib.cofi_gemm_f32_layernorm(_p(a), _ld(a), _p(w), _ld(w), _p(out), _ld(out), M, N, K, _p(bias), _p(gamma), _p(beta), eps,
+                                     int(relu), _p(res), 0 if res is None else _ld(res), _p(ws), 0 if ws is None else ws.numel(), _stream())
+    _lib.check(rc, "cofi_gemm_f32_layernorm")
+    return out
+
+
+def group_stats_from_colpart(colpart, M: int, groups: int, eps: float = 1e-5):
+    lib = _lib.load()
+    nslab, C, _ = colpart.shape
+    stats = torch.empty((groups, 2), dtype=torch.float32, device=colpart.device)
+    _lib.check(lib.cofi_group_stats_from_colpart(_p(colpart), nslab, M, C, groups, eps, _p(stats), _stream()), "cofi_group_stats_from_colpart")
+    return stats
+
+
+def col_inv_norm_from_colpart(colpart, C: int, eps: float = 1e-12):
+    lib = _lib.load()
+    nslab, ncols, _ = colpart.shape
+    out = torch.empty((C,), dtype=torch.float32, device=colpart.device)
+    _lib.check(lib.cofi_col_inv_norm_from_colpart(_p(colpart), nslab, ncols, C, eps, _p(out), _stream()), "cofi_col_inv_norm_from_colpart")
     return out
 
 

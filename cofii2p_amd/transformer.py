@@ -32,20 +32,22 @@ def _layer(w, xcat: torch.Tensor, src: torch.Tensor, out: torch.Tensor, self_att
     transformer.py:43-64."""
     C = xcat.shape[1] // 2
     x = xcat[:, :C]
+    # projections; the token-axis norm of Q (F.normalize over dim=1, transformer.py:53) comes from the GEMM's
+    # fused column statistics
     if self_attn:
-        qkv = ops.gemm(x, w["qkv.weight"])
+        qkv, part = ops.gemm_colstats(x, w["qkv.weight"])
         q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
     else:
-        q = ops.gemm(x, w["q_proj.weight"])
+        q, part = ops.gemm_colstats(x, w["q_proj.weight"])
         kv = ops.gemm(src, w["kv.weight"])
         k, v = kv[:, :C], kv[:, C:]
-    qscale = ops.col_inv_norm(q)  # F.normalize over the token axis (transformer.py:53)
+    qscale = ops.col_inv_norm_from_colpart(part, C)
     msg = ops.attention(q, k, v, q_colscale=qscale, nhead=nhead)
-    merged = ops.gemm(msg, w["merge.weight"])
-    ops.layer_norm(merged, w["norm1.weight"], w["norm1.bias"], out=xcat[:, C:])
+    # merge Linear + LayerNorm1 in one kernel, written into the right half of the concat buffer
+    ops.gemm_layernorm(msg, w["merge.weight"], w["norm1.weight"], w["norm1.bias"], out=xcat[:, C:])
     h = ops.gemm(xcat, w["mlp.0.weight"], act=ops.ACT_RELU)
-    h = ops.gemm(h, w["mlp.2.weight"])
-    ops.layer_norm(h, w["norm2.weight"], w["norm2.bias"], res=x, out=out)
+    # second MLP Linear + LayerNorm2 + residual in one kernel
+    ops.gemm_layernorm(h, w["mlp.2.weight"], w["norm2.weight"], w["norm2.bias"], res=x, out=out)
     return out
 
 
@@ -85,9 +87,11 @@ def run_transformer(layers, kinds, ts: TokenStreams, nhead: int = 4):
     for w, kind in zip(layers, kinds):
         xi, xp = ts.img[ts.cur_img], ts.pc[ts.cur_pc]
         oi, op = ts.img[ts.cur_img ^ 1], ts.pc[ts.cur_pc ^ 1]
-        if kind == "self":
+        if kind == "self":  # the two modalities are independent here: point stream on a side HIP stream
+            with ops.Branch(xi.device, 2) as br:
+                _layer(w, xp, xp[:, :C], op[:, :C], True, nhead)
             _layer(w, xi, xi[:, :C], oi[:, :C], True, nhead)
-            _layer(w, xp, xp[:, :C], op[:, :C], True, nhead)
+            br.join(op)
         else:
             _layer(w, xi, xp[:, :C], oi[:, :C], False, nhead)
             _layer(w, xp, oi[:, :C], op[:, :C], False, nhead)

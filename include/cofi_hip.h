@@ -105,6 +105,20 @@ int cofi_gather_rows(const float *x, int ldx, int N, int C, const int32_t *idx, 
 size_t cofi_gemm_f32_workspace(int M, int N, int K);
 int cofi_gemm_f32(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K, const float *bias,
                   const float *rowdiv, int act, void *ws, size_t ws_bytes, cofi_stream_t stream);
+/* Same contraction with fused COLUMN STATISTICS: colpart (nslab, N, 2) receives, per row slab, the sum and
+ * the sum of squares of every output column (after bias / rowdiv / act), nslab =
+ * cofi_gemm_f32_stat_slabs(M,N,K).  cofi_group_stats_from_colpart / cofi_col_inv_norm_from_colpart turn
+ * them into GroupNorm statistics (modules.py:45-48) or the token-axis Q scale (transformer.py:53) without
+ * re-reading the activation. */
+int cofi_gemm_f32_stat_slabs(int M, int N, int K);
+int cofi_gemm_f32_colstats(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K,
+                           const float *bias, const float *rowdiv, int act, float *colpart, void *ws, size_t ws_bytes,
+                           cofi_stream_t stream);
+/* Contraction with fused row LayerNorm (N <= 128): C = relu?(LN(A W^T + bias) * gamma + beta) + res.
+ * Replaces Linear + nn.LayerNorm (+ residual) of model/transformer/transformer.py:57-58,61-64. */
+int cofi_gemm_f32_layernorm(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K,
+                            const float *bias, const float *gamma, const float *beta, float eps, int relu, const float *res, int ldr,
+                            void *ws, size_t ws_bytes /* cofi_gemm_f32_workspace(M,N,K) */, cofi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K5  stack-mode GroupNorm (+ LeakyReLU / residual).
@@ -120,6 +134,9 @@ int cofi_gemm_f32(const float *A, int lda, const float *W, int ldw, float *C, in
  *   R = gn(res; res_stats, rg, rb)     otherwise        (modules.py:222-240 residual tail)
  * slope = 1 is the identity, 0 is ReLU, 0.1 the reference's LeakyReLU.
  */
+int cofi_group_stats_from_colpart(const float *colpart, int nslab, int M, int C, int groups, float eps, float *stats,
+                                  cofi_stream_t stream);
+int cofi_col_inv_norm_from_colpart(const float *colpart, int nslab, int ncols, int C, float eps, float *out, cofi_stream_t stream);
 size_t cofi_group_stats_workspace(int M, int C, int groups);
 int cofi_group_stats(const float *x, int ldx, int M, int C, int groups, float eps, float *stats, void *ws, size_t ws_bytes,
                      cofi_stream_t stream);

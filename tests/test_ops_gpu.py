@@ -53,6 +53,36 @@ def test_gemm(ops, M, N, K):
     close(ops.gemm(G(a), G(w), bias=G(bias), act=ops.ACT_SIGMOID), torch.sigmoid(ref + bias.double()).float(), 2e-4)
 
 
+@pytest.mark.parametrize("M,N,K,groups", [(1280, 128, 128, 128), (1000, 64, 480, 32), (1280, 2048, 512, 32), (20480, 32, 128, 32), (77, 96, 36, 32)])
+def test_gemm_fused_column_statistics(ops, M, N, K, groups):
+    g = torch.Generator().manual_seed(M + N)
+    a, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    rd = torch.randint(1, 5, (M,), generator=g).float()
+    y, part = ops.gemm_colstats(G(a), G(w), bias=G(b), rowdiv=G(rd))
+    ref = ((a.double() @ w.double().t()) / rd[:, None].double() + b.double())
+    close(y, ref.float(), 2e-4)
+    st = ops.group_stats_from_colpart(part, M, groups).cpu()
+    gr = ref.reshape(M, groups, N // groups)
+    mean, var = gr.mean((0, 2)), gr.var((0, 2), unbiased=False)
+    close(st[:, 0], mean.float(), 1e-4)
+    close(st[:, 1], torch.rsqrt(var + 1e-5).float(), 1e-4)
+    close(ops.col_inv_norm_from_colpart(part, min(N, 32)), (1.0 / ref[:, : min(N, 32)].norm(dim=0)).float(), 1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(1280, 128, 128), (1280, 128, 256), (100, 64, 64), (33, 100, 36)])
+def test_gemm_fused_layernorm(ops, M, N, K):
+    g = torch.Generator().manual_seed(M + K)
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5
+    ga, be, r = 1 + 0.1 * torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = torch.nn.functional.layer_norm(a @ w.t(), (N,), ga, be)
+    close(ops.gemm_layernorm(G(a), G(w), G(ga), G(be)), ref, 5e-5)
+    close(ops.gemm_layernorm(G(a), G(w), G(ga), G(be), relu=True, res=G(r)), torch.relu(ref) + r, 5e-5)
+    buf = torch.zeros(M, 2 * N + 8, device=DEV)  # strided output view
+    ops.gemm_layernorm(G(a), G(w), G(ga), G(be), out=buf[:, N + 8:])
+    close(buf[:, N + 8:], ref, 5e-5)
+    assert float(buf[:, : N + 8].abs().max()) == 0.0
+
+
 def test_gemm_strided_views(ops):
     g = torch.Generator().manual_seed(5)
     buf = torch.randn(200, 256, generator=g)

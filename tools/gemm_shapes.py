@@ -40,9 +40,11 @@ def main():
     kt = bench.KernelTimer()
     kt.record(model, frames[0])
     rows = {}
-    for fn, a, k, (fl, by) in kt.calls[args.kernel]:
+    names = ["gemm", "gemm_colstats", "gemm_layernorm"] if args.kernel == "gemm" else [args.kernel]
+    calls = [(n,) + c for n in names for c in kt.calls.get(n, [])]
+    for name, fn, a, k, (fl, by) in calls:
         if args.kernel == "gemm":
-            key = (a[0].shape[0], a[1].shape[0], a[0].shape[1], "bias" if k.get("bias") is not None else "", "div" if k.get("rowdiv") is not None else "")
+            key = (name.replace("gemm", "g"), a[0].shape[0], a[1].shape[0], a[0].shape[1], "div" if k.get("rowdiv") is not None else "")
         else:
             key = tuple(tuple(t.shape) for t in a if torch.is_tensor(t))[:4]
         t = time_graph(lambda: fn(*a, **k))
