@@ -274,13 +274,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     rowwise_epilogue<BM, BN, false>(g, lds, TLD, m0, n0, blockIdx.y, lds);  // `red` aliases the tile: it is written after a barrier
 }
 
-// split-K tail: SK_ROWS x 128-column tiles (small, so that even M = 1280 gives >= 80 workgroups per 128
-// columns), same row-wise epilogue reading the partial sums; a tile spans whole rows when N <= 128, which is
-// what the fused LayerNorm needs
-constexpr int SK_ROWS = 16;
+// split-K tail, same row-wise epilogue reading the partial sums.  Two tilings:
+//   64 rows x 32 columns  (plain / column statistics): slabs of 64 rows keep the statistics table small and
+//                          even M = 1280, N = 256 still gives 160 workgroups;
+//   16 rows x 128 columns (fused LayerNorm): a tile spans whole rows (N <= 128).
+constexpr int SK_ROWS = 64, SK_COLS = 32, SKLN_ROWS = 16;
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs g) {
-    __shared__ float red[8 * 128 * 2];
-    rowwise_epilogue<SK_ROWS, 128, true>(g, nullptr, 0, blockIdx.y * SK_ROWS, blockIdx.x * 128, blockIdx.y, red);
+    __shared__ float red[32 * SK_COLS * 2];
+    rowwise_epilogue<SK_ROWS, SK_COLS, true>(g, nullptr, 0, blockIdx.y * SK_ROWS, blockIdx.x * SK_COLS, blockIdx.y, red);
+}
+__global__ __launch_bounds__(256) void splitk_epilogue_ln_kernel(GemmArgs g) {
+    rowwise_epilogue<SKLN_ROWS, 128, true>(g, nullptr, 0, blockIdx.y * SKLN_ROWS, blockIdx.x * 128, blockIdx.y, nullptr);
 }
 
 struct Plan {
@@ -333,7 +337,12 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
         hipLaunchKernelGGL((gemm_kernel<64, 128, 1, 2>), grid, dim3(256), 0, s, g);
     else
         hipLaunchKernelGGL((gemm_kernel<64, 64, 1, 1>), grid, dim3(256), 0, s, g);
-    if (p.ksplit > 1) hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(cofi_cdiv(g.N, 128), cofi_cdiv(g.M, SK_ROWS)), dim3(256), 0, s, g);
+    if (p.ksplit > 1) {
+        if (g.ln_gamma)
+            hipLaunchKernelGGL(splitk_epilogue_ln_kernel, dim3(1, cofi_cdiv(g.M, SKLN_ROWS)), dim3(256), 0, s, g);
+        else
+            hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(cofi_cdiv(g.N, SK_COLS), cofi_cdiv(g.M, SK_ROWS)), dim3(256), 0, s, g);
+    }
     return cofi_launch_status();
 }
 

@@ -85,20 +85,29 @@ __global__ __launch_bounds__(256) void group_stats_final_kernel(const double *pa
     }
 }
 
-// GroupNorm statistics from the GEMM's fused column partials: one wave per group, fp64 fold in a fixed order
+// GroupNorm statistics from the GEMM's fused column partials: one wave per group; lanes stride over the
+// (slab, channel-of-group) pairs with the channel index fastest (contiguous float2 reads), fp64 butterfly.
 __global__ __launch_bounds__(256) void group_stats_from_colpart_kernel(const float *colpart, int nslab, int C, int groups, double count,
                                                                         float eps, float *stats) {
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= groups) return;
     const int lane = threadIdx.x & 63;
     const int cpg = C / groups;
-    const int total = nslab * cpg;
     double s = 0.0, q = 0.0;
-    for (int e = lane; e < total; e += 64) {
-        const int b = e / cpg, c = g * cpg + e % cpg;
-        const float2 t = *reinterpret_cast<const float2 *>(colpart + ((size_t)b * C + c) * 2);
-        s += (double)t.x;
-        q += (double)t.y;
+    if (cpg >= 64) {
+        for (int b = 0; b < nslab; ++b)
+            for (int c = lane; c < cpg; c += 64) {
+                const float2 t = *reinterpret_cast<const float2 *>(colpart + ((size_t)b * C + g * cpg + c) * 2);
+                s += (double)t.x;
+                q += (double)t.y;
+            }
+    } else {  // cpg is a power of two < 64: lane -> (slab phase, channel)
+        const int c = lane % cpg, bp = lane / cpg, nb = 64 / cpg;
+        for (int b = bp; b < nslab; b += nb) {
+            const float2 t = *reinterpret_cast<const float2 *>(colpart + ((size_t)b * C + g * cpg + c) * 2);
+            s += (double)t.x;
+            q += (double)t.y;
+        }
     }
     s = wave_sum_d(s);
     q = wave_sum_d(q);
@@ -111,13 +120,19 @@ __global__ __launch_bounds__(256) void group_stats_from_colpart_kernel(const flo
     }
 }
 
-// out[c] = 1 / max(sqrt(sum over slabs of colpart[slab, c].sumsq), eps) for the first C of ncols columns
-__global__ void col_inv_norm_from_colpart_kernel(const float *colpart, int nslab, int ncols, int C, float eps, float *out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// out[c] = 1 / max(sqrt(sum over slabs of colpart[slab, c].sumsq), eps) for the first C of ncols columns;
+// 4 slab phases per column folded through LDS in a fixed order
+__global__ __launch_bounds__(256) void col_inv_norm_from_colpart_kernel(const float *colpart, int nslab, int ncols, int C, float eps,
+                                                                         float *out) {
+    __shared__ double red[4][64];
+    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     double q = 0.0;
-    for (int b = 0; b < nslab; ++b) q += (double)colpart[((size_t)b * ncols + c) * 2 + 1];
-    out[c] = 1.0f / fmaxf((float)sqrt(q), eps);
+    if (c < C)
+        for (int b = ph; b < nslab; b += 4) q += (double)colpart[((size_t)b * ncols + c) * 2 + 1];
+    red[ph][cl] = q;
+    __syncthreads();
+    if (ph == 0 && c < C) out[c] = 1.0f / fmaxf((float)sqrt((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])), eps);
 }
 
 struct GnApplyArgs {
@@ -318,6 +333,7 @@ __global__ void pos_sine_kernel(PosArgs a) {
 extern "C" int cofi_group_stats_from_colpart(const float *colpart, int nslab, int M, int C, int groups, float eps, float *stats,
                                              cofi_stream_t stream) {
     if (!colpart || !stats || nslab <= 0 || M <= 0 || C <= 0 || groups <= 0 || (C % groups)) return COFI_EINVAL;
+    if ((C / groups) < 64 && ((C / groups) & ((C / groups) - 1))) return COFI_EUNSUPPORTED;
     hipLaunchKernelGGL(group_stats_from_colpart_kernel, dim3(cofi_cdiv(groups, 4)), dim3(256), 0, cofi_s(stream), colpart, nslab, C, groups,
                        (double)M * (C / groups), eps, stats);
     return cofi_launch_status();
@@ -326,7 +342,7 @@ extern "C" int cofi_group_stats_from_colpart(const float *colpart, int nslab, in
 extern "C" int cofi_col_inv_norm_from_colpart(const float *colpart, int nslab, int ncols, int C, float eps, float *out,
                                               cofi_stream_t stream) {
     if (!colpart || !out || nslab <= 0 || C <= 0 || ncols < C) return COFI_EINVAL;
-    hipLaunchKernelGGL(col_inv_norm_from_colpart_kernel, dim3(cofi_cdiv(C, 128)), dim3(128), 0, cofi_s(stream), colpart, nslab, ncols, C,
+    hipLaunchKernelGGL(col_inv_norm_from_colpart_kernel, dim3(cofi_cdiv(C, 64)), dim3(256), 0, cofi_s(stream), colpart, nslab, ncols, C,
                        eps, out);
     return cofi_launch_status();
 }
