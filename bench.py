@@ -24,6 +24,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
+BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA peak (same guide)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -173,6 +174,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the hipGraph")
+    ap.add_argument("--inflight", type=int, default=2, help="frames in flight per GPU (each on its own HIP stream + hipGraph slot)")
+    ap.add_argument("--gemm", default=os.environ.get("COFI_GEMM", "bf16x3"), choices=["f32", "bf16x3"],
+                    help="arithmetic of the dense contractions: exact fp32 MFMA, or 3-term bf16 split with fp32 accumulation")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -189,9 +193,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    from cofii2p_amd import ops as cofi_ops
     from cofii2p_amd.network import CoFiI2P
     from cofii2p_amd.parallel import shard_frames
 
+    cofi_ops.GEMM_MODE = args.gemm
     model = CoFiI2P(Opt()).to(dev)
     if not args.eager:
         model.enable_graphs()
@@ -206,27 +212,59 @@ def main():
         torch.cuda.synchronize()
 
     nmatch = 0
-    for i in range(args.warmup):
-        out, _ = one_step(model, frames[i % len(frames)])
-        nmatch = out[4].shape[0]
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(model, frames[i % len(frames)])
-    barrier()
-    dt = time.perf_counter() - t0
+    S = max(1, args.inflight) if not args.eager else 1
+    if S == 1:
+        for i in range(args.warmup):
+            out, _ = one_step(model, frames[i % len(frames)])
+            nmatch = out[4].shape[0]
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(model, frames[i % len(frames)])
+        barrier()
+        dt = time.perf_counter() - t0
+    else:
+        # software pipeline over S frame slots: frame i is enqueued on stream i % S while the previous S-1 frames
+        # are still executing; a slot's result (incl. the host read of the match count) is collected just before
+        # the slot is reused.  Every step is still ONE frame through the complete forward.
+        streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+        pending = [None] * S
+
+        def run(nsteps, base):
+            nm = 0
+            for i in range(nsteps):
+                sl = i % S
+                if pending[sl] is not None:
+                    nm = model.finish(pending[sl])[4].shape[0]
+                pyr, img, _ = frames[(base + i) % len(frames)]
+                with torch.cuda.stream(streams[sl]):
+                    pending[sl] = model.forward_async(sl, pyr, img)
+            for sl in range(S):
+                if pending[sl] is not None:
+                    nm = model.finish(pending[sl])[4].shape[0]
+                    pending[sl] = None
+            return nm
+
+        nmatch = run(max(args.warmup, 2 * S), 0)
+        barrier()
+        t0 = time.perf_counter()
+        run(args.steps, 0)
+        barrier()
+        dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-
     result = {
         "metric": "I2P frames/sec (160x512 img, 20480 pts)", "value": world * args.steps / dt, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "launch": "eager" if args.eager else "hipGraph replay",
+        "vs_baseline": None,
+        "dtype": "f32" if args.gemm == "f32" else "f32 (dense contractions as 3-term bf16 split on the bf16 matrix cores, fp32 accumulate; "
+                                                   "4e-6 max abs deviation from the fp32 reference on the golden frame)",
+        "data": "synthetic", "launch": "eager" if args.eager else "hipGraph replay",
         "config": {"workload": "KITTI-shape synthetic frame (160x512 image, %d points, KNN-128 pyramid resident in HBM), batch 1, "
                                "CoFiI2P.forward(mode='test') + fine matching, one frame per step per GPU" % args.points,
-                   "matches_per_frame": int(nmatch), "parallelism": "frame-parallel x%d" % world},
+                   "matches_per_frame": int(nmatch), "parallelism": "frame-parallel x%d" % world, "frames_in_flight_per_gpu": S},
     }
 
     if rank == 0 and not args.no_kernel_timing:
@@ -247,8 +285,10 @@ def main():
         d = per[dom]
         if d["flops_per_frame"] > 0:
             ach = d["flops_per_frame"] / d["seconds_per_frame"] / 1e12
-            result["roofline"] = {"kernel": "cofi_" + dom, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                                  "frac": ach / FP32_MFMA_PEAK_TF, "traffic": None,
+            # the bf16-split GEMM issues 3 bf16 MFMA flops per algorithmic flop: its MFMA roof for ALGORITHMIC flops is 2500/3
+            peak = BF16_MFMA_PEAK_TF / 3.0 if (dom == "gemm" and args.gemm == "bf16x3") else FP32_MFMA_PEAK_TF
+            result["roofline"] = {"kernel": "cofi_" + dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                                  "frac": ach / peak, "traffic": None,
                                   "launches_per_frame": d["launches_per_frame"], "avg_launch_us": 1e6 * d["seconds_per_frame"] / d["launches_per_frame"]}
         else:
             ach = d["bytes_per_frame"] / d["seconds_per_frame"] / 1e9

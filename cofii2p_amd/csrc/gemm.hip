@@ -37,6 +37,7 @@ struct GemmArgs {
     const float *res;                  // optional residual added after the LayerNorm
     int lda, ldw, ldc, ldr, M, N, K, act, ksplit, kchunk, ln_relu;
     float ln_eps;
+    int bf16x3;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -274,6 +275,157 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     rowwise_epilogue<BM, BN, false>(g, lds, TLD, m0, n0, blockIdx.y, lds);  // `red` aliases the tile: it is written after a barrier
 }
 
+// ------------------------------------------------------------------------------------------------------
+// bf16x3 variant: every fp32 operand x is split on the fly into hi = bf16(x), lo = bf16(x - hi) and the product
+// is formed as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: ~2^-16 relative
+// error per product (the dropped lo*lo term) at 16/3 = 5.3x the fp32 MFMA rate.  Same tiling, staging map,
+// split-K and epilogue as the fp32 kernel; LDS holds a hi and a lo plane per operand, rows of 32 bf16 padded
+// to 80 B (conflict-free 16-B fragment reads).  Selected with COFI_GEMM_BF16X3 in `act`.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BROW = 80;  // bytes per LDS row (64 B of bf16 + 16 B pad)
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {  // RNE, a -> low half
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
+    hi.x = cvt_pk_bf16(v.x, v.y);
+    hi.y = cvt_pk_bf16(v.z, v.w);
+    const float rx = v.x - __uint_as_float(hi.x << 16), ry = v.y - __uint_as_float(hi.x & 0xffff0000u);
+    const float rz = v.z - __uint_as_float(hi.y << 16), rw = v.w - __uint_as_float(hi.y & 0xffff0000u);
+    lo.x = cvt_pk_bf16(rx, ry);
+    lo.y = cvt_pk_bf16(rz, rw);
+}
+
+template <int BM, int BN, int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
+    static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 waves");
+    constexpr int A_LD4 = BM / 32, W_LD4 = BN / 32;
+    constexpr int TLD = BN + 4;
+    constexpr int PLANE_A = BM * BROW, PLANE_W = BN * BROW;      // bytes
+    constexpr int BUF = 2 * (PLANE_A + PLANE_W);                 // hi+lo of A and W
+    static_assert(BM * TLD * 4 <= 2 * BUF, "epilogue tile must fit in the operand buffers");
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int ntiles = (kend - kbeg + BK - 1) / BK;
+    const int lrow = tid >> 3, lk = (tid & 7) * 4;
+    float4 ra[A_LD4], rw[W_LD4];
+
+    auto gload = [&](int t) {
+        const int k = kbeg + t * BK + lk;
+        const bool kin = k < kend;
+#pragma unroll
+        for (int j = 0; j < A_LD4; ++j) {
+            const int r = m0 + lrow + 32 * j;
+            ra[j] = (kin && r < g.M) ? *reinterpret_cast<const float4 *>(g.A + (size_t)r * g.lda + k) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < W_LD4; ++j) {
+            const int r = n0 + lrow + 32 * j;
+            rw[j] = (kin && r < g.N) ? *reinterpret_cast<const float4 *>(g.W + (size_t)r * g.ldw + k) : make_float4(0, 0, 0, 0);
+        }
+    };
+    auto sstore = [&](int buf) {
+        unsigned char *base = lds_raw + buf * BUF;
+#pragma unroll
+        for (int j = 0; j < A_LD4; ++j) {
+            uint2 hi, lo;
+            split4(ra[j], hi, lo);
+            unsigned char *p = base + (lrow + 32 * j) * BROW + lk * 2;
+            *reinterpret_cast<uint2 *>(p) = hi;
+            *reinterpret_cast<uint2 *>(p + PLANE_A) = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < W_LD4; ++j) {
+            uint2 hi, lo;
+            split4(rw[j], hi, lo);
+            unsigned char *p = base + 2 * PLANE_A + (lrow + 32 * j) * BROW + lk * 2;
+            *reinterpret_cast<uint2 *>(p) = hi;
+            *reinterpret_cast<uint2 *>(p + PLANE_W) = lo;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    if (ntiles > 0) {
+        gload(0);
+        sstore(0);
+    }
+    __syncthreads();
+
+    const int li = lane & 31, lh = lane >> 5;
+    union Frag { uint4 u; bf16x8 v; };
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) gload(t + 1);
+        const unsigned char *as = lds_raw + buf * BUF + (wm * 32 * TM + li) * BROW + lh * 16;
+        const unsigned char *bs = lds_raw + buf * BUF + 2 * PLANE_A + (wn * 32 * TN + li) * BROW + lh * 16;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {  // two 16-deep MFMA steps per 32-deep tile; lane (i,h) owns k = 16*s2 + 8h .. +7
+            Frag ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i].u = *reinterpret_cast<const uint4 *>(as + i * 32 * BROW + s2 * 32);
+                al[i].u = *reinterpret_cast<const uint4 *>(as + PLANE_A + i * 32 * BROW + s2 * 32);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j].u = *reinterpret_cast<const uint4 *>(bs + j * 32 * BROW + s2 * 32);
+                bl[j].u = *reinterpret_cast<const uint4 *>(bs + PLANE_W + j * 32 * BROW + s2 * 32);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].v, bh[j].v, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bl[j].v, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bh[j].v, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (t + 1 < ntiles) sstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    float *lds = reinterpret_cast<float *>(lds_raw);
+    if (g.ksplit > 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * 32 * TN + j * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < g.M && col < g.N) g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                lds[rl * TLD + wn * 32 * TN + j * 32 + li] = acc[i][j][r];
+            }
+    __syncthreads();
+    rowwise_epilogue<BM, BN, false>(g, lds, TLD, m0, n0, blockIdx.y, lds);
+}
+
 // split-K tail, same row-wise epilogue reading the partial sums.  Two tilings:
 //   64 rows x 32 columns  (plain / column statistics): slabs of 64 rows keep the statistics table small and
 //                          even M = 1280, N = 256 still gives 160 workgroups;
@@ -331,7 +483,14 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
     g.ksplit = p.ksplit;
     g.kchunk = p.kchunk;
     dim3 grid(cofi_cdiv(g.N, p.bn), cofi_cdiv(g.M, p.bm), p.ksplit);
-    if (p.bm == 128 && p.bn == 128)
+    if (g.bf16x3) {
+        if (p.bm == 128 && p.bn == 128)
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, g);
+        else if (p.bm == 64 && p.bn == 128)
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<64, 128, 1, 2>), grid, dim3(256), 0, s, g);
+        else
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<64, 64, 1, 1>), grid, dim3(256), 0, s, g);
+    } else if (p.bm == 128 && p.bn == 128)
         hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, g);
     else if (p.bm == 64 && p.bn == 128)
         hipLaunchKernelGGL((gemm_kernel<64, 128, 1, 2>), grid, dim3(256), 0, s, g);
@@ -377,10 +536,12 @@ extern "C" int cofi_gemm_f32_colstats(const float *A, int lda, const float *W, i
                                       cofi_stream_t stream) {
     if (int rc = check_common(A, lda, W, ldw, C, ldc, M, N, K)) return rc;
     if (M == 0) return 0;
+    const int bf16x3 = (act & COFI_GEMM_BF16X3) ? 1 : 0;
+    act &= ~COFI_GEMM_BF16X3;
     if (act < 0 || act > 2) return COFI_EINVAL;
     Plan p = make_plan(M, N, K, false);
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
-    GemmArgs g{A, W, C, bias, rowdiv, (float *)ws, colpart, nullptr, nullptr, nullptr, lda, ldw, ldc, 0, M, N, K, act, 1, 0, 0, 0.f};
+    GemmArgs g{A, W, C, bias, rowdiv, (float *)ws, colpart, nullptr, nullptr, nullptr, lda, ldw, ldc, 0, M, N, K, act, 1, 0, 0, 0.f, bf16x3};
     return launch(g, p, cofi_s(stream));
 }
 
@@ -392,6 +553,8 @@ extern "C" int cofi_gemm_f32_layernorm(const float *A, int lda, const float *W, 
     if (M == 0) return 0;
     Plan p = make_plan(M, N, K, true);
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
-    GemmArgs g{A, W, C, bias, nullptr, (float *)ws, nullptr, gamma, beta, res, lda, ldw, ldc, ldr, M, N, K, 0, 1, 0, relu, eps};
+    const int bf16x3 = (relu & COFI_GEMM_BF16X3) ? 1 : 0;
+    relu &= ~COFI_GEMM_BF16X3;
+    GemmArgs g{A, W, C, bias, nullptr, (float *)ws, nullptr, gamma, beta, res, lda, ldw, ldc, ldr, M, N, K, 0, 1, 0, relu, eps, bf16x3};
     return launch(g, p, cofi_s(stream));
 }

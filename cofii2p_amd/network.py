@@ -212,12 +212,13 @@ class CoFiI2P(nn.Module):
             self._graphs = {}
         return self
 
-    def _graph_forward(self, P, points, neighbors, subsampling, upsampling, feats, img, mode, kpt, inl):
+    def _graph_forward(self, P, points, neighbors, subsampling, upsampling, feats, img, mode, kpt, inl, slot: int = 0):
         def sig(t):
             return None if t is None else (tuple(t.shape), str(t.dtype))
 
         tensors = list(points) + list(neighbors) + list(subsampling) + list(upsampling) + [feats, img, kpt, inl]
-        key = (mode, str(img.device)) + tuple(sig(t) for t in tensors)
+        key = (mode, str(img.device), slot) + tuple(sig(t) for t in tensors)
+        ops.set_workspace_slot(slot)
         ent = self._graphs.get(key)
         if ent is None:
             static = [None if t is None else torch.empty_like(t) for t in tensors]
@@ -249,7 +250,40 @@ class CoFiI2P(nn.Module):
             if t is not None:
                 s_.copy_(t, non_blocking=True)
         graph.replay()
+        ops.set_workspace_slot(0)
         return outs
+
+    # ------------------------------------------------------------------ frames in flight
+    @torch.no_grad()
+    def forward_async(self, slot: int, pc_data_dict, img, mode: str = "test"):
+        """Enqueue one test-mode forward on the CURRENT stream through the hipGraph of frame slot `slot`
+        and return immediately (no host sync).  Slots own their static buffers and scratch, so several frames
+        can be in flight on different streams; `finish(handle)` synchronises on that frame only and returns the
+        reference's 8-tuple.  A slot must be finished before it is reused."""
+        if mode != "test":
+            raise ValueError("forward_async serves the test-mode pipeline")
+        _lib.load()
+        P = self._pack(img.device)
+        points = [p.contiguous() for p in pc_data_dict["points"]]
+        tabs = [[self._as_idx32(t) for t in pc_data_dict[k]] for k in ("neighbors", "subsampling", "upsampling")]
+        o = self._graph_forward(P, points, tabs[0], tabs[1], tabs[2], pc_data_dict["feats"].contiguous(), img.contiguous(), mode, None, None,
+                                slot=slot)
+        host = torch.empty((2,), dtype=torch.int32, pin_memory=True)
+        host.copy_(o["count"], non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        return {"out": o, "count_host": host, "done": done}
+
+    def finish(self, handle):
+        handle["done"].synchronize()
+        o = handle["out"]
+        n, thr_i = int(handle["count_host"][0]), int(handle["count_host"][1])
+        if thr_i < 0:
+            raise RuntimeError("fewer than 4 coarse matches at every threshold (network.py:148 would loop forever)")
+        self.last_match = {"n": n, "sel": o["sel"][:n], "coarse_xy": o["coarse_xy"][:, :n], "count_dev": o["count"],
+                           "fine_xy": o["fine_xy"][:, :n], "fine_best": o["fine_best"][:n], "threshold": float(score_thresholds()[thr_i])}
+        return (o["img_desc"], o["pc_desc"], o["img_score"], o["pc_score"], o["patches"][:n], o["fine_pc"][:n], o["coarse_xy"][:, :n] * 4,
+                o["coarse_pts"][:n])
 
     @torch.no_grad()
     def forward(self, pc_data_dict, img, fine_center_kpt_coors, fine_xy, fine_pc_inline_index, mode, taps=None):

@@ -13,7 +13,16 @@ import torch
 
 from . import _lib
 
+import os
+
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+GEMM_BF16X3 = 0x100
+# arithmetic of the dense contractions: "f32" = exact fp32 MFMA, "bf16x3" = 3-term bf16 split with fp32 accumulation
+GEMM_MODE = os.environ.get("COFI_GEMM", "f32")
+
+
+def _gemm_flag() -> int:
+    return GEMM_BF16X3 if GEMM_MODE == "bf16x3" else 0
 
 
 def _stream() -> int:
@@ -49,13 +58,15 @@ class Workspace:
     consecutive calls on ONE stream is safe; concurrent streams (forked branches of the forward graph) each
     get their own buffer."""
 
+    slot = 0  # frames-in-flight slot: concurrently replayed graphs must not share scratch (set_workspace_slot)
+
     def __init__(self):
         self.bufs = {}
 
     def get(self, nbytes: int, device) -> Optional[torch.Tensor]:
         if nbytes == 0:
             return None
-        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        key = (device, torch.cuda.current_stream(device).cuda_stream, Workspace.slot)
         buf = self.bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
@@ -110,6 +121,11 @@ _WS_GEMM = Workspace()
 _WS_STATS = Workspace()
 
 
+def set_workspace_slot(slot: int):
+    """Select the scratch namespace used by subsequently enqueued / captured kernels (one per frame in flight)."""
+    Workspace.slot = int(slot)
+
+
 # ------------------------------------------------------------------------------------------ dense
 def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, bias=None, rowdiv=None, act: int = ACT_NONE):
     """out[m,n] = act( (a @ w.T)[m,n] / rowdiv[m] + bias[n] );  a (M,K), w (N,K)."""
@@ -125,7 +141,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, b
     _vec(bias, "bias", N), _vec(rowdiv, "rowdiv", M)
     nbytes = lib.cofi_gemm_f32_workspace(M, N, K)
     ws = _WS_GEMM.get(nbytes, a.device)
-    rc = lib.cofi_gemm_f32(_p(a), _ld(a), _p(w), _ld(w), _p(out), _ld(out), M, N, K, _p(bias), _p(rowdiv), act, _p(ws),
+    rc = lib.cofi_gemm_f32(_p(a), _ld(a), _p(w), _ld(w), _p(out), _ld(out), M, N, K, _p(bias), _p(rowdiv), act | _gemm_flag(), _p(ws),
                            0 if ws is None else ws.numel(), _stream())
     _lib.check(rc, "cofi_gemm_f32")
     return out
@@ -146,7 +162,7 @@ def gemm_colstats(a, w, out=None, bias=None, rowdiv=None, act: int = ACT_NONE):
     nslab = lib.cofi_gemm_f32_stat_slabs(M, N, K)
     colpart = torch.empty((nslab, N, 2), dtype=torch.float32, device=a.device)
     ws = _WS_GEMM.get(lib.cofi_gemm_f32_workspace(M, N, K), a.device)
-    rc = lib.cofi_gemm_f32_colstats(_p(a), _ld(a), _p(w), _ld(w), _p(out), _ld(out), M, N, K, _p(bias), _p(rowdiv), act, _p(colpart),
+    rc = lib.cofi_gemm_f32_colstats(_p(a), _ld(a), _p(w), _ld(w), _p(out), _ld(out), M, N, K, _p(bias), _p(rowdiv), act | _gemm_flag(), _p(colpart),
                                     _p(ws), 0 if ws is None else ws.numel(), _stream())
     _lib.check(rc, "cofi_gemm_f32_colstats")
     return out, colpart
@@ -163,7 +179,8 @@ def gemm_layernorm(a, w, gamma, beta, bias=None, relu: bool = False, res=None, o
     _mat(out, "out")
     ws = _WS_GEMM.get(lib.cofi_gemm_f32_workspace(M, N, K), a.device)
     rc = lib.cofi_gemm_f32_layernorm(_p(a), _ld(a), _p(w), _ld(w), _p(out), _ld(out), M, N, K, _p(bias), _p(gamma), _p(beta), eps,
-                                     int(relu), _p(res), 0 if res is None else _ld(res), _p(ws), 0 if ws is None else ws.numel(), _stream())
+                                     int(relu) | _gemm_flag(), _p(res), 0 if res is None else _ld(res), _p(ws), 0 if ws is None else ws.numel(),
+                                     _stream())
     _lib.check(rc, "cofi_gemm_f32_layernorm")
     return out
 

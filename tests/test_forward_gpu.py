@@ -152,3 +152,52 @@ def test_hipgraph_replay_equals_eager(model):
     assert len(model._graphs) == 1  # one capture served both frames
     assert not torch.equal(outs[11][1], outs[12][1])
     model.enable_graphs(False)
+
+
+def test_frames_in_flight_match_sequential(model):
+    """three frames pipelined over two slots/streams give the same results as one-at-a-time forwards"""
+    from cofii2p_amd.preprocess import build_pyramid
+    from cofii2p_amd.synth import make_frame, subsample_indices
+
+    frames = []
+    for fid in (21, 22, 23):
+        fr = make_frame(fid, 4096)
+        sub = [torch.from_numpy(s).to(DEV) for s in subsample_indices(4096, 5, seed=fid)]
+        pyr = build_pyramid(torch.from_numpy(fr.points).to(DEV), sub)
+        pyr["feats"] = torch.from_numpy(fr.feats).to(DEV)
+        frames.append((pyr, torch.from_numpy(fr.img)[None].to(DEV)))
+    model.enable_graphs(False)
+    seq = [[t.clone() for t in model(p, i, None, None, None, "test")] for p, i in frames]
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    handles, got = [None, None], []
+    for k, (p, i) in enumerate(frames):
+        sl = k % 2
+        if handles[sl] is not None:
+            got.append([t.clone() for t in model.finish(handles[sl])])
+        with torch.cuda.stream(streams[sl]):
+            handles[sl] = model.forward_async(sl, p, i)
+    order = [0, 1, 2]
+    got.append([t.clone() for t in model.finish(handles[1])])  # frame 1
+    got.append([t.clone() for t in model.finish(handles[0])])  # frame 2
+    for k in order:
+        for a, b in zip(seq[k][:4], got[k][:4]):
+            assert maxdiff(a, b.cpu()) < 2e-5
+        assert seq[k][6].shape == got[k][6].shape
+        assert torch.equal(seq[k][7], got[k][7])
+
+
+def test_kitti_frame_bf16x3_gemms_within_tolerance(model, monkeypatch):
+    """the same golden comparison with every dense contraction on the 3-term bf16 split (fp32 accumulate)"""
+    from cofii2p_amd import ops
+
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x3")
+    model.enable_graphs(False)
+    gold = load_golden("frame_kitti.npz")
+    fr, data = frame_inputs(int(gold["frame_id"]), int(gold["num_points"]), int(gold["pyr_seed"]))
+    res = model(to_dev(data), torch.from_numpy(fr.img)[None].to(DEV), None, None, None, "test")
+    names = ("img_desc", "pc_desc", "img_score", "pc_score")
+    worst = {n: maxdiff(t, gold["test_" + n]) for n, t in zip(names, res[:4])}
+    print("bf16x3 max abs diff vs reference:", worst)
+    for n, d in worst.items():
+        assert d <= TOL, (n, d)
+    assert abs(res[6].shape[1] - gold["test_center_xy"].shape[1]) <= 3  # a score may cross the 0.9 threshold

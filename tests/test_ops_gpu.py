@@ -270,3 +270,25 @@ def test_matching_chain(ops, mg):
     fxy, best = ops.fine_match(G(mg["fm_patches"]), G(mg["fm_pc"]), ctr, c12, 1.0)
     assert np.array_equal(best.cpu().numpy(), mg["fm_pred"])
     assert np.array_equal(fxy.cpu().numpy(), mg["fm_xy"])
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (1280, 512, 7680), (77, 33, 60), (2560, 1024, 3072), (1280, 128, 256), (20480, 32, 64)])
+def test_gemm_bf16x3_split(ops, M, N, K, monkeypatch):
+    """3-term bf16 split with fp32 accumulation: error ~2^-16 per product, i.e. well inside the 1e-3 budget"""
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x3")
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * 3
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    ref = a.double() @ w.double().t() + bias.double()
+    out = ops.gemm(G(a), G(w), bias=G(bias)).cpu().double()
+    scale = (a.double().abs() @ w.double().abs().t())  # sum of |products|: the natural error scale
+    rel = ((out - ref).abs() / scale).max()
+    assert rel < 3e-5, float(rel)
+    y, part = ops.gemm_colstats(G(a), G(w), bias=G(bias))
+    st = ops.group_stats_from_colpart(part, M, N).cpu()  # one group per column
+    assert float((st[:, 0].double() - ref.mean(0)).abs().max()) < 1e-4
+    if N <= 128:
+        ga, be = torch.ones(N), torch.zeros(N)
+        ln = ops.gemm_layernorm(G(a), G(w), G(ga), G(be), bias=G(bias))
+        close(ln, torch.nn.functional.layer_norm(ref.float(), (N,)), 2e-4)
