@@ -46,6 +46,9 @@ SIGNATURES = {
     "cofi_l2norm_rows": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
     "cofi_transpose": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "cofi_l2norm_cols": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P]),
+    "cofi_instance_norm_nchw": (_I, [_P, _I, _I, _F, _P, _I, _I, _P, _P]),
+    "cofi_bias_act_nchw": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "cofi_upsample2x_cat": (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
     "cofi_row_argmin_1m": (_I, [_P, _I, _I, _I, _P, _P]),
     "cofi_select_matches": (_I, [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P]),
     "cofi_gather_points_sel": (_I, [_P, _P, _P, _I, _P, _P]),

@@ -461,9 +461,11 @@ Plan make_plan(int M, int N, int K, bool fused_ln) {
     long nb = blocks(p.bm, p.bn);
     int ktiles = cofi_cdiv(K, BK);
     int ks = 1;
-    if (nb < 384) {
+    // Split K only when the serial k-loop is long: a split costs a second kernel (the reduction epilogue,
+    // ~5 us of launch + latency), which a loop of <= 8 k-tiles (K <= 256) cannot win back.
+    if (nb < 384 && ktiles > 8) {
         ks = (int)((512 + nb - 1) / nb);
-        int maxks = ktiles / 2;
+        int maxks = ktiles / 4;
         if (maxks < 1) maxks = 1;
         if (ks > maxks) ks = maxks;
         if (ks > 32) ks = 32;

@@ -85,35 +85,37 @@ __global__ __launch_bounds__(256) void group_stats_final_kernel(const double *pa
     }
 }
 
-// GroupNorm statistics from the GEMM's fused column partials: one wave per group; lanes stride over the
-// (slab, channel-of-group) pairs with the channel index fastest (contiguous float2 reads), fp64 butterfly.
+// GroupNorm statistics from the GEMM's fused column partials: one workgroup per group, 256 threads stride over
+// the (slab, channel-of-group) pairs (channel fastest: contiguous float2 reads) with two independent fp64
+// accumulators, then a fixed-order wave butterfly + 4-wave LDS fold.
 __global__ __launch_bounds__(256) void group_stats_from_colpart_kernel(const float *colpart, int nslab, int C, int groups, double count,
                                                                         float eps, float *stats) {
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= groups) return;
-    const int lane = threadIdx.x & 63;
+    __shared__ double red[4][2];
+    const int g = blockIdx.x;
     const int cpg = C / groups;
-    double s = 0.0, q = 0.0;
-    if (cpg >= 64) {
-        for (int b = 0; b < nslab; ++b)
-            for (int c = lane; c < cpg; c += 64) {
-                const float2 t = *reinterpret_cast<const float2 *>(colpart + ((size_t)b * C + g * cpg + c) * 2);
-                s += (double)t.x;
-                q += (double)t.y;
-            }
-    } else {  // cpg is a power of two < 64: lane -> (slab phase, channel)
-        const int c = lane % cpg, bp = lane / cpg, nb = 64 / cpg;
-        for (int b = bp; b < nslab; b += nb) {
-            const float2 t = *reinterpret_cast<const float2 *>(colpart + ((size_t)b * C + g * cpg + c) * 2);
-            s += (double)t.x;
-            q += (double)t.y;
-        }
+    const int total = nslab * cpg;
+    const float *base = colpart + (size_t)g * cpg * 2;
+    double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+    int e = threadIdx.x;
+    for (; e + 256 < total; e += 512) {
+        const int b0 = e / cpg, c0 = e - b0 * cpg, b1 = (e + 256) / cpg, c1 = (e + 256) - b1 * cpg;
+        const float2 t0 = *reinterpret_cast<const float2 *>(base + ((size_t)b0 * C + c0) * 2);
+        const float2 t1 = *reinterpret_cast<const float2 *>(base + ((size_t)b1 * C + c1) * 2);
+        s0 += (double)t0.x; q0 += (double)t0.y;
+        s1 += (double)t1.x; q1 += (double)t1.y;
     }
-    s = wave_sum_d(s);
-    q = wave_sum_d(q);
-    if (lane == 0) {
-        const double mean = s / count;
-        double var = q / count - mean * mean;
+    if (e < total) {
+        const int b0 = e / cpg, c0 = e - b0 * cpg;
+        const float2 t0 = *reinterpret_cast<const float2 *>(base + ((size_t)b0 * C + c0) * 2);
+        s0 += (double)t0.x; q0 += (double)t0.y;
+    }
+    const double s = wave_sum_d(s0 + s1), q = wave_sum_d(q0 + q1);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s; red[threadIdx.x >> 6][1] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double ts = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]), tq = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        const double mean = ts / count;
+        double var = tq / count - mean * mean;
         if (var < 0.0) var = 0.0;
         stats[2 * g + 0] = (float)mean;
         stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
@@ -142,34 +144,46 @@ struct GnApplyArgs {
     float slope;
 };
 
+// Thread = one float4 column chunk (its 4 channels' scale/shift are folded once: y = x*sc + sh), looping over a
+// strided set of rows: the inner loop is load - 4 fma - select - store with whole rows covered by adjacent lanes.
 __global__ __launch_bounds__(256) void group_norm_apply_kernel(GnApplyArgs a) {
     const int c4n = a.C >> 2;
-    const size_t total = (size_t)a.M * c4n;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int m = (int)(e / c4n), c = (int)(e % c4n) * 4;
-        const float4 xv = *reinterpret_cast<const float4 *>(a.x + (size_t)m * a.ldx + c);
-        float v[4] = {xv.x, xv.y, xv.z, xv.w};
-        float r[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.res) {
-            const float4 rv = *reinterpret_cast<const float4 *>(a.res + (size_t)m * a.ldr + c);
-            r[0] = rv.x; r[1] = rv.y; r[2] = rv.z; r[3] = rv.w;
-        }
+    const int tpr = c4n < 256 ? c4n : 256;           // threads per row (C <= 1024 -> one pass over the columns)
+    const int rpb = 256 / tpr;                        // rows per block step
+    const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    if (tr >= rpb) return;
+    for (int cb = tc; cb < c4n; cb += tpr) {
+        const int c = cb * 4;
+        float sc[4], sh[4], rsc[4], rsh[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int ch = c + i, g = ch / a.cpg;
-            float t = (v[i] - a.stats[2 * g]) * a.stats[2 * g + 1];
-            if (a.gamma) t = t * a.gamma[ch] + a.beta[ch];
-            if (a.res) {
-                float rr = r[i];
-                if (a.res_stats) {
-                    rr = (rr - a.res_stats[2 * g]) * a.res_stats[2 * g + 1];
-                    if (a.res_gamma) rr = rr * a.res_gamma[ch] + a.res_beta[ch];
-                }
-                t += rr;
+            const float mean = a.stats[2 * g], rstd = a.stats[2 * g + 1];
+            const float ga = a.gamma ? a.gamma[ch] : 1.f, be = a.gamma ? a.beta[ch] : 0.f;
+            sc[i] = rstd * ga;
+            sh[i] = be - mean * rstd * ga;
+            rsc[i] = 1.f; rsh[i] = 0.f;
+            if (a.res && a.res_stats) {
+                const float rm = a.res_stats[2 * g], rr = a.res_stats[2 * g + 1];
+                const float rg = a.res_gamma ? a.res_gamma[ch] : 1.f, rb = a.res_gamma ? a.res_beta[ch] : 0.f;
+                rsc[i] = rr * rg;
+                rsh[i] = rb - rm * rr * rg;
             }
-            v[i] = t >= 0.f ? t : t * a.slope;
         }
-        *reinterpret_cast<float4 *>(a.y + (size_t)m * a.ldy + c) = make_float4(v[0], v[1], v[2], v[3]);
+        for (int m = blockIdx.x * rpb + tr; m < a.M; m += gridDim.x * rpb) {
+            const float4 xv = *reinterpret_cast<const float4 *>(a.x + (size_t)m * a.ldx + c);
+            float v[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = v[i] * sc[i] + sh[i];
+            if (a.res) {
+                const float4 rv = *reinterpret_cast<const float4 *>(a.res + (size_t)m * a.ldr + c);
+                v[0] += rv.x * rsc[0] + rsh[0]; v[1] += rv.y * rsc[1] + rsh[1];
+                v[2] += rv.z * rsc[2] + rsh[2]; v[3] += rv.w * rsc[3] + rsh[3];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = v[i] >= 0.f ? v[i] : v[i] * a.slope;
+            *reinterpret_cast<float4 *>(a.y + (size_t)m * a.ldy + c) = make_float4(v[0], v[1], v[2], v[3]);
+        }
     }
 }
 
@@ -268,22 +282,28 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float *x, int ld
     }
 }
 
-// (C,P) channel-major map: normalise every pixel's C-vector; lanes = consecutive pixels
+// (C,P) channel-major map: normalise every pixel's C-vector.  Block = 64 pixels x 4 channel phases (lanes =
+// consecutive pixels: coalesced rows of the map), phases folded through LDS in a fixed order.
 __global__ __launch_bounds__(256) void l2norm_cols_kernel(const float *x, int ldx, int C, int P, float *y_cp, int ldy, float *y_pc,
                                                           int ldt) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
+    __shared__ float red[4][64];
+    const int pl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + pl;
     float q = 0.f;
-    for (int c = 0; c < C; ++c) {
-        const float v = x[(size_t)c * ldx + p];
-        q += v * v;
-    }
-    const float inv = 1.0f / fmaxf(sqrtf(q), 1e-12f);
-    for (int c = 0; c < C; ++c) {
-        const float v = x[(size_t)c * ldx + p] * inv;
-        if (y_cp) y_cp[(size_t)c * ldy + p] = v;
-        if (y_pc) y_pc[(size_t)p * ldt + c] = v;
-    }
+    if (p < P)
+        for (int c = ph; c < C; c += 4) {
+            const float v = x[(size_t)c * ldx + p];
+            q += v * v;
+        }
+    red[ph][pl] = q;
+    __syncthreads();
+    const float inv = 1.0f / fmaxf(sqrtf((red[0][pl] + red[1][pl]) + (red[2][pl] + red[3][pl])), 1e-12f);
+    if (p < P)
+        for (int c = ph; c < C; c += 4) {
+            const float v = x[(size_t)c * ldx + p] * inv;
+            if (y_cp) y_cp[(size_t)c * ldy + p] = v;
+            if (y_pc) y_pc[(size_t)p * ldt + c] = v;
+        }
 }
 
 __global__ void transpose_kernel(const float *x, int ldx, int M, int C, float *y, int ldy) {
@@ -333,8 +353,7 @@ __global__ void pos_sine_kernel(PosArgs a) {
 extern "C" int cofi_group_stats_from_colpart(const float *colpart, int nslab, int M, int C, int groups, float eps, float *stats,
                                              cofi_stream_t stream) {
     if (!colpart || !stats || nslab <= 0 || M <= 0 || C <= 0 || groups <= 0 || (C % groups)) return COFI_EINVAL;
-    if ((C / groups) < 64 && ((C / groups) & ((C / groups) - 1))) return COFI_EUNSUPPORTED;
-    hipLaunchKernelGGL(group_stats_from_colpart_kernel, dim3(cofi_cdiv(groups, 4)), dim3(256), 0, cofi_s(stream), colpart, nslab, C, groups,
+    hipLaunchKernelGGL(group_stats_from_colpart_kernel, dim3(groups), dim3(256), 0, cofi_s(stream), colpart, nslab, C, groups,
                        (double)M * (C / groups), eps, stats);
     return cofi_launch_status();
 }
@@ -375,9 +394,10 @@ extern "C" int cofi_group_norm_apply(const float *x, int ldx, int M, int C, int 
     if ((gamma == nullptr) != (beta == nullptr) || (res_gamma == nullptr) != (res_beta == nullptr)) return COFI_EINVAL;
     if (res && (ldr & 3)) return COFI_EINVAL;
     GnApplyArgs a{x, stats, gamma, beta, res, res_stats, res_gamma, res_beta, y, ldx, ldr, ldy, M, C, C / groups, slope};
-    size_t total = (size_t)M * (C >> 2);
-    int nb = (int)((total + 255) / 256);
-    if (nb > 4096) nb = 4096;
+    const int c4n = C >> 2, tpr = c4n < 256 ? c4n : 256, rpb = 256 / tpr;
+    int nb = cofi_cdiv(M, rpb * 4);  // ~4 rows per thread
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
     hipLaunchKernelGGL(group_norm_apply_kernel, dim3(nb), dim3(256), 0, cofi_s(stream), a);
     return cofi_launch_status();
 }
@@ -406,7 +426,7 @@ extern "C" int cofi_l2norm_rows(const float *x, int ldx, int M, int C, float *y,
 extern "C" int cofi_l2norm_cols(const float *x, int ldx, int C, int P, float *y_cp, int ldy, float *y_pc, int ldt,
                                 cofi_stream_t stream) {
     if (!x || C <= 0 || P <= 0 || ldx < P || (y_cp && ldy < P) || (y_pc && ldt < C)) return COFI_EINVAL;
-    hipLaunchKernelGGL(l2norm_cols_kernel, dim3(cofi_cdiv(P, 64)), dim3(64), 0, cofi_s(stream), x, ldx, C, P, y_cp, ldy, y_pc, ldt);
+    hipLaunchKernelGGL(l2norm_cols_kernel, dim3(cofi_cdiv(P, 64)), dim3(256), 0, cofi_s(stream), x, ldx, C, P, y_cp, ldy, y_pc, ldt);
     return cofi_launch_status();
 }
 

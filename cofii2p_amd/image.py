@@ -11,6 +11,7 @@ from typing import Dict, List
 import torch
 import torch.nn.functional as F
 
+from . import ops
 from .spec import RESNET_LAYERS
 
 
@@ -31,15 +32,12 @@ def pack_image(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     return out
 
 
-def _inorm(x):
-    return F.instance_norm(x, eps=1e-5)
-
-
 def resnet34(P, img: torch.Tensor, full: bool = True) -> List[torch.Tensor]:
     """imagenet.py:196-217.  Returns [s2, s4, s8, s16, s32, gap]; with full=False the maps nothing
-    downstream reads (layer3, layer4, avg-pool: network.py:87-89) are skipped and returned as None."""
+    downstream reads (layer3, layer4, avg-pool: network.py:87-89) are skipped and returned as None.
+    Convolutions / max-pool: MIOpen; InstanceNorm + ReLU + residual tails: one HIP kernel each."""
     p = "img_encoder.backbone."
-    x = F.relu(_inorm(F.conv2d(img, P[p + "conv1.weight"], stride=2, padding=3)))
+    x = ops.instance_norm_nchw(F.conv2d(img, P[p + "conv1.weight"], stride=2, padding=3), relu=True)
     outs = [x]
     x = F.max_pool2d(x, 3, 2, 1)
     for li, (planes, blocks, stride) in enumerate(RESNET_LAYERS, start=1):
@@ -49,24 +47,26 @@ def resnet34(P, img: torch.Tensor, full: bool = True) -> List[torch.Tensor]:
         for b in range(blocks):
             q = "%slayer%d.%d." % (p, li, b)
             st = stride if b == 0 else 1
-            y = F.relu(_inorm(F.conv2d(x, P[q + "conv1.weight"], stride=st, padding=1)))
-            y = _inorm(F.conv2d(y, P[q + "conv2.weight"], padding=1))
-            if (q + "downsample.0.weight") in P:
-                x = _inorm(F.conv2d(x, P[q + "downsample.0.weight"], stride=st))
-            x = F.relu(y + x)
+            y = ops.instance_norm_nchw(F.conv2d(x, P[q + "conv1.weight"], stride=st, padding=1), relu=True)
+            y = F.conv2d(y, P[q + "conv2.weight"], padding=1)
+            if (q + "downsample.0.weight") in P:  # relu(IN(y) + IN(downsample(x)))
+                x = ops.instance_norm_nchw(y, relu=True, res=F.conv2d(x, P[q + "downsample.0.weight"], stride=st), res_norm=True)
+            else:  # relu(IN(y) + x)
+                x = ops.instance_norm_nchw(y, relu=True, res=x)
         outs.append(x)
     outs.append(F.adaptive_avg_pool2d(x, 1) if full else None)
     return outs
 
 
 def _residual_conv(P, p: str, x):
-    skip = F.conv2d(x, P[p + "conv_skip.0.w"], P[p + "conv_skip.0.b"], padding=1)
-    y = F.relu(F.conv2d(x, P[p + "conv1.w"], P[p + "conv1.b"], padding=1))
-    y = F.conv2d(y, P[p + "conv2.w"], P[p + "conv2.b"], padding=1)
-    return F.relu(y + skip)
+    """imagenet.py:397-411 with the eval-mode BatchNorms folded into the convolutions (pack_image)."""
+    skip = F.conv2d(x, P[p + "conv_skip.0.w"], padding=1)
+    y = ops.bias_act_nchw(F.conv2d(x, P[p + "conv1.w"], padding=1), P[p + "conv1.b"], relu=True)
+    y = F.conv2d(y, P[p + "conv2.w"], padding=1)
+    return ops.bias_act_nchw(y, P[p + "conv2.b"], res=skip, res_bias=P[p + "conv_skip.0.b"], relu=True)
 
 
 def upsample_stage(P, name: str, low, skip):
     """imagenet.py:431-444."""
-    x = torch.cat([F.interpolate(low, scale_factor=2, mode="bilinear", align_corners=False), skip], 1)
+    x = ops.upsample2x_cat(low, skip)
     return _residual_conv(P, name + ".conv.1.", _residual_conv(P, name + ".conv.0.", x))

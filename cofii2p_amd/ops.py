@@ -358,6 +358,37 @@ def pos_sine(coords, out, accumulate: bool, d_model: int = 128):
     return out
 
 
+# ------------------------------------------------------------------------------------------ image-branch glue
+def instance_norm_nchw(x, relu: bool = False, res=None, res_norm: bool = False, eps: float = 1e-5):
+    """x (1,C,H,W) contiguous -> relu?(IN(x) + [res | IN(res)])."""
+    lib = _lib.load()
+    if not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous() or x.shape[0] != 1:
+        raise _lib.CofiError("instance_norm_nchw: contiguous CUDA fp32 (1,C,H,W) expected")
+    _, C, H, W = x.shape
+    y = torch.empty_like(x)
+    mode = 0 if res is None else (2 if res_norm else 1)
+    _lib.check(lib.cofi_instance_norm_nchw(_p(x), C, H * W, eps, _p(res), mode, int(relu), _p(y), _stream()), "cofi_instance_norm_nchw")
+    return y
+
+
+def bias_act_nchw(x, bias=None, res=None, res_bias=None, relu: bool = True):
+    lib = _lib.load()
+    _, C, H, W = x.shape
+    y = torch.empty_like(x)
+    _lib.check(lib.cofi_bias_act_nchw(_p(x), _p(bias), _p(res), _p(res_bias), C, H * W, int(relu), _p(y), _stream()), "cofi_bias_act_nchw")
+    return y
+
+
+def upsample2x_cat(low, skip):
+    """(1,C1,h,w), (1,C2,2h,2w) -> (1,C1+C2,2h,2w): bilinear x2 (align_corners=False) + channel concat."""
+    lib = _lib.load()
+    _, C1, h, w = low.shape
+    C2 = skip.shape[1]
+    out = torch.empty((1, C1 + C2, 2 * h, 2 * w), dtype=torch.float32, device=low.device)
+    _lib.check(lib.cofi_upsample2x_cat(_p(low.contiguous()), C1, h, w, _p(skip.contiguous()), C2, _p(out), _stream()), "cofi_upsample2x_cat")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ attention
 def attention(q, k, v, q_colscale=None, nhead: int = 4, out=None):
     lib = _lib.load()

@@ -186,6 +186,21 @@ int cofi_transpose(const float *x, int ldx, int M, int C, float *y, int ldy, cof
 int cofi_l2norm_cols(const float *x, int ldx, int C, int P, float *y_cp, int ldy, float *y_pc, int ldt, cofi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K13 glue (the dense convolutions themselves run through MIOpen): channel-major (C, P = H*W) maps.
+ * cofi_instance_norm_nchw: y[c,:] = relu?( IN(x[c,:]) + R ), IN = affine-less InstanceNorm2d (eps, biased
+ *   variance; model/imagenet.py:123), R = 0 (res_mode 0) | res[c,:] (1) | IN(res[c,:]) (2): the BasicBlock tail of
+ *   model/imagenet.py:58-73.  P % 4 == 0.
+ * cofi_bias_act_nchw: y = relu?( x + bias[c] + res + res_bias[c] ): ResidualConv with eval-mode BatchNorm folded
+ *   into the convolutions (model/imagenet.py:397-411).
+ * cofi_upsample2x_cat: out[:C1] = bilinear x2 of low (align_corners=False), out[C1:] = skip
+ *   (model/imagenet.py:433,441-443: nn.Upsample + torch.cat). */
+int cofi_instance_norm_nchw(const float *x, int C, int P, float eps, const float *res, int res_mode, int relu, float *y,
+                            cofi_stream_t stream);
+int cofi_bias_act_nchw(const float *x, const float *bias, const float *res, const float *res_bias, int C, int P, int relu, float *y,
+                       cofi_stream_t stream);
+int cofi_upsample2x_cat(const float *low, int C1, int h, int w, const float *skip, int C2, float *out, cofi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K10-K12  coarse + fine matching without host round trips (model/network.py:145-161,167-226,
  * evaluation/eval_all.py:99-105).
  * cofi_row_argmin_1m: pix[n] = argmin_p (1 - sim[n,p]) with the lowest index on ties

@@ -292,3 +292,19 @@ def test_gemm_bf16x3_split(ops, M, N, K, monkeypatch):
         ga, be = torch.ones(N), torch.zeros(N)
         ln = ops.gemm_layernorm(G(a), G(w), G(ga), G(be), bias=G(bias))
         close(ln, torch.nn.functional.layer_norm(ref.float(), (N,)), 2e-4)
+
+
+def test_image_glue_kernels(ops):
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(9)
+    for (C, H, W) in ((64, 80, 256), (128, 20, 64), (512, 5, 16)):
+        x, r = torch.randn(1, C, H, W, generator=g) * 2 + 0.3, torch.randn(1, C, H, W, generator=g)
+        close(ops.instance_norm_nchw(G(x), relu=True), F.relu(F.instance_norm(x)), 2e-5)
+        close(ops.instance_norm_nchw(G(x), relu=True, res=G(r)), F.relu(F.instance_norm(x) + r), 2e-5)
+        close(ops.instance_norm_nchw(G(x), relu=True, res=G(r), res_norm=True), F.relu(F.instance_norm(x) + F.instance_norm(r)), 2e-5)
+        b, b2 = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        close(ops.bias_act_nchw(G(x), G(b), res=G(r), res_bias=G(b2)), F.relu(x + b[None, :, None, None] + r + b2[None, :, None, None]), 1e-6)
+    low, skip = torch.randn(1, 128, 20, 64, generator=g), torch.randn(1, 64, 40, 128, generator=g)
+    ref = torch.cat([F.interpolate(low, scale_factor=2, mode="bilinear", align_corners=False), skip], 1)
+    close(ops.upsample2x_cat(G(low), G(skip)), ref, 1e-6)

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): kernel trace + separate PMC passes of the default bench configuration.
+# Only the markdown summaries are kept (the rocpd databases are too large to travel back).
+# usage: tools/profile_round.sh <tag>     outputs under gpurun_out/prof_<tag>/
+set -u
+TAG=${1:-r01}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof_$TAG
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $R/bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-kernel-timing"
+run_trace() {  # name, extra bench args
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_$1 -o x -- $BENCH $2 > $OUT/$1.log 2>&1
+  python $R/tools/rocpd_summary.py $(find /tmp/prof_$1 -name '*_results.db' | head -1) > $OUT/$1_kernel_trace.md 2>&1
+  rm -rf /tmp/prof_$1
+}
+run_pmc() {  # name, counters
+  rocprofv3 --kernel-trace --pmc $2 -d /tmp/prof_$1 -o x -- $BENCH --inflight 1 > $OUT/$1.log 2>&1
+  python $R/tools/rocpd_pmc_summary.py $(find /tmp/prof_$1 -name '*_results.db' | head -1) > $OUT/$1_pmc.md 2>&1
+  rm -rf /tmp/prof_$1
+}
+run_trace inflight2 ""
+run_trace inflight1 "--inflight 1"
+run_pmc fetch "FETCH_SIZE"
+run_pmc write "WRITE_SIZE"
+run_pmc mfma "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"
+grep -h '"value"' $OUT/*.log | cut -c1-160
+ls -la $OUT
