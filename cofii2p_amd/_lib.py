@@ -46,6 +46,11 @@ SIGNATURES = {
     "cofi_l2norm_rows": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
     "cofi_transpose": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "cofi_l2norm_cols": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P]),
+    "cofi_conv2d_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _Z, _P]),
+    "cofi_im2col_stem": (_I, [_P, _I, _I, _I, _P, _P]),
+    "cofi_maxpool3x3s2_nhwc": (_I, [_P, _I, _I, _I, _P, _P]),
+    "cofi_upsample2x_cat_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P]),
+    "cofi_extract_patches_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _F, _P, _I, _P, _P]),
     "cofi_instance_norm_nchw": (_I, [_P, _I, _I, _F, _P, _I, _I, _P, _P]),
     "cofi_bias_act_nchw": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "cofi_upsample2x_cat": (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),

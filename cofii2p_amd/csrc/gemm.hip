@@ -38,6 +38,46 @@ struct GemmArgs {
     int lda, ldw, ldc, ldr, M, N, K, act, ksplit, kchunk, ln_relu;
     float ln_eps;
     int bf16x3;
+    // implicit-GEMM convolution (cv_ks > 0): A is an NHWC map (H*W rows of lda floats), row m of the GEMM is
+    // output pixel (m / Wo, m % Wo), column k is (tap = k / Cin, channel = k % Cin); K = ks*ks*Cin
+    int cv_ks, cv_H, cv_W, cv_Cin, cv_Wo, cv_stride, cv_pad;
+};
+
+// A-operand tile loader shared by both MFMA kernels: float4 number j of this thread covers row m0 + lrow + 32j,
+// k .. k+3.  Dense: A[row, k].  Convolution: the input pixel under tap k / Cin of output pixel `row`, zero
+// outside the image (Cin % 4 == 0, so a float4 never straddles two taps).
+template <int A_LD4>
+struct ATileLoader {
+    int yo[A_LD4], xo[A_LD4];
+    __device__ __forceinline__ void init(const GemmArgs &g, int m0, int lrow) {
+        if (g.cv_ks) {
+#pragma unroll
+            for (int j = 0; j < A_LD4; ++j) {
+                const int r = m0 + lrow + 32 * j;
+                yo[j] = r / g.cv_Wo;
+                xo[j] = r - yo[j] * g.cv_Wo;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(const GemmArgs &g, int m0, int lrow, int k, bool kin, float4 (&ra)[A_LD4]) const {
+        if (g.cv_ks == 0) {
+#pragma unroll
+            for (int j = 0; j < A_LD4; ++j) {
+                const int r = m0 + lrow + 32 * j;
+                ra[j] = (kin && r < g.M) ? *reinterpret_cast<const float4 *>(g.A + (size_t)r * g.lda + k) : make_float4(0, 0, 0, 0);
+            }
+        } else {
+            const int tap = k / g.cv_Cin, c = k - tap * g.cv_Cin;
+            const int dy = tap / g.cv_ks, dx = tap - dy * g.cv_ks;
+#pragma unroll
+            for (int j = 0; j < A_LD4; ++j) {
+                const int r = m0 + lrow + 32 * j;
+                const int yi = yo[j] * g.cv_stride - g.cv_pad + dy, xi = xo[j] * g.cv_stride - g.cv_pad + dx;
+                const bool ok = kin && r < g.M && (unsigned)yi < (unsigned)g.cv_H && (unsigned)xi < (unsigned)g.cv_W;
+                ra[j] = ok ? *reinterpret_cast<const float4 *>(g.A + ((size_t)yi * g.cv_W + xi) * g.lda + c) : make_float4(0, 0, 0, 0);
+            }
+        }
+    }
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -121,6 +161,11 @@ __device__ __forceinline__ void rowwise_epilogue(const GemmArgs &g, const float 
                 }
             }
         } else {
+            if (g.res && rin) {  // plain residual (second conv of a ResidualConv + its skip conv): added before the activation
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < g.N) v[e] += g.res[(size_t)row * g.ldr + col + e];
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], g.act);
         }
@@ -182,15 +227,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
     const int lrow = tid >> 3, lk = (tid & 7) * 4;  // staging map: 8 lanes cover one 128-B row slice
     float4 ra[A_LD4], rw[W_LD4];
+    ATileLoader<A_LD4> aload;
+    aload.init(g, m0, lrow);
 
     auto gload = [&](int t) {
         const int k = kbeg + t * BK + lk;
         const bool kin = k < kend;
-#pragma unroll
-        for (int j = 0; j < A_LD4; ++j) {
-            const int r = m0 + lrow + 32 * j;
-            ra[j] = (kin && r < g.M) ? *reinterpret_cast<const float4 *>(g.A + (size_t)r * g.lda + k) : make_float4(0, 0, 0, 0);
-        }
+        aload.load(g, m0, lrow, k, kin, ra);
 #pragma unroll
         for (int j = 0; j < W_LD4; ++j) {
             const int r = n0 + lrow + 32 * j;
@@ -316,15 +359,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     const int ntiles = (kend - kbeg + BK - 1) / BK;
     const int lrow = tid >> 3, lk = (tid & 7) * 4;
     float4 ra[A_LD4], rw[W_LD4];
+    ATileLoader<A_LD4> aload;
+    aload.init(g, m0, lrow);
 
     auto gload = [&](int t) {
         const int k = kbeg + t * BK + lk;
         const bool kin = k < kend;
-#pragma unroll
-        for (int j = 0; j < A_LD4; ++j) {
-            const int r = m0 + lrow + 32 * j;
-            ra[j] = (kin && r < g.M) ? *reinterpret_cast<const float4 *>(g.A + (size_t)r * g.lda + k) : make_float4(0, 0, 0, 0);
-        }
+        aload.load(g, m0, lrow, k, kin, ra);
 #pragma unroll
         for (int j = 0; j < W_LD4; ++j) {
             const int r = n0 + lrow + 32 * j;
@@ -543,7 +584,7 @@ extern "C" int cofi_gemm_f32_colstats(const float *A, int lda, const float *W, i
     if (act < 0 || act > 2) return COFI_EINVAL;
     Plan p = make_plan(M, N, K, false);
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
-    GemmArgs g{A, W, C, bias, rowdiv, (float *)ws, colpart, nullptr, nullptr, nullptr, lda, ldw, ldc, 0, M, N, K, act, 1, 0, 0, 0.f, bf16x3};
+    GemmArgs g{A, W, C, bias, rowdiv, (float *)ws, colpart, nullptr, nullptr, nullptr, lda, ldw, ldc, 0, M, N, K, act, 1, 0, 0, 0.f, bf16x3, 0, 0, 0, 0, 0, 0, 0};
     return launch(g, p, cofi_s(stream));
 }
 
@@ -557,6 +598,23 @@ extern "C" int cofi_gemm_f32_layernorm(const float *A, int lda, const float *W, 
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
     const int bf16x3 = (relu & COFI_GEMM_BF16X3) ? 1 : 0;
     relu &= ~COFI_GEMM_BF16X3;
-    GemmArgs g{A, W, C, bias, nullptr, (float *)ws, nullptr, gamma, beta, res, lda, ldw, ldc, ldr, M, N, K, 0, 1, 0, relu, eps, bf16x3};
+    GemmArgs g{A, W, C, bias, nullptr, (float *)ws, nullptr, gamma, beta, res, lda, ldw, ldc, ldr, M, N, K, 0, 1, 0, relu, eps, bf16x3, 0, 0, 0, 0, 0, 0, 0};
+    return launch(g, p, cofi_s(stream));
+}
+
+extern "C" int cofi_conv2d_nhwc(const float *x, int ldx, int H, int W, int Cin, const float *Wt, int Cout, int ks, int stride, int pad,
+                                const float *bias, const float *res, int ldr, int act, float *y, int ldy, float *colpart, void *ws,
+                                size_t ws_bytes, cofi_stream_t stream) {
+    if (!x || !Wt || !y || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ks != 1 && ks != 3) || stride <= 0 || pad < 0) return COFI_EINVAL;
+    if ((Cin & 3) || (ldx & 3) || ldx < Cin || ldy < Cout || (res && ldr < Cout) || ((uintptr_t)x & 15) || ((uintptr_t)Wt & 15)) return COFI_EINVAL;
+    const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
+    const int M = Ho * Wo, K = ks * ks * Cin;
+    const int bf16x3 = (act & COFI_GEMM_BF16X3) ? 1 : 0;
+    act &= ~COFI_GEMM_BF16X3;
+    if (act < 0 || act > 2) return COFI_EINVAL;
+    Plan p = make_plan(M, Cout, K, false);
+    if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * Cout * sizeof(float))) return COFI_EWORKSPACE;
+    GemmArgs g{x, Wt, y, bias, nullptr, (float *)ws, colpart, nullptr, nullptr, res, ldx, K, ldy, ldr, M, Cout, K, act, 1, 0, 0, 0.f, bf16x3,
+               ks, H, W, Cin, Wo, stride, pad};
     return launch(g, p, cofi_s(stream));
 }

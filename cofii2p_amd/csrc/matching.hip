@@ -123,6 +123,21 @@ __global__ void extract_patches_kernel(const float *fmap, int C, int H2, int W2,
     }
 }
 
+// NHWC variant: fmap row (y*W2 + x) holds the C channels of a pixel
+__global__ void extract_patches_nhwc_kernel(const float *fmap, int ldf, int C, int H2, int W2, const float *xy, int ldxy, float cscale,
+                                            const int32_t *count_dev, int cap, float *patches) {
+    const int i = blockIdx.x;
+    if (i >= min(*count_dev, cap)) return;
+    const int left = (int)floorf(xy[i] * cscale - 2.0f), top = (int)floorf(xy[ldxy + i] * cscale - 2.0f);
+    for (int e = threadIdx.x; e < C * 16; e += blockDim.x) {
+        const int c = e % C, t = e / C, r = t >> 2, w = t & 3;  // lanes sweep channels: contiguous reads
+        const int yy = top + r, xx = left + w;
+        float v = 0.f;
+        if (yy >= 0 && yy < H2 && xx >= 0 && xx < W2) v = fmap[((size_t)yy * W2 + xx) * ldf + c];
+        patches[((size_t)i * C + c) * 16 + t] = v;
+    }
+}
+
 __global__ void gather_rows_sel_kernel(const float *x, int ldx, int C, const int32_t *row_idx, const int32_t *count_dev, int cap,
                                        float *out, int ldo) {
     const int i = blockIdx.x;
@@ -199,6 +214,14 @@ extern "C" int cofi_extract_patches(const float *fmap, int C, int H2, int W2, co
     if (!fmap || !coarse_xy || !count_dev || !patches || C <= 0 || H2 <= 0 || W2 <= 0 || cap <= 0) return COFI_EINVAL;
     hipLaunchKernelGGL(extract_patches_kernel, dim3(cap), dim3(256), 0, cofi_s(stream), fmap, C, H2, W2, coarse_xy, ldxy, center_scale,
                        count_dev, cap, patches);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_extract_patches_nhwc(const float *fmap, int ldf, int C, int H2, int W2, const float *coarse_xy, int ldxy,
+                                         float center_scale, const int32_t *count_dev, int cap, float *patches, cofi_stream_t stream) {
+    if (!fmap || !coarse_xy || !count_dev || !patches || C <= 0 || H2 <= 0 || W2 <= 0 || cap <= 0 || ldf < C) return COFI_EINVAL;
+    hipLaunchKernelGGL(extract_patches_nhwc_kernel, dim3(cap), dim3(256), 0, cofi_s(stream), fmap, ldf, C, H2, W2, coarse_xy, ldxy,
+                       center_scale, count_dev, cap, patches);
     return cofi_launch_status();
 }
 

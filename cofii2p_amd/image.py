@@ -1,10 +1,14 @@
 """Image branch: ResNet-34 (affine-less InstanceNorm) + two bilinear up-sample / ResidualConv stages
 (reference: model/imagenet.py:119-217, 377-444).
 
-Round-1 status: the dense 3x3/7x7 convolutions, InstanceNorm, max-pool and
-bilinear resize run through PyTorch-ROCm's MIOpen/ATen device ops; BatchNorm (eval mode, running
-statistics) is folded into the convolution weights once at pack time.  Everything downstream of
-the feature maps (L2 normalisation, token layout, matching) is hand-written HIP.
+Default path (`*_nhwc`): feature maps are NHWC = pixel-major (H*W, C) matrices like every other activation
+of the network; a convolution is an implicit GEMM on the MFMA kernel (`cofi_conv2d_nhwc`), whose epilogue
+emits the per-channel column statistics InstanceNorm needs (or fuses the folded-BatchNorm bias, ReLU and the
+skip convolution of a ResidualConv); InstanceNorm + ReLU + residual is the stack-mode GroupNorm apply kernel
+with one group per channel.  No MIOpen, no layout transposes, bit-reproducible.
+
+`resnet34` / `upsample_stage` (NCHW) keep the MIOpen convolutions with HIP glue; they are selected with
+COFI_IMAGE=miopen for A/B measurements only.
 """
 from typing import Dict, List
 
@@ -15,8 +19,19 @@ from . import ops
 from .spec import RESNET_LAYERS
 
 
+def _nhwc_weight(w: torch.Tensor, kpad: int = 0) -> torch.Tensor:
+    """OIHW -> (O, kh*kw*I) with k = (dy*kw + dx)*I + c (the implicit-GEMM column order), optionally zero padded."""
+    o = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+    if kpad and kpad > o.shape[1]:
+        o = torch.cat([o, torch.zeros((o.shape[0], kpad - o.shape[1]), dtype=o.dtype, device=o.device)], 1)
+    return o.contiguous()
+
+
 def pack_image(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     out = {}
+    for k, v in sd.items():
+        if k.startswith("img_encoder.backbone.") and k.endswith("weight") and v.dim() == 4:
+            out[k + ".nhwc"] = _nhwc_weight(v, 160 if k.endswith("backbone.conv1.weight") else 0)
     for k, v in sd.items():
         if k.startswith("img_encoder.backbone.") and k.endswith("weight") and v.dim() == 4:
             out[k] = v.contiguous()
@@ -28,6 +43,7 @@ def pack_image(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
                 w = sd[p + conv + ".weight"]
                 scale = sd[p + bn + ".weight"] * torch.rsqrt(sd[p + bn + ".running_var"] + eps)
                 out[p + conv + ".w"] = (w * scale[:, None, None, None]).contiguous()
+                out[p + conv + ".w.nhwc"] = _nhwc_weight(w * scale[:, None, None, None])
                 out[p + conv + ".b"] = (sd[p + bn + ".bias"] - sd[p + bn + ".running_mean"] * scale).contiguous()
     return out
 
@@ -70,3 +86,60 @@ def upsample_stage(P, name: str, low, skip):
     """imagenet.py:431-444."""
     x = ops.upsample2x_cat(low, skip)
     return _residual_conv(P, name + ".conv.1.", _residual_conv(P, name + ".conv.0.", x))
+
+
+# ---------------------------------------------------------------------------------------------- NHWC path
+def _in_relu(y, part, res=None, res_part=None):
+    """relu(InstanceNorm(y) + [res | InstanceNorm(res)]) on (P, C) maps: one group per channel."""
+    P, C = y.shape
+    st = ops.group_stats_from_colpart(part, P, C)
+    rst = None if res_part is None else ops.group_stats_from_colpart(res_part, P, C)
+    return ops.group_norm_apply(y, st, slope=0.0, res=res, res_stats=rst)
+
+
+def resnet34_nhwc(P, img: torch.Tensor, full: bool = True):
+    """imagenet.py:196-217 on NHWC maps.  img (1,3,H,W).  Returns ([s2, s4, s8, s16, s32, gap], [(H,W) per map])."""
+    p = "img_encoder.backbone."
+    col, H, W = ops.im2col_stem(img[0].contiguous())
+    y, part = ops.gemm_colstats(col, P[p + "conv1.weight.nhwc"])
+    x = _in_relu(y, part)
+    outs, dims = [x], [(H, W)]
+    x, H, W = ops.maxpool3x3s2_nhwc(x, H, W)
+    for li, (planes, blocks, stride) in enumerate(RESNET_LAYERS, start=1):
+        if not full and li > 2:
+            outs.append(None)
+            dims.append(None)
+            continue
+        for b in range(blocks):
+            q = "%slayer%d.%d." % (p, li, b)
+            st = stride if b == 0 else 1
+            y1, part1, Ho, Wo = ops.conv2d_nhwc(x, H, W, P[q + "conv1.weight.nhwc"], 3, st, 1, colstats=True)
+            a = _in_relu(y1, part1)
+            y2, part2, _, _ = ops.conv2d_nhwc(a, Ho, Wo, P[q + "conv2.weight.nhwc"], 3, 1, 1, colstats=True)
+            if (q + "downsample.0.weight.nhwc") in P:
+                d, partd, _, _ = ops.conv2d_nhwc(x, H, W, P[q + "downsample.0.weight.nhwc"], 1, st, 0, colstats=True)
+                x = _in_relu(y2, part2, res=d, res_part=partd)
+            else:
+                x = _in_relu(y2, part2, res=x)
+            H, W = Ho, Wo
+        outs.append(x)
+        dims.append((H, W))
+    outs.append(x.mean(0, keepdim=True) if full else None)  # AdaptiveAvgPool2d(1): unused downstream (network.py:87)
+    dims.append((1, 1))
+    return outs, dims
+
+
+def _residual_conv_nhwc(P, p: str, x, H, W):
+    """imagenet.py:397-411: three implicit-GEMM convolutions; folded-BN bias, ReLU and the skip add live in the
+    epilogues."""
+    skip, _, _ = ops.conv2d_nhwc(x, H, W, P[p + "conv_skip.0.w.nhwc"], 3, 1, 1, bias=P[p + "conv_skip.0.b"])
+    y, _, _ = ops.conv2d_nhwc(x, H, W, P[p + "conv1.w.nhwc"], 3, 1, 1, bias=P[p + "conv1.b"], act=ops.ACT_RELU)
+    out, _, _ = ops.conv2d_nhwc(y, H, W, P[p + "conv2.w.nhwc"], 3, 1, 1, bias=P[p + "conv2.b"], res=skip, act=ops.ACT_RELU)
+    return out
+
+
+def upsample_stage_nhwc(P, name: str, low, h, w, skip):
+    """imagenet.py:431-444 on NHWC maps: low (h*w, C1), skip (4hw, C2) -> (4hw, Cout)."""
+    x = ops.upsample2x_cat_nhwc(low, h, w, skip)
+    x = _residual_conv_nhwc(P, name + ".conv.0.", x, 2 * h, 2 * w)
+    return _residual_conv_nhwc(P, name + ".conv.1.", x, 2 * h, 2 * w)

@@ -72,6 +72,9 @@ class CoFiI2P(nn.Module):
         self.compute_unused_image_maps = True  # layer3/layer4/avg-pool of the ResNet (network.py:87-89)
         self._use_graphs = False
         self._graphs = {}
+        import os
+
+        self.image_backend = os.environ.get("COFI_IMAGE", "nhwc")  # "nhwc": implicit-GEMM HIP convolutions; "miopen": A/B only
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
         self.eval()
 
@@ -140,13 +143,20 @@ class CoFiI2P(nn.Module):
         T_img, C = H8 * W8, D_MODEL
         ts = transformer.TokenStreams(T_img, N4, D_MODEL, dev)
         # ---- image branch (network.py:77,90,104-106,110) on a side stream, concurrent with the point encoder
+        nhwc = self.image_backend == "nhwc"
         with ops.Branch(dev, 0) as br_img:
-            img_set = image.resnet34(P, img, full=self.compute_unused_image_maps)
-            s2, s4, s8 = img_set[0], img_set[1], img_set[2]
-            s8n, _ = ops.l2norm_cols(s8[0].reshape(C, T_img), tokens_out=ts.img[0][:, :D_MODEL])
             gy, gx = torch.meshgrid(torch.arange(H8, device=dev, dtype=torch.int32), torch.arange(W8, device=dev, dtype=torch.int32),
                                     indexing="ij")
             grid = torch.stack([gy, gx], -1).reshape(T_img, 2).contiguous()
+            if nhwc:
+                img_set, dims = image.resnet34_nhwc(P, img, full=self.compute_unused_image_maps)
+                s2, s4, s8 = img_set[0], img_set[1], img_set[2]  # (H*W, C) pixel-major
+                s8n = ops.l2norm_rows(s8)  # the normalised s8 map also feeds the up-sampler (network.py:90,129)
+                ops.l2norm_rows(s8, out=ts.img[0][:, :D_MODEL])
+            else:
+                img_set = image.resnet34(P, img, full=self.compute_unused_image_maps)
+                s2, s4, s8 = img_set[0], img_set[1], img_set[2]
+                s8n, _ = ops.l2norm_cols(s8[0].reshape(C, T_img), tokens_out=ts.img[0][:, :D_MODEL])
             ops.pos_sine(grid, ts.img[0], accumulate=True)
         # ---- point branch (network.py:76,83-84,107,111)
         pc_set = kpfpn.run_fpn(P, points, neighbors, subsampling, upsampling, feats, taps=taps)
@@ -159,11 +169,17 @@ class CoFiI2P(nn.Module):
 
         # ---- fine image descriptors (network.py:129-130): only image data -> side stream, under the transformer
         with ops.Branch(dev, 0) as br_up:
-            up4 = image.upsample_stage(P, "img_upsample_1", s8n.reshape(1, C, H8, W8), s4)
-            up2_raw = image.upsample_stage(P, "img_upsample_2", up4, s2)
-            C2, H2, W2 = up2_raw.shape[1:]
-            up2, _ = ops.l2norm_cols(up2_raw[0].reshape(C2, H2 * W2), want_tokens=False)
-            up2 = up2.reshape(C2, H2, W2)
+            if nhwc:
+                up4 = image.upsample_stage_nhwc(P, "img_upsample_1", s8n, H8, W8, s4)
+                up2_raw = image.upsample_stage_nhwc(P, "img_upsample_2", up4, 2 * H8, 2 * W8, s2)
+                H2, W2, C2 = 4 * H8, 4 * W8, up2_raw.shape[1]
+                up2 = ops.l2norm_rows(up2_raw)  # (H2*W2, C2) pixel-major fine image descriptors
+            else:
+                up4 = image.upsample_stage(P, "img_upsample_1", s8n.reshape(1, C, H8, W8), s4)
+                up2_raw = image.upsample_stage(P, "img_upsample_2", up4, s2)
+                C2, H2, W2 = up2_raw.shape[1:]
+                up2, _ = ops.l2norm_cols(up2_raw[0].reshape(C2, H2 * W2), want_tokens=False)
+                up2 = up2.reshape(C2, H2, W2)
 
         # ---- transformer (network.py:113-115)
         tok_img, tok_pc = transformer.run_transformer(self._layers, LAYER_KINDS, ts, N_HEAD)
@@ -186,7 +202,8 @@ class CoFiI2P(nn.Module):
             cnt = torch.zeros((2,), dtype=torch.int32, device=dev)
             cnt[0] = K
             ctr = fine_center_kpt_coors.to(torch.float32).contiguous()
-            out["patches"] = ops.extract_patches(up2, ctr, cnt, K, 1.0).reshape(K, C2, 4, 4)
+            pat = ops.extract_patches_nhwc(up2, H2, W2, ctr, cnt, K, 1.0) if nhwc else ops.extract_patches(up2, ctr, cnt, K, 1.0)
+            out["patches"] = pat.reshape(K, C2, 4, 4)
             out["fine_pc"] = ops.gather_rows(fine_pc, self._as_idx32(fine_pc_inline_index.reshape(-1)))
             return out
         # ---- test mode: coarse matching + patch extraction (network.py:145-161), count stays on the device
@@ -195,7 +212,7 @@ class CoFiI2P(nn.Module):
         sel, xy, cnt = ops.select_matches(pc_score.reshape(-1), pix, W8, H8, score_thresholds(), 4)
         out["coarse_pts"] = ops.gather_points_sel(points[-1], sel, cnt)
         node = ops.nearest_node_sel(points[1], points[-1], sel, cnt)
-        out["patches"] = ops.extract_patches(up2, xy, cnt, N4, 4.0)
+        out["patches"] = ops.extract_patches_nhwc(up2, H2, W2, xy, cnt, N4, 4.0) if nhwc else ops.extract_patches(up2, xy, cnt, N4, 4.0)
         out["fine_pc"] = ops.gather_rows_sel(fine_pc, node, cnt, N4)
         out["fine_xy"], out["fine_best"] = ops.fine_match(out["patches"], out["fine_pc"], xy, cnt, 4.0)  # eval_all.py:99-105
         out.update(sel=sel, coarse_xy=xy, count=cnt)

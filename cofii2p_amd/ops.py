@@ -358,7 +358,73 @@ def pos_sine(coords, out, accumulate: bool, d_model: int = 128):
     return out
 
 
-# ------------------------------------------------------------------------------------------ image-branch glue
+# ------------------------------------------------------------------------------------------ image branch, NHWC
+def conv2d_nhwc(x, H: int, W: int, w, ks: int, stride: int = 1, pad: int = 1, bias=None, res=None, act: int = ACT_NONE,
+                colstats: bool = False, out=None):
+    """Implicit-GEMM convolution on an NHWC map x (H*W, Cin) [row-major view, any leading dimension];
+    w (Cout, ks*ks*Cin).  -> y (Ho*Wo, Cout) [, colpart]."""
+    lib = _lib.load()
+    _mat(x, "x"), _mat(w, "w")
+    Cin, Cout = x.shape[1], w.shape[0]
+    if x.shape[0] != H * W or w.shape[1] != ks * ks * Cin:
+        raise _lib.CofiError("conv2d_nhwc: shape mismatch x %s w %s H %d W %d ks %d" % (tuple(x.shape), tuple(w.shape), H, W, ks))
+    Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    M, K = Ho * Wo, ks * ks * Cin
+    if out is None:
+        out = torch.empty((M, Cout), dtype=torch.float32, device=x.device)
+    part = None
+    if colstats:
+        part = torch.empty((lib.cofi_gemm_f32_stat_slabs(M, Cout, K), Cout, 2), dtype=torch.float32, device=x.device)
+    ws = _WS_GEMM.get(lib.cofi_gemm_f32_workspace(M, Cout, K), x.device)
+    rc = lib.cofi_conv2d_nhwc(_p(x), _ld(x), H, W, Cin, _p(w), Cout, ks, stride, pad, _p(bias), _p(res), 0 if res is None else _ld(res),
+                              act | _gemm_flag(), _p(out), _ld(out), _p(part), _p(ws), 0 if ws is None else ws.numel(), _stream())
+    _lib.check(rc, "cofi_conv2d_nhwc")
+    return (out, part, Ho, Wo) if colstats else (out, Ho, Wo)
+
+
+def im2col_stem(img_chw, kpad: int = 160):
+    lib = _lib.load()
+    C, H, W = img_chw.shape
+    if C != 3 or not img_chw.is_contiguous():
+        raise _lib.CofiError("im2col_stem: contiguous (3,H,W) image expected")
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((Ho * Wo, kpad), dtype=torch.float32, device=img_chw.device)
+    _lib.check(lib.cofi_im2col_stem(_p(img_chw), H, W, kpad, _p(out), _stream()), "cofi_im2col_stem")
+    return out, Ho, Wo
+
+
+def maxpool3x3s2_nhwc(x, H: int, W: int):
+    lib = _lib.load()
+    C = x.shape[1]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((Ho * Wo, C), dtype=torch.float32, device=x.device)
+    _lib.check(lib.cofi_maxpool3x3s2_nhwc(_p(x), H, W, C, _p(out), _stream()), "cofi_maxpool3x3s2_nhwc")
+    return out, Ho, Wo
+
+
+def upsample2x_cat_nhwc(low, h: int, w: int, skip):
+    """low (h*w, C1), skip (4*h*w, C2) -> (4*h*w, C1+C2)."""
+    lib = _lib.load()
+    _mat(low, "low"), _mat(skip, "skip")
+    C1, C2 = low.shape[1], skip.shape[1]
+    out = torch.empty((4 * h * w, C1 + C2), dtype=torch.float32, device=low.device)
+    _lib.check(lib.cofi_upsample2x_cat_nhwc(_p(low), _ld(low), C1, h, w, _p(skip), _ld(skip), C2, _p(out), _ld(out), _stream()),
+               "cofi_upsample2x_cat_nhwc")
+    return out
+
+
+def extract_patches_nhwc(fmap, H2: int, W2: int, xy, cnt, cap: int, center_scale: float):
+    lib = _lib.load()
+    _mat(fmap, "fmap")
+    C = fmap.shape[1]
+    out = torch.empty((cap, C, 16), dtype=torch.float32, device=fmap.device)
+    rc = lib.cofi_extract_patches_nhwc(_p(fmap), _ld(fmap), C, H2, W2, _p(xy), xy.stride(0), float(center_scale), _p(cnt), cap, _p(out),
+                                       _stream())
+    _lib.check(rc, "cofi_extract_patches_nhwc")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ image-branch glue (NCHW / MIOpen variant)
 def instance_norm_nchw(x, relu: bool = False, res=None, res_norm: bool = False, eps: float = 1e-5):
     """x (1,C,H,W) contiguous -> relu?(IN(x) + [res | IN(res)])."""
     lib = _lib.load()

@@ -186,7 +186,27 @@ int cofi_transpose(const float *x, int ldx, int M, int C, float *y, int ldy, cof
 int cofi_l2norm_cols(const float *x, int ldx, int C, int P, float *y_cp, int ldy, float *y_pc, int ldt, cofi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * K13 glue (the dense convolutions themselves run through MIOpen): channel-major (C, P = H*W) maps.
+ * K13  image convolutions as implicit GEMM on the same MFMA kernel (no im2col buffer): x is an NHWC map
+ * (H*W rows, ldx floats per pixel: a channel-concatenation is just a wider row), Wt is (Cout, ks*ks*Cin) with
+ * k = (dy*ks + dx)*Cin + c, output y is NHWC (Ho*Wo, Cout).  ks in {1,3}, Cin % 4 == 0.
+ *   y = act( conv(x) + bias + res )    and, if colpart != NULL, per-slab column statistics (InstanceNorm2d
+ * statistics of model/imagenet.py:123 are per-channel = per-column; slab count / workspace as for
+ * cofi_gemm_f32 with M = Ho*Wo, N = Cout, K = ks*ks*Cin).  Replaces nn.Conv2d of model/imagenet.py:25-33,
+ * 137,380-395 (ResNet-34 trunk, ResidualConv).  `act` may carry COFI_GEMM_BF16X3.
+ * cofi_im2col_stem: the 7x7/2 pad-3 stem convolution on the 3-channel NCHW image (imagenet.py:137) as
+ *   an explicit (Ho*Wo, Kpad) matrix, k = (dy*7 + dx)*3 + c, zero padded to Kpad.
+ * cofi_maxpool3x3s2_nhwc: nn.MaxPool2d(3, 2, 1) (imagenet.py:141).
+ * cofi_upsample2x_cat_nhwc: bilinear x2 (align_corners=False) of `low` + channel concat with `skip`
+ *   (imagenet.py:433,441-443), NHWC. */
+int cofi_conv2d_nhwc(const float *x, int ldx, int H, int W, int Cin, const float *Wt, int Cout, int ks, int stride, int pad,
+                     const float *bias, const float *res, int ldr, int act, float *y, int ldy, float *colpart, void *ws, size_t ws_bytes,
+                     cofi_stream_t stream);
+int cofi_im2col_stem(const float *img_chw, int H, int W, int Kpad, float *out, cofi_stream_t stream);
+int cofi_maxpool3x3s2_nhwc(const float *x, int H, int W, int C, float *y, cofi_stream_t stream);
+int cofi_upsample2x_cat_nhwc(const float *low, int ldl, int C1, int h, int w, const float *skip, int lds, int C2, float *out, int ldo,
+                             cofi_stream_t stream);
+
+/* K13 glue, channel-major (C, P = H*W) variants (used when the convolutions run through MIOpen instead).
  * cofi_instance_norm_nchw: y[c,:] = relu?( IN(x[c,:]) + R ), IN = affine-less InstanceNorm2d (eps, biased
  *   variance; model/imagenet.py:123), R = 0 (res_mode 0) | res[c,:] (1) | IN(res[c,:]) (2): the BasicBlock tail of
  *   model/imagenet.py:58-73.  P % 4 == 0.
@@ -222,6 +242,9 @@ int cofi_gather_points_sel(const float *pts, const int32_t *sel, const int32_t *
                            cofi_stream_t stream);
 int cofi_extract_patches(const float *fmap, int C, int H2, int W2, const float *coarse_xy, int ldxy, float center_scale,
                          const int32_t *count_dev, int cap, float *patches, cofi_stream_t stream);
+/* same, reading an NHWC map (H2*W2 rows of ldf floats) */
+int cofi_extract_patches_nhwc(const float *fmap, int ldf, int C, int H2, int W2, const float *coarse_xy, int ldxy, float center_scale,
+                              const int32_t *count_dev, int cap, float *patches, cofi_stream_t stream);
 int cofi_gather_rows_sel(const float *x, int ldx, int C, const int32_t *row_idx, const int32_t *count_dev, int cap, float *out,
                          int ldo, cofi_stream_t stream);
 int cofi_fine_match(const float *patches, const float *pc_feats, int ldp, int C, const float *coarse_xy, int ldxy,

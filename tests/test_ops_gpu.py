@@ -308,3 +308,54 @@ def test_image_glue_kernels(ops):
     low, skip = torch.randn(1, 128, 20, 64, generator=g), torch.randn(1, 64, 40, 128, generator=g)
     ref = torch.cat([F.interpolate(low, scale_factor=2, mode="bilinear", align_corners=False), skip], 1)
     close(ops.upsample2x_cat(G(low), G(skip)), ref, 1e-6)
+
+
+def _nhwc(t):  # (1,C,H,W) -> (H*W, C)
+    return t[0].permute(1, 2, 0).reshape(-1, t.shape[1]).contiguous()
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,ks,stride,pad", [(64, 64, 40, 128, 3, 1, 1), (64, 128, 40, 128, 3, 2, 1), (64, 128, 40, 128, 1, 2, 0),
+                                                        (192, 128, 40, 128, 3, 1, 1), (256, 512, 10, 32, 3, 2, 1), (32, 16, 7, 9, 3, 1, 1)])
+def test_conv2d_nhwc_implicit_gemm(ops, Cin, Cout, H, W, ks, stride, pad):
+    import torch.nn.functional as F
+
+    from cofii2p_amd.image import _nhwc_weight
+
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(1, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    y, Ho, Wo = ops.conv2d_nhwc(G(_nhwc(x)), H, W, G(_nhwc_weight(w)), ks, stride, pad, bias=G(b))
+    assert (Ho, Wo) == tuple(ref.shape[2:])
+    close(y, _nhwc(ref), 2e-4)
+    r = torch.randn(Ho * Wo, Cout, generator=g)
+    y2, part, _, _ = ops.conv2d_nhwc(G(_nhwc(x)), H, W, G(_nhwc_weight(w)), ks, stride, pad, bias=G(b), res=G(r), act=ops.ACT_RELU, colstats=True)
+    refr = torch.relu(_nhwc(ref) + r)
+    close(y2, refr, 2e-4)
+    st = ops.group_stats_from_colpart(part, Ho * Wo, Cout).cpu()
+    close(st[:, 0], refr.mean(0), 2e-4)
+
+
+def test_image_nhwc_glue(ops):
+    import torch.nn.functional as F
+
+    from cofii2p_amd.image import _nhwc_weight
+
+    g = torch.Generator().manual_seed(4)
+    img = torch.rand(1, 3, 64, 96, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    col, Ho, Wo = ops.im2col_stem(G(img[0]))
+    y = ops.gemm(col, G(_nhwc_weight(w, 160)))
+    close(y, _nhwc(F.conv2d(img, w, stride=2, padding=3)), 2e-4)
+    x = torch.randn(1, 64, 32, 48, generator=g)
+    yp, H2, W2 = ops.maxpool3x3s2_nhwc(G(_nhwc(x)), 32, 48)
+    close(yp, _nhwc(F.max_pool2d(x, 3, 2, 1)), 0)
+    low, skip = torch.randn(1, 128, 20, 64, generator=g), torch.randn(1, 64, 40, 128, generator=g)
+    ref = torch.cat([F.interpolate(low, scale_factor=2, mode="bilinear", align_corners=False), skip], 1)
+    close(ops.upsample2x_cat_nhwc(G(_nhwc(low)), 20, 64, G(_nhwc(skip))), _nhwc(ref), 1e-6)
+    # InstanceNorm + ReLU + residual through the per-channel GroupNorm machinery
+    xm = _nhwc(x)
+    yv, part = ops.gemm_colstats(G(xm), G(torch.eye(64)))
+    out = ops.group_norm_apply(yv, ops.group_stats_from_colpart(part, xm.shape[0], 64), slope=0.0, res=G(xm))
+    close(out, _nhwc(F.relu(F.instance_norm(x) + x)), 2e-5)
