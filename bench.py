@@ -61,7 +61,7 @@ class KernelTimer:
     algorithmic work.  Pass 2 replays, per entry point, exactly those launches back-to-back inside one
     hipGraph and times the replay with events: no CPU launch gaps, the same shapes/data as the frame."""
 
-    NAMES = ("gemm", "gemm_colstats", "gemm_layernorm", "group_stats_from_colpart", "col_inv_norm_from_colpart", "kpconv_aggregate", "attention", "neighbor_maxpool", "group_stats", "group_norm_apply", "layer_norm", "l2norm_rows",
+    NAMES = ("gemm", "gemm_colstats", "gemm_layernorm", "conv2d_nhwc", "group_stats_from_colpart", "col_inv_norm_from_colpart", "kpconv_aggregate", "attention", "neighbor_maxpool", "group_stats", "group_norm_apply", "layer_norm", "l2norm_rows",
              "gather_rows", "row_sum_positive", "col_inv_norm")
 
     def __init__(self):
@@ -73,6 +73,13 @@ class KernelTimer:
             M, K = a[0].shape
             N = a[1].shape[0]
             return 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)
+        if name == "conv2d_nhwc":
+            x, H, W, w, ks = a[0], a[1], a[2], a[3], a[4]
+            stride = a[5] if len(a) > 5 else k.get("stride", 1)
+            pad = a[6] if len(a) > 6 else k.get("pad", 1)
+            Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+            M, N, K = Ho * Wo, w.shape[0], w.shape[1]
+            return 2.0 * M * N * K, 4.0 * (x.numel() + w.numel() + M * N)
         if name == "kpconv_aggregate":
             feats, idx = a[0], a[3]
             M, H = idx.shape
@@ -273,9 +280,9 @@ def main():
         kt.record(model, frames[0])
         per = kt.measure()
         del kt
-        # the three GEMM entry points launch the same MFMA kernel (different fused epilogues): one roofline row
+        # the GEMM / implicit-GEMM convolution entry points launch the same MFMA kernel (different loaders / epilogues): one roofline row
         gsum = {"seconds_per_frame": 0.0, "flops_per_frame": 0.0, "bytes_per_frame": 0.0, "launches_per_frame": 0}
-        for n in ("gemm", "gemm_colstats", "gemm_layernorm"):
+        for n in ("gemm", "gemm_colstats", "gemm_layernorm", "conv2d_nhwc"):
             if n in per:
                 for k in gsum:
                     gsum[k] += per[n][k]

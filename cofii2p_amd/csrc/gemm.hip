@@ -92,60 +92,84 @@ template <int ROWS, int BN, bool FROM_WS>
 __device__ __forceinline__ void rowwise_epilogue(const GemmArgs &g, const float *tile, int TLD, int m0, int n0, int slab, float *red) {
     constexpr int TPR = BN / 4;        // threads per row
     constexpr int RPP = 256 / TPR;     // rows per pass
+    constexpr int NP = ROWS / RPP;     // passes
     const int tc = threadIdx.x % TPR, tr = threadIdx.x / TPR;
     const int col = n0 + 4 * tc;
     const bool vec_ok = ((g.N & 3) == 0) && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
+    const bool res_vec = g.res && ((g.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.res) & 15) == 0) && col + 3 < g.N;
     float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
-    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias) {
+    // column-indexed parameters are loop invariant: load them once
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f}, gam4[4] = {1.f, 1.f, 1.f, 1.f}, bet4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (col + e < g.N) bias4[e] = g.bias[col + e];
-    }
-    for (int r0 = 0; r0 < ROWS; r0 += RPP) {
-        const int rl = r0 + tr, row = m0 + rl;
+    for (int e = 0; e < 4; ++e)
+        if (col + e < g.N) {
+            if (g.bias) bias4[e] = g.bias[col + e];
+            if (g.ln_gamma) { gam4[e] = g.ln_gamma[col + e]; bet4[e] = g.ln_beta[col + e]; }
+        }
+    // phase 1: issue every row-indexed load of all passes (independent, so their latencies overlap)
+    float v[NP][4], rs[NP][4], rd[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int rl = p * RPP + tr, row = m0 + rl;
         const bool rin = row < g.M;
-        float v[4];
+        rd[p] = (g.rowdiv && rin) ? g.rowdiv[row] : 1.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rs[p][e] = 0.f;
+        if (g.res && rin) {
+            const float *rp = g.res + (size_t)row * g.ldr + col;
+            if (res_vec) {
+                const float4 t = *reinterpret_cast<const float4 *>(rp);
+                rs[p][0] = t.x; rs[p][1] = t.y; rs[p][2] = t.z; rs[p][3] = t.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < g.N) rs[p][e] = rp[e];
+            }
+        }
         if constexpr (FROM_WS) {
-            v[0] = v[1] = v[2] = v[3] = 0.f;
+            v[p][0] = v[p][1] = v[p][2] = v[p][3] = 0.f;
             if (rin) {
                 const size_t total = (size_t)g.M * g.N;
                 for (int z = 0; z < g.ksplit; ++z) {
-                    const float *p = g.ws + (size_t)z * total + (size_t)row * g.N + col;
+                    const float *q = g.ws + (size_t)z * total + (size_t)row * g.N + col;
                     if ((g.N & 3) == 0 && col < g.N) {
-                        const float4 t = *reinterpret_cast<const float4 *>(p);
-                        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                        const float4 t = *reinterpret_cast<const float4 *>(q);
+                        v[p][0] += t.x; v[p][1] += t.y; v[p][2] += t.z; v[p][3] += t.w;
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (col + e < g.N) v[e] += p[e];
+                            if (col + e < g.N) v[p][e] += q[e];
                     }
                 }
             }
         } else {
             const float4 t = *reinterpret_cast<const float4 *>(tile + rl * TLD + 4 * tc);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            v[p][0] = t.x; v[p][1] = t.y; v[p][2] = t.z; v[p][3] = t.w;
         }
-        const float rd = (g.rowdiv && rin) ? g.rowdiv[row] : 1.0f;
+    }
+    // phase 2: arithmetic + stores
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int row = m0 + p * RPP + tr;
+        const bool rin = row < g.M;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float x = v[e];
-            if (g.rowdiv) x = x / rd;
-            x += bias4[e];
-            v[e] = x;
+            float x = v[p][e];
+            if (g.rowdiv) x = x / rd[p];
+            v[p][e] = x + bias4[e];
         }
         if (g.ln_gamma) {
             // LayerNorm over the N (<= BN) columns of this row: the TPR threads of a row are adjacent lanes
             float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s += (col + e < g.N) ? v[e] : 0.f;
+            for (int e = 0; e < 4; ++e) s += (col + e < g.N) ? v[p][e] : 0.f;
 #pragma unroll
             for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o, 64);
             const float mean = s / (float)g.N;
             float q = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float d = v[e] - mean;
+                const float d = v[p][e] - mean;
                 q += (col + e < g.N) ? d * d : 0.f;
             }
 #pragma unroll
@@ -153,37 +177,29 @@ __device__ __forceinline__ void rowwise_epilogue(const GemmArgs &g, const float 
             const float rstd = 1.0f / sqrtf(q / (float)g.N + g.ln_eps);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (col + e < g.N) {
-                    float x = (v[e] - mean) * rstd * g.ln_gamma[col + e] + g.ln_beta[col + e];
-                    if (g.ln_relu) x = fmaxf(x, 0.f);
-                    if (g.res && rin) x += g.res[(size_t)row * g.ldr + col + e];
-                    v[e] = x;
-                }
+                float x = (v[p][e] - mean) * rstd * gam4[e] + bet4[e];
+                if (g.ln_relu) x = fmaxf(x, 0.f);
+                v[p][e] = x + rs[p][e];
             }
         } else {
-            if (g.res && rin) {  // plain residual (second conv of a ResidualConv + its skip conv): added before the activation
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (col + e < g.N) v[e] += g.res[(size_t)row * g.ldr + col + e];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], g.act);
+            for (int e = 0; e < 4; ++e) v[p][e] = apply_act(v[p][e] + rs[p][e], g.act);  // residual before the activation
         }
         if (rin) {
             if (g.colpart) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    cs[e] += v[e];
-                    cq[e] += v[e] * v[e];
+                    cs[e] += v[p][e];
+                    cq[e] += v[p][e] * v[p][e];
                 }
             }
             float *dst = g.C + (size_t)row * g.ldc + col;
             if (vec_ok && col + 3 < g.N) {
-                *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4 *>(dst) = make_float4(v[p][0], v[p][1], v[p][2], v[p][3]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (col + e < g.N) dst[e] = v[e];
+                    if (col + e < g.N) dst[e] = v[p][e];
             }
         }
     }
@@ -341,44 +357,75 @@ __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
     lo.y = cvt_pk_bf16(rz, rw);
 }
 
-template <int BM, int BN, int TM, int TN>
+// K-tile of 128 per iteration (BK3): at batch 1 most problems give <= 1 workgroup per CU, so the loop is bound by
+// the L2/HBM round trip per k-tile, not by the matrix cores; a 4x deeper tile keeps 4x the bytes in flight per wave
+// and needs 4x fewer barriers.  One LDS buffer + a register-staged next tile:
+//   issue global loads (t+1) -> MFMAs on tile t from LDS -> barrier -> split + write tile t+1 -> barrier.
+// (The 128x128 tile uses BK3 = 64: 128 would need 139 KB of LDS and the whole VGPR file for one workgroup.)
+template <int BM, int BN, int TM, int TN, int BK3>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 waves");
-    constexpr int A_LD4 = BM / 32, W_LD4 = BN / 32;
+    constexpr int BROW3 = BK3 * 2 + 16;   // bytes per LDS row: bf16 values + 16 B pad (68 / 36 dwords: conflict-free b128 reads)
+    constexpr int LPR = BK3 / 4;          // lanes per row slice (float4 each)
+    constexpr int RPP = 256 / LPR;        // rows per staging pass
+    constexpr int A_LD4 = BM / RPP, W_LD4 = BN / RPP;            // float4 loads per thread and tile
     constexpr int TLD = BN + 4;
-    constexpr int PLANE_A = BM * BROW, PLANE_W = BN * BROW;      // bytes
+    constexpr int PLANE_A = BM * BROW3, PLANE_W = BN * BROW3;    // bytes
     constexpr int BUF = 2 * (PLANE_A + PLANE_W);                 // hi+lo of A and W
-    static_assert(BM * TLD * 4 <= 2 * BUF, "epilogue tile must fit in the operand buffers");
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * BUF];
+    static_assert(BM * TLD * 4 <= BUF, "epilogue tile must fit in the operand buffer");
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
-    const int ntiles = (kend - kbeg + BK - 1) / BK;
-    const int lrow = tid >> 3, lk = (tid & 7) * 4;
+    const int ntiles = (kend - kbeg + BK3 - 1) / BK3;
+    const int lrow = tid / LPR, lk = (tid % LPR) * 4;            // LPR lanes cover one row slice; RPP rows per pass
     float4 ra[A_LD4], rw[W_LD4];
-    ATileLoader<A_LD4> aload;
-    aload.init(g, m0, lrow);
 
+    // conv-mode pixel coordinates of this thread's A rows (row = m0 + lrow + 8j)
+    int yo[A_LD4], xo[A_LD4];
+    if (g.cv_ks) {
+#pragma unroll
+        for (int j = 0; j < A_LD4; ++j) {
+            const int r = m0 + lrow + RPP * j;
+            yo[j] = r / g.cv_Wo;
+            xo[j] = r - yo[j] * g.cv_Wo;
+        }
+    }
     auto gload = [&](int t) {
-        const int k = kbeg + t * BK + lk;
+        const int k = kbeg + t * BK3 + lk;
         const bool kin = k < kend;
-        aload.load(g, m0, lrow, k, kin, ra);
+        if (g.cv_ks == 0) {
+#pragma unroll
+            for (int j = 0; j < A_LD4; ++j) {
+                const int r = m0 + lrow + RPP * j;
+                ra[j] = (kin && r < g.M) ? *reinterpret_cast<const float4 *>(g.A + (size_t)r * g.lda + k) : make_float4(0, 0, 0, 0);
+            }
+        } else {
+            const int tap = k / g.cv_Cin, c = k - tap * g.cv_Cin;
+            const int dy = tap / g.cv_ks, dx = tap - dy * g.cv_ks;
+#pragma unroll
+            for (int j = 0; j < A_LD4; ++j) {
+                const int r = m0 + lrow + RPP * j;
+                const int yi = yo[j] * g.cv_stride - g.cv_pad + dy, xi = xo[j] * g.cv_stride - g.cv_pad + dx;
+                const bool ok = kin && r < g.M && (unsigned)yi < (unsigned)g.cv_H && (unsigned)xi < (unsigned)g.cv_W;
+                ra[j] = ok ? *reinterpret_cast<const float4 *>(g.A + ((size_t)yi * g.cv_W + xi) * g.lda + c) : make_float4(0, 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < W_LD4; ++j) {
-            const int r = n0 + lrow + 32 * j;
+            const int r = n0 + lrow + RPP * j;
             rw[j] = (kin && r < g.N) ? *reinterpret_cast<const float4 *>(g.W + (size_t)r * g.ldw + k) : make_float4(0, 0, 0, 0);
         }
     };
-    auto sstore = [&](int buf) {
-        unsigned char *base = lds_raw + buf * BUF;
+    auto sstore = [&]() {
 #pragma unroll
         for (int j = 0; j < A_LD4; ++j) {
             uint2 hi, lo;
             split4(ra[j], hi, lo);
-            unsigned char *p = base + (lrow + 32 * j) * BROW + lk * 2;
+            unsigned char *p = lds_raw + (lrow + RPP * j) * BROW3 + lk * 2;
             *reinterpret_cast<uint2 *>(p) = hi;
             *reinterpret_cast<uint2 *>(p + PLANE_A) = lo;
         }
@@ -386,7 +433,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
         for (int j = 0; j < W_LD4; ++j) {
             uint2 hi, lo;
             split4(rw[j], hi, lo);
-            unsigned char *p = base + 2 * PLANE_A + (lrow + 32 * j) * BROW + lk * 2;
+            unsigned char *p = lds_raw + 2 * PLANE_A + (lrow + RPP * j) * BROW3 + lk * 2;
             *reinterpret_cast<uint2 *>(p) = hi;
             *reinterpret_cast<uint2 *>(p + PLANE_W) = lo;
         }
@@ -402,29 +449,28 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
 
     if (ntiles > 0) {
         gload(0);
-        sstore(0);
+        sstore();
     }
     __syncthreads();
 
     const int li = lane & 31, lh = lane >> 5;
     union Frag { uint4 u; bf16x8 v; };
+    const unsigned char *as = lds_raw + (wm * 32 * TM + li) * BROW3 + lh * 16;
+    const unsigned char *bs = lds_raw + 2 * PLANE_A + (wn * 32 * TN + li) * BROW3 + lh * 16;
     for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
         if (t + 1 < ntiles) gload(t + 1);
-        const unsigned char *as = lds_raw + buf * BUF + (wm * 32 * TM + li) * BROW + lh * 16;
-        const unsigned char *bs = lds_raw + buf * BUF + 2 * PLANE_A + (wn * 32 * TN + li) * BROW + lh * 16;
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {  // two 16-deep MFMA steps per 32-deep tile; lane (i,h) owns k = 16*s2 + 8h .. +7
+        for (int s2 = 0; s2 < BK3 / 16; ++s2) {  // 16-deep MFMA steps; lane (i,h) owns k = 16*s2 + 8h .. +7
             Frag ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                ah[i].u = *reinterpret_cast<const uint4 *>(as + i * 32 * BROW + s2 * 32);
-                al[i].u = *reinterpret_cast<const uint4 *>(as + PLANE_A + i * 32 * BROW + s2 * 32);
+                ah[i].u = *reinterpret_cast<const uint4 *>(as + i * 32 * BROW3 + s2 * 32);
+                al[i].u = *reinterpret_cast<const uint4 *>(as + PLANE_A + i * 32 * BROW3 + s2 * 32);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                bh[j].u = *reinterpret_cast<const uint4 *>(bs + j * 32 * BROW + s2 * 32);
-                bl[j].u = *reinterpret_cast<const uint4 *>(bs + PLANE_W + j * 32 * BROW + s2 * 32);
+                bh[j].u = *reinterpret_cast<const uint4 *>(bs + j * 32 * BROW3 + s2 * 32);
+                bl[j].u = *reinterpret_cast<const uint4 *>(bs + PLANE_W + j * 32 * BROW3 + s2 * 32);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -435,8 +481,11 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bh[j].v, acc[i][j], 0, 0, 0);
                 }
         }
-        if (t + 1 < ntiles) sstore(buf ^ 1);
-        __syncthreads();
+        __syncthreads();              // every wave is done reading tile t
+        if (t + 1 < ntiles) {
+            sstore();
+            __syncthreads();          // tile t+1 visible
+        }
     }
 
     float *lds = reinterpret_cast<float *>(lds_raw);
@@ -503,15 +552,16 @@ Plan make_plan(int M, int N, int K, bool fused_ln) {
     int ktiles = cofi_cdiv(K, BK);
     int ks = 1;
     // Split K only when the serial k-loop is long: a split costs a second kernel (the reduction epilogue,
-    // ~5 us of launch + latency), which a loop of <= 8 k-tiles (K <= 256) cannot win back.
-    if (nb < 384 && ktiles > 8) {
+    // ~5 us of launch + latency), which a loop of <= 16 k-tiles (K <= 512) cannot win back.
+    if (nb < 384 && ktiles > 16) {
         ks = (int)((512 + nb - 1) / nb);
-        int maxks = ktiles / 4;
+        int maxks = ktiles / 8;  // >= 256 k-values per split
         if (maxks < 1) maxks = 1;
         if (ks > maxks) ks = maxks;
         if (ks > 32) ks = 32;
     }
     int tiles_per = cofi_cdiv(ktiles, ks);
+    tiles_per = (tiles_per + 3) & ~3;  // k-chunks in multiples of 128: the bf16x3 kernel steps K by 128
     p.kchunk = tiles_per * BK;
     p.ksplit = cofi_cdiv(K, p.kchunk);
     if (fused_ln && p.ksplit == 1 && p.bn < N) {  // un-split: one tile must span the whole row (N <= 128)
@@ -528,11 +578,11 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
     dim3 grid(cofi_cdiv(g.N, p.bn), cofi_cdiv(g.M, p.bm), p.ksplit);
     if (g.bf16x3) {
         if (p.bm == 128 && p.bn == 128)
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, g);
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<128, 128, 2, 2, 64>), grid, dim3(256), 0, s, g);
         else if (p.bm == 64 && p.bn == 128)
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<64, 128, 1, 2>), grid, dim3(256), 0, s, g);
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<64, 128, 1, 2, 128>), grid, dim3(256), 0, s, g);
         else
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<64, 64, 1, 1>), grid, dim3(256), 0, s, g);
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<64, 64, 1, 1, 128>), grid, dim3(256), 0, s, g);
     } else if (p.bm == 128 && p.bn == 128)
         hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, g);
     else if (p.bm == 64 && p.bn == 128)

@@ -470,6 +470,25 @@ def attention(q, k, v, q_colscale=None, nhead: int = 4, out=None):
     return out
 
 
+def split_bf16(w: torch.Tensor):
+    """fp32 -> (hi, lo) bf16 planes as int16 tensors: hi = bf16(w) (RNE), lo = bf16(w - hi)."""
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
+    return hi.contiguous().view(torch.int16), lo.contiguous().view(torch.int16)
+
+
+def loftr_tail(msg, x, w, out, eps: float = 1e-5):
+    """out = x + LN2(relu([x | LN1(msg Wm^T)] W0^T) W2^T) in one kernel; `w` holds the pre-split planes."""
+    lib = _lib.load()
+    _mat(msg, "msg"), _mat(x, "x"), _mat(out, "out")
+    L = msg.shape[0]
+    rc = lib.cofi_loftr_tail_bf16x3(_p(msg), _ld(msg), _p(x), _ld(x), _p(w["merge.hi"]), _p(w["merge.lo"]), _p(w["norm1.weight"]),
+                                    _p(w["norm1.bias"]), _p(w["mlp.0.hi"]), _p(w["mlp.0.lo"]), _p(w["mlp.2.hi"]), _p(w["mlp.2.lo"]),
+                                    _p(w["norm2.weight"]), _p(w["norm2.bias"]), eps, _p(out), _ld(out), L, _stream())
+    _lib.check(rc, "cofi_loftr_tail_bf16x3")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ KNN / indices
 def knn(support, query, k: int, return_dist: bool = False):
     lib = _lib.load()

@@ -15,7 +15,10 @@ def pack_layer(sd: Dict[str, torch.Tensor], p: str) -> Dict[str, torch.Tensor]:
     """Fused projection weights of one LoFTREncoderLayer: [Wq;Wk;Wv] (3C,C) for self layers,
     [Wk;Wv] for cross layers; everything else is used in place (nn.Linear layout == GEMM layout)."""
     wq, wk, wv = sd[p + "q_proj.weight"], sd[p + "k_proj.weight"], sd[p + "v_proj.weight"]
-    return {
+    out = {}
+    for name in ("merge", "mlp.0", "mlp.2"):  # bf16 hi/lo planes for the fused layer tail
+        out[name + ".hi"], out[name + ".lo"] = ops.split_bf16(sd[p + name + ".weight"])
+    out.update({
         "q_proj.weight": wq.contiguous(),
         "kv.weight": torch.cat([wk, wv], 0).contiguous(),
         "qkv.weight": torch.cat([wq, wk, wv], 0).contiguous(),
@@ -24,7 +27,8 @@ def pack_layer(sd: Dict[str, torch.Tensor], p: str) -> Dict[str, torch.Tensor]:
         "mlp.2.weight": sd[p + "mlp.2.weight"].contiguous(),
         "norm1.weight": sd[p + "norm1.weight"].contiguous(), "norm1.bias": sd[p + "norm1.bias"].contiguous(),
         "norm2.weight": sd[p + "norm2.weight"].contiguous(), "norm2.bias": sd[p + "norm2.bias"].contiguous(),
-    }
+    })
+    return out
 
 
 def _layer(w, xcat: torch.Tensor, src: torch.Tensor, out: torch.Tensor, self_attn: bool, nhead: int = 4):
@@ -43,6 +47,9 @@ def _layer(w, xcat: torch.Tensor, src: torch.Tensor, out: torch.Tensor, self_att
         k, v = kv[:, :C], kv[:, C:]
     qscale = ops.col_inv_norm_from_colpart(part, C)
     msg = ops.attention(q, k, v, q_colscale=qscale, nhead=nhead)
+    if ops.GEMM_MODE == "bf16x3" and C == 128:
+        # merge + LN1 + concat + MLP + LN2 + residual: one kernel, intermediates stay in LDS
+        return ops.loftr_tail(msg, x, w, out)
     # merge Linear + LayerNorm1 in one kernel, written into the right half of the concat buffer
     ops.gemm_layernorm(msg, w["merge.weight"], w["norm1.weight"], w["norm1.bias"], out=xcat[:, C:])
     h = ops.gemm(xcat, w["mlp.0.weight"], act=ops.ACT_RELU)

@@ -169,6 +169,17 @@ int cofi_attention_fwd(const float *Q, int ldq, const float *K, int ldk, const f
 int cofi_col_inv_norm(const float *x, int ldx, int M, int C, float eps, float *out, cofi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K7  fused tail of one LoFTR encoder layer (d_model = 128), one kernel:
+ *   out = x + LN2( relu([x | LN1(msg Wm^T)] W0^T) W2^T )         model/transformer/transformer.py:57-64
+ * msg (L,128) ldm = attention output; x (L,128) ldx = layer input; weights PRE-SPLIT into bf16 hi/lo planes
+ * ((N,K) row-major uint16 each: hi = bf16(w), lo = bf16(w - hi)); arithmetic = 3-term bf16 split with fp32
+ * accumulation (as COFI_GEMM_BF16X3).  The intermediates never leave LDS. */
+int cofi_loftr_tail_bf16x3(const float *msg, int ldm, const float *x, int ldx, const uint16_t *wm_hi, const uint16_t *wm_lo,
+                           const float *n1_gamma, const float *n1_beta, const uint16_t *w0_hi, const uint16_t *w0_lo,
+                           const uint16_t *w2_hi, const uint16_t *w2_lo, const float *n2_gamma, const float *n2_beta, float eps,
+                           float *out, int ldo, int L, cofi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K8 / glue.
  * cofi_pos_sine: model/transformer/position_encoding.py:29-50.  coords (T, n_dim) fp32 (or int32 grid
  * coordinates when coords_are_int), dim_t_host = the F frequencies (host array, F <= 64);

@@ -359,3 +359,17 @@ def test_image_nhwc_glue(ops):
     yv, part = ops.gemm_colstats(G(xm), G(torch.eye(64)))
     out = ops.group_norm_apply(yv, ops.group_stats_from_colpart(part, xm.shape[0], 64), slope=0.0, res=G(xm))
     close(out, _nhwc(F.relu(F.instance_norm(x) + x)), 2e-5)
+
+
+def test_loftr_layer_fused_tail_bf16x3(ops, mg, monkeypatch):
+    """the one-kernel layer tail (merge+LN1+MLP+LN2+residual) against the reference layer output"""
+    from cofii2p_amd.transformer import loftr_layer
+
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x3")
+    w = {k[len("lay_w_"):]: G(mg[k]) for k in mg.files if k.startswith("lay_w_")}
+    out = loftr_layer(w, G(mg["lay_x"]), G(mg["lay_src"]))  # L = 48: exercises the row tail of the 32-row tiles
+    close(out, mg["lay_out"], 1e-4)
+    g = torch.Generator().manual_seed(8)
+    x, src = torch.randn(1280, 128, generator=g), torch.randn(300, 128, generator=g)
+    sd = {k: v.cpu() for k, v in w.items()}
+    close(loftr_layer(w, G(x), G(src)), O.loftr_layer({"l." + k: v for k, v in sd.items()}, "l.", x, src), 1e-4)

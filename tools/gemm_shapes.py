@@ -40,10 +40,12 @@ def main():
     kt = bench.KernelTimer()
     kt.record(model, frames[0])
     rows = {}
-    names = ["gemm", "gemm_colstats", "gemm_layernorm"] if args.kernel == "gemm" else [args.kernel]
+    names = ["gemm", "gemm_colstats", "gemm_layernorm", "conv2d_nhwc"] if args.kernel == "gemm" else [args.kernel]
     calls = [(n,) + c for n in names for c in kt.calls.get(n, [])]
     for name, fn, a, k, (fl, by) in calls:
-        if args.kernel == "gemm":
+        if name == "conv2d_nhwc":
+            key = ("conv", a[0].shape[0], a[3].shape[0], a[3].shape[1], "s%d" % (a[5] if len(a) > 5 else 1))
+        elif args.kernel == "gemm":
             key = (name.replace("gemm", "g"), a[0].shape[0], a[1].shape[0], a[0].shape[1], "div" if k.get("rowdiv") is not None else "")
         else:
             key = tuple(tuple(t.shape) for t in a if torch.is_tensor(t))[:4]
