@@ -61,7 +61,7 @@ class KernelTimer:
     algorithmic work.  Pass 2 replays, per entry point, exactly those launches back-to-back inside one
     hipGraph and times the replay with events: no CPU launch gaps, the same shapes/data as the frame."""
 
-    NAMES = ("gemm", "gemm_colstats", "gemm_layernorm", "conv2d_nhwc", "group_stats_from_colpart", "col_inv_norm_from_colpart", "kpconv_aggregate", "attention", "neighbor_maxpool", "group_stats", "group_norm_apply", "layer_norm", "l2norm_rows",
+    NAMES = ("gemm", "gemm_colstats", "gemm_layernorm", "conv2d_nhwc", "loftr_tail", "group_stats_from_colpart", "col_inv_norm_from_colpart", "kpconv_aggregate", "attention", "neighbor_maxpool", "group_stats", "group_norm_apply", "layer_norm", "l2norm_rows",
              "gather_rows", "row_sum_positive", "col_inv_norm")
 
     def __init__(self):
@@ -73,6 +73,9 @@ class KernelTimer:
             M, K = a[0].shape
             N = a[1].shape[0]
             return 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)
+        if name == "loftr_tail":
+            L = a[0].shape[0]
+            return 2.0 * L * (128 * 128 + 256 * 256 + 256 * 128), 4.0 * (3 * L * 128 + 128 * 128 + 256 * 256 + 256 * 128)
         if name == "conv2d_nhwc":
             x, H, W, w, ks = a[0], a[1], a[2], a[3], a[4]
             stride = a[5] if len(a) > 5 else k.get("stride", 1)
@@ -140,6 +143,19 @@ class KernelTimer:
                          "launches_per_frame": len(calls)}
             del g
         return out
+
+
+def pmc_traffic(kernel_family):
+    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json, produced by tools/pmc_to_json.py from separate FETCH_SIZE / WRITE_SIZE runs of this
+    same command; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  None if absent."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path)).get(kernel_family, {}).get("traffic_bytes_per_launch")
+    except Exception:
+        return None
 
 
 def cpu_baseline(frame, n_frames=2):
@@ -295,7 +311,8 @@ def main():
             # the bf16-split GEMM issues 3 bf16 MFMA flops per algorithmic flop: its MFMA roof for ALGORITHMIC flops is 2500/3
             peak = BF16_MFMA_PEAK_TF / 3.0 if (dom == "gemm" and args.gemm == "bf16x3") else FP32_MFMA_PEAK_TF
             result["roofline"] = {"kernel": "cofi_" + dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                                  "frac": ach / peak, "traffic": None,
+                                  "frac": ach / peak, "traffic": pmc_traffic(dom),
+                                  "algorithmic_bytes_per_launch": d["bytes_per_frame"] / d["launches_per_frame"],
                                   "launches_per_frame": d["launches_per_frame"], "avg_launch_us": 1e6 * d["seconds_per_frame"] / d["launches_per_frame"]}
         else:
             ach = d["bytes_per_frame"] / d["seconds_per_frame"] / 1e9

@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""profiles/<tag>_fetch_pmc.md + <tag>_write_pmc.md (tools/rocpd_pmc_summary.py tables) -> profiles/pmc_traffic.json.
+Kernel families: gemm = every gemm_*kernel + splitk epilogues (the launches behind cofi_gemm_f32* / cofi_conv2d_nhwc),
+attention, kpconv_aggregate, neighbor_maxpool, group_norm_apply.
+HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in KB and on gfx950 FETCH_SIZE counts
+128-B requests at 64 B for wide coalesced reads (MI355X_MICROARCH.md §HBM)."""
+import json
+import re
+import sys
+
+FAMILIES = {"gemm": ("gemm_kernel", "gemm_bf16x3_kernel", "splitk_epilogue"), "attention": ("attention_fwd_kernel",),
+            "kpconv_aggregate": ("kpconv_aggregate_kernel",), "neighbor_maxpool": ("neighbor_maxpool_kernel",),
+            "group_norm_apply": ("group_norm_apply_kernel",)}
+
+
+def parse(path, counter):
+    out = {}
+    for line in open(path):
+        m = re.match(r"\| `(.*?)` \| (\w+) \| (\d+) \| ([\d.e+\-]+) \| ([\d.e+\-]+) \|", line)
+        if m and m.group(2) == counter:
+            out[m.group(1)] = (int(m.group(3)), float(m.group(4)))
+    return out
+
+
+def main():
+    fetch, write, frames, launches_main = parse(sys.argv[1], "FETCH_SIZE"), parse(sys.argv[2], "WRITE_SIZE"), int(sys.argv[3]), None
+    res = {}
+    for fam, pats in FAMILIES.items():
+        f = sum(v[1] for k, v in fetch.items() if any(p in k for p in pats))
+        w = sum(v[1] for k, v in write.items() if any(p in k for p in pats))
+        n_main = sum(v[0] for k, v in fetch.items() if any(p in k for p in pats) and "splitk" not in k)
+        if n_main == 0:
+            continue
+        res[fam] = {"fetch_kb_total": f, "write_kb_total": w, "main_launches": n_main, "frames": frames,
+                    "traffic_bytes_per_launch": (2 * f + w) * 1024 / n_main, "traffic_bytes_per_frame": (2 * f + w) * 1024 / frames}
+    json.dump(res, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
