@@ -533,10 +533,41 @@ struct Plan {
     int bm, bn, ksplit, kchunk;
 };
 
+// Tuned plans for the shapes of the KITTI / nuScenes-shaped forward (tools/tune_gemm.py on MI355X, bf16x3 kernel):
+// {M, N, K, bm, bn, ksplit}.  Anything not listed falls through to the heuristic below.
+struct TunedPlan { int M, N, K, bm, bn, ks; };
+#include "gemm_plans.inc"
+
+// tuning hook (tools/tune_gemm.py only): forces the next plans; not used by the product path
+int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;
+
+Plan finish_plan(int K, int bm, int bn, int ks) {
+    Plan p;
+    p.bm = bm; p.bn = bn;
+    int ktiles = cofi_cdiv(K, BK);
+    if (ks < 1) ks = 1;
+    int tiles_per = cofi_cdiv(ktiles, ks);
+    tiles_per = (tiles_per + 3) & ~3;  // k-chunks in multiples of 128: the bf16x3 kernel steps K by 128
+    p.kchunk = tiles_per * BK;
+    p.ksplit = cofi_cdiv(K, p.kchunk);
+    return p;
+}
+
 // Heuristic: largest tile that still gives >= ~1 workgroup per CU, then split K until the chip
 // (256 CUs) is covered about twice, keeping >= 2 k-tiles (64 values) per split.
 Plan make_plan(int M, int N, int K, bool fused_ln) {
     Plan p;
+    if (g_force_bm) {
+        p = finish_plan(K, g_force_bm, g_force_bn, g_force_ks);
+        if (fused_ln && p.ksplit == 1 && p.bn < N) { p.bm = 64; p.bn = 128; }
+        return p;
+    }
+    for (const TunedPlan &t : kTunedPlans)
+        if (t.M == M && t.N == N && t.K == K) {
+            p = finish_plan(K, t.bm, t.bn, t.ks);
+            if (fused_ln && p.ksplit == 1 && p.bn < N) { p.bm = 64; p.bn = 128; }
+            return p;
+        }
     auto blocks = [&](int bm, int bn) { return (long)cofi_cdiv(M, bm) * cofi_cdiv(N, bn); };
     if (N > 64 && M > 64 && blocks(128, 128) >= 200) {
         p.bm = 128; p.bn = 128;
@@ -667,4 +698,12 @@ extern "C" int cofi_conv2d_nhwc(const float *x, int ldx, int H, int W, int Cin, 
     GemmArgs g{x, Wt, y, bias, nullptr, (float *)ws, colpart, nullptr, nullptr, res, ldx, K, ldy, ldr, M, Cout, K, act, 1, 0, 0, 0.f, bf16x3,
                ks, H, W, Cin, Wo, stride, pad};
     return launch(g, p, cofi_s(stream));
+}
+
+// Tuning hook for tools/tune_gemm.py: force (bm, bn, ksplit) for subsequent plans; (0,0,0) restores the table + heuristic.
+extern "C" int cofi_gemm_debug_force_plan(int bm, int bn, int ksplit) {
+    const bool ok = (bm == 0 && bn == 0) || ((bm == 64 || bm == 128) && (bn == 64 || bn == 128) && !(bm == 128 && bn == 64));
+    if (!ok || ksplit < 0) return COFI_EINVAL;
+    g_force_bm = bm; g_force_bn = bn; g_force_ks = ksplit;
+    return 0;
 }

@@ -109,6 +109,9 @@ int cofi_gather_rows(const float *x, int ldx, int N, int C, const int32_t *idx, 
 size_t cofi_gemm_f32_workspace(int M, int N, int K);
 int cofi_gemm_f32(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K, const float *bias,
                   const float *rowdiv, int act, void *ws, size_t ws_bytes, cofi_stream_t stream);
+/* Tuning hook (tools/tune_gemm.py): force the tile / split-K plan of subsequent calls; (0,0,0) restores the
+ * tuned table + heuristic.  Process-global; not used by the product path. */
+int cofi_gemm_debug_force_plan(int bm, int bn, int ksplit);
 /* Same contraction with fused COLUMN STATISTICS: colpart (nslab, N, 2) receives, per row slab, the sum and
  * the sum of squares of every output column (after bias / rowdiv / act), nslab =
  * cofi_gemm_f32_stat_slabs(M,N,K).  cofi_group_stats_from_colpart / cofi_col_inv_norm_from_colpart turn
