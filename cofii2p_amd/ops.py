@@ -21,6 +21,11 @@ GEMM_BF16X3 = 0x100
 GEMM_MODE = os.environ.get("COFI_GEMM", "f32")
 
 
+# Which intra-frame fork/join branches are taken (see Branch).  With >= 2 frames in flight the frames themselves fill
+# the GPU and intra-frame forks only add join overhead; with one frame in flight they shorten the critical path.
+BRANCH_MASK = int(os.environ.get("COFI_BRANCH_MASK", "7"))
+
+
 def _gemm_flag() -> int:
     return GEMM_BF16X3 if GEMM_MODE == "bf16x3" else 0
 
@@ -87,7 +92,9 @@ class Branch:
     _pool = {}
 
     def __init__(self, device, slot: int = 0, enabled: bool = True):
-        self.enabled = enabled
+        # BRANCH_MASK bit i enables fork/join slot i (0: image branch, 1: residual shortcut, 2: self-attention streams)
+        self.enabled = enabled and bool((BRANCH_MASK >> slot) & 1)
+        enabled = self.enabled
         self.device = device
         if enabled:
             key = (str(device), slot)
