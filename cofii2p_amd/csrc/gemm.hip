@@ -53,28 +53,36 @@ struct ATileLoader {
         if (g.cv_ks) {
 #pragma unroll
             for (int j = 0; j < A_LD4; ++j) {
-                const int r = m0 + lrow + 32 * j;
+                const int r = min(m0 + lrow + 32 * j, g.M - 1);
                 yo[j] = r / g.cv_Wo;
                 xo[j] = r - yo[j] * g.cv_Wo;
             }
         }
     }
+    // Every load is UNCONDITIONAL on a clamped (always valid) address and masked afterwards with a select: predicated
+    // loads compile to one exec-masked basic block each, which stops the scheduler from batching the loads of a tile
+    // and puts an s_waitcnt vmcnt(0) behind every one of them.
     __device__ __forceinline__ void load(const GemmArgs &g, int m0, int lrow, int k, bool kin, float4 (&ra)[A_LD4]) const {
+        const float4 zero = make_float4(0, 0, 0, 0);
+        const int kc = kin ? k : 0;
         if (g.cv_ks == 0) {
 #pragma unroll
             for (int j = 0; j < A_LD4; ++j) {
                 const int r = m0 + lrow + 32 * j;
-                ra[j] = (kin && r < g.M) ? *reinterpret_cast<const float4 *>(g.A + (size_t)r * g.lda + k) : make_float4(0, 0, 0, 0);
+                const float4 v = *reinterpret_cast<const float4 *>(g.A + (size_t)min(r, g.M - 1) * g.lda + kc);
+                ra[j] = (kin && r < g.M) ? v : zero;
             }
         } else {
-            const int tap = k / g.cv_Cin, c = k - tap * g.cv_Cin;
+            const int tap = kc / g.cv_Cin, c = kc - tap * g.cv_Cin;
             const int dy = tap / g.cv_ks, dx = tap - dy * g.cv_ks;
 #pragma unroll
             for (int j = 0; j < A_LD4; ++j) {
                 const int r = m0 + lrow + 32 * j;
                 const int yi = yo[j] * g.cv_stride - g.cv_pad + dy, xi = xo[j] * g.cv_stride - g.cv_pad + dx;
                 const bool ok = kin && r < g.M && (unsigned)yi < (unsigned)g.cv_H && (unsigned)xi < (unsigned)g.cv_W;
-                ra[j] = ok ? *reinterpret_cast<const float4 *>(g.A + ((size_t)yi * g.cv_W + xi) * g.lda + c) : make_float4(0, 0, 0, 0);
+                const int yc = min(max(yi, 0), g.cv_H - 1), xc = min(max(xi, 0), g.cv_W - 1);
+                const float4 v = *reinterpret_cast<const float4 *>(g.A + ((size_t)yc * g.cv_W + xc) * g.lda + c);
+                ra[j] = ok ? v : zero;
             }
         }
     }
@@ -253,7 +261,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < W_LD4; ++j) {
             const int r = n0 + lrow + 32 * j;
-            rw[j] = (kin && r < g.N) ? *reinterpret_cast<const float4 *>(g.W + (size_t)r * g.ldw + k) : make_float4(0, 0, 0, 0);
+            const float4 v = *reinterpret_cast<const float4 *>(g.W + (size_t)min(r, g.N - 1) * g.ldw + (kin ? k : 0));
+            rw[j] = (kin && r < g.N) ? v : make_float4(0, 0, 0, 0);
         }
     };
     auto sstore = [&](int buf) {
@@ -389,42 +398,52 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     if (g.cv_ks) {
 #pragma unroll
         for (int j = 0; j < A_LD4; ++j) {
-            const int r = m0 + lrow + RPP * j;
+            const int r = min(m0 + lrow + RPP * j, g.M - 1);
             yo[j] = r / g.cv_Wo;
             xo[j] = r - yo[j] * g.cv_Wo;
         }
     }
+    // Loads are unconditional on clamped addresses; validity is kept as a bit mask and applied when the registers are
+    // consumed (sstore), so nothing touches a loaded value — and no s_waitcnt is needed — until after the MFMAs.
+    unsigned amask = 0, wmask = 0;
     auto gload = [&](int t) {
         const int k = kbeg + t * BK3 + lk;
         const bool kin = k < kend;
+        const int kc = kin ? k : 0;
+        amask = 0; wmask = 0;
         if (g.cv_ks == 0) {
 #pragma unroll
             for (int j = 0; j < A_LD4; ++j) {
                 const int r = m0 + lrow + RPP * j;
-                ra[j] = (kin && r < g.M) ? *reinterpret_cast<const float4 *>(g.A + (size_t)r * g.lda + k) : make_float4(0, 0, 0, 0);
+                ra[j] = *reinterpret_cast<const float4 *>(g.A + (size_t)min(r, g.M - 1) * g.lda + kc);
+                amask |= (kin && r < g.M) ? (1u << j) : 0u;
             }
         } else {
-            const int tap = k / g.cv_Cin, c = k - tap * g.cv_Cin;
+            const int tap = kc / g.cv_Cin, c = kc - tap * g.cv_Cin;
             const int dy = tap / g.cv_ks, dx = tap - dy * g.cv_ks;
 #pragma unroll
             for (int j = 0; j < A_LD4; ++j) {
                 const int r = m0 + lrow + RPP * j;
                 const int yi = yo[j] * g.cv_stride - g.cv_pad + dy, xi = xo[j] * g.cv_stride - g.cv_pad + dx;
                 const bool ok = kin && r < g.M && (unsigned)yi < (unsigned)g.cv_H && (unsigned)xi < (unsigned)g.cv_W;
-                ra[j] = ok ? *reinterpret_cast<const float4 *>(g.A + ((size_t)yi * g.cv_W + xi) * g.lda + c) : make_float4(0, 0, 0, 0);
+                const int yc = min(max(yi, 0), g.cv_H - 1), xc = min(max(xi, 0), g.cv_W - 1);
+                ra[j] = *reinterpret_cast<const float4 *>(g.A + ((size_t)yc * g.cv_W + xc) * g.lda + c);
+                amask |= ok ? (1u << j) : 0u;
             }
         }
 #pragma unroll
         for (int j = 0; j < W_LD4; ++j) {
             const int r = n0 + lrow + RPP * j;
-            rw[j] = (kin && r < g.N) ? *reinterpret_cast<const float4 *>(g.W + (size_t)r * g.ldw + k) : make_float4(0, 0, 0, 0);
+            rw[j] = *reinterpret_cast<const float4 *>(g.W + (size_t)min(r, g.N - 1) * g.ldw + kc);
+            wmask |= (kin && r < g.N) ? (1u << j) : 0u;
         }
     };
     auto sstore = [&]() {
+        const float4 zero = make_float4(0, 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < A_LD4; ++j) {
             uint2 hi, lo;
-            split4(ra[j], hi, lo);
+            split4(((amask >> j) & 1u) ? ra[j] : zero, hi, lo);
             unsigned char *p = lds_raw + (lrow + RPP * j) * BROW3 + lk * 2;
             *reinterpret_cast<uint2 *>(p) = hi;
             *reinterpret_cast<uint2 *>(p + PLANE_A) = lo;
@@ -432,7 +451,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < W_LD4; ++j) {
             uint2 hi, lo;
-            split4(rw[j], hi, lo);
+            split4(((wmask >> j) & 1u) ? rw[j] : zero, hi, lo);
             unsigned char *p = lds_raw + 2 * PLANE_A + (lrow + RPP * j) * BROW3 + lk * 2;
             *reinterpret_cast<uint2 *>(p) = hi;
             *reinterpret_cast<uint2 *>(p + PLANE_W) = lo;
