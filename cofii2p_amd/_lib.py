@@ -25,33 +25,33 @@ SIGNATURES = {
     "cofi_idx64_to_idx32": (_I, [_P, _P, _Z, _P]),
     "cofi_idx32_to_idx64": (_I, [_P, _P, _Z, _P]),
     "cofi_row_sum_positive": (_I, [_P, _I, _I, _I, _P, _P]),
-    "cofi_kpconv_aggregate": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _F, _P, _P, _I, _P, _P]),
-    "cofi_neighbor_maxpool": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _P]),
-    "cofi_gather_rows": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _P]),
+    "cofi_kpconv_aggregate": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _F, _P, _P, _I, _P, _I, _P]),
+    "cofi_neighbor_maxpool": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P]),
+    "cofi_gather_rows": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P]),
     "cofi_gemm_f32_workspace": (_Z, [_I, _I, _I]),
     "cofi_gemm_f32": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _Z, _P]),
     "cofi_gemm_debug_force_plan": (_I, [_I, _I, _I]),
     "cofi_gemm_f32_stat_slabs": (_I, [_I, _I, _I]),
     "cofi_gemm_f32_colstats": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _Z, _P]),
     "cofi_gemm_f32_layernorm": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _F, _I, _P, _I, _P, _Z, _P]),
-    "cofi_group_stats_from_colpart": (_I, [_P, _I, _I, _I, _I, _F, _P, _P]),
-    "cofi_col_inv_norm_from_colpart": (_I, [_P, _I, _I, _I, _F, _P, _P]),
+    "cofi_group_stats_from_colpart": (_I, [_P, _I, _I, _I, _I, _F, _P, _I, _P]),
+    "cofi_col_inv_norm_from_colpart": (_I, [_P, _I, _I, _I, _F, _P, _I, _P]),
     "cofi_group_stats_workspace": (_Z, [_I, _I, _I]),
     "cofi_group_stats": (_I, [_P, _I, _I, _I, _I, _F, _P, _P, _Z, _P]),
-    "cofi_group_norm_apply": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _F, _P, _I, _P]),
+    "cofi_group_norm_apply": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _F, _P, _I, _I, _P]),
     "cofi_layer_norm": (_I, [_P, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _I, _P]),
     "cofi_loftr_tail_bf16x3": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
     "cofi_attention_workspace": (_Z, [_I, _I, _I, _I]),
-    "cofi_attention_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P, _Z, _P]),
+    "cofi_attention_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P, _Z, _I, _P]),
     "cofi_col_inv_norm": (_I, [_P, _I, _I, _I, _F, _P, _P]),
     "cofi_pos_sine": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _P, _I, _P]),
     "cofi_l2norm_rows": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
     "cofi_transpose": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "cofi_l2norm_cols": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P]),
-    "cofi_conv2d_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _Z, _P]),
-    "cofi_im2col_stem": (_I, [_P, _I, _I, _I, _P, _P]),
-    "cofi_maxpool3x3s2_nhwc": (_I, [_P, _I, _I, _I, _P, _P]),
-    "cofi_upsample2x_cat_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P]),
+    "cofi_conv2d_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _Z, _I, _P]),
+    "cofi_im2col_stem": (_I, [_P, _I, _I, _I, _P, _I, _P]),
+    "cofi_maxpool3x3s2_nhwc": (_I, [_P, _I, _I, _I, _P, _I, _P]),
+    "cofi_upsample2x_cat_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P]),
     "cofi_extract_patches_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _F, _P, _I, _P, _P]),
     "cofi_instance_norm_nchw": (_I, [_P, _I, _I, _F, _P, _I, _I, _P, _P]),
     "cofi_bias_act_nchw": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),

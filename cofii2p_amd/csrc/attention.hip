@@ -39,6 +39,14 @@ __global__ __launch_bounds__(64 * NW) void attention_fwd_kernel(AttnArgs a) {
     const int li = lane & 31, lh = lane >> 5;
     const int head = blockIdx.y, q0 = blockIdx.x * 32;
     const int hc = head * D;
+    {   // stack mode: frame blockIdx.z owns L query rows and S key rows
+        const size_t f = blockIdx.z;
+        a.Q += f * a.L * a.ldq;
+        a.K += f * a.S * a.ldk;
+        a.V += f * a.S * a.ldv;
+        a.O += f * a.L * a.ldo;
+        if (a.qs) a.qs += f * a.H * D;
+    }
 
     // Q fragment: lane (q = li, h) holds Q[q][8c+4h+e], pre-multiplied by colscale * scale * log2(e)
     float qf[16];
@@ -189,7 +197,7 @@ extern "C" size_t cofi_attention_workspace(int L, int S, int H, int D) {
 }
 
 extern "C" int cofi_attention_fwd(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, const float *q_colscale,
-                                  float *O, int ldo, int L, int S, int H, int D, float scale, void *ws, size_t ws_bytes,
+                                  float *O, int ldo, int L, int S, int H, int D, float scale, void *ws, size_t ws_bytes, int frames,
                                   cofi_stream_t stream) {
     (void)ws; (void)ws_bytes;
     if (!Q || !K || !V || !O || L <= 0 || S <= 0 || H <= 0) return COFI_EINVAL;
@@ -198,6 +206,7 @@ extern "C" int cofi_attention_fwd(const float *Q, int ldq, const float *K, int l
     if (((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)O & 15) || (q_colscale && ((uintptr_t)q_colscale & 15)))
         return COFI_EINVAL;
     AttnArgs a{Q, K, V, q_colscale, O, ldq, ldk, ldv, ldo, L, S, H, scale * 1.4426950408889634f};
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3(cofi_cdiv(L, 32), H), dim3(64 * NW), 0, cofi_s(stream), a);
+    if (frames <= 0) return COFI_EINVAL;
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3(cofi_cdiv(L, 32), H, frames), dim3(64 * NW), 0, cofi_s(stream), a);
     return cofi_launch_status();
 }

@@ -41,6 +41,7 @@ struct GemmArgs {
     // implicit-GEMM convolution (cv_ks > 0): A is an NHWC map (H*W rows of lda floats), row m of the GEMM is
     // output pixel (m / Wo, m % Wo), column k is (tap = k / Cin, channel = k % Cin); K = ks*ks*Cin
     int cv_ks, cv_H, cv_W, cv_Cin, cv_Wo, cv_stride, cv_pad;
+    int cv_Pout;  // output pixels per frame (stack mode: GEMM row m is frame m / cv_Pout, pixel m % cv_Pout)
 };
 
 // A-operand tile loader shared by both MFMA kernels: float4 number j of this thread covers row m0 + lrow + 32j,
@@ -48,14 +49,16 @@ struct GemmArgs {
 // outside the image (Cin % 4 == 0, so a float4 never straddles two taps).
 template <int A_LD4>
 struct ATileLoader {
-    int yo[A_LD4], xo[A_LD4];
+    int yo[A_LD4], xo[A_LD4], fb[A_LD4];  // output pixel coordinates and first input row of the frame
     __device__ __forceinline__ void init(const GemmArgs &g, int m0, int lrow) {
         if (g.cv_ks) {
 #pragma unroll
             for (int j = 0; j < A_LD4; ++j) {
                 const int r = min(m0 + lrow + 32 * j, g.M - 1);
-                yo[j] = r / g.cv_Wo;
-                xo[j] = r - yo[j] * g.cv_Wo;
+                const int f = r / g.cv_Pout, pix = r - f * g.cv_Pout;
+                fb[j] = f * g.cv_H * g.cv_W;
+                yo[j] = pix / g.cv_Wo;
+                xo[j] = pix - yo[j] * g.cv_Wo;
             }
         }
     }
@@ -81,7 +84,7 @@ struct ATileLoader {
                 const int yi = yo[j] * g.cv_stride - g.cv_pad + dy, xi = xo[j] * g.cv_stride - g.cv_pad + dx;
                 const bool ok = kin && r < g.M && (unsigned)yi < (unsigned)g.cv_H && (unsigned)xi < (unsigned)g.cv_W;
                 const int yc = min(max(yi, 0), g.cv_H - 1), xc = min(max(xi, 0), g.cv_W - 1);
-                const float4 v = *reinterpret_cast<const float4 *>(g.A + ((size_t)yc * g.cv_W + xc) * g.lda + c);
+                const float4 v = *reinterpret_cast<const float4 *>(g.A + ((size_t)fb[j] + (size_t)yc * g.cv_W + xc) * g.lda + c);
                 ra[j] = ok ? v : zero;
             }
         }
@@ -394,13 +397,15 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     float4 ra[A_LD4], rw[W_LD4];
 
     // conv-mode pixel coordinates of this thread's A rows (row = m0 + lrow + 8j)
-    int yo[A_LD4], xo[A_LD4];
+    int yo[A_LD4], xo[A_LD4], fb[A_LD4];
     if (g.cv_ks) {
 #pragma unroll
         for (int j = 0; j < A_LD4; ++j) {
             const int r = min(m0 + lrow + RPP * j, g.M - 1);
-            yo[j] = r / g.cv_Wo;
-            xo[j] = r - yo[j] * g.cv_Wo;
+            const int f = r / g.cv_Pout, pix = r - f * g.cv_Pout;
+            fb[j] = f * g.cv_H * g.cv_W;
+            yo[j] = pix / g.cv_Wo;
+            xo[j] = pix - yo[j] * g.cv_Wo;
         }
     }
     // Loads are unconditional on clamped addresses; validity is kept as a bit mask and applied when the registers are
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
                 const int yi = yo[j] * g.cv_stride - g.cv_pad + dy, xi = xo[j] * g.cv_stride - g.cv_pad + dx;
                 const bool ok = kin && r < g.M && (unsigned)yi < (unsigned)g.cv_H && (unsigned)xi < (unsigned)g.cv_W;
                 const int yc = min(max(yi, 0), g.cv_H - 1), xc = min(max(xi, 0), g.cv_W - 1);
-                ra[j] = *reinterpret_cast<const float4 *>(g.A + ((size_t)yc * g.cv_W + xc) * g.lda + c);
+                ra[j] = *reinterpret_cast<const float4 *>(g.A + ((size_t)fb[j] + (size_t)yc * g.cv_W + xc) * g.lda + c);
                 amask |= ok ? (1u << j) : 0u;
             }
         }
@@ -684,7 +689,7 @@ extern "C" int cofi_gemm_f32_colstats(const float *A, int lda, const float *W, i
     if (act < 0 || act > 2) return COFI_EINVAL;
     Plan p = make_plan(M, N, K, false);
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
-    GemmArgs g{A, W, C, bias, rowdiv, (float *)ws, colpart, nullptr, nullptr, nullptr, lda, ldw, ldc, 0, M, N, K, act, 1, 0, 0, 0.f, bf16x3, 0, 0, 0, 0, 0, 0, 0};
+    GemmArgs g{A, W, C, bias, rowdiv, (float *)ws, colpart, nullptr, nullptr, nullptr, lda, ldw, ldc, 0, M, N, K, act, 1, 0, 0, 0.f, bf16x3, 0, 0, 0, 0, 0, 0, 0, 1};
     return launch(g, p, cofi_s(stream));
 }
 
@@ -698,24 +703,25 @@ extern "C" int cofi_gemm_f32_layernorm(const float *A, int lda, const float *W, 
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
     const int bf16x3 = (relu & COFI_GEMM_BF16X3) ? 1 : 0;
     relu &= ~COFI_GEMM_BF16X3;
-    GemmArgs g{A, W, C, bias, nullptr, (float *)ws, nullptr, gamma, beta, res, lda, ldw, ldc, ldr, M, N, K, 0, 1, 0, relu, eps, bf16x3, 0, 0, 0, 0, 0, 0, 0};
+    GemmArgs g{A, W, C, bias, nullptr, (float *)ws, nullptr, gamma, beta, res, lda, ldw, ldc, ldr, M, N, K, 0, 1, 0, relu, eps, bf16x3, 0, 0, 0, 0, 0, 0, 0, 1};
     return launch(g, p, cofi_s(stream));
 }
 
 extern "C" int cofi_conv2d_nhwc(const float *x, int ldx, int H, int W, int Cin, const float *Wt, int Cout, int ks, int stride, int pad,
                                 const float *bias, const float *res, int ldr, int act, float *y, int ldy, float *colpart, void *ws,
-                                size_t ws_bytes, cofi_stream_t stream) {
+                                size_t ws_bytes, int frames, cofi_stream_t stream) {
     if (!x || !Wt || !y || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ks != 1 && ks != 3) || stride <= 0 || pad < 0) return COFI_EINVAL;
     if ((Cin & 3) || (ldx & 3) || ldx < Cin || ldy < Cout || (res && ldr < Cout) || ((uintptr_t)x & 15) || ((uintptr_t)Wt & 15)) return COFI_EINVAL;
     const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
-    const int M = Ho * Wo, K = ks * ks * Cin;
+    if (frames <= 0) return COFI_EINVAL;
+    const int M = Ho * Wo * frames, K = ks * ks * Cin;
     const int bf16x3 = (act & COFI_GEMM_BF16X3) ? 1 : 0;
     act &= ~COFI_GEMM_BF16X3;
     if (act < 0 || act > 2) return COFI_EINVAL;
     Plan p = make_plan(M, Cout, K, false);
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * Cout * sizeof(float))) return COFI_EWORKSPACE;
     GemmArgs g{x, Wt, y, bias, nullptr, (float *)ws, colpart, nullptr, nullptr, res, ldx, K, ldy, ldr, M, Cout, K, act, 1, 0, 0, 0.f, bf16x3,
-               ks, H, W, Cin, Wo, stride, pad};
+               ks, H, W, Cin, Wo, stride, pad, Ho * Wo};
     return launch(g, p, cofi_s(stream));
 }
 

@@ -98,25 +98,27 @@ __global__ void upsample2x_cat_kernel(const float *low, int C1, int h, int w, co
 
 // ------------------------------------------------------------------------------------ NHWC kernels
 // stem: out[p, (dy*7+dx)*3 + c] = img[c, 2*yo - 3 + dy, 2*xo - 3 + dx], zero outside / beyond 147
-__global__ void im2col_stem_kernel(const float *img, int H, int W, int Ho, int Wo, int Kpad, float *out) {
-    const size_t total = (size_t)Ho * Wo * Kpad;
+__global__ void im2col_stem_kernel(const float *img, int H, int W, int Ho, int Wo, int Kpad, float *out, int frames) {
+    const size_t total = (size_t)frames * Ho * Wo * Kpad;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int k = (int)(e % Kpad), p = (int)(e / Kpad);
+        const int k = (int)(e % Kpad), pg = (int)(e / Kpad), f = pg / (Ho * Wo), p = pg - f * (Ho * Wo);
         float v = 0.f;
         if (k < 147) {
             const int tap = k / 3, c = k - 3 * tap, dy = tap / 7, dx = tap - 7 * dy;
             const int yi = 2 * (p / Wo) - 3 + dy, xi = 2 * (p % Wo) - 3 + dx;
-            if ((unsigned)yi < (unsigned)H && (unsigned)xi < (unsigned)W) v = img[((size_t)c * H + yi) * W + xi];
+            if ((unsigned)yi < (unsigned)H && (unsigned)xi < (unsigned)W) v = img[(((size_t)f * 3 + c) * H + yi) * W + xi];
         }
         out[e] = v;
     }
 }
 
-__global__ void maxpool3x3s2_nhwc_kernel(const float *x, int H, int W, int C, int Ho, int Wo, float *y) {
+__global__ void maxpool3x3s2_nhwc_kernel(const float *x0, int H, int W, int C, int Ho, int Wo, float *y, int frames) {
     const int c4n = C >> 2;
-    const size_t total = (size_t)Ho * Wo * c4n;
+    const size_t total = (size_t)frames * Ho * Wo * c4n;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(e % c4n), p = (int)(e / c4n), yo = p / Wo, xo = p - yo * Wo;
+        const int c4 = (int)(e % c4n), pg = (int)(e / c4n), f = pg / (Ho * Wo), pl = pg - f * (Ho * Wo), yo = pl / Wo, xo = pl - yo * Wo;
+        const float *x = x0 + (size_t)f * H * W * C;
+        const int p = pg;
         float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         for (int dy = 0; dy < 3; ++dy)
             for (int dx = 0; dx < 3; ++dx) {
@@ -130,12 +132,13 @@ __global__ void maxpool3x3s2_nhwc_kernel(const float *x, int H, int W, int C, in
     }
 }
 
-__global__ void upsample2x_cat_nhwc_kernel(const float *low, int ldl, int C1, int h, int w, const float *skip, int lds, int C2, float *out,
-                                           int ldo) {
+__global__ void upsample2x_cat_nhwc_kernel(const float *low0, int ldl, int C1, int h, int w, const float *skip, int lds, int C2, float *out,
+                                           int ldo, int frames) {
     const int H = 2 * h, W = 2 * w, ct = (C1 + C2) >> 2;
-    const size_t total = (size_t)H * W * ct;
+    const size_t total = (size_t)frames * H * W * ct;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(e % ct) * 4, p = (int)(e / ct), yo = p / W, xo = p - yo * W;
+        const int c = (int)(e % ct) * 4, p = (int)(e / ct), f = p / (H * W), pl = p - f * (H * W), yo = pl / W, xo = pl - yo * W;
+        const float *low = low0 + (size_t)f * h * w * ldl;
         float4 v;
         if (c >= C1) {
             v = *reinterpret_cast<const float4 *>(skip + (size_t)p * lds + (c - C1));
@@ -159,34 +162,36 @@ __global__ void upsample2x_cat_nhwc_kernel(const float *low, int ldl, int C1, in
 
 }  // namespace
 
-extern "C" int cofi_im2col_stem(const float *img_chw, int H, int W, int Kpad, float *out, cofi_stream_t stream) {
-    if (!img_chw || !out || H <= 0 || W <= 0 || Kpad < 147 || (Kpad & 3)) return COFI_EINVAL;
+extern "C" int cofi_im2col_stem(const float *img_chw, int H, int W, int Kpad, float *out, int frames, cofi_stream_t stream) {
+    if (!img_chw || !out || H <= 0 || W <= 0 || Kpad < 147 || (Kpad & 3) || frames <= 0) return COFI_EINVAL;
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
-    size_t total = (size_t)Ho * Wo * Kpad;
+    size_t total = (size_t)frames * Ho * Wo * Kpad;
     int nb = (int)((total + 255) / 256);
     if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(im2col_stem_kernel, dim3(nb), dim3(256), 0, cofi_s(stream), img_chw, H, W, Ho, Wo, Kpad, out);
+    hipLaunchKernelGGL(im2col_stem_kernel, dim3(nb), dim3(256), 0, cofi_s(stream), img_chw, H, W, Ho, Wo, Kpad, out, frames);
     return cofi_launch_status();
 }
 
-extern "C" int cofi_maxpool3x3s2_nhwc(const float *x, int H, int W, int C, float *y, cofi_stream_t stream) {
-    if (!x || !y || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return COFI_EINVAL;
+extern "C" int cofi_maxpool3x3s2_nhwc(const float *x, int H, int W, int C, float *y, int frames, cofi_stream_t stream) {
+    if (!x || !y || H <= 0 || W <= 0 || C <= 0 || (C & 3) || frames <= 0) return COFI_EINVAL;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    size_t total = (size_t)Ho * Wo * (C >> 2);
+    size_t total = (size_t)frames * Ho * Wo * (C >> 2);
     int nb = (int)((total + 255) / 256);
     if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(maxpool3x3s2_nhwc_kernel, dim3(nb), dim3(256), 0, cofi_s(stream), x, H, W, C, Ho, Wo, y);
+    hipLaunchKernelGGL(maxpool3x3s2_nhwc_kernel, dim3(nb), dim3(256), 0, cofi_s(stream), x, H, W, C, Ho, Wo, y, frames);
     return cofi_launch_status();
 }
 
 extern "C" int cofi_upsample2x_cat_nhwc(const float *low, int ldl, int C1, int h, int w, const float *skip, int lds, int C2, float *out,
-                                        int ldo, cofi_stream_t stream) {
+                                        int ldo, int frames, cofi_stream_t stream) {
     if (!low || !out || C1 <= 0 || h <= 0 || w <= 0 || C2 < 0 || (C2 && !skip) || (C1 & 3) || (C2 & 3) || (ldl & 3) || (lds & 3) || (ldo & 3))
         return COFI_EINVAL;
-    size_t total = (size_t)4 * h * w * ((C1 + C2) >> 2);
+    if (frames <= 0) return COFI_EINVAL;
+    size_t total = (size_t)frames * 4 * h * w * ((C1 + C2) >> 2);
     int nb = (int)((total + 255) / 256);
     if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(upsample2x_cat_nhwc_kernel, dim3(nb), dim3(256), 0, cofi_s(stream), low, ldl, C1, h, w, skip, lds, C2, out, ldo);
+    hipLaunchKernelGGL(upsample2x_cat_nhwc_kernel, dim3(nb), dim3(256), 0, cofi_s(stream), low, ldl, C1, h, w, skip, lds, C2, out, ldo,
+                       frames);
     return cofi_launch_status();
 }
 

@@ -20,8 +20,9 @@ struct KpArgs {
     const int32_t *idx;
     const uint8_t *row_pos;
     float *agg, *cnt;
-    int ldf, N, C, M, H, ld_agg;
+    int ldf, N, C, M, H, ld_agg;   // N = support rows PER FRAME, M = total query rows
     float sigma;
+    int Mpf;                       // query rows per frame (stack mode: frame f owns queries [f*Mpf, ..) and support [f*N, ..))
 };
 
 // VEC = contiguous channels one lane loads per neighbour (1, 2 or 4 -> dword / dwordx2 / dwordx4), NCH =
@@ -43,6 +44,12 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
     if (m >= a.M) return;
     const int j = lane & 15, g = lane >> 4;
     const int c0 = blockIdx.y * (16 * VEC * NCH);
+    {   // stack mode: shift the support-side bases to this query's frame (indices are frame-local)
+        const size_t fo = (size_t)(m / a.Mpf) * a.N;
+        a.feats += fo * a.ldf;
+        a.s_pts += fo * 3;
+        a.row_pos += fo;
+    }
     const float qx = a.q_pts[3 * m], qy = a.q_pts[3 * m + 1], qz = a.q_pts[3 * m + 2];
     const bool kvalid = j < 15;
     const float kx = kvalid ? a.kp[3 * j] : 0.f, ky = kvalid ? a.kp[3 * j + 1] : 0.f, kz = kvalid ? a.kp[3 * j + 2] : 0.f;
@@ -158,10 +165,11 @@ __global__ void row_sum_positive_kernel(const float *feats, int ld, int N, int C
 // Chunks are the slow grid axis: all queries of one chunk run together and its source slice
 // (N x 128 B <= 2.6 MB) stays resident in every XCD's 4 MB L2.
 __global__ __launch_bounds__(256) void neighbor_maxpool_kernel(const float *x, int ldx, int N, int C, const int32_t *idx, int M,
-                                                               int H, float *out, int ldo) {
+                                                               int H, float *out, int ldo, int Mpf) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int m = blockIdx.x * 4 + wv;
     if (m >= M) return;
+    x += (size_t)(m / Mpf) * N * ldx;  // stack mode: frame-local indices
     const int g = lane >> 3, c = blockIdx.y * 32 + (lane & 7) * 4;
     const int32_t *irow = idx + (size_t)m * H;
     float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
@@ -184,8 +192,9 @@ __global__ __launch_bounds__(256) void neighbor_maxpool_kernel(const float *x, i
 
 // out[m,:] = x[idx[m*idx_stride], :] (zero row for idx == N)
 __global__ void gather_rows_kernel(const float *x, int ldx, int N, int C, const int32_t *idx, int idx_stride, int M, float *out,
-                                   int ldo) {
+                                   int ldo, int Mpf) {
     const int m = blockIdx.x;
+    x += (size_t)(m / Mpf) * N * ldx;  // stack mode: frame-local indices
     const int id = idx[(size_t)m * idx_stride];
     const bool valid = (unsigned)id < (unsigned)N;
     const int c4 = C >> 2;
@@ -210,11 +219,12 @@ extern "C" int cofi_row_sum_positive(const float *feats, int ld, int N, int C, u
 
 extern "C" int cofi_kpconv_aggregate(const float *feats, int ldf, int N, int C, const float *q_pts, const float *s_pts,
                                      const int32_t *idx, int M, int H, const float *kernel_points, float sigma,
-                                     const uint8_t *row_pos, float *agg, int ld_agg, float *cnt, cofi_stream_t stream) {
+                                     const uint8_t *row_pos, float *agg, int ld_agg, float *cnt, int frames, cofi_stream_t stream) {
     if (!feats || !q_pts || !s_pts || !idx || !kernel_points || !row_pos || !agg || !cnt) return COFI_EINVAL;
-    if (N <= 0 || C <= 0 || M < 0 || H <= 0 || (H & 3) || ldf < C || ld_agg < 15 * C || !(sigma > 0.f)) return COFI_EINVAL;
+    if (N <= 0 || C <= 0 || M < 0 || H <= 0 || (H & 3) || ldf < C || ld_agg < 15 * C || !(sigma > 0.f) || frames <= 0) return COFI_EINVAL;
     if (M == 0) return 0;
-    KpArgs a{feats, q_pts, s_pts, kernel_points, idx, row_pos, agg, cnt, ldf, N, C, M, H, ld_agg, sigma};
+    KpArgs a{feats, q_pts, s_pts, kernel_points, idx, row_pos, agg, cnt, ldf, N, C, M * frames, H, ld_agg, sigma, M};
+    M *= frames;
     hipStream_t s = cofi_s(stream);
     const int mb = cofi_cdiv(M, 4);
     if ((C & 3) == 0 && (ldf & 3) == 0 && C >= 64) {
@@ -231,20 +241,22 @@ extern "C" int cofi_kpconv_aggregate(const float *feats, int ldf, int N, int C, 
 }
 
 extern "C" int cofi_neighbor_maxpool(const float *x, int ldx, int N, int C, const int32_t *idx, int M, int H, float *out, int ldo,
-                                     cofi_stream_t stream) {
+                                     int frames, cofi_stream_t stream) {
     if (!x || !idx || !out || N <= 0 || C <= 0 || M < 0 || H <= 0 || ldx < C || ldo < C) return COFI_EINVAL;
     if ((C & 3) || (ldx & 3) || (ldo & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return COFI_EINVAL;
     if (M == 0) return 0;
-    hipLaunchKernelGGL(neighbor_maxpool_kernel, dim3(cofi_cdiv(M, 4), cofi_cdiv(C, 32)), dim3(256), 0, cofi_s(stream), x, ldx, N,
-                       C, idx, M, H, out, ldo);
+    if (frames <= 0) return COFI_EINVAL;
+    hipLaunchKernelGGL(neighbor_maxpool_kernel, dim3(cofi_cdiv(M * frames, 4), cofi_cdiv(C, 32)), dim3(256), 0, cofi_s(stream), x, ldx, N,
+                       C, idx, M * frames, H, out, ldo, M);
     return cofi_launch_status();
 }
 
 extern "C" int cofi_gather_rows(const float *x, int ldx, int N, int C, const int32_t *idx, int idx_stride, int M, float *out,
-                                int ldo, cofi_stream_t stream) {
+                                int ldo, int frames, cofi_stream_t stream) {
     if (!x || !idx || !out || N <= 0 || C <= 0 || M < 0 || idx_stride <= 0 || ldx < C || ldo < C) return COFI_EINVAL;
     if (M == 0) return 0;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(M), dim3(C >= 1024 ? 256 : (C >= 256 ? 128 : 64)), 0, cofi_s(stream), x, ldx, N, C,
-                       idx, idx_stride, M, out, ldo);
+    if (frames <= 0) return COFI_EINVAL;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(M * frames), dim3(C >= 1024 ? 256 : (C >= 256 ? 128 : 64)), 0, cofi_s(stream), x, ldx, N,
+                       C, idx, idx_stride, M * frames, out, ldo, M);
     return cofi_launch_status();
 }

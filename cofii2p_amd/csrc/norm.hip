@@ -90,11 +90,13 @@ __global__ __launch_bounds__(256) void group_stats_final_kernel(const double *pa
 // accumulators, then a fixed-order wave butterfly + 4-wave LDS fold.
 __global__ __launch_bounds__(256) void group_stats_from_colpart_kernel(const float *colpart, int nslab, int C, int groups, double count,
                                                                         float eps, float *stats) {
+    // grid = (groups, frames): nslab / count are PER FRAME; frame f owns slabs [f*nslab, (f+1)*nslab)
     __shared__ double red[4][2];
     const int g = blockIdx.x;
     const int cpg = C / groups;
     const int total = nslab * cpg;
-    const float *base = colpart + (size_t)g * cpg * 2;
+    const float *base = colpart + ((size_t)blockIdx.y * nslab * C + (size_t)g * cpg) * 2;
+    stats += (size_t)blockIdx.y * groups * 2;
     double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
     int e = threadIdx.x;
     for (; e + 256 < total; e += 512) {
@@ -126,6 +128,9 @@ __global__ __launch_bounds__(256) void group_stats_from_colpart_kernel(const flo
 // 4 slab phases per column folded through LDS in a fixed order
 __global__ __launch_bounds__(256) void col_inv_norm_from_colpart_kernel(const float *colpart, int nslab, int ncols, int C, float eps,
                                                                          float *out) {
+    // grid = (column tiles, frames): nslab is per frame
+    colpart += (size_t)blockIdx.y * nslab * ncols * 2;
+    out += (size_t)blockIdx.y * C;
     __shared__ double red[4][64];
     const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -140,8 +145,9 @@ __global__ __launch_bounds__(256) void col_inv_norm_from_colpart_kernel(const fl
 struct GnApplyArgs {
     const float *x, *stats, *gamma, *beta, *res, *res_stats, *res_gamma, *res_beta;
     float *y;
-    int ldx, ldr, ldy, M, C, cpg;
+    int ldx, ldr, ldy, M, C, cpg;   // M = rows PER FRAME; grid.y = frame
     float slope;
+    int groups;
 };
 
 // Thread = one float4 column chunk (its 4 channels' scale/shift are folded once: y = x*sc + sh), looping over a
@@ -152,6 +158,14 @@ __global__ __launch_bounds__(256) void group_norm_apply_kernel(GnApplyArgs a) {
     const int rpb = 256 / tpr;                        // rows per block step
     const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
     if (tr >= rpb) return;
+    {   // frame blockIdx.y: its rows, its statistics
+        const size_t f = blockIdx.y;
+        a.x += f * a.M * a.ldx;
+        a.y += f * a.M * a.ldy;
+        a.stats += f * a.groups * 2;
+        if (a.res) a.res += f * a.M * a.ldr;
+        if (a.res_stats) a.res_stats += f * a.groups * 2;
+    }
     for (int cb = tc; cb < c4n; cb += tpr) {
         const int c = cb * 4;
         float sc[4], sh[4], rsc[4], rsh[4];
@@ -351,18 +365,19 @@ __global__ void pos_sine_kernel(PosArgs a) {
 }  // namespace
 
 extern "C" int cofi_group_stats_from_colpart(const float *colpart, int nslab, int M, int C, int groups, float eps, float *stats,
-                                             cofi_stream_t stream) {
-    if (!colpart || !stats || nslab <= 0 || M <= 0 || C <= 0 || groups <= 0 || (C % groups)) return COFI_EINVAL;
-    hipLaunchKernelGGL(group_stats_from_colpart_kernel, dim3(groups), dim3(256), 0, cofi_s(stream), colpart, nslab, C, groups,
-                       (double)M * (C / groups), eps, stats);
+                                             int frames, cofi_stream_t stream) {
+    if (!colpart || !stats || nslab <= 0 || M <= 0 || C <= 0 || groups <= 0 || (C % groups) || frames <= 0) return COFI_EINVAL;
+    if ((nslab % frames) || (M % frames)) return COFI_EINVAL;  // slabs must not straddle frames
+    hipLaunchKernelGGL(group_stats_from_colpart_kernel, dim3(groups, frames), dim3(256), 0, cofi_s(stream), colpart, nslab / frames, C,
+                       groups, (double)(M / frames) * (C / groups), eps, stats);
     return cofi_launch_status();
 }
 
-extern "C" int cofi_col_inv_norm_from_colpart(const float *colpart, int nslab, int ncols, int C, float eps, float *out,
+extern "C" int cofi_col_inv_norm_from_colpart(const float *colpart, int nslab, int ncols, int C, float eps, float *out, int frames,
                                               cofi_stream_t stream) {
-    if (!colpart || !out || nslab <= 0 || C <= 0 || ncols < C) return COFI_EINVAL;
-    hipLaunchKernelGGL(col_inv_norm_from_colpart_kernel, dim3(cofi_cdiv(C, 64)), dim3(256), 0, cofi_s(stream), colpart, nslab, ncols, C,
-                       eps, out);
+    if (!colpart || !out || nslab <= 0 || C <= 0 || ncols < C || frames <= 0 || (nslab % frames)) return COFI_EINVAL;
+    hipLaunchKernelGGL(col_inv_norm_from_colpart_kernel, dim3(cofi_cdiv(C, 64), frames), dim3(256), 0, cofi_s(stream), colpart,
+                       nslab / frames, ncols, C, eps, out);
     return cofi_launch_status();
 }
 
@@ -388,17 +403,19 @@ extern "C" int cofi_group_stats(const float *x, int ldx, int M, int C, int group
 
 extern "C" int cofi_group_norm_apply(const float *x, int ldx, int M, int C, int groups, const float *stats, const float *gamma,
                                      const float *beta, const float *res, int ldr, const float *res_stats,
-                                     const float *res_gamma, const float *res_beta, float slope, float *y, int ldy,
+                                     const float *res_gamma, const float *res_beta, float slope, float *y, int ldy, int frames,
                                      cofi_stream_t stream) {
     if (!x || !stats || !y || M <= 0 || C <= 0 || groups <= 0 || (C % groups) || (C & 3) || (ldx & 3) || (ldy & 3)) return COFI_EINVAL;
     if ((gamma == nullptr) != (beta == nullptr) || (res_gamma == nullptr) != (res_beta == nullptr)) return COFI_EINVAL;
     if (res && (ldr & 3)) return COFI_EINVAL;
-    GnApplyArgs a{x, stats, gamma, beta, res, res_stats, res_gamma, res_beta, y, ldx, ldr, ldy, M, C, C / groups, slope};
+    if (frames <= 0 || (M % frames)) return COFI_EINVAL;
+    const int Mf = M / frames;
+    GnApplyArgs a{x, stats, gamma, beta, res, res_stats, res_gamma, res_beta, y, ldx, ldr, ldy, Mf, C, C / groups, slope, groups};
     const int c4n = C >> 2, tpr = c4n < 256 ? c4n : 256, rpb = 256 / tpr;
-    int nb = cofi_cdiv(M, rpb * 4);  // ~4 rows per thread
+    int nb = cofi_cdiv(Mf, rpb * 4);  // ~4 rows per thread
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(group_norm_apply_kernel, dim3(nb), dim3(256), 0, cofi_s(stream), a);
+    hipLaunchKernelGGL(group_norm_apply_kernel, dim3(nb, frames), dim3(256), 0, cofi_s(stream), a);
     return cofi_launch_status();
 }
 

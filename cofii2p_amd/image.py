@@ -89,22 +89,40 @@ def upsample_stage(P, name: str, low, skip):
 
 
 # ---------------------------------------------------------------------------------------------- NHWC path
-def _in_relu(y, part, res=None, res_part=None):
-    """relu(InstanceNorm(y) + [res | InstanceNorm(res)]) on (P, C) maps: one group per channel."""
+def _slabs_ok(y, part, frames):
+    return frames == 1 or (part.shape[0] % frames == 0 and y.shape[0] % part.shape[0] == 0
+                           and (y.shape[0] // frames) % (y.shape[0] // part.shape[0]) == 0)
+
+
+def _in_relu(y, part, res=None, res_part=None, frames: int = 1):
+    """relu(InstanceNorm(y) + [res | InstanceNorm(res)]) on (P, C) maps: one group per channel (per frame)."""
     P, C = y.shape
-    st = ops.group_stats_from_colpart(part, P, C)
-    rst = None if res_part is None else ops.group_stats_from_colpart(res_part, P, C)
-    return ops.group_norm_apply(y, st, slope=0.0, res=res, res_stats=rst)
+    if not _slabs_ok(y, part, frames) or (res_part is not None and not _slabs_ok(res, res_part, frames)):
+        # tiny maps whose pixel count is not a multiple of the statistics slab (5x16 map of layer4): per-frame statistics the
+        # plain way, one frame at a time
+        Pf = P // frames
+        outs = []
+        for f in range(frames):
+            yf = y[f * Pf:(f + 1) * Pf]
+            st = ops.group_stats(yf, C)
+            rf = None if res is None else res[f * Pf:(f + 1) * Pf]
+            rst = None if res_part is None else ops.group_stats(rf, C)
+            outs.append(ops.group_norm_apply(yf, st, slope=0.0, res=rf, res_stats=rst))
+        return torch.cat(outs, 0)
+    st = ops.group_stats_from_colpart(part, P, C, frames=frames)
+    rst = None if res_part is None else ops.group_stats_from_colpart(res_part, P, C, frames=frames)
+    return ops.group_norm_apply(y, st, slope=0.0, res=res, res_stats=rst, frames=frames)
 
 
 def resnet34_nhwc(P, img: torch.Tensor, full: bool = True):
     """imagenet.py:196-217 on NHWC maps.  img (1,3,H,W).  Returns ([s2, s4, s8, s16, s32, gap], [(H,W) per map])."""
     p = "img_encoder.backbone."
-    col, H, W = ops.im2col_stem(img[0].contiguous())
+    frames = img.shape[0]
+    col, H, W = ops.im2col_stem(img.contiguous())
     y, part = ops.gemm_colstats(col, P[p + "conv1.weight.nhwc"])
-    x = _in_relu(y, part)
+    x = _in_relu(y, part, frames=frames)
     outs, dims = [x], [(H, W)]
-    x, H, W = ops.maxpool3x3s2_nhwc(x, H, W)
+    x, H, W = ops.maxpool3x3s2_nhwc(x, H, W, frames)
     for li, (planes, blocks, stride) in enumerate(RESNET_LAYERS, start=1):
         if not full and li > 2:
             outs.append(None)
@@ -113,33 +131,33 @@ def resnet34_nhwc(P, img: torch.Tensor, full: bool = True):
         for b in range(blocks):
             q = "%slayer%d.%d." % (p, li, b)
             st = stride if b == 0 else 1
-            y1, part1, Ho, Wo = ops.conv2d_nhwc(x, H, W, P[q + "conv1.weight.nhwc"], 3, st, 1, colstats=True)
-            a = _in_relu(y1, part1)
-            y2, part2, _, _ = ops.conv2d_nhwc(a, Ho, Wo, P[q + "conv2.weight.nhwc"], 3, 1, 1, colstats=True)
+            y1, part1, Ho, Wo = ops.conv2d_nhwc(x, H, W, P[q + "conv1.weight.nhwc"], 3, st, 1, colstats=True, frames=frames)
+            a = _in_relu(y1, part1, frames=frames)
+            y2, part2, _, _ = ops.conv2d_nhwc(a, Ho, Wo, P[q + "conv2.weight.nhwc"], 3, 1, 1, colstats=True, frames=frames)
             if (q + "downsample.0.weight.nhwc") in P:
-                d, partd, _, _ = ops.conv2d_nhwc(x, H, W, P[q + "downsample.0.weight.nhwc"], 1, st, 0, colstats=True)
-                x = _in_relu(y2, part2, res=d, res_part=partd)
+                d, partd, _, _ = ops.conv2d_nhwc(x, H, W, P[q + "downsample.0.weight.nhwc"], 1, st, 0, colstats=True, frames=frames)
+                x = _in_relu(y2, part2, res=d, res_part=partd, frames=frames)
             else:
-                x = _in_relu(y2, part2, res=x)
+                x = _in_relu(y2, part2, res=x, frames=frames)
             H, W = Ho, Wo
         outs.append(x)
         dims.append((H, W))
-    outs.append(x.mean(0, keepdim=True) if full else None)  # AdaptiveAvgPool2d(1): unused downstream (network.py:87)
+    outs.append(x.reshape(frames, -1, x.shape[1]).mean(1) if full else None)  # AdaptiveAvgPool2d(1): unused downstream (network.py:87)
     dims.append((1, 1))
     return outs, dims
 
 
-def _residual_conv_nhwc(P, p: str, x, H, W):
+def _residual_conv_nhwc(P, p: str, x, H, W, frames: int = 1):
     """imagenet.py:397-411: three implicit-GEMM convolutions; folded-BN bias, ReLU and the skip add live in the
     epilogues."""
-    skip, _, _ = ops.conv2d_nhwc(x, H, W, P[p + "conv_skip.0.w.nhwc"], 3, 1, 1, bias=P[p + "conv_skip.0.b"])
-    y, _, _ = ops.conv2d_nhwc(x, H, W, P[p + "conv1.w.nhwc"], 3, 1, 1, bias=P[p + "conv1.b"], act=ops.ACT_RELU)
-    out, _, _ = ops.conv2d_nhwc(y, H, W, P[p + "conv2.w.nhwc"], 3, 1, 1, bias=P[p + "conv2.b"], res=skip, act=ops.ACT_RELU)
+    skip, _, _ = ops.conv2d_nhwc(x, H, W, P[p + "conv_skip.0.w.nhwc"], 3, 1, 1, bias=P[p + "conv_skip.0.b"], frames=frames)
+    y, _, _ = ops.conv2d_nhwc(x, H, W, P[p + "conv1.w.nhwc"], 3, 1, 1, bias=P[p + "conv1.b"], act=ops.ACT_RELU, frames=frames)
+    out, _, _ = ops.conv2d_nhwc(y, H, W, P[p + "conv2.w.nhwc"], 3, 1, 1, bias=P[p + "conv2.b"], res=skip, act=ops.ACT_RELU, frames=frames)
     return out
 
 
-def upsample_stage_nhwc(P, name: str, low, h, w, skip):
+def upsample_stage_nhwc(P, name: str, low, h, w, skip, frames: int = 1):
     """imagenet.py:431-444 on NHWC maps: low (h*w, C1), skip (4hw, C2) -> (4hw, Cout)."""
-    x = ops.upsample2x_cat_nhwc(low, h, w, skip)
-    x = _residual_conv_nhwc(P, name + ".conv.0.", x, 2 * h, 2 * w)
-    return _residual_conv_nhwc(P, name + ".conv.1.", x, 2 * h, 2 * w)
+    x = ops.upsample2x_cat_nhwc(low, h, w, skip, frames)
+    x = _residual_conv_nhwc(P, name + ".conv.0.", x, 2 * h, 2 * w, frames)
+    return _residual_conv_nhwc(P, name + ".conv.1.", x, 2 * h, 2 * w, frames)

@@ -24,51 +24,59 @@ def pack_encoder(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     return out
 
 
-def _kpconv(P, p: str, feats, q_pts, s_pts, idx, sigma: float):
+def _stats(y, part, frames: int):
+    """GroupNorm statistics per frame from the GEMM's column partials (stack mode: (frames, groups, 2))."""
+    if frames > 1 and (part.shape[0] % frames or (y.shape[0] // frames) % (y.shape[0] // part.shape[0])):
+        raise ops._lib.CofiError("stack mode needs per-frame row counts that are multiples of the statistics slab (%d rows, %d slabs, %d frames)"
+                                 % (y.shape[0], part.shape[0], frames))
+    return ops.group_stats_from_colpart(part, y.shape[0], GN_GROUPS, frames=frames)
+
+
+def _kpconv(P, p: str, feats, q_pts, s_pts, idx, sigma: float, frames: int = 1):
     """-> (KPConv output, its GroupNorm statistics).  The statistics come out of the GEMM epilogue (column
     partials) instead of another pass over the activation."""
-    agg, cnt = ops.kpconv_aggregate(feats, q_pts, s_pts, idx, P[p + "KPConv.kernel_points"], sigma)
+    agg, cnt = ops.kpconv_aggregate(feats, q_pts, s_pts, idx, P[p + "KPConv.kernel_points"], sigma, frames=frames)
     y, part = ops.gemm_colstats(agg, P[p + "KPConv.weights"], bias=P[p + "KPConv.bias"], rowdiv=cnt)
-    return y, ops.group_stats_from_colpart(part, y.shape[0], GN_GROUPS)
+    return y, _stats(y, part, frames)
 
 
-def _unary_raw(P, p: str, x):
+def _unary_raw(P, p: str, x, frames: int = 1):
     y, part = ops.gemm_colstats(x, P[p + "mlp.weight"], bias=P[p + "mlp.bias"])
-    return y, ops.group_stats_from_colpart(part, y.shape[0], GN_GROUPS)
+    return y, _stats(y, part, frames)
 
 
-def _unary(P, p: str, x, slope: float, out=None):
-    y, st = _unary_raw(P, p, x)
-    return ops.group_norm_apply(y, st, P[p + "norm.norm.weight"], P[p + "norm.norm.bias"], slope=slope, out=out)
+def _unary(P, p: str, x, slope: float, out=None, frames: int = 1):
+    y, st = _unary_raw(P, p, x, frames)
+    return ops.group_norm_apply(y, st, P[p + "norm.norm.weight"], P[p + "norm.norm.bias"], slope=slope, out=out, frames=frames)
 
 
-def run_block(P, blk: KPBlock, feats, q_pts, s_pts, idx, out=None, concurrent: bool = True):
+def run_block(P, blk: KPBlock, feats, q_pts, s_pts, idx, out=None, concurrent: bool = True, frames: int = 1):
     p = "pc_encoder.%s." % blk.name
     if blk.kind == "conv":  # modules.py:155-159
-        y, st = _kpconv(P, p, feats, q_pts, s_pts, idx, blk.sigma)
-        return ops.group_norm_apply(y, st, P[p + "norm.norm.weight"], P[p + "norm.norm.bias"], slope=LRELU, out=out)
+        y, st = _kpconv(P, p, feats, q_pts, s_pts, idx, blk.sigma, frames)
+        return ops.group_norm_apply(y, st, P[p + "norm.norm.weight"], P[p + "norm.norm.bias"], slope=LRELU, out=out, frames=frames)
     # modules.py:222-240.  The shortcut (max-pool / Linear+GN statistics) only meets the main branch in the
     # final fused normalise+add+LeakyReLU: it runs on a side stream.
     has_branch = blk.strided or blk.has_shortcut_unary
     with ops.Branch(feats.device, 1, enabled=concurrent and has_branch) as br:
-        sc = ops.neighbor_maxpool(feats, idx) if blk.strided else feats
+        sc = ops.neighbor_maxpool(feats, idx, frames=frames) if blk.strided else feats
         ys = sts = None
         if blk.has_shortcut_unary:
-            ys, sts = _unary_raw(P, p + "unary_shortcut.", sc)
-    x = _unary(P, p + "unary1.", feats, LRELU) if blk.cin != blk.mid else feats
-    y, st = _kpconv(P, p, x, q_pts, s_pts, idx, blk.sigma)
-    x = ops.group_norm_apply(y, st, P[p + "norm_conv.norm.weight"], P[p + "norm_conv.norm.bias"], slope=LRELU)
-    y2, st2 = _unary_raw(P, p + "unary2.", x)
+            ys, sts = _unary_raw(P, p + "unary_shortcut.", sc, frames)
+    x = _unary(P, p + "unary1.", feats, LRELU, frames=frames) if blk.cin != blk.mid else feats
+    y, st = _kpconv(P, p, x, q_pts, s_pts, idx, blk.sigma, frames)
+    x = ops.group_norm_apply(y, st, P[p + "norm_conv.norm.weight"], P[p + "norm_conv.norm.bias"], slope=LRELU, frames=frames)
+    y2, st2 = _unary_raw(P, p + "unary2.", x, frames)
     br.join(sc, ys, sts)
     g2, b2 = P[p + "unary2.norm.norm.weight"], P[p + "unary2.norm.norm.bias"]
     if blk.has_shortcut_unary:
         return ops.group_norm_apply(y2, st2, g2, b2, slope=LRELU, res=ys, res_stats=sts,
                                     res_gamma=P[p + "unary_shortcut.norm.norm.weight"],
-                                    res_beta=P[p + "unary_shortcut.norm.norm.bias"], out=out)
-    return ops.group_norm_apply(y2, st2, g2, b2, slope=LRELU, res=sc, out=out)
+                                    res_beta=P[p + "unary_shortcut.norm.norm.bias"], out=out, frames=frames)
+    return ops.group_norm_apply(y2, st2, g2, b2, slope=LRELU, res=sc, out=out, frames=frames)
 
 
-def run_fpn(P, points: List[torch.Tensor], neighbors, subsampling, upsampling, feats, taps=None):
+def run_fpn(P, points: List[torch.Tensor], neighbors, subsampling, upsampling, feats, taps=None, frames: int = 1):
     """Returns [latent_s2 (N1,64), latent_s3 (N2,512), latent_s4 (N3,1024), feats_s5 (N4,2048)].
     The last block of stages 1..3 writes directly into the right part of the decoder's concat
     buffer (kp_backbone.py:112,117,122 torch.cat)."""
@@ -94,16 +102,16 @@ def run_fpn(P, points: List[torch.Tensor], neighbors, subsampling, upsampling, f
         if st in cat and last_of_stage[st] == blk.name:
             w = stage_width[st]
             out = cat[st][:, cat[st].shape[1] - w:]
-        x = run_block(P, blk, x, q, s, idx, out=out)
+        x = run_block(P, blk, x, q, s, idx, out=out, frames=frames)
         stage_out[st] = x
         if taps is not None:
             taps[blk.name] = x
     s5 = stage_out[4]
-    ops.gather_rows(s5, upsampling[3], out=cat[3][:, :2048])
-    l4 = _unary(P, "pc_encoder.decoder4.", cat[3], LRELU)
-    ops.gather_rows(l4, upsampling[2], out=cat[2][:, :1024])
-    l3 = _unary(P, "pc_encoder.decoder3.", cat[2], LRELU)
-    ops.gather_rows(l3, upsampling[1], out=cat[1][:, :512])
+    ops.gather_rows(s5, upsampling[3], out=cat[3][:, :2048], frames=frames)
+    l4 = _unary(P, "pc_encoder.decoder4.", cat[3], LRELU, frames=frames)
+    ops.gather_rows(l4, upsampling[2], out=cat[2][:, :1024], frames=frames)
+    l3 = _unary(P, "pc_encoder.decoder3.", cat[2], LRELU, frames=frames)
+    ops.gather_rows(l3, upsampling[1], out=cat[1][:, :512], frames=frames)
     l2 = ops.gemm(cat[1], P["pc_encoder.decoder2.mlp.weight"], bias=P["pc_encoder.decoder2.mlp.bias"])
     if taps is not None:
         taps.update(decoder4=l4, decoder3=l3, decoder2=l2)

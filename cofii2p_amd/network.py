@@ -115,14 +115,14 @@ class CoFiI2P(nn.Module):
     def _as_idx32(t: torch.Tensor) -> torch.Tensor:
         return ops.idx_to_int32(t) if t.dtype != torch.int32 else t.contiguous()
 
-    def _score_head(self, P, head: str, tokens: torch.Tensor) -> torch.Tensor:
+    def _score_head(self, P, head: str, tokens: torch.Tensor, frames: int = 1) -> torch.Tensor:
         """network.py:42-43 on token-major data: 1x1 conv = GEMM, InstanceNorm over positions =
         per-column normalisation (group width 1), ReLU = slope 0."""
         T = tokens.shape[0]
         y, part = ops.gemm_colstats(tokens, P[head + ".0.weight"])
-        y = ops.group_norm_apply(y, ops.group_stats_from_colpart(part, T, y.shape[1]), slope=0.0)
+        y = ops.group_norm_apply(y, ops.group_stats_from_colpart(part, T, y.shape[1], frames=frames), slope=0.0, frames=frames)
         y, part = ops.gemm_colstats(y, P[head + ".3.weight"])
-        y = ops.group_norm_apply(y, ops.group_stats_from_colpart(part, T, y.shape[1]), slope=0.0)
+        y = ops.group_norm_apply(y, ops.group_stats_from_colpart(part, T, y.shape[1], frames=frames), slope=0.0, frames=frames)
         return ops.gemm(y, P[head + ".6.weight"], act=ops.ACT_SIGMOID)  # (T,1)
 
     def _pc_feature_mlp(self, P, x: torch.Tensor) -> torch.Tensor:
@@ -136,21 +136,32 @@ class CoFiI2P(nn.Module):
     def _run_device(self, P, points, neighbors, subsampling, upsampling, feats, img, mode, fine_center_kpt_coors,
                     fine_pc_inline_index, taps=None):
         """Everything of network.py:74-161 that runs on the device.  Test-mode outputs are sized at
-        capacity (N4 rows) with the match count left in device memory: capturable in a hipGraph."""
+        capacity (N4 rows) with the match count left in device memory: capturable in a hipGraph.
+
+        STACK MODE: ``img`` is (B,3,H,W) and every point-side tensor holds B equally sized frames stacked along
+        its rows (index tables frame-local).  All per-frame statistics (GroupNorm, InstanceNorm, the token-axis
+        Q normalisation), the neighbour gathers, attention and the matching are computed per frame inside the
+        same launches; row-wise kernels (GEMMs, LayerNorm, ...) just see B times more rows.  Outputs are lists
+        with one entry per frame."""
         dev = img.device
-        N4 = points[-1].shape[0]
+        B = img.shape[0]
+        if mode != "test" and B != 1:
+            raise ValueError("stack mode (B > 1) serves mode='test'")
+        N4 = points[-1].shape[0] // B
         H8, W8 = img.shape[2] // 8, img.shape[3] // 8
         T_img, C = H8 * W8, D_MODEL
-        ts = transformer.TokenStreams(T_img, N4, D_MODEL, dev)
+        ts = transformer.TokenStreams(B * T_img, B * N4, D_MODEL, dev)
         # ---- image branch (network.py:77,90,104-106,110) on a side stream, concurrent with the point encoder
         nhwc = self.image_backend == "nhwc"
+        if B != 1 and not nhwc:
+            raise ValueError("stack mode needs the NHWC image backend")
         with ops.Branch(dev, 0) as br_img:
             gy, gx = torch.meshgrid(torch.arange(H8, device=dev, dtype=torch.int32), torch.arange(W8, device=dev, dtype=torch.int32),
                                     indexing="ij")
-            grid = torch.stack([gy, gx], -1).reshape(T_img, 2).contiguous()
+            grid = torch.stack([gy, gx], -1).reshape(T_img, 2).repeat(B, 1).contiguous()
             if nhwc:
                 img_set, dims = image.resnet34_nhwc(P, img, full=self.compute_unused_image_maps)
-                s2, s4, s8 = img_set[0], img_set[1], img_set[2]  # (H*W, C) pixel-major
+                s2, s4, s8 = img_set[0], img_set[1], img_set[2]  # (B*H*W, C) pixel-major
                 s8n = ops.l2norm_rows(s8)  # the normalised s8 map also feeds the up-sampler (network.py:90,129)
                 ops.l2norm_rows(s8, out=ts.img[0][:, :D_MODEL])
             else:
@@ -159,8 +170,8 @@ class CoFiI2P(nn.Module):
                 s8n, _ = ops.l2norm_cols(s8[0].reshape(C, T_img), tokens_out=ts.img[0][:, :D_MODEL])
             ops.pos_sine(grid, ts.img[0], accumulate=True)
         # ---- point branch (network.py:76,83-84,107,111)
-        pc_set = kpfpn.run_fpn(P, points, neighbors, subsampling, upsampling, feats, taps=taps)
-        fine_pc = ops.l2norm_rows(pc_set[0])  # (N1,64)
+        pc_set = kpfpn.run_fpn(P, points, neighbors, subsampling, upsampling, feats, taps=taps, frames=B)
+        fine_pc = ops.l2norm_rows(pc_set[0])  # (B*N1,64)
         ops.l2norm_rows(self._pc_feature_mlp(P, pc_set[-1]), out=ts.pc[0][:, :D_MODEL])
         ops.pos_sine(points[-1], ts.pc[0], accumulate=True)
         br_img.join(s2, s4, s8n, ts.img[0])
@@ -170,10 +181,10 @@ class CoFiI2P(nn.Module):
         # ---- fine image descriptors (network.py:129-130): only image data -> side stream, under the transformer
         with ops.Branch(dev, 0) as br_up:
             if nhwc:
-                up4 = image.upsample_stage_nhwc(P, "img_upsample_1", s8n, H8, W8, s4)
-                up2_raw = image.upsample_stage_nhwc(P, "img_upsample_2", up4, 2 * H8, 2 * W8, s2)
+                up4 = image.upsample_stage_nhwc(P, "img_upsample_1", s8n, H8, W8, s4, frames=B)
+                up2_raw = image.upsample_stage_nhwc(P, "img_upsample_2", up4, 2 * H8, 2 * W8, s2, frames=B)
                 H2, W2, C2 = 4 * H8, 4 * W8, up2_raw.shape[1]
-                up2 = ops.l2norm_rows(up2_raw)  # (H2*W2, C2) pixel-major fine image descriptors
+                up2 = ops.l2norm_rows(up2_raw)  # (B*H2*W2, C2) pixel-major fine image descriptors
             else:
                 up4 = image.upsample_stage(P, "img_upsample_1", s8n.reshape(1, C, H8, W8), s4)
                 up2_raw = image.upsample_stage(P, "img_upsample_2", up4, s2)
@@ -182,41 +193,48 @@ class CoFiI2P(nn.Module):
                 up2 = up2.reshape(C2, H2, W2)
 
         # ---- transformer (network.py:113-115)
-        tok_img, tok_pc = transformer.run_transformer(self._layers, LAYER_KINDS, ts, N_HEAD)
+        tok_img, tok_pc = transformer.run_transformer(self._layers, LAYER_KINDS, ts, N_HEAD, frames=B)
 
         # ---- scores + coarse descriptors (network.py:123-126)
-        pc_score = self._score_head(P, "pc_score_layer", tok_pc)  # (N4,1)
-        img_score = self._score_head(P, "img_score_layer", tok_img)  # (T,1)
-        pc_desc_tok = ops.l2norm_rows(tok_pc)  # (N4,128) token-major copy for the similarity GEMM
+        pc_score = self._score_head(P, "pc_score_layer", tok_pc, B)  # (B*N4,1)
+        img_score = self._score_head(P, "img_score_layer", tok_img, B)  # (B*T,1)
+        pc_desc_tok = ops.l2norm_rows(tok_pc)  # (B*N4,128) token-major copy for the similarity GEMM
         img_desc_tok = ops.l2norm_rows(tok_img)
-        pc_desc = ops.transpose(pc_desc_tok)  # (128,N4)
-        img_desc = ops.transpose(img_desc_tok).reshape(1, C, H8, W8)
         br_up.join(up2)
         if taps is not None:
             taps.update(up2=up2, fine_pc=fine_pc, tok_img_out=tok_img, tok_pc_out=tok_pc)
-
-        out = {"img_desc": img_desc, "pc_desc": pc_desc, "img_score": img_score.reshape(1, 1, H8, W8),
-               "pc_score": pc_score.reshape(1, 1, N4)}
-        if mode in ("train", "val"):
-            K = fine_center_kpt_coors.shape[1]
-            cnt = torch.zeros((2,), dtype=torch.int32, device=dev)
-            cnt[0] = K
-            ctr = fine_center_kpt_coors.to(torch.float32).contiguous()
-            pat = ops.extract_patches_nhwc(up2, H2, W2, ctr, cnt, K, 1.0) if nhwc else ops.extract_patches(up2, ctr, cnt, K, 1.0)
-            out["patches"] = pat.reshape(K, C2, 4, 4)
-            out["fine_pc"] = ops.gather_rows(fine_pc, self._as_idx32(fine_pc_inline_index.reshape(-1)))
-            return out
-        # ---- test mode: coarse matching + patch extraction (network.py:145-161), count stays on the device
-        sim = ops.gemm(pc_desc_tok, img_desc_tok)  # (N4, T): <pc, pixel>
-        pix = ops.row_argmin_1m(sim)
-        sel, xy, cnt = ops.select_matches(pc_score.reshape(-1), pix, W8, H8, score_thresholds(), 4)
-        out["coarse_pts"] = ops.gather_points_sel(points[-1], sel, cnt)
-        node = ops.nearest_node_sel(points[1], points[-1], sel, cnt)
-        out["patches"] = ops.extract_patches_nhwc(up2, H2, W2, xy, cnt, N4, 4.0) if nhwc else ops.extract_patches(up2, xy, cnt, N4, 4.0)
-        out["fine_pc"] = ops.gather_rows_sel(fine_pc, node, cnt, N4)
-        out["fine_xy"], out["fine_best"] = ops.fine_match(out["patches"], out["fine_pc"], xy, cnt, 4.0)  # eval_all.py:99-105
-        out.update(sel=sel, coarse_xy=xy, count=cnt)
-        return out
+        N1 = points[1].shape[0] // B
+        P2 = H2 * W2
+        outs = []
+        for f in range(B):  # per-frame tail: output layouts + matching (small kernels)
+            pdt, idt = pc_desc_tok[f * N4:(f + 1) * N4], img_desc_tok[f * T_img:(f + 1) * T_img]
+            o = {"img_desc": ops.transpose(idt).reshape(1, C, H8, W8), "pc_desc": ops.transpose(pdt),
+                 "img_score": img_score[f * T_img:(f + 1) * T_img].reshape(1, 1, H8, W8), "pc_score": pc_score[f * N4:(f + 1) * N4].reshape(1, 1, N4)}
+            fpc = fine_pc[f * N1:(f + 1) * N1]
+            up2_f = up2[f * P2:(f + 1) * P2] if nhwc else up2
+            if mode in ("train", "val"):
+                K = fine_center_kpt_coors.shape[1]
+                cnt = torch.zeros((2,), dtype=torch.int32, device=dev)
+                cnt[0] = K
+                ctr = fine_center_kpt_coors.to(torch.float32).contiguous()
+                pat = ops.extract_patches_nhwc(up2_f, H2, W2, ctr, cnt, K, 1.0) if nhwc else ops.extract_patches(up2_f, ctr, cnt, K, 1.0)
+                o["patches"] = pat.reshape(K, C2, 4, 4)
+                o["fine_pc"] = ops.gather_rows(fpc, self._as_idx32(fine_pc_inline_index.reshape(-1)))
+            else:
+                # ---- test mode: coarse matching + patch extraction (network.py:145-161), count stays on the device
+                pts4, pts1 = points[-1][f * N4:(f + 1) * N4], points[1][f * N1:(f + 1) * N1]
+                sim = ops.gemm(pdt, idt)  # (N4, T): <pc, pixel>
+                pix = ops.row_argmin_1m(sim)
+                sel, xy, cnt = ops.select_matches(o["pc_score"].reshape(-1), pix, W8, H8, score_thresholds(), 4)
+                o["coarse_pts"] = ops.gather_points_sel(pts4, sel, cnt)
+                node = ops.nearest_node_sel(pts1, pts4, sel, cnt)
+                o["patches"] = (ops.extract_patches_nhwc(up2_f, H2, W2, xy, cnt, N4, 4.0) if nhwc
+                                else ops.extract_patches(up2_f, xy, cnt, N4, 4.0))
+                o["fine_pc"] = ops.gather_rows_sel(fpc, node, cnt, N4)
+                o["fine_xy"], o["fine_best"] = ops.fine_match(o["patches"], o["fine_pc"], xy, cnt, 4.0)  # eval_all.py:99-105
+                o.update(sel=sel, coarse_xy=xy, count=cnt)
+            outs.append(o)
+        return outs
 
     # ------------------------------------------------------------------ hipGraph replay
     def enable_graphs(self, flag: bool = True):
@@ -273,39 +291,60 @@ class CoFiI2P(nn.Module):
         ops.BRANCH_MASK = saved_mask
         return outs
 
-    # ------------------------------------------------------------------ frames in flight
+    # ------------------------------------------------------------------ frames in flight / stack-mode batches
+    @staticmethod
+    def stack_frames(pyramids, imgs):
+        """B single-frame inputs -> one stack-mode input: every tensor concatenated along its rows (index tables stay
+        frame-local, int32), images stacked to (B,3,H,W).  All frames must have identical sizes."""
+        out = {}
+        for k in ("points", "neighbors", "subsampling", "upsampling"):
+            out[k] = [torch.cat([CoFiI2P._as_idx32(p[k][i]) if k != "points" else p[k][i] for p in pyramids], 0).contiguous()
+                      for i in range(len(pyramids[0][k]))]
+        out["feats"] = torch.cat([p["feats"] for p in pyramids], 0).contiguous()
+        return out, torch.cat([im.reshape(1, *im.shape[-3:]) for im in imgs], 0).contiguous()
+
     @torch.no_grad()
     def forward_async(self, slot: int, pc_data_dict, img, mode: str = "test"):
-        """Enqueue one test-mode forward on the CURRENT stream through the hipGraph of frame slot `slot`
-        and return immediately (no host sync).  Slots own their static buffers and scratch, so several frames
-        can be in flight on different streams; `finish(handle)` synchronises on that frame only and returns the
-        reference's 8-tuple.  A slot must be finished before it is reused."""
+        """Enqueue one test-mode forward on the CURRENT stream through the hipGraph of slot `slot` and return
+        immediately (no host sync).  `img` (1,3,H,W) = one frame, or (B,3,H,W) with a stack-mode `pc_data_dict`
+        (see stack_frames) = B frames through the same launches.  Slots own their static buffers and scratch, so
+        several submissions can be in flight on different streams; `finish(handle)` synchronises on that
+        submission only.  A slot must be finished before it is reused."""
         if mode != "test":
             raise ValueError("forward_async serves the test-mode pipeline")
         _lib.load()
         P = self._pack(img.device)
         points = [p.contiguous() for p in pc_data_dict["points"]]
         tabs = [[self._as_idx32(t) for t in pc_data_dict[k]] for k in ("neighbors", "subsampling", "upsampling")]
-        # frames in flight fill the GPU by themselves: the per-frame graph is a linear chain (intra-frame fork/join
-        # only adds join latency then — measured 306 vs 250 frames/s)
-        o = self._graph_forward(P, points, tabs[0], tabs[1], tabs[2], pc_data_dict["feats"].contiguous(), img.contiguous(), mode, None, None,
-                                slot=slot, branch_mask=0)
-        host = torch.empty((2,), dtype=torch.int32, pin_memory=True)
-        host.copy_(o["count"], non_blocking=True)
+        # submissions in flight fill the GPU by themselves: the per-submission graph is a linear chain (intra-frame
+        # fork/join only adds join latency then — measured 306 vs 250 frames/s)
+        outs = self._graph_forward(P, points, tabs[0], tabs[1], tabs[2], pc_data_dict["feats"].contiguous(), img.contiguous(), mode, None,
+                                   None, slot=slot, branch_mask=0)
+        host = torch.empty((len(outs), 2), dtype=torch.int32, pin_memory=True)
+        for f, o in enumerate(outs):
+            host[f].copy_(o["count"], non_blocking=True)
         done = torch.cuda.Event()
         done.record()
-        return {"out": o, "count_host": host, "done": done}
+        return {"out": outs, "count_host": host, "done": done}
 
-    def finish(self, handle):
-        handle["done"].synchronize()
-        o = handle["out"]
-        n, thr_i = int(handle["count_host"][0]), int(handle["count_host"][1])
+    def _slice_result(self, o, n: int, thr_i: int):
         if thr_i < 0:
             raise RuntimeError("fewer than 4 coarse matches at every threshold (network.py:148 would loop forever)")
         self.last_match = {"n": n, "sel": o["sel"][:n], "coarse_xy": o["coarse_xy"][:, :n], "count_dev": o["count"],
                            "fine_xy": o["fine_xy"][:, :n], "fine_best": o["fine_best"][:n], "threshold": float(score_thresholds()[thr_i])}
         return (o["img_desc"], o["pc_desc"], o["img_score"], o["pc_score"], o["patches"][:n], o["fine_pc"][:n], o["coarse_xy"][:, :n] * 4,
                 o["coarse_pts"][:n])
+
+    def finish(self, handle):
+        """-> the reference's 8-tuple for a single-frame submission, or a list of B 8-tuples for a stack-mode one
+        (`handle["fine_xy"]` then holds the per-frame fine matches)."""
+        handle["done"].synchronize()
+        res, fine = [], []
+        for f, o in enumerate(handle["out"]):
+            res.append(self._slice_result(o, int(handle["count_host"][f, 0]), int(handle["count_host"][f, 1])))
+            fine.append(self.last_match["fine_xy"])
+        handle["fine_xy"] = fine
+        return res[0] if len(res) == 1 else res
 
     @torch.no_grad()
     def forward(self, pc_data_dict, img, fine_center_kpt_coors, fine_xy, fine_pc_inline_index, mode, taps=None):
@@ -324,19 +363,14 @@ class CoFiI2P(nn.Module):
         feats = pc_data_dict["feats"].contiguous()
         if getattr(self, "_use_graphs", False) and taps is None:
             o = self._graph_forward(P, points, neighbors, subsampling, upsampling, feats, img.contiguous(), mode, fine_center_kpt_coors,
-                                    fine_pc_inline_index)
+                                    fine_pc_inline_index)[0]
         else:
             o = self._run_device(P, points, neighbors, subsampling, upsampling, feats, img, mode, fine_center_kpt_coors,
-                                 fine_pc_inline_index, taps=taps)
+                                 fine_pc_inline_index, taps=taps)[0]
         if mode in ("train", "val"):
             return o["img_desc"], o["pc_desc"], o["img_score"], o["pc_score"], o["patches"], o["fine_pc"], None, None
         n, thr_i = (int(v) for v in o["count"].cpu())  # the only device->host synchronisation of forward
-        if thr_i < 0:
-            raise RuntimeError("fewer than 4 coarse matches at every threshold (network.py:148 would loop forever)")
-        self.last_match = {"n": n, "sel": o["sel"][:n], "coarse_xy": o["coarse_xy"][:, :n], "count_dev": o["count"],
-                           "fine_xy": o["fine_xy"][:, :n], "fine_best": o["fine_best"][:n], "threshold": float(score_thresholds()[thr_i])}
-        return (o["img_desc"], o["pc_desc"], o["img_score"], o["pc_score"], o["patches"][:n], o["fine_pc"][:n], o["coarse_xy"][:, :n] * 4,
-                o["coarse_pts"][:n])
+        return self._slice_result(o, n, thr_i)
 
 
 def fine_matching(fine_img_feature_patch, fine_pc_inline_feature, fine_center_xy):

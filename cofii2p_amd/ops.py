@@ -175,6 +175,16 @@ def gemm_colstats(a, w, out=None, bias=None, rowdiv=None, act: int = ACT_NONE):
     return out, colpart
 
 
+def colstats_frames_ok(M_total: int, N: int, K: int, frames: int) -> bool:
+    """True if the statistics slabs of a (M_total,N,K) contraction do not straddle frame boundaries (stack mode)."""
+    if frames == 1:
+        return True
+    nslab = _lib.load().cofi_gemm_f32_stat_slabs(M_total, N, K)
+    if nslab % frames or M_total % nslab:
+        return False
+    return (M_total // frames) % (M_total // nslab) == 0
+
+
 def gemm_layernorm(a, w, gamma, beta, bias=None, relu: bool = False, res=None, out=None, eps: float = 1e-5):
     """out = relu?(LayerNorm(a @ w.T + bias) * gamma + beta) + res, one kernel (N <= 128)."""
     lib = _lib.load()
@@ -192,19 +202,22 @@ def gemm_layernorm(a, w, gamma, beta, bias=None, relu: bool = False, res=None, o
     return out
 
 
-def group_stats_from_colpart(colpart, M: int, groups: int, eps: float = 1e-5):
+def group_stats_from_colpart(colpart, M: int, groups: int, eps: float = 1e-5, frames: int = 1):
+    """M = total rows.  -> stats (groups,2), or (frames, groups, 2) in stack mode (slabs must not straddle frames)."""
     lib = _lib.load()
     nslab, C, _ = colpart.shape
-    stats = torch.empty((groups, 2), dtype=torch.float32, device=colpart.device)
-    _lib.check(lib.cofi_group_stats_from_colpart(_p(colpart), nslab, M, C, groups, eps, _p(stats), _stream()), "cofi_group_stats_from_colpart")
+    stats = torch.empty((groups, 2) if frames == 1 else (frames, groups, 2), dtype=torch.float32, device=colpart.device)
+    _lib.check(lib.cofi_group_stats_from_colpart(_p(colpart), nslab, M, C, groups, eps, _p(stats), frames, _stream()),
+               "cofi_group_stats_from_colpart")
     return stats
 
 
-def col_inv_norm_from_colpart(colpart, C: int, eps: float = 1e-12):
+def col_inv_norm_from_colpart(colpart, C: int, eps: float = 1e-12, frames: int = 1):
     lib = _lib.load()
     nslab, ncols, _ = colpart.shape
-    out = torch.empty((C,), dtype=torch.float32, device=colpart.device)
-    _lib.check(lib.cofi_col_inv_norm_from_colpart(_p(colpart), nslab, ncols, C, eps, _p(out), _stream()), "cofi_col_inv_norm_from_colpart")
+    out = torch.empty((C,) if frames == 1 else (frames, C), dtype=torch.float32, device=colpart.device)
+    _lib.check(lib.cofi_col_inv_norm_from_colpart(_p(colpart), nslab, ncols, C, eps, _p(out), frames, _stream()),
+               "cofi_col_inv_norm_from_colpart")
     return out
 
 
@@ -217,38 +230,39 @@ def row_sum_positive(feats: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def kpconv_aggregate(feats, q_pts, s_pts, idx, kernel_points, sigma: float, row_pos=None):
-    """-> agg (M, 15*C), cnt (M,) float.  idx int32 (M,H)."""
+def kpconv_aggregate(feats, q_pts, s_pts, idx, kernel_points, sigma: float, row_pos=None, frames: int = 1):
+    """-> agg (M, 15*C), cnt (M,) float.  idx int32 (M,H).  Stack mode: `frames` equally sized frames stacked along
+    the rows of every argument, idx frame-local."""
     lib = _lib.load()
     _mat(feats, "feats"), _mat(idx, "idx", torch.int32)
     if not (q_pts.is_contiguous() and s_pts.is_contiguous() and kernel_points.is_contiguous() and idx.is_contiguous()):
         raise _lib.CofiError("kpconv_aggregate: points / idx / kernel_points must be contiguous")
     N, C = feats.shape
     M, H = idx.shape
-    if s_pts.shape != (N, 3) or q_pts.shape != (M, 3) or kernel_points.shape != (15, 3):
+    if s_pts.shape != (N, 3) or q_pts.shape != (M, 3) or kernel_points.shape != (15, 3) or N % frames or M % frames:
         raise _lib.CofiError("kpconv_aggregate: shape mismatch")
     if row_pos is None:
         row_pos = row_sum_positive(feats)
     agg = torch.empty((M, 15 * C), dtype=torch.float32, device=feats.device)
     cnt = torch.empty((M,), dtype=torch.float32, device=feats.device)
-    rc = lib.cofi_kpconv_aggregate(_p(feats), _ld(feats), N, C, _p(q_pts), _p(s_pts), _p(idx), M, H, _p(kernel_points), float(sigma),
-                                   _p(row_pos), _p(agg), 15 * C, _p(cnt), _stream())
+    rc = lib.cofi_kpconv_aggregate(_p(feats), _ld(feats), N // frames, C, _p(q_pts), _p(s_pts), _p(idx), M // frames, H,
+                                   _p(kernel_points), float(sigma), _p(row_pos), _p(agg), 15 * C, _p(cnt), frames, _stream())
     _lib.check(rc, "cofi_kpconv_aggregate")
     return agg, cnt
 
 
-def neighbor_maxpool(x, idx, out=None):
+def neighbor_maxpool(x, idx, out=None, frames: int = 1):
     lib = _lib.load()
     _mat(x, "x"), _mat(idx, "idx", torch.int32)
     M, H = idx.shape
     if out is None:
         out = torch.empty((M, x.shape[1]), dtype=torch.float32, device=x.device)
-    _lib.check(lib.cofi_neighbor_maxpool(_p(x), _ld(x), x.shape[0], x.shape[1], _p(idx), M, H, _p(out), _ld(out), _stream()),
-               "cofi_neighbor_maxpool")
+    _lib.check(lib.cofi_neighbor_maxpool(_p(x), _ld(x), x.shape[0] // frames, x.shape[1], _p(idx), M // frames, H, _p(out), _ld(out),
+                                         frames, _stream()), "cofi_neighbor_maxpool")
     return out
 
 
-def gather_rows(x, idx, out=None):
+def gather_rows(x, idx, out=None, frames: int = 1):
     """out[m] = x[idx[m, 0]] (zero row for idx == N).  idx (M,) or (M,H) int32."""
     lib = _lib.load()
     _mat(x, "x")
@@ -258,8 +272,8 @@ def gather_rows(x, idx, out=None):
     stride = idx.stride(0) if idx.dim() == 2 else 1
     if out is None:
         out = torch.empty((M, x.shape[1]), dtype=torch.float32, device=x.device)
-    _lib.check(lib.cofi_gather_rows(_p(x), _ld(x), x.shape[0], x.shape[1], _p(idx), stride, M, _p(out), _ld(out), _stream()),
-               "cofi_gather_rows")
+    _lib.check(lib.cofi_gather_rows(_p(x), _ld(x), x.shape[0] // frames, x.shape[1], _p(idx), stride, M // frames, _p(out), _ld(out),
+                                    frames, _stream()), "cofi_gather_rows")
     return out
 
 
@@ -275,15 +289,16 @@ def group_stats(x, groups: int, eps: float = 1e-5):
 
 
 def group_norm_apply(x, stats, gamma=None, beta=None, slope: float = 1.0, res=None, res_stats=None, res_gamma=None, res_beta=None,
-                     out=None):
+                     out=None, frames: int = 1):
+    """stats (groups,2) or, in stack mode, (frames, groups, 2)."""
     lib = _lib.load()
     _mat(x, "x")
     M, C = x.shape
-    groups = stats.shape[0]
+    groups = stats.shape[-2]
     if out is None:
         out = torch.empty((M, C), dtype=torch.float32, device=x.device)
     rc = lib.cofi_group_norm_apply(_p(x), _ld(x), M, C, groups, _p(stats), _p(gamma), _p(beta), _p(res), 0 if res is None else _ld(res),
-                                   _p(res_stats), _p(res_gamma), _p(res_beta), float(slope), _p(out), _ld(out), _stream())
+                                   _p(res_stats), _p(res_gamma), _p(res_beta), float(slope), _p(out), _ld(out), frames, _stream())
     _lib.check(rc, "cofi_group_norm_apply")
     return out
 
@@ -367,16 +382,16 @@ def pos_sine(coords, out, accumulate: bool, d_model: int = 128):
 
 # ------------------------------------------------------------------------------------------ image branch, NHWC
 def conv2d_nhwc(x, H: int, W: int, w, ks: int, stride: int = 1, pad: int = 1, bias=None, res=None, act: int = ACT_NONE,
-                colstats: bool = False, out=None):
+                colstats: bool = False, out=None, frames: int = 1):
     """Implicit-GEMM convolution on an NHWC map x (H*W, Cin) [row-major view, any leading dimension];
     w (Cout, ks*ks*Cin).  -> y (Ho*Wo, Cout) [, colpart]."""
     lib = _lib.load()
     _mat(x, "x"), _mat(w, "w")
     Cin, Cout = x.shape[1], w.shape[0]
-    if x.shape[0] != H * W or w.shape[1] != ks * ks * Cin:
+    if x.shape[0] != frames * H * W or w.shape[1] != ks * ks * Cin:
         raise _lib.CofiError("conv2d_nhwc: shape mismatch x %s w %s H %d W %d ks %d" % (tuple(x.shape), tuple(w.shape), H, W, ks))
     Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
-    M, K = Ho * Wo, ks * ks * Cin
+    M, K = frames * Ho * Wo, ks * ks * Cin
     if out is None:
         out = torch.empty((M, Cout), dtype=torch.float32, device=x.device)
     part = None
@@ -384,38 +399,41 @@ def conv2d_nhwc(x, H: int, W: int, w, ks: int, stride: int = 1, pad: int = 1, bi
         part = torch.empty((lib.cofi_gemm_f32_stat_slabs(M, Cout, K), Cout, 2), dtype=torch.float32, device=x.device)
     ws = _WS_GEMM.get(lib.cofi_gemm_f32_workspace(M, Cout, K), x.device)
     rc = lib.cofi_conv2d_nhwc(_p(x), _ld(x), H, W, Cin, _p(w), Cout, ks, stride, pad, _p(bias), _p(res), 0 if res is None else _ld(res),
-                              act | _gemm_flag(), _p(out), _ld(out), _p(part), _p(ws), 0 if ws is None else ws.numel(), _stream())
+                              act | _gemm_flag(), _p(out), _ld(out), _p(part), _p(ws), 0 if ws is None else ws.numel(), frames, _stream())
     _lib.check(rc, "cofi_conv2d_nhwc")
     return (out, part, Ho, Wo) if colstats else (out, Ho, Wo)
 
 
-def im2col_stem(img_chw, kpad: int = 160):
+def im2col_stem(img, kpad: int = 160):
+    """img (3,H,W) or (frames,3,H,W) contiguous -> (frames*Ho*Wo, kpad), Ho, Wo."""
     lib = _lib.load()
-    C, H, W = img_chw.shape
-    if C != 3 or not img_chw.is_contiguous():
-        raise _lib.CofiError("im2col_stem: contiguous (3,H,W) image expected")
+    if img.dim() == 3:
+        img = img[None]
+    F_, C, H, W = img.shape
+    if C != 3 or not img.is_contiguous():
+        raise _lib.CofiError("im2col_stem: contiguous (frames,3,H,W) image expected")
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    out = torch.empty((Ho * Wo, kpad), dtype=torch.float32, device=img_chw.device)
-    _lib.check(lib.cofi_im2col_stem(_p(img_chw), H, W, kpad, _p(out), _stream()), "cofi_im2col_stem")
+    out = torch.empty((F_ * Ho * Wo, kpad), dtype=torch.float32, device=img.device)
+    _lib.check(lib.cofi_im2col_stem(_p(img), H, W, kpad, _p(out), F_, _stream()), "cofi_im2col_stem")
     return out, Ho, Wo
 
 
-def maxpool3x3s2_nhwc(x, H: int, W: int):
+def maxpool3x3s2_nhwc(x, H: int, W: int, frames: int = 1):
     lib = _lib.load()
     C = x.shape[1]
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    out = torch.empty((Ho * Wo, C), dtype=torch.float32, device=x.device)
-    _lib.check(lib.cofi_maxpool3x3s2_nhwc(_p(x), H, W, C, _p(out), _stream()), "cofi_maxpool3x3s2_nhwc")
+    out = torch.empty((frames * Ho * Wo, C), dtype=torch.float32, device=x.device)
+    _lib.check(lib.cofi_maxpool3x3s2_nhwc(_p(x), H, W, C, _p(out), frames, _stream()), "cofi_maxpool3x3s2_nhwc")
     return out, Ho, Wo
 
 
-def upsample2x_cat_nhwc(low, h: int, w: int, skip):
-    """low (h*w, C1), skip (4*h*w, C2) -> (4*h*w, C1+C2)."""
+def upsample2x_cat_nhwc(low, h: int, w: int, skip, frames: int = 1):
+    """low (frames*h*w, C1), skip (frames*4*h*w, C2) -> (frames*4*h*w, C1+C2)."""
     lib = _lib.load()
     _mat(low, "low"), _mat(skip, "skip")
     C1, C2 = low.shape[1], skip.shape[1]
-    out = torch.empty((4 * h * w, C1 + C2), dtype=torch.float32, device=low.device)
-    _lib.check(lib.cofi_upsample2x_cat_nhwc(_p(low), _ld(low), C1, h, w, _p(skip), _ld(skip), C2, _p(out), _ld(out), _stream()),
+    out = torch.empty((frames * 4 * h * w, C1 + C2), dtype=torch.float32, device=low.device)
+    _lib.check(lib.cofi_upsample2x_cat_nhwc(_p(low), _ld(low), C1, h, w, _p(skip), _ld(skip), C2, _p(out), _ld(out), frames, _stream()),
                "cofi_upsample2x_cat_nhwc")
     return out
 
@@ -463,7 +481,8 @@ def upsample2x_cat(low, skip):
 
 
 # ------------------------------------------------------------------------------------------ attention
-def attention(q, k, v, q_colscale=None, nhead: int = 4, out=None):
+def attention(q, k, v, q_colscale=None, nhead: int = 4, out=None, frames: int = 1):
+    """Stack mode: q (frames*L, HD), k/v (frames*S, HD), q_colscale (frames, HD)."""
     lib = _lib.load()
     _mat(q, "q"), _mat(k, "k"), _mat(v, "v")
     L, HD = q.shape
@@ -471,8 +490,8 @@ def attention(q, k, v, q_colscale=None, nhead: int = 4, out=None):
     D = HD // nhead
     if out is None:
         out = torch.empty((L, HD), dtype=torch.float32, device=q.device)
-    rc = lib.cofi_attention_fwd(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(q_colscale), _p(out), _ld(out), L, S, nhead, D,
-                                1.0 / math.sqrt(D), None, 0, _stream())
+    rc = lib.cofi_attention_fwd(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(q_colscale), _p(out), _ld(out), L // frames, S // frames,
+                                nhead, D, 1.0 / math.sqrt(D), None, 0, frames, _stream())
     _lib.check(rc, "cofi_attention_fwd")
     return out
 

@@ -31,7 +31,7 @@ def pack_layer(sd: Dict[str, torch.Tensor], p: str) -> Dict[str, torch.Tensor]:
     return out
 
 
-def _layer(w, xcat: torch.Tensor, src: torch.Tensor, out: torch.Tensor, self_attn: bool, nhead: int = 4):
+def _layer(w, xcat: torch.Tensor, src: torch.Tensor, out: torch.Tensor, self_attn: bool, nhead: int = 4, frames: int = 1):
     """xcat (L,2C): x in [:, :C]; src (S,C) view; out (L,C) view receiving x + message.
     transformer.py:43-64."""
     C = xcat.shape[1] // 2
@@ -45,8 +45,8 @@ def _layer(w, xcat: torch.Tensor, src: torch.Tensor, out: torch.Tensor, self_att
         q, part = ops.gemm_colstats(x, w["q_proj.weight"])
         kv = ops.gemm(src, w["kv.weight"])
         k, v = kv[:, :C], kv[:, C:]
-    qscale = ops.col_inv_norm_from_colpart(part, C)
-    msg = ops.attention(q, k, v, q_colscale=qscale, nhead=nhead)
+    qscale = ops.col_inv_norm_from_colpart(part, C, frames=frames)  # per frame: the token axis of ONE frame
+    msg = ops.attention(q, k, v, q_colscale=qscale, nhead=nhead, frames=frames)
     if ops.GEMM_MODE == "bf16x3" and C == 128:
         # merge + LN1 + concat + MLP + LN2 + residual: one kernel, intermediates stay in LDS
         return ops.loftr_tail(msg, x, w, out)
@@ -87,7 +87,7 @@ class TokenStreams:
         return self.pc[self.cur_pc][:, : self.C]
 
 
-def run_transformer(layers, kinds, ts: TokenStreams, nhead: int = 4):
+def run_transformer(layers, kinds, ts: TokenStreams, nhead: int = 4, frames: int = 1):
     """transformer.py:85-104.  Self layers share weights between the streams; in a cross layer the
     point stream attends to the ALREADY UPDATED image stream (:99-100)."""
     C = ts.C
@@ -96,12 +96,12 @@ def run_transformer(layers, kinds, ts: TokenStreams, nhead: int = 4):
         oi, op = ts.img[ts.cur_img ^ 1], ts.pc[ts.cur_pc ^ 1]
         if kind == "self":  # the two modalities are independent here: point stream on a side HIP stream
             with ops.Branch(xi.device, 2) as br:
-                _layer(w, xp, xp[:, :C], op[:, :C], True, nhead)
-            _layer(w, xi, xi[:, :C], oi[:, :C], True, nhead)
+                _layer(w, xp, xp[:, :C], op[:, :C], True, nhead, frames)
+            _layer(w, xi, xi[:, :C], oi[:, :C], True, nhead, frames)
             br.join(op)
         else:
-            _layer(w, xi, xp[:, :C], oi[:, :C], False, nhead)
-            _layer(w, xp, oi[:, :C], op[:, :C], False, nhead)
+            _layer(w, xi, xp[:, :C], oi[:, :C], False, nhead, frames)
+            _layer(w, xp, oi[:, :C], op[:, :C], False, nhead, frames)
         ts.cur_img ^= 1
         ts.cur_pc ^= 1
     return ts.img_tokens(), ts.pc_tokens()

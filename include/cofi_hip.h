@@ -17,6 +17,11 @@
  *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it, allocates
  *     nothing, keeps no global state and is re-entrant;
  *   - scratch memory is passed in (`ws`, `ws_bytes`), sized by the matching `*_workspace` query;
+ *   - STACK MODE: entry points with a `frames` parameter process `frames` equally sized frames stacked along the
+ *     row axis in one launch; N / M / L / S / H / W are then PER-FRAME sizes, index tables hold frame-local
+ *     indices, per-frame statistics / scales are laid out (frames, ...).  frames = 1 is the single-frame case.
+ *     Row-wise entry points (GEMM, LayerNorm, L2 norm, position embedding, fused layer tail) need no such
+ *     parameter: call them with the stacked row count;
  *   - return value: 0 on success, a positive hipError_t from the launch, or a negative
  *     COFI_E* code for argument errors (nothing is launched in that case).
  */
@@ -86,14 +91,14 @@ int cofi_idx32_to_idx64(const int32_t *src, int64_t *dst, size_t n, cofi_stream_
 int cofi_row_sum_positive(const float *feats, int ld, int N, int C, uint8_t *row_pos, cofi_stream_t stream);
 int cofi_kpconv_aggregate(const float *feats, int ldf, int N, int C, const float *q_pts, const float *s_pts, const int32_t *idx,
                           int M, int H, const float *kernel_points /* (15,3) */, float sigma, const uint8_t *row_pos,
-                          float *agg, int ld_agg, float *cnt, cofi_stream_t stream);
+                          float *agg, int ld_agg, float *cnt, int frames, cofi_stream_t stream);
 
 /* K3 / K4  neighbour max-pool and nearest up-sample.
  * Replace model/kpconv/functional.py:53-66 (`maxpool`) and :5-21 (`nearest_upsample`): a zero
  * pad row stands behind index N. */
-int cofi_neighbor_maxpool(const float *x, int ldx, int N, int C, const int32_t *idx, int M, int H, float *out, int ldo,
+int cofi_neighbor_maxpool(const float *x, int ldx, int N, int C, const int32_t *idx, int M, int H, float *out, int ldo, int frames,
                           cofi_stream_t stream);
-int cofi_gather_rows(const float *x, int ldx, int N, int C, const int32_t *idx, int idx_stride, int M, float *out, int ldo,
+int cofi_gather_rows(const float *x, int ldx, int N, int C, const int32_t *idx, int idx_stride, int M, float *out, int ldo, int frames,
                      cofi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -141,15 +146,16 @@ int cofi_gemm_f32_layernorm(const float *A, int lda, const float *W, int ldw, fl
  *   R = gn(res; res_stats, rg, rb)     otherwise        (modules.py:222-240 residual tail)
  * slope = 1 is the identity, 0 is ReLU, 0.1 the reference's LeakyReLU.
  */
-int cofi_group_stats_from_colpart(const float *colpart, int nslab, int M, int C, int groups, float eps, float *stats,
+int cofi_group_stats_from_colpart(const float *colpart, int nslab, int M, int C, int groups, float eps, float *stats, int frames,
                                   cofi_stream_t stream);
-int cofi_col_inv_norm_from_colpart(const float *colpart, int nslab, int ncols, int C, float eps, float *out, cofi_stream_t stream);
+int cofi_col_inv_norm_from_colpart(const float *colpart, int nslab, int ncols, int C, float eps, float *out, int frames,
+                                   cofi_stream_t stream);
 size_t cofi_group_stats_workspace(int M, int C, int groups);
 int cofi_group_stats(const float *x, int ldx, int M, int C, int groups, float eps, float *stats, void *ws, size_t ws_bytes,
                      cofi_stream_t stream);
 int cofi_group_norm_apply(const float *x, int ldx, int M, int C, int groups, const float *stats, const float *gamma,
                           const float *beta, const float *res, int ldr, const float *res_stats, const float *res_gamma,
-                          const float *res_beta, float slope, float *y, int ldy, cofi_stream_t stream);
+                          const float *res_beta, float slope, float *y, int ldy, int frames, cofi_stream_t stream);
 
 /* Row LayerNorm: y = act(LN(x) * gamma + beta) (+ res).  Replaces nn.LayerNorm at
  * model/transformer/transformer.py:40-41,58,62 and model/network.py:29.  C <= 2048, C % 4 == 0. */
@@ -167,7 +173,7 @@ int cofi_layer_norm(const float *x, int ldx, int M, int C, const float *gamma, c
  */
 size_t cofi_attention_workspace(int L, int S, int H, int D);
 int cofi_attention_fwd(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, const float *q_colscale,
-                       float *O, int ldo, int L, int S, int H, int D, float scale, void *ws, size_t ws_bytes,
+                       float *O, int ldo, int L, int S, int H, int D, float scale, void *ws, size_t ws_bytes, int frames,
                        cofi_stream_t stream);
 int cofi_col_inv_norm(const float *x, int ldx, int M, int C, float eps, float *out, cofi_stream_t stream);
 
@@ -214,11 +220,11 @@ int cofi_l2norm_cols(const float *x, int ldx, int C, int P, float *y_cp, int ldy
  *   (imagenet.py:433,441-443), NHWC. */
 int cofi_conv2d_nhwc(const float *x, int ldx, int H, int W, int Cin, const float *Wt, int Cout, int ks, int stride, int pad,
                      const float *bias, const float *res, int ldr, int act, float *y, int ldy, float *colpart, void *ws, size_t ws_bytes,
-                     cofi_stream_t stream);
-int cofi_im2col_stem(const float *img_chw, int H, int W, int Kpad, float *out, cofi_stream_t stream);
-int cofi_maxpool3x3s2_nhwc(const float *x, int H, int W, int C, float *y, cofi_stream_t stream);
+                     int frames, cofi_stream_t stream);
+int cofi_im2col_stem(const float *img_chw, int H, int W, int Kpad, float *out, int frames, cofi_stream_t stream);
+int cofi_maxpool3x3s2_nhwc(const float *x, int H, int W, int C, float *y, int frames, cofi_stream_t stream);
 int cofi_upsample2x_cat_nhwc(const float *low, int ldl, int C1, int h, int w, const float *skip, int lds, int C2, float *out, int ldo,
-                             cofi_stream_t stream);
+                             int frames, cofi_stream_t stream);
 
 /* K13 glue, channel-major (C, P = H*W) variants (used when the convolutions run through MIOpen instead).
  * cofi_instance_norm_nchw: y[c,:] = relu?( IN(x[c,:]) + R ), IN = affine-less InstanceNorm2d (eps, biased

@@ -201,3 +201,31 @@ def test_kitti_frame_bf16x3_gemms_within_tolerance(model, monkeypatch):
     for n, d in worst.items():
         assert d <= TOL, (n, d)
     assert abs(res[6].shape[1] - gold["test_center_xy"].shape[1]) <= 3  # a score may cross the 0.9 threshold
+
+
+def test_stack_mode_batch_equals_single_frames(model):
+    """B = 3 frames stacked through ONE set of launches (per-frame GroupNorm / InstanceNorm / Q-norm statistics,
+    frame-local neighbour tables, batched attention) == the same frames run one at a time"""
+    from cofii2p_amd.network import CoFiI2P
+    from cofii2p_amd.preprocess import build_pyramid
+    from cofii2p_amd.synth import make_frame, subsample_indices
+
+    pyrs, imgs = [], []
+    for fid in (31, 32, 33):
+        fr = make_frame(fid, 4096)
+        sub = [torch.from_numpy(s).to(DEV) for s in subsample_indices(4096, 5, seed=fid)]
+        pyr = build_pyramid(torch.from_numpy(fr.points).to(DEV), sub)
+        pyr["feats"] = torch.from_numpy(fr.feats).to(DEV)
+        pyrs.append(pyr)
+        imgs.append(torch.from_numpy(fr.img)[None].to(DEV))
+    model.enable_graphs(False)
+    seq = [[t.clone() for t in model(p, i, None, None, None, "test")] for p, i in zip(pyrs, imgs)]
+    stacked, img = CoFiI2P.stack_frames(pyrs, imgs)
+    got = model.finish(model.forward_async(5, stacked, img))
+    assert len(got) == 3
+    for k in range(3):
+        for a, b in zip(seq[k][:4], got[k][:4]):
+            assert maxdiff(a, b.cpu()) < 2e-5, maxdiff(a, b.cpu())
+        assert seq[k][6].shape == got[k][6].shape
+        assert torch.equal(seq[k][7], got[k][7])
+        assert (seq[k][6] == got[k][6]).float().mean() > 0.98
