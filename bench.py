@@ -81,7 +81,7 @@ class KernelTimer:
             stride = a[5] if len(a) > 5 else k.get("stride", 1)
             pad = a[6] if len(a) > 6 else k.get("pad", 1)
             Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
-            M, N, K = Ho * Wo, w.shape[0], w.shape[1]
+            M, N, K = k.get("frames", 1) * Ho * Wo, w.shape[0], w.shape[1]
             return 2.0 * M * N * K, 4.0 * (x.numel() + w.numel() + M * N)
         if name == "kpconv_aggregate":
             feats, idx = a[0], a[3]
@@ -92,13 +92,16 @@ class KernelTimer:
         if name == "attention":
             L, HD = a[0].shape
             S = a[1].shape[0]
-            return 4.0 * L * S * HD, 4.0 * (2 * L * HD + 2 * S * HD)
+            return 4.0 * L * S * HD / k.get("frames", 1), 4.0 * (2 * L * HD + 2 * S * HD)
         if name == "neighbor_maxpool":
             x, idx = a[0], a[1]
             return 0.0, 4.0 * (x.numel() + idx.numel() + idx.shape[0] * x.shape[1])
         return 0.0, 8.0 * a[0].numel()
 
     def record(self, model, frame):
+        self.record_fn(lambda: one_step(model, frame))
+
+    def record_fn(self, run):
         from cofii2p_amd import ops
 
         orig = {}
@@ -113,7 +116,7 @@ class KernelTimer:
 
             setattr(ops, name, rec)
         try:
-            one_step(model, frame)
+            run()
         finally:
             for name, fn in orig.items():
                 setattr(ops, name, fn)
@@ -198,6 +201,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the hipGraph")
     ap.add_argument("--inflight", type=int, default=2, help="frames in flight per GPU (each on its own HIP stream + hipGraph slot)")
+    ap.add_argument("--no-batch-sweep", action="store_true", help="skip the extra stack-mode batch-4/16 measurements")
+    ap.add_argument("--batch", type=int, default=1, help="frames per submission in stack mode (BASELINE configs[2] uses 16); a step is then one batch")
     ap.add_argument("--gemm", default=os.environ.get("COFI_GEMM", "bf16x3"), choices=["f32", "bf16x3"],
                     help="arithmetic of the dense contractions: exact fp32 MFMA, or 3-term bf16 split with fp32 accumulation")
     args = ap.parse_args()
@@ -236,7 +241,38 @@ def main():
 
     nmatch = 0
     S = max(1, args.inflight) if not args.eager else 1
-    if S == 1:
+    Bsz = max(1, args.batch)
+    if Bsz > 1:
+        # stack mode: Bsz frames per submission through the same launches, S submissions in flight
+        batches = []
+        for b in range(2):
+            grp = [frames[(b * Bsz + i) % len(frames)] for i in range(Bsz)]
+            batches.append(CoFiI2P.stack_frames([g[0] for g in grp], [g[1] for g in grp]))
+        streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+        pending = [None] * S
+
+        def runb(nsteps):
+            nm = 0
+            for i in range(nsteps):
+                sl = i % S
+                if pending[sl] is not None:
+                    nm = model.finish(pending[sl])[0][4].shape[0]
+                pyr, img = batches[i % len(batches)]
+                with torch.cuda.stream(streams[sl]):
+                    pending[sl] = model.forward_async(sl, pyr, img)
+            for sl in range(S):
+                if pending[sl] is not None:
+                    nm = model.finish(pending[sl])[0][4].shape[0]
+                    pending[sl] = None
+            return nm
+
+        nmatch = runb(max(args.warmup, 2 * S))
+        barrier()
+        t0 = time.perf_counter()
+        runb(args.steps)
+        barrier()
+        dt = time.perf_counter() - t0
+    elif S == 1:
         for i in range(args.warmup):
             out, _ = one_step(model, frames[i % len(frames)])
             nmatch = out[4].shape[0]
@@ -279,23 +315,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     result = {
-        "metric": "I2P frames/sec (160x512 img, 20480 pts)", "value": world * args.steps / dt, "unit": "frames/s", "n_gpus": world,
+        "metric": "I2P frames/sec (160x512 img, 20480 pts)", "value": world * args.steps * Bsz / dt, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32" if args.gemm == "f32" else "f32 (dense contractions as 3-term bf16 split on the bf16 matrix cores, fp32 accumulate; "
                                                    "4e-6 max abs deviation from the fp32 reference on the golden frame)",
         "data": "synthetic", "launch": "eager" if args.eager else "hipGraph replay",
-        "config": {"workload": "KITTI-shape synthetic frame (160x512 image, %d points, KNN-128 pyramid resident in HBM), batch 1, "
-                               "CoFiI2P.forward(mode='test') + fine matching, one frame per step per GPU" % args.points,
+        "config": {"workload": "KITTI-shape synthetic frame (160x512 image, %d points, KNN-128 pyramid resident in HBM), batch %d, "
+                               "CoFiI2P.forward(mode='test') + fine matching, one %s per step per GPU"
+                               % (args.points, Bsz, "frame" if Bsz == 1 else "stack-mode batch of %d frames" % Bsz),
                    "matches_per_frame": int(nmatch), "parallelism": "frame-parallel x%d" % world, "frames_in_flight_per_gpu": S},
     }
 
     if rank == 0 and not args.no_kernel_timing:
         model.enable_graphs(False)
         kt = KernelTimer()
-        kt.record(model, frames[0])
+        if Bsz == 1:
+            kt.record(model, frames[0])
+        else:
+            pyr_b, img_b = batches[0]
+            P_b = model._pack(dev)
+            kt.record_fn(lambda: model._run_device(P_b, pyr_b["points"], pyr_b["neighbors"], pyr_b["subsampling"], pyr_b["upsampling"],
+                                                   pyr_b["feats"], img_b, "test", None, None))
         per = kt.measure()
         del kt
+        for v in per.values():  # per FRAME figures (launch counts stay per submission)
+            for kk in ("seconds_per_frame", "flops_per_frame", "bytes_per_frame"):
+                v[kk] /= Bsz
+            v["launches_per_frame"] = v["launches_per_frame"] / Bsz
         # the GEMM / implicit-GEMM convolution entry points launch the same MFMA kernel (different loaders / epilogues): one roofline row
         gsum = {"seconds_per_frame": 0.0, "flops_per_frame": 0.0, "bytes_per_frame": 0.0, "launches_per_frame": 0}
         for n in ("gemm", "gemm_colstats", "gemm_layernorm", "conv2d_nhwc"):
@@ -325,6 +372,34 @@ def main():
                                             "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TF,
                                             "avg_launch_us": 1e6 * a["seconds_per_frame"] / a["launches_per_frame"]}
         result["kernel_ms_per_frame"] = {n: round(1e3 * v["seconds_per_frame"], 4) for n, v in sorted(per.items(), key=lambda kv: -kv[1]["seconds_per_frame"])}
+    if rank == 0 and world == 1 and Bsz == 1 and not args.eager and not args.no_batch_sweep:
+        # additional information (BASELINE configs[2]): the same frames in stack-mode batches through the same kernels
+        model.enable_graphs(True)
+        sweep = {}
+        for bsz in (4, 16):
+            grp = [frames[i % len(frames)] for i in range(bsz)]
+            pyr_b, img_b = CoFiI2P.stack_frames([g[0] for g in grp], [g[1] for g in grp])
+            st = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            pend = [None, None]
+            nst = max(6, args.steps // bsz)
+            for phase in range(2):  # 0 = warm-up (captures the graphs), 1 = timed
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(nst):
+                    sl = i % 2
+                    if pend[sl] is not None:
+                        model.finish(pend[sl])
+                    with torch.cuda.stream(st[sl]):
+                        pend[sl] = model.forward_async(10 + sl, pyr_b, img_b)
+                for sl in range(2):
+                    if pend[sl] is not None:
+                        model.finish(pend[sl])
+                        pend[sl] = None
+                torch.cuda.synchronize()
+                dtb = time.perf_counter() - t0
+            sweep["batch_%d" % bsz] = {"frames_per_s": nst * bsz / dtb, "ms_per_frame": 1e3 * dtb / (nst * bsz), "submissions_in_flight": 2}
+            del pyr_b, img_b
+        result["stack_mode_batches"] = sweep
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(frames[0])
     if rank == 0:
