@@ -15,6 +15,14 @@
 
 namespace {
 
+// XCD-aware, bijective remap of a 1-D block id: the dispatcher sends block b to XCD b % 8; remapping gives every XCD one
+// CONTIGUOUS eighth of the (spatially sorted) queries, so its private 4 MB L2 only ever sees the source rows of one
+// spatial region (N*C*4/8 bytes <= 1.3 MB) instead of the whole 10.5 MB source.
+__device__ __forceinline__ int xcd_contiguous_block(int b, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = b & 7, i = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
 struct KpArgs {
     const float *feats, *q_pts, *s_pts, *kp;
     const int32_t *idx;
@@ -23,6 +31,9 @@ struct KpArgs {
     int ldf, N, C, M, H, ld_agg;   // N = support rows PER FRAME, M = total query rows
     float sigma;
     int Mpf;                       // query rows per frame (stack mode: frame f owns queries [f*Mpf, ..) and support [f*N, ..))
+    const int32_t *order;          // optional processing order (frame-local query ids, stacked per frame): wave w of the grid
+                                   // handles query order[w].  A spatially sorted order makes the waves resident on one CU work on
+                                   // neighbouring queries whose neighbour rows overlap, so the gather is served from L1 instead of L2.
 };
 
 // VEC = contiguous channels one lane loads per neighbour (1, 2 or 4 -> dword / dwordx2 / dwordx4), NCH =
@@ -40,8 +51,9 @@ struct KpStep {  // operands of one 4-neighbour step, loaded one step ahead of t
 template <int VEC, int NCH>
 __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
     const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int m = xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
     if (m >= a.M) return;
+    if (a.order) m = (m / a.Mpf) * a.Mpf + a.order[m];
     const int j = lane & 15, g = lane >> 4;
     const int c0 = blockIdx.y * (16 * VEC * NCH);
     {   // stack mode: shift the support-side bases to this query's frame (indices are frame-local)
@@ -165,10 +177,11 @@ __global__ void row_sum_positive_kernel(const float *feats, int ld, int N, int C
 // Chunks are the slow grid axis: all queries of one chunk run together and its source slice
 // (N x 128 B <= 2.6 MB) stays resident in every XCD's 4 MB L2.
 __global__ __launch_bounds__(256) void neighbor_maxpool_kernel(const float *x, int ldx, int N, int C, const int32_t *idx, int M,
-                                                               int H, float *out, int ldo, int Mpf) {
+                                                               int H, float *out, int ldo, int Mpf, const int32_t *order) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int m = blockIdx.x * 4 + wv;
+    int m = xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + wv;
     if (m >= M) return;
+    if (order) m = (m / Mpf) * Mpf + order[m];  // spatially sorted processing order (see KpArgs::order)
     x += (size_t)(m / Mpf) * N * ldx;  // stack mode: frame-local indices
     const int g = lane >> 3, c = blockIdx.y * 32 + (lane & 7) * 4;
     const int32_t *irow = idx + (size_t)m * H;
@@ -219,11 +232,12 @@ extern "C" int cofi_row_sum_positive(const float *feats, int ld, int N, int C, u
 
 extern "C" int cofi_kpconv_aggregate(const float *feats, int ldf, int N, int C, const float *q_pts, const float *s_pts,
                                      const int32_t *idx, int M, int H, const float *kernel_points, float sigma,
-                                     const uint8_t *row_pos, float *agg, int ld_agg, float *cnt, int frames, cofi_stream_t stream) {
+                                     const uint8_t *row_pos, float *agg, int ld_agg, float *cnt, int frames, const int32_t *order,
+                                     cofi_stream_t stream) {
     if (!feats || !q_pts || !s_pts || !idx || !kernel_points || !row_pos || !agg || !cnt) return COFI_EINVAL;
     if (N <= 0 || C <= 0 || M < 0 || H <= 0 || (H & 3) || ldf < C || ld_agg < 15 * C || !(sigma > 0.f) || frames <= 0) return COFI_EINVAL;
     if (M == 0) return 0;
-    KpArgs a{feats, q_pts, s_pts, kernel_points, idx, row_pos, agg, cnt, ldf, N, C, M * frames, H, ld_agg, sigma, M};
+    KpArgs a{feats, q_pts, s_pts, kernel_points, idx, row_pos, agg, cnt, ldf, N, C, M * frames, H, ld_agg, sigma, M, order};
     M *= frames;
     hipStream_t s = cofi_s(stream);
     const int mb = cofi_cdiv(M, 4);
@@ -241,13 +255,13 @@ extern "C" int cofi_kpconv_aggregate(const float *feats, int ldf, int N, int C, 
 }
 
 extern "C" int cofi_neighbor_maxpool(const float *x, int ldx, int N, int C, const int32_t *idx, int M, int H, float *out, int ldo,
-                                     int frames, cofi_stream_t stream) {
+                                     int frames, const int32_t *order, cofi_stream_t stream) {
     if (!x || !idx || !out || N <= 0 || C <= 0 || M < 0 || H <= 0 || ldx < C || ldo < C) return COFI_EINVAL;
     if ((C & 3) || (ldx & 3) || (ldo & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return COFI_EINVAL;
     if (M == 0) return 0;
     if (frames <= 0) return COFI_EINVAL;
     hipLaunchKernelGGL(neighbor_maxpool_kernel, dim3(cofi_cdiv(M * frames, 4), cofi_cdiv(C, 32)), dim3(256), 0, cofi_s(stream), x, ldx, N,
-                       C, idx, M * frames, H, out, ldo, M);
+                       C, idx, M * frames, H, out, ldo, M, order);
     return cofi_launch_status();
 }
 

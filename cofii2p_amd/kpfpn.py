@@ -32,10 +32,10 @@ def _stats(y, part, frames: int):
     return ops.group_stats_from_colpart(part, y.shape[0], GN_GROUPS, frames=frames)
 
 
-def _kpconv(P, p: str, feats, q_pts, s_pts, idx, sigma: float, frames: int = 1):
+def _kpconv(P, p: str, feats, q_pts, s_pts, idx, sigma: float, frames: int = 1, order=None):
     """-> (KPConv output, its GroupNorm statistics).  The statistics come out of the GEMM epilogue (column
     partials) instead of another pass over the activation."""
-    agg, cnt = ops.kpconv_aggregate(feats, q_pts, s_pts, idx, P[p + "KPConv.kernel_points"], sigma, frames=frames)
+    agg, cnt = ops.kpconv_aggregate(feats, q_pts, s_pts, idx, P[p + "KPConv.kernel_points"], sigma, frames=frames, order=order)
     y, part = ops.gemm_colstats(agg, P[p + "KPConv.weights"], bias=P[p + "KPConv.bias"], rowdiv=cnt)
     return y, _stats(y, part, frames)
 
@@ -50,21 +50,21 @@ def _unary(P, p: str, x, slope: float, out=None, frames: int = 1):
     return ops.group_norm_apply(y, st, P[p + "norm.norm.weight"], P[p + "norm.norm.bias"], slope=slope, out=out, frames=frames)
 
 
-def run_block(P, blk: KPBlock, feats, q_pts, s_pts, idx, out=None, concurrent: bool = True, frames: int = 1):
+def run_block(P, blk: KPBlock, feats, q_pts, s_pts, idx, out=None, concurrent: bool = True, frames: int = 1, order=None):
     p = "pc_encoder.%s." % blk.name
     if blk.kind == "conv":  # modules.py:155-159
-        y, st = _kpconv(P, p, feats, q_pts, s_pts, idx, blk.sigma, frames)
+        y, st = _kpconv(P, p, feats, q_pts, s_pts, idx, blk.sigma, frames, order)
         return ops.group_norm_apply(y, st, P[p + "norm.norm.weight"], P[p + "norm.norm.bias"], slope=LRELU, out=out, frames=frames)
     # modules.py:222-240.  The shortcut (max-pool / Linear+GN statistics) only meets the main branch in the
     # final fused normalise+add+LeakyReLU: it runs on a side stream.
     has_branch = blk.strided or blk.has_shortcut_unary
     with ops.Branch(feats.device, 1, enabled=concurrent and has_branch) as br:
-        sc = ops.neighbor_maxpool(feats, idx, frames=frames) if blk.strided else feats
+        sc = ops.neighbor_maxpool(feats, idx, frames=frames, order=order) if blk.strided else feats
         ys = sts = None
         if blk.has_shortcut_unary:
             ys, sts = _unary_raw(P, p + "unary_shortcut.", sc, frames)
     x = _unary(P, p + "unary1.", feats, LRELU, frames=frames) if blk.cin != blk.mid else feats
-    y, st = _kpconv(P, p, x, q_pts, s_pts, idx, blk.sigma, frames)
+    y, st = _kpconv(P, p, x, q_pts, s_pts, idx, blk.sigma, frames, order)
     x = ops.group_norm_apply(y, st, P[p + "norm_conv.norm.weight"], P[p + "norm_conv.norm.bias"], slope=LRELU, frames=frames)
     y2, st2 = _unary_raw(P, p + "unary2.", x, frames)
     br.join(sc, ys, sts)
@@ -76,7 +76,8 @@ def run_block(P, blk: KPBlock, feats, q_pts, s_pts, idx, out=None, concurrent: b
     return ops.group_norm_apply(y2, st2, g2, b2, slope=LRELU, res=sc, out=out, frames=frames)
 
 
-def run_fpn(P, points: List[torch.Tensor], neighbors, subsampling, upsampling, feats, taps=None, frames: int = 1):
+def run_fpn(P, points: List[torch.Tensor], neighbors, subsampling, upsampling, feats, taps=None, frames: int = 1, order=None):
+    """`order` (optional): per stage, the frame-local processing order of the stage's points (spatially sorted)."""
     """Returns [latent_s2 (N1,64), latent_s3 (N2,512), latent_s4 (N3,1024), feats_s5 (N4,2048)].
     The last block of stages 1..3 writes directly into the right part of the decoder's concat
     buffer (kp_backbone.py:112,117,122 torch.cat)."""
@@ -102,7 +103,7 @@ def run_fpn(P, points: List[torch.Tensor], neighbors, subsampling, upsampling, f
         if st in cat and last_of_stage[st] == blk.name:
             w = stage_width[st]
             out = cat[st][:, cat[st].shape[1] - w:]
-        x = run_block(P, blk, x, q, s, idx, out=out, frames=frames)
+        x = run_block(P, blk, x, q, s, idx, out=out, frames=frames, order=None if order is None else order[st])
         stage_out[st] = x
         if taps is not None:
             taps[blk.name] = x

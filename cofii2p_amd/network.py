@@ -134,7 +134,7 @@ class CoFiI2P(nn.Module):
 
     # ------------------------------------------------------------------ device-side forward (no host sync)
     def _run_device(self, P, points, neighbors, subsampling, upsampling, feats, img, mode, fine_center_kpt_coors,
-                    fine_pc_inline_index, taps=None):
+                    fine_pc_inline_index, taps=None, order=None):
         """Everything of network.py:74-161 that runs on the device.  Test-mode outputs are sized at
         capacity (N4 rows) with the match count left in device memory: capturable in a hipGraph.
 
@@ -170,7 +170,7 @@ class CoFiI2P(nn.Module):
                 s8n, _ = ops.l2norm_cols(s8[0].reshape(C, T_img), tokens_out=ts.img[0][:, :D_MODEL])
             ops.pos_sine(grid, ts.img[0], accumulate=True)
         # ---- point branch (network.py:76,83-84,107,111)
-        pc_set = kpfpn.run_fpn(P, points, neighbors, subsampling, upsampling, feats, taps=taps, frames=B)
+        pc_set = kpfpn.run_fpn(P, points, neighbors, subsampling, upsampling, feats, taps=taps, frames=B, order=order)
         fine_pc = ops.l2norm_rows(pc_set[0])  # (B*N1,64)
         ops.l2norm_rows(self._pc_feature_mlp(P, pc_set[-1]), out=ts.pc[0][:, :D_MODEL])
         ops.pos_sine(points[-1], ts.pc[0], accumulate=True)
@@ -248,11 +248,12 @@ class CoFiI2P(nn.Module):
         return self
 
     def _graph_forward(self, P, points, neighbors, subsampling, upsampling, feats, img, mode, kpt, inl, slot: int = 0,
-                       branch_mask: int = 7):
+                       branch_mask: int = 7, order=None):
         def sig(t):
             return None if t is None else (tuple(t.shape), str(t.dtype))
 
-        tensors = list(points) + list(neighbors) + list(subsampling) + list(upsampling) + [feats, img, kpt, inl]
+        order = [] if order is None else list(order)
+        tensors = list(points) + list(neighbors) + list(subsampling) + list(upsampling) + order + [feats, img, kpt, inl]
         key = (mode, str(img.device), slot, branch_mask) + tuple(sig(t) for t in tensors)
         ops.set_workspace_slot(slot)
         saved_mask, ops.BRANCH_MASK = ops.BRANCH_MASK, branch_mask  # which intra-frame forks the capture records
@@ -262,10 +263,10 @@ class CoFiI2P(nn.Module):
             for s_, t in zip(static, tensors):
                 if t is not None:
                     s_.copy_(t)
-            n = [len(points), len(neighbors), len(subsampling), len(upsampling)]
-            o = [0, n[0], n[0] + n[1], n[0] + n[1] + n[2], sum(n)]
-            args = (static[o[0]:o[1]], static[o[1]:o[2]], static[o[2]:o[3]], static[o[3]:o[4]], static[o[4]], static[o[4] + 1], mode,
-                    static[o[4] + 2], static[o[4] + 3])
+            n = [len(points), len(neighbors), len(subsampling), len(upsampling), len(order)]
+            o = [0, n[0], n[0] + n[1], n[0] + n[1] + n[2], n[0] + n[1] + n[2] + n[3], sum(n)]
+            args = (static[o[0]:o[1]], static[o[1]:o[2]], static[o[2]:o[3]], static[o[3]:o[4]], static[o[5]], static[o[5] + 1], mode,
+                    static[o[5] + 2], static[o[5] + 3], None, (static[o[4]:o[5]] or None))
             # warm-up AND capture run on one persistent stream, so every per-stream workspace is grown (in the
             # ordinary allocator pool) before the capture starts and nothing is allocated for it inside
             if getattr(self, "_capture_stream", None) is None or self._capture_stream.device != img.device:
@@ -301,6 +302,8 @@ class CoFiI2P(nn.Module):
             out[k] = [torch.cat([CoFiI2P._as_idx32(p[k][i]) if k != "points" else p[k][i] for p in pyramids], 0).contiguous()
                       for i in range(len(pyramids[0][k]))]
         out["feats"] = torch.cat([p["feats"] for p in pyramids], 0).contiguous()
+        if all("order" in p for p in pyramids):
+            out["order"] = [torch.cat([p["order"][i] for p in pyramids], 0).contiguous() for i in range(len(pyramids[0]["order"]))]
         return out, torch.cat([im.reshape(1, *im.shape[-3:]) for im in imgs], 0).contiguous()
 
     @torch.no_grad()
@@ -319,7 +322,7 @@ class CoFiI2P(nn.Module):
         # submissions in flight fill the GPU by themselves: the per-submission graph is a linear chain (intra-frame
         # fork/join only adds join latency then — measured 306 vs 250 frames/s)
         outs = self._graph_forward(P, points, tabs[0], tabs[1], tabs[2], pc_data_dict["feats"].contiguous(), img.contiguous(), mode, None,
-                                   None, slot=slot, branch_mask=0)
+                                   None, slot=slot, branch_mask=0, order=pc_data_dict.get("order"))
         host = torch.empty((len(outs), 2), dtype=torch.int32, pin_memory=True)
         for f, o in enumerate(outs):
             host[f].copy_(o["count"], non_blocking=True)
@@ -361,12 +364,13 @@ class CoFiI2P(nn.Module):
         subsampling = [self._as_idx32(t) for t in pc_data_dict["subsampling"]]
         upsampling = [self._as_idx32(t) for t in pc_data_dict["upsampling"]]
         feats = pc_data_dict["feats"].contiguous()
+        order = pc_data_dict.get("order")  # optional: spatially sorted processing order per stage (preprocess.morton_order)
         if getattr(self, "_use_graphs", False) and taps is None:
             o = self._graph_forward(P, points, neighbors, subsampling, upsampling, feats, img.contiguous(), mode, fine_center_kpt_coors,
-                                    fine_pc_inline_index)[0]
+                                    fine_pc_inline_index, order=order)[0]
         else:
             o = self._run_device(P, points, neighbors, subsampling, upsampling, feats, img, mode, fine_center_kpt_coors,
-                                 fine_pc_inline_index, taps=taps)[0]
+                                 fine_pc_inline_index, taps=taps, order=order)[0]
         if mode in ("train", "val"):
             return o["img_desc"], o["pc_desc"], o["img_score"], o["pc_score"], o["patches"], o["fine_pc"], None, None
         n, thr_i = (int(v) for v in o["count"].cpu())  # the only device->host synchronisation of forward

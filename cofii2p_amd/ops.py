@@ -230,7 +230,7 @@ def row_sum_positive(feats: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def kpconv_aggregate(feats, q_pts, s_pts, idx, kernel_points, sigma: float, row_pos=None, frames: int = 1):
+def kpconv_aggregate(feats, q_pts, s_pts, idx, kernel_points, sigma: float, row_pos=None, frames: int = 1, order=None):
     """-> agg (M, 15*C), cnt (M,) float.  idx int32 (M,H).  Stack mode: `frames` equally sized frames stacked along
     the rows of every argument, idx frame-local."""
     lib = _lib.load()
@@ -246,19 +246,19 @@ def kpconv_aggregate(feats, q_pts, s_pts, idx, kernel_points, sigma: float, row_
     agg = torch.empty((M, 15 * C), dtype=torch.float32, device=feats.device)
     cnt = torch.empty((M,), dtype=torch.float32, device=feats.device)
     rc = lib.cofi_kpconv_aggregate(_p(feats), _ld(feats), N // frames, C, _p(q_pts), _p(s_pts), _p(idx), M // frames, H,
-                                   _p(kernel_points), float(sigma), _p(row_pos), _p(agg), 15 * C, _p(cnt), frames, _stream())
+                                   _p(kernel_points), float(sigma), _p(row_pos), _p(agg), 15 * C, _p(cnt), frames, _p(order), _stream())
     _lib.check(rc, "cofi_kpconv_aggregate")
     return agg, cnt
 
 
-def neighbor_maxpool(x, idx, out=None, frames: int = 1):
+def neighbor_maxpool(x, idx, out=None, frames: int = 1, order=None):
     lib = _lib.load()
     _mat(x, "x"), _mat(idx, "idx", torch.int32)
     M, H = idx.shape
     if out is None:
         out = torch.empty((M, x.shape[1]), dtype=torch.float32, device=x.device)
     _lib.check(lib.cofi_neighbor_maxpool(_p(x), _ld(x), x.shape[0] // frames, x.shape[1], _p(idx), M // frames, H, _p(out), _ld(out),
-                                         frames, _stream()), "cofi_neighbor_maxpool")
+                                         frames, _p(order), _stream()), "cofi_neighbor_maxpool")
     return out
 
 

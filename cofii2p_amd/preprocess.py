@@ -10,6 +10,23 @@ from . import ops
 from .spec import NUM_NEIGHBORS
 
 
+def morton_order(points: torch.Tensor) -> torch.Tensor:
+    """int32 permutation that sorts the points along a 30-bit Morton (Z-order) curve.  Used only as the PROCESSING
+    order of the gather kernels (cofi_kpconv_aggregate / cofi_neighbor_maxpool): consecutive waves then work on
+    neighbouring queries whose KNN rows overlap, which turns L2 gathers into L1 hits.  Results do not depend on it."""
+    lo, hi = points.min(0)[0], points.max(0)[0]
+    q = ((points - lo) / (hi - lo).clamp_min(1e-9) * 1023.0).long().clamp_(0, 1023)
+
+    def spread(v):  # 10 bits -> every third bit
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        return (v | (v << 2)) & 0x09249249
+
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    return torch.argsort(code).to(torch.int32).contiguous()
+
+
 def build_pyramid(points: torch.Tensor, subsample: List[torch.Tensor], k: int = NUM_NEIGHBORS, int64: bool = False) -> Dict:
     """points (N,3) CUDA fp32; subsample[i] = indices (CUDA int64/int32) into stage i selecting stage
     i+1 (the reference draws them with np.random.choice WITH replacement, preprocess_data.py:58).
@@ -26,7 +43,8 @@ def build_pyramid(points: torch.Tensor, subsample: List[torch.Tensor], k: int = 
             upsampling.append(ops.knn(pts[i + 1], pts[i], k))
     conv = ops.idx_to_int64 if int64 else (lambda t: t)
     return {"points": pts, "lengths": [int(p.shape[0]) for p in pts], "neighbors": [conv(t) for t in neighbors],
-            "subsampling": [conv(t) for t in subsampling], "upsampling": [conv(t) for t in upsampling]}
+            "subsampling": [conv(t) for t in subsampling], "upsampling": [conv(t) for t in upsampling],
+            "order": [morton_order(p) for p in pts]}  # optional extra key: processing order of the gather kernels
 
 
 def precompute_point_cloud_stack_mode(points, intensity, normals, lengths, num_stages, device="cuda", rng: Optional[np.random.RandomState] = None):

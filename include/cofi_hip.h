@@ -91,13 +91,15 @@ int cofi_idx32_to_idx64(const int32_t *src, int64_t *dst, size_t n, cofi_stream_
 int cofi_row_sum_positive(const float *feats, int ld, int N, int C, uint8_t *row_pos, cofi_stream_t stream);
 int cofi_kpconv_aggregate(const float *feats, int ldf, int N, int C, const float *q_pts, const float *s_pts, const int32_t *idx,
                           int M, int H, const float *kernel_points /* (15,3) */, float sigma, const uint8_t *row_pos,
-                          float *agg, int ld_agg, float *cnt, int frames, cofi_stream_t stream);
+                          float *agg, int ld_agg, float *cnt, int frames, const int32_t *order /* optional (frames*M) frame-local
+                          processing order of the queries, e.g. Morton-sorted: results do not depend on it */,
+                          cofi_stream_t stream);
 
 /* K3 / K4  neighbour max-pool and nearest up-sample.
  * Replace model/kpconv/functional.py:53-66 (`maxpool`) and :5-21 (`nearest_upsample`): a zero
  * pad row stands behind index N. */
 int cofi_neighbor_maxpool(const float *x, int ldx, int N, int C, const int32_t *idx, int M, int H, float *out, int ldo, int frames,
-                          cofi_stream_t stream);
+                          const int32_t *order /* optional, as above */, cofi_stream_t stream);
 int cofi_gather_rows(const float *x, int ldx, int N, int C, const int32_t *idx, int idx_stride, int M, float *out, int ldo, int frames,
                      cofi_stream_t stream);
 
