@@ -40,18 +40,25 @@ struct KpArgs {
 // channel chunks of 16*VEC per pass.  MFMA column j of accumulator (ch, a) is channel
 // c0 + ch*16*VEC + VEC*j + a: a permutation of the channel axis that turns the B-operand gather into
 // 16 lanes x 4*VEC contiguous bytes per neighbour row.
+//
+// The texture-address unit of a CU is shared by its 4 SIMDs and spends ~16 cycles per wave-wide memory instruction,
+// while one 4-neighbour step is only NCH*VEC MFMAs (32 cycles each) per SIMD: the kernel is kept to ONE feature load
+// per (step, channel chunk).  Everything else a step needs - the neighbour's offset from the query, its validity, its
+// row id - is staged per 64 neighbours with coalesced/gather loads by lane = neighbour, parked in a wave-private LDS
+// record, and fetched back per step with one broadcast ds_read_b128 (4 distinct addresses per wave).
+constexpr int KP_PHASE = 128;  // neighbour records staged per wave and phase (H <= 128: one phase)
+constexpr int KP_PAD = 32;     // shadow records behind the phase: the pipeline's look-ahead (<= 7 steps) reads them
+
 template <int VEC, int NCH>
-struct KpStep {  // operands of one 4-neighbour step, loaded one step ahead of their use
-    float px, py, pz;
+struct KpFeat {
     float f[NCH][VEC];
-    int pos;
-    bool valid;
 };
 
 template <int VEC, int NCH>
 __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
-    const int lane = threadIdx.x & 63;
-    int m = xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+    __shared__ float4 rec_s[4][KP_PHASE + KP_PAD];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int m = xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + wv;
     if (m >= a.M) return;
     if (a.order) m = (m / a.Mpf) * a.Mpf + a.order[m];
     const int j = lane & 15, g = lane >> 4;
@@ -72,65 +79,100 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
         for (int v = 0; v < VEC; ++v) acc[ch][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int npos = 0;
     const int32_t *irow = a.idx + (size_t)m * a.H;
-    const int steps = a.H >> 2;
-    // per-lane channel offsets, clamped so that every load is unconditional (branch-free inner loop);
-    // out-of-range channels / shadow neighbours are zeroed by select, not skipped
-    int coff[NCH];
-    bool cok[NCH];
+    // per-lane channel byte offsets, clamped so that every load is unconditional (branch-free inner loop).  A lane whose
+    // channels are out of range multiplies whatever it loaded into MFMA columns that are never stored; a shadow neighbour
+    // has weight 0 (its record points at row 0, finite data).
+    unsigned coffb[NCH];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int c = c0 + ch * 16 * VEC + VEC * j;
-        cok[ch] = c < a.C;
-        coff[ch] = cok[ch] ? c : 0;
+        coffb[ch] = c < a.C ? 4u * c : 0u;
     }
+    const char *fbase = reinterpret_cast<const char *>(a.feats);
+    const unsigned ldfb = 4u * a.ldf;
+    float4 *rec = rec_s[wv];
+    if (lane < KP_PAD) rec[KP_PHASE + lane] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));  // look-ahead lands here
+    const float inv_sigma = 1.0f / a.sigma;
 
-    // The neighbour row is read once, coalesced (lane l holds idx[4*s0 + l]); step t takes idx[4t+g] from the
-    // owning lane by shuffle.  Loads of step t+1 are issued before the MFMAs of step t.
-    for (int s0 = 0; s0 < steps; s0 += 16) {
-        const int h0 = 4 * s0 + lane;
-        const int myidx = h0 < a.H ? irow[h0] : a.N;
-        auto issue = [&](int t, KpStep<VEC, NCH> &r) {
-            const int id = __shfl(myidx, 4 * t + g, 64);
-            r.valid = (unsigned)id < (unsigned)a.N;
-            const int idc = r.valid ? id : 0;
+    for (int h0 = 0; h0 < a.H; h0 += KP_PHASE) {
+        const int nh = a.H - h0 < KP_PHASE ? a.H - h0 : KP_PHASE;  // multiple of 4
+        // ---- stage the records of this phase: lane = neighbour; all index loads first, then all gathers
+        int idr[KP_PHASE / 64];
+#pragma unroll
+        for (int r = 0; r < KP_PHASE / 64; ++r) {
+            const int hl = r * 64 + lane;
+            idr[r] = irow[h0 + (hl < nh ? hl : 0)];
+            if (hl >= nh) idr[r] = a.N;
+        }
+        float px[KP_PHASE / 64], py[KP_PHASE / 64], pz[KP_PHASE / 64];
+        int pos[KP_PHASE / 64];
+#pragma unroll
+        for (int r = 0; r < KP_PHASE / 64; ++r) {
+            const int idc = (unsigned)idr[r] < (unsigned)a.N ? idr[r] : 0;
             const float *sp = a.s_pts + 3 * (size_t)idc;
-            r.px = sp[0]; r.py = sp[1]; r.pz = sp[2];
-            const float *fr = a.feats + (size_t)idc * a.ldf;
+            px[r] = sp[0]; py[r] = sp[1]; pz[r] = sp[2];
+            pos[r] = a.row_pos[idc];
+        }
+#pragma unroll
+        for (int r = 0; r < KP_PHASE / 64; ++r) {
+            const bool valid = (unsigned)idr[r] < (unsigned)a.N;
+            npos += __popcll(__ballot(valid && pos[r] != 0));
+            // kpconv.py:93: neighbours centred on the query; id < 0 marks a shadow neighbour
+            rec[r * 64 + lane] = make_float4(px[r] - qx, py[r] - qy, pz[r] - qz, __int_as_float(valid ? idr[r] : -1));
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int steps = nh >> 2;
+        const float4 *rg = rec + g;  // record of neighbour 4t+g = rg[4t]; reads past the phase hit later records or the pad
+        // The loads ARE the software pipeline.  Each one is followed by a compiler-level memory barrier (no instruction):
+        // without it the optimiser folds the loop-carried loaded values into loop-carried ADDRESSES and re-issues every
+        // load at its use, which serialises the L2 latency into each step.
+        auto fetch = [&](int t) -> float4 {
+            const float4 v = rg[4 * t];
+            asm volatile("" ::: "memory");
+            return v;
+        };
+        auto issue = [&](const float4 &rc, KpFeat<VEC, NCH> &f) {
+            const int id = __float_as_int(rc.w);
+            const unsigned rowb = (unsigned)(id < 0 ? 0 : id) * ldfb;  // byte offset of the row (< 4 GiB, checked by the host)
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
+                const char *src = fbase + (size_t)(rowb + coffb[ch]);
                 if constexpr (VEC == 4) {
-                    const float4 tt = *reinterpret_cast<const float4 *>(fr + coff[ch]);
-                    r.f[ch][0] = tt.x; r.f[ch][1] = tt.y; r.f[ch][2] = tt.z; r.f[ch][3] = tt.w;
+                    const f32x4 tt = *reinterpret_cast<const f32x4 *>(src);
+                    f.f[ch][0] = tt[0]; f.f[ch][1] = tt[1]; f.f[ch][2] = tt[2]; f.f[ch][3] = tt[3];
                 } else if constexpr (VEC == 2) {
-                    const float2 tt = *reinterpret_cast<const float2 *>(fr + coff[ch]);
-                    r.f[ch][0] = tt.x; r.f[ch][1] = tt.y;
+                    const f32x2 tt = *reinterpret_cast<const f32x2 *>(src);
+                    f.f[ch][0] = tt[0]; f.f[ch][1] = tt[1];
                 } else {
-                    r.f[ch][0] = fr[coff[ch]];
+                    f.f[ch][0] = *reinterpret_cast<const float *>(src);
                 }
             }
-            r.pos = a.row_pos[idc];
+            asm volatile("" ::: "memory");
         };
-        auto consume = [&](const KpStep<VEC, NCH> &r) {
-            // kpconv.py:93-99: ((s - q) - kp)^2 summed, sqrt, 1 - d/sigma, clamp at 0
-            const float dx = (r.px - qx) - kx, dy = (r.py - qy) - ky, dz = (r.pz - qz) - kz;
+        auto consume = [&](const float4 &rc, const KpFeat<VEC, NCH> &f) {
+            // kpconv.py:93-99: ((s - q) - kp)^2 summed, sqrt, 1 - d/sigma, clamp at 0 (straight-line: select, no branch)
+            const float dx = rc.x - kx, dy = rc.y - ky, dz = rc.z - kz;
             const float sq = (dx * dx + dy * dy) + dz * dz;
-            const float w = (kvalid && r.valid) ? fmaxf(1.0f - sqrtf(sq) / a.sigma, 0.0f) : 0.0f;
-            npos += (r.valid && j == 0) ? r.pos : 0;
+            const float wr = fmaxf(1.0f - __builtin_amdgcn_sqrtf(sq) * inv_sigma, 0.0f);
+            const float w = (kvalid & (__float_as_int(rc.w) >= 0)) ? wr : 0.0f;
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
                 for (int v = 0; v < VEC; ++v)
-                    acc[ch][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, cok[ch] ? r.f[ch][v] : 0.0f, acc[ch][v], 0, 0, 0);
+                    acc[ch][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, f.f[ch][v], acc[ch][v], 0, 0, 0);
         };
-        KpStep<VEC, NCH> ra, rb;
-        issue(0, ra);
-#pragma unroll
-        for (int t = 0; t < 16; t += 2) {  // tail steps (H < 64) see the shadow index N and contribute zero
-            issue(t + 1, rb);
-            consume(ra);
-            if (t + 2 < 16) issue(t + 2, ra);
-            consume(rb);
+        // software pipeline: slot k fetches the record of step k+3 (LDS), runs the MFMAs of step k behind it, then issues
+        // the feature loads of step k+3 (L2) - three feature loads stay in flight per wave
+        float4 R0 = fetch(0), R1 = fetch(1), R2 = fetch(2), R3;
+        KpFeat<VEC, NCH> F0, F1, F2, F3;
+        issue(R0, F0); issue(R1, F1); issue(R2, F2);
+        for (int t = 0; t < steps; t += 4) {  // steps in [steps, roundup4) read shadow records and add zero
+            R3 = fetch(t + 3); consume(R0, F0); issue(R3, F3);
+            R0 = fetch(t + 4); consume(R1, F1); issue(R0, F0);
+            R1 = fetch(t + 5); consume(R2, F2); issue(R1, F1);
+            R2 = fetch(t + 6); consume(R3, F3); issue(R2, F2);
         }
+        __builtin_amdgcn_wave_barrier();
     }
     // D layout 16x16: row (kernel point) = 4*g + r, col = j  ->  channels c .. c+VEC-1 contiguous
     float *orow = a.agg + (size_t)m * a.ld_agg;
@@ -153,11 +195,7 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
             }
         }
     }
-    if (blockIdx.y == 0) {
-        npos += __shfl_xor(npos, 16, 64);
-        npos += __shfl_xor(npos, 32, 64);
-        if (lane == 0) a.cnt[m] = (float)(npos > 1 ? npos : 1);
-    }
+    if (blockIdx.y == 0 && lane == 0) a.cnt[m] = (float)(npos > 1 ? npos : 1);
 }
 
 // row_pos[n] = (sum_c feats[n,c] > 0); one wave per row (kpconv.py:113-114 applied per source row)
@@ -187,11 +225,28 @@ __global__ __launch_bounds__(256) void neighbor_maxpool_kernel(const float *x, i
     const int32_t *irow = idx + (size_t)m * H;
     float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     const bool cin = c < C;
-    for (int h = g; h < H; h += 8) {
-        const int id = irow[h];
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)id < (unsigned)N && cin) v = *reinterpret_cast<const float4 *>(x + (size_t)id * ldx + c);
-        best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+    const float *xc = x + (cin ? c : 0);
+    // 64 neighbours per round: the index row is read once, coalesced (lane = neighbour), and handed to the 8 lane groups by
+    // shuffle, so the only per-neighbour memory instruction is the 1-KB feature load (8 rows x 128 B); the 8 loads of a round
+    // are issued back to back.  Shadow neighbours (idx == N) read row 0 and are replaced by the zero row afterwards.
+    for (int h0 = 0; h0 < H; h0 += 64) {
+        const int hl = h0 + lane;
+        const int myid = hl < H ? irow[hl] : INT_MIN;   // INT_MIN: past the row (ignored); anything else outside [0,N): zero row
+        float4 v[8];
+        int ids[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            ids[i] = __shfl(myid, 8 * i + g, 64);
+            const unsigned row = (unsigned)ids[i] < (unsigned)N ? ids[i] : 0;
+            v[i] = *reinterpret_cast<const float4 *>(xc + (size_t)row * ldx);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool real = (unsigned)ids[i] < (unsigned)N;
+            const float other = ids[i] == INT_MIN ? -INFINITY : 0.f;
+            best.x = fmaxf(best.x, real ? v[i].x : other); best.y = fmaxf(best.y, real ? v[i].y : other);
+            best.z = fmaxf(best.z, real ? v[i].z : other); best.w = fmaxf(best.w, real ? v[i].w : other);
+        }
     }
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1) {
@@ -236,6 +291,7 @@ extern "C" int cofi_kpconv_aggregate(const float *feats, int ldf, int N, int C, 
                                      cofi_stream_t stream) {
     if (!feats || !q_pts || !s_pts || !idx || !kernel_points || !row_pos || !agg || !cnt) return COFI_EINVAL;
     if (N <= 0 || C <= 0 || M < 0 || H <= 0 || (H & 3) || ldf < C || ld_agg < 15 * C || !(sigma > 0.f) || frames <= 0) return COFI_EINVAL;
+    if ((size_t)N * ldf * 4 >= ((size_t)1 << 32)) return COFI_EUNSUPPORTED;  // 32-bit row offsets inside one frame
     if (M == 0) return 0;
     KpArgs a{feats, q_pts, s_pts, kernel_points, idx, row_pos, agg, cnt, ldf, N, C, M * frames, H, ld_agg, sigma, M, order};
     M *= frames;
