@@ -46,6 +46,24 @@ def make_inputs(model_dev, frame_ids, num_points):
     return frames
 
 
+def record_kernel_calls(model, dev, points=20480, batch=1):
+    """KernelTimer holding every C-ABI call of one submission (one frame, or a stack-mode batch) - used by tools/."""
+    from cofii2p_amd.network import CoFiI2P
+
+    frames = make_inputs(dev, list(range(batch)), points)
+    one_step(model, frames[0])
+    model.enable_graphs(False)
+    kt = KernelTimer()
+    if batch == 1:
+        kt.record(model, frames[0])
+    else:
+        pyr_b, img_b = CoFiI2P.stack_frames([f[0] for f in frames], [f[1] for f in frames])
+        P_b = model._pack(dev)
+        kt.record_fn(lambda: model._run_device(P_b, pyr_b["points"], pyr_b["neighbors"], pyr_b["subsampling"], pyr_b["upsampling"],
+                                               pyr_b["feats"], img_b, "test", None, None))
+    return kt
+
+
 def one_step(model, frame):
     """forward(mode='test') computes the coarse matches, the 4x4 patches AND (in the same hipGraph) the
     caller-side fine matching of eval_all.py:99-105; the returned tuple is the reference's 8-tuple."""

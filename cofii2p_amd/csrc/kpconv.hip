@@ -58,7 +58,8 @@ template <int VEC, int NCH>
 __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
     __shared__ float4 rec_s[4][KP_PHASE + KP_PAD];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int m = xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + wv;
+    // the query id is wave-uniform: keep it (and everything derived from it) in scalar registers
+    int m = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + wv);
     if (m >= a.M) return;
     if (a.order) m = (m / a.Mpf) * a.Mpf + a.order[m];
     const int j = lane & 15, g = lane >> 4;
@@ -70,8 +71,9 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
         a.row_pos += fo;
     }
     const float qx = a.q_pts[3 * m], qy = a.q_pts[3 * m + 1], qz = a.q_pts[3 * m + 2];
-    const bool kvalid = j < 15;
-    const float kx = kvalid ? a.kp[3 * j] : 0.f, ky = kvalid ? a.kp[3 * j + 1] : 0.f, kz = kvalid ? a.kp[3 * j + 2] : 0.f;
+    // MFMA row 15 (lane j == 15) is a padding row that is never stored: it may hold any finite weight
+    const int jk = j < 15 ? j : 0;
+    const float kx = a.kp[3 * jk], ky = a.kp[3 * jk + 1], kz = a.kp[3 * jk + 2];
     f32x4 acc[NCH][VEC];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch)
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
     const char *fbase = reinterpret_cast<const char *>(a.feats);
     const unsigned ldfb = 4u * a.ldf;
     float4 *rec = rec_s[wv];
-    if (lane < KP_PAD) rec[KP_PHASE + lane] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));  // look-ahead lands here
+    if (lane < KP_PAD) rec[KP_PHASE + lane] = make_float4(1e18f, 0.f, 0.f, __int_as_float(0));  // look-ahead lands here
     const float inv_sigma = 1.0f / a.sigma;
 
     for (int h0 = 0; h0 < a.H; h0 += KP_PHASE) {
@@ -117,8 +119,9 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
         for (int r = 0; r < KP_PHASE / 64; ++r) {
             const bool valid = (unsigned)idr[r] < (unsigned)a.N;
             npos += __popcll(__ballot(valid && pos[r] != 0));
-            // kpconv.py:93: neighbours centred on the query; id < 0 marks a shadow neighbour
-            rec[r * 64 + lane] = make_float4(px[r] - qx, py[r] - qy, pz[r] - qz, __int_as_float(valid ? idr[r] : -1));
+            // kpconv.py:93: neighbours centred on the query.  A shadow neighbour sits 1e18 away (influence exactly 0, as for
+            // the reference's 1e6 shadow point) and points at row 0, so the step loop needs no validity test.
+            rec[r * 64 + lane] = make_float4(valid ? px[r] - qx : 1e18f, py[r] - qy, pz[r] - qz, __int_as_float(valid ? idr[r] : 0));
         }
         __builtin_amdgcn_wave_barrier();
         const int steps = nh >> 2;
@@ -132,11 +135,11 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
             return v;
         };
         auto issue = [&](const float4 &rc, KpFeat<VEC, NCH> &f) {
-            const int id = __float_as_int(rc.w);
-            const unsigned rowb = (unsigned)(id < 0 ? 0 : id) * ldfb;  // byte offset of the row (< 4 GiB, checked by the host)
+            const unsigned id = (unsigned)__float_as_int(rc.w);
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
-                const char *src = fbase + (size_t)(rowb + coffb[ch]);
+                // byte offset of (row, channel chunk): < 4 GiB with id, ldfb < 2^24 (checked by the host) -> one full-rate mad
+                const char *src = fbase + (size_t)(__umul24(id, ldfb) + coffb[ch]);
                 if constexpr (VEC == 4) {
                     const f32x4 tt = *reinterpret_cast<const f32x4 *>(src);
                     f.f[ch][0] = tt[0]; f.f[ch][1] = tt[1]; f.f[ch][2] = tt[2]; f.f[ch][3] = tt[3];
@@ -153,8 +156,7 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
             // kpconv.py:93-99: ((s - q) - kp)^2 summed, sqrt, 1 - d/sigma, clamp at 0 (straight-line: select, no branch)
             const float dx = rc.x - kx, dy = rc.y - ky, dz = rc.z - kz;
             const float sq = (dx * dx + dy * dy) + dz * dz;
-            const float wr = fmaxf(1.0f - __builtin_amdgcn_sqrtf(sq) * inv_sigma, 0.0f);
-            const float w = (kvalid & (__float_as_int(rc.w) >= 0)) ? wr : 0.0f;
+            const float w = fmaxf(1.0f - __builtin_amdgcn_sqrtf(sq) * inv_sigma, 0.0f);
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
@@ -291,7 +293,7 @@ extern "C" int cofi_kpconv_aggregate(const float *feats, int ldf, int N, int C, 
                                      cofi_stream_t stream) {
     if (!feats || !q_pts || !s_pts || !idx || !kernel_points || !row_pos || !agg || !cnt) return COFI_EINVAL;
     if (N <= 0 || C <= 0 || M < 0 || H <= 0 || (H & 3) || ldf < C || ld_agg < 15 * C || !(sigma > 0.f) || frames <= 0) return COFI_EINVAL;
-    if ((size_t)N * ldf * 4 >= ((size_t)1 << 32)) return COFI_EUNSUPPORTED;  // 32-bit row offsets inside one frame
+    if ((size_t)N * ldf * 4 >= ((size_t)1 << 32) || N >= (1 << 24) || (size_t)ldf * 4 >= (1u << 24)) return COFI_EUNSUPPORTED;  // 24x24-bit row offsets
     if (M == 0) return 0;
     KpArgs a{feats, q_pts, s_pts, kernel_points, idx, row_pos, agg, cnt, ldf, N, C, M * frames, H, ld_agg, sigma, M, order};
     M *= frames;

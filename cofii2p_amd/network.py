@@ -74,6 +74,8 @@ class CoFiI2P(nn.Module):
         self._graphs = {}
         import os
 
+        # intra-frame fork/join slots captured by forward_async (bit 0 image branch, 1 residual shortcuts, 2 attention streams)
+        self.async_branch_mask = int(os.environ.get("COFI_ASYNC_BRANCH_MASK", "0"))
         self.image_backend = os.environ.get("COFI_IMAGE", "nhwc")  # "nhwc": implicit-GEMM HIP convolutions; "miopen": A/B only
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
         self.eval()
@@ -322,7 +324,7 @@ class CoFiI2P(nn.Module):
         # submissions in flight fill the GPU by themselves: the per-submission graph is a linear chain (intra-frame
         # fork/join only adds join latency then — measured 306 vs 250 frames/s)
         outs = self._graph_forward(P, points, tabs[0], tabs[1], tabs[2], pc_data_dict["feats"].contiguous(), img.contiguous(), mode, None,
-                                   None, slot=slot, branch_mask=0, order=pc_data_dict.get("order"))
+                                   None, slot=slot, branch_mask=self.async_branch_mask, order=pc_data_dict.get("order"))
         host = torch.empty((len(outs), 2), dtype=torch.int32, pin_memory=True)
         for f, o in enumerate(outs):
             host[f].copy_(o["count"], non_blocking=True)

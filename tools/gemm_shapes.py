@@ -30,15 +30,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--points", type=int, default=20480)
     ap.add_argument("--kernel", default="gemm")
+    ap.add_argument("--batch", type=int, default=1)
     args = ap.parse_args()
     from cofii2p_amd.network import CoFiI2P
 
     dev = torch.device("cuda", 0)
     model = CoFiI2P(bench.Opt()).to(dev)
-    frames = bench.make_inputs(dev, [0], args.points)
-    bench.one_step(model, frames[0])
-    kt = bench.KernelTimer()
-    kt.record(model, frames[0])
+    kt = bench.record_kernel_calls(model, dev, args.points, args.batch)
     rows = {}
     names = ["gemm", "gemm_colstats", "gemm_layernorm", "conv2d_nhwc"] if args.kernel == "gemm" else [args.kernel]
     calls = [(n,) + c for n in names for c in kt.calls.get(n, [])]
@@ -57,7 +55,7 @@ def main():
     print("%-46s %5s %9s %9s %8s" % ("shape", "calls", "us/call", "TF/s", "% time"))
     for key, r in sorted(rows.items(), key=lambda kv: -kv[1][1]):
         print("%-46s %5d %9.2f %9.2f %8.1f" % (str(key), r[0], 1e6 * r[1] / r[0], r[2] / (r[1] / r[0]) / 1e12, 100 * r[1] / tot))
-    print("total %.1f us per frame" % (1e6 * tot))
+    print("total %.1f us per submission (batch %d: %.1f us per frame)" % (1e6 * tot, args.batch, 1e6 * tot / args.batch))
 
 
 if __name__ == "__main__":
