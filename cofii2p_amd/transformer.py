@@ -8,7 +8,11 @@ from typing import Dict
 
 import torch
 
+import os
+
 from . import ops
+
+JOINT_SELF = os.environ.get("COFI_JOINT_SELF", "1") != "0"  # A/B switch for the joint self-attention layers
 
 
 def pack_layer(sd: Dict[str, torch.Tensor], p: str) -> Dict[str, torch.Tensor]:
@@ -71,12 +75,16 @@ def loftr_layer(w, x: torch.Tensor, src: torch.Tensor, nhead: int = 4) -> torch.
 
 
 class TokenStreams:
-    """Ping-pong (L,2C) buffers for the image and point streams."""
+    """Ping-pong (L,2C) buffers for the image and point streams.  Both streams of one ping-pong phase share ONE
+    allocation ([image rows | point rows]): a self layer, whose weights are shared by the two streams, then runs
+    over both at once (stack mode with twice the frames) when the streams have equally many tokens per frame."""
 
     def __init__(self, L_img: int, L_pc: int, C: int, device):
         self.C = C
-        self.img = [torch.empty((L_img, 2 * C), dtype=torch.float32, device=device) for _ in range(2)]
-        self.pc = [torch.empty((L_pc, 2 * C), dtype=torch.float32, device=device) for _ in range(2)]
+        self.both = [torch.empty((L_img + L_pc, 2 * C), dtype=torch.float32, device=device) for _ in range(2)]
+        self.img = [b[:L_img] for b in self.both]
+        self.pc = [b[L_img:] for b in self.both]
+        self.joint = L_img == L_pc
         self.cur_img = 0
         self.cur_pc = 0
 
@@ -94,7 +102,11 @@ def run_transformer(layers, kinds, ts: TokenStreams, nhead: int = 4, frames: int
     for w, kind in zip(layers, kinds):
         xi, xp = ts.img[ts.cur_img], ts.pc[ts.cur_pc]
         oi, op = ts.img[ts.cur_img ^ 1], ts.pc[ts.cur_pc ^ 1]
-        if kind == "self":  # the two modalities are independent here: point stream on a side HIP stream
+        if kind == "self" and ts.joint and ts.cur_img == ts.cur_pc and JOINT_SELF:
+            # shared weights, independent streams: one pass over [image tokens | point tokens] as 2*frames frames
+            xb, ob = ts.both[ts.cur_img], ts.both[ts.cur_img ^ 1]
+            _layer(w, xb, xb[:, :C], ob[:, :C], True, nhead, 2 * frames)
+        elif kind == "self":  # the two modalities are independent here: point stream on a side HIP stream
             with ops.Branch(xi.device, 2) as br:
                 _layer(w, xp, xp[:, :C], op[:, :C], True, nhead, frames)
             _layer(w, xi, xi[:, :C], oi[:, :C], True, nhead, frames)
