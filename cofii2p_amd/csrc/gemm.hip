@@ -21,6 +21,8 @@
 // Deep-K / small-MN problems are split over K (gridDim.z) into a workspace and reduced in fixed
 // order by splitk_epilogue_kernel (same row-wise epilogue): deterministic, no float atomics.
 #include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -98,11 +100,11 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 // Row-wise epilogue over a ROWS x BN tile held row-major in LDS (`tile`, leading dimension TLD) or summed
-// from split-K partials.  Thread (tr, tc): row phase tr, float4 column chunk tc.  256 threads.
-template <int ROWS, int BN, bool FROM_WS>
+// from split-K partials.  Thread (tr, tc): row phase tr, float4 column chunk tc.  NT threads.
+template <int ROWS, int BN, bool FROM_WS, int NT = 256>
 __device__ __forceinline__ void rowwise_epilogue(const GemmArgs &g, const float *tile, int TLD, int m0, int n0, int slab, float *red) {
     constexpr int TPR = BN / 4;        // threads per row
-    constexpr int RPP = 256 / TPR;     // rows per pass
+    constexpr int RPP = NT / TPR;      // rows per pass
     constexpr int NP = ROWS / RPP;     // passes
     const int tc = threadIdx.x % TPR, tr = threadIdx.x / TPR;
     const int col = n0 + 4 * tc;
@@ -374,21 +376,29 @@ __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
 // and needs 4x fewer barriers.  One LDS buffer + a register-staged next tile:
 //   issue global loads (t+1) -> MFMAs on tile t from LDS -> barrier -> split + write tile t+1 -> barrier.
 // (The 128x128 tile uses BK3 = 64: 128 would need 139 KB of LDS and the whole VGPR file for one workgroup.)
-template <int BM, int BN, int TM, int TN, int BK3>
-__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
+// KW = 1: 4 waves (2x2 over the tile), up to 2 workgroups per CU - the throughput configuration.
+// KW = 2/4: 8/16 waves; wave group kq = wave / 4 multiplies only the kq-th 1/KW of every K-tile and the KW partial
+//           accumulators are summed through LDS in a fixed order at the end.  A workgroup that is alone on its CU (small
+//           grids) is bound by the serial chain load -> split -> LDS -> MFMA of ONE wave per SIMD (~2 us per 128-deep tile,
+//           measured); KW waves per SIMD split the conversion work KW ways and overlap each other's phases.
+template <int BM, int BN, int TM, int TN, int BK3, int KW = 1>
+__global__ __launch_bounds__(256 * KW) void gemm_bf16x3_kernel(GemmArgs g) {
     static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 waves");
+    constexpr int NT = 256 * KW;
     constexpr int BROW3 = BK3 * 2 + 16;   // bytes per LDS row: bf16 values + 16 B pad (68 / 36 dwords: conflict-free b128 reads)
     constexpr int LPR = BK3 / 4;          // lanes per row slice (float4 each)
-    constexpr int RPP = 256 / LPR;        // rows per staging pass
+    constexpr int RPP = NT / LPR;         // rows per staging pass
     constexpr int A_LD4 = BM / RPP, W_LD4 = BN / RPP;            // float4 loads per thread and tile
+    static_assert(A_LD4 >= 1 && W_LD4 >= 1 && (BK3 / 16) % KW == 0, "tile too small for this many waves");
     constexpr int TLD = BN + 4;
     constexpr int PLANE_A = BM * BROW3, PLANE_W = BN * BROW3;    // bytes
     constexpr int BUF = 2 * (PLANE_A + PLANE_W);                 // hi+lo of A and W
-    static_assert(BM * TLD * 4 <= BUF, "epilogue tile must fit in the operand buffer");
+    static_assert(BM * TLD * 4 <= BUF && (NT / (BN / 4)) * BN * 2 * 4 <= BUF, "epilogue tile must fit in the operand buffer");
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int kq = wave >> 2, wq = wave & 3;   // K share, position in the 2x2 wave grid
+    const int wm = wq >> 1, wn = wq & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
@@ -396,7 +406,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     const int lrow = tid / LPR, lk = (tid % LPR) * 4;            // LPR lanes cover one row slice; RPP rows per pass
     float4 ra[A_LD4], rw[W_LD4];
 
-    // conv-mode pixel coordinates of this thread's A rows (row = m0 + lrow + 8j)
+    // conv-mode pixel coordinates of this thread's A rows (row = m0 + lrow + RPP*j)
     int yo[A_LD4], xo[A_LD4], fb[A_LD4];
     if (g.cv_ks) {
 #pragma unroll
@@ -471,20 +481,14 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    if (ntiles > 0) {
-        gload(0);
-        sstore();
-    }
-    __syncthreads();
-
     const int li = lane & 31, lh = lane >> 5;
     union Frag { uint4 u; bf16x8 v; };
-    const unsigned char *as = lds_raw + (wm * 32 * TM + li) * BROW3 + lh * 16;
-    const unsigned char *bs = lds_raw + 2 * PLANE_A + (wn * 32 * TN + li) * BROW3 + lh * 16;
-    for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) gload(t + 1);
+    constexpr int STEPS = BK3 / 16 / KW;   // 16-deep MFMA steps of this wave per tile
+    const unsigned char *as = lds_raw + (wm * 32 * TM + li) * BROW3 + lh * 16 + kq * STEPS * 32;
+    const unsigned char *bs = lds_raw + 2 * PLANE_A + (wn * 32 * TN + li) * BROW3 + lh * 16 + kq * STEPS * 32;
+    auto compute = [&]() {
 #pragma unroll
-        for (int s2 = 0; s2 < BK3 / 16; ++s2) {  // 16-deep MFMA steps; lane (i,h) owns k = 16*s2 + 8h .. +7
+        for (int s2 = 0; s2 < STEPS; ++s2) {  // lane (i,h) owns k = 16*(kq*STEPS + s2) + 8h .. +7
             Frag ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -505,6 +509,19 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bh[j].v, acc[i][j], 0, 0, 0);
                 }
         }
+    };
+    // One LDS buffer + a register-staged next tile: issue global loads (t+1) -> MFMAs on tile t -> barrier -> split + write
+    // tile t+1 -> barrier.  (Measured on MI355X: deeper register prefetch (2-3 tiles in flight, exact vmcnt) and a second LDS
+    // buffer do NOT shorten the ~1 us a lone workgroup spends per 64 KB tile - that is the CU's L2 fill rate; only spreading
+    // the tiles over more CUs does, which is what split-K is tuned for.)
+    if (ntiles > 0) {
+        gload(0);
+        sstore();
+    }
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) gload(t + 1);
+        compute();
         __syncthreads();              // every wave is done reading tile t
         if (t + 1 < ntiles) {
             sstore();
@@ -513,6 +530,39 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     }
 
     float *lds = reinterpret_cast<float *>(lds_raw);
+    if constexpr (KW > 1) {
+        // sum of the KW partial accumulators in ascending kq order (fixed -> deterministic): wave group q adds its share to the
+        // row-major LDS tile in round q; after the last round group 0 holds ... the tile itself is what the epilogue reads
+#pragma unroll
+        for (int q = 0; q < KW; ++q) {
+            if (kq == q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rl = wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            float *p = lds + rl * TLD + wn * 32 * TN + j * 32 + li;
+                            *p = (q == 0) ? acc[i][j][r] : *p + acc[i][j][r];
+                        }
+            }
+            __syncthreads();
+        }
+        if (g.ksplit > 1) {
+            // partial sums of this K chunk: the tile goes out row by row (float per thread, coalesced 256-B segments)
+            for (int e = tid; e < BM * BN; e += NT) {
+                const int rl = e / BN, cl = e - rl * BN;
+                const int row = m0 + rl, col = n0 + cl;
+                if (row < g.M && col < g.N) g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = lds[rl * TLD + cl];
+            }
+            return;
+        }
+        // `red` of the epilogue aliases the tile: park it behind the tile instead (BUF >= tile + red, checked below)
+        static_assert(BM * TLD * 4 + (NT / (BN / 4)) * BN * 2 * 4 <= BUF, "tile + reduction scratch must fit in the operand buffer");
+        rowwise_epilogue<BM, BN, false, NT>(g, lds, TLD, m0, n0, blockIdx.y, lds + BM * TLD);
+        return;
+    }
     if (g.ksplit > 1) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -626,6 +676,20 @@ Plan make_plan(int M, int N, int K, bool fused_ln) {
     return p;
 }
 
+// Latency configuration of the 64x64 kernel (8 or 16 waves sharing every K-tile): grids small enough that each workgroup
+// is alone on its CU; 16 waves once a workgroup runs >= 4 K-tiles.  COFI_GEMM_KW = "<kw>:<max blocks>" overrides for A/B
+// runs (kw 0 = the rule above with another bound, "1:0" disables).
+int latency_kw(const Plan &p, int M, int N) {
+    static const struct Cfg { int kw; long max_blocks; } cfg = [] {
+        Cfg c{0, 256};
+        if (const char *e = getenv("COFI_GEMM_KW")) sscanf(e, "%d:%ld", &c.kw, &c.max_blocks);
+        return c;
+    }();
+    const long nb = (long)cofi_cdiv(M, p.bm) * cofi_cdiv(N, p.bn) * p.ksplit;
+    if (p.bm != 64 || p.bn != 64 || nb > cfg.max_blocks) return 1;
+    return cfg.kw ? cfg.kw : (p.kchunk >= 4 * 128 ? 4 : 2);
+}
+
 int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
     GemmArgs g = g0;
     g.ksplit = p.ksplit;
@@ -636,6 +700,10 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
             hipLaunchKernelGGL((gemm_bf16x3_kernel<128, 128, 2, 2, 64>), grid, dim3(256), 0, s, g);
         else if (p.bm == 64 && p.bn == 128)
             hipLaunchKernelGGL((gemm_bf16x3_kernel<64, 128, 1, 2, 128>), grid, dim3(256), 0, s, g);
+        else if (int kw = latency_kw(p, g.M, g.N); kw == 4)
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<64, 64, 1, 1, 128, 4>), grid, dim3(1024), 0, s, g);
+        else if (kw == 2)
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<64, 64, 1, 1, 128, 2>), grid, dim3(512), 0, s, g);
         else
             hipLaunchKernelGGL((gemm_bf16x3_kernel<64, 64, 1, 1, 128>), grid, dim3(256), 0, s, g);
     } else if (p.bm == 128 && p.bn == 128)

@@ -272,7 +272,9 @@ def test_matching_chain(ops, mg):
     assert np.array_equal(fxy.cpu().numpy(), mg["fm_xy"])
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (1280, 512, 7680), (77, 33, 60), (2560, 1024, 3072), (1280, 128, 256), (20480, 32, 64)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (1280, 512, 7680), (77, 33, 60), (2560, 1024, 3072), (1280, 128, 256), (20480, 32, 64),
+                                   # small grids with >= 3 K-tiles per workgroup: the two-tiles-in-flight configuration (odd / even / ragged tile counts)
+                                   (320, 256, 2304), (80, 512, 4608), (1280, 128, 1152), (100, 64, 1000), (64, 64, 384), (130, 60, 516)])
 def test_gemm_bf16x3_split(ops, M, N, K, monkeypatch):
     """3-term bf16 split with fp32 accumulation: error ~2^-16 per product, i.e. well inside the 1e-3 budget"""
     monkeypatch.setattr(ops, "GEMM_MODE", "bf16x3")
