@@ -31,6 +31,7 @@ SIGNATURES = {
     "cofi_gemm_f32_workspace": (_Z, [_I, _I, _I]),
     "cofi_gemm_f32": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _Z, _P]),
     "cofi_gemm_debug_force_plan": (_I, [_I, _I, _I]),
+    "cofi_split_bf16_planes": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "cofi_gemm_f32_stat_slabs": (_I, [_I, _I, _I]),
     "cofi_gemm_f32_colstats": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _Z, _P]),
     "cofi_gemm_f32_layernorm": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _F, _I, _P, _I, _P, _Z, _P]),

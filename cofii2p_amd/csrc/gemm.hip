@@ -40,6 +40,8 @@ struct GemmArgs {
     int lda, ldw, ldc, ldr, M, N, K, act, ksplit, kchunk, ln_relu;
     float ln_eps;
     int bf16x3;
+    int wsplit;        // W is pre-split: W points at the bf16 hi plane (rows of ldw bf16), the lo plane starts w_lo_off elements later
+    long w_lo_off;
     // implicit-GEMM convolution (cv_ks > 0): A is an NHWC map (H*W rows of lda floats), row m of the GEMM is
     // output pixel (m / Wo, m % Wo), column k is (tap = k / Cin, channel = k % Cin); K = ks*ks*Cin
     int cv_ks, cv_H, cv_W, cv_Cin, cv_Wo, cv_stride, cv_pad;
@@ -362,6 +364,14 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {  // RNE, a -
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ void split4(const f32x4 v, uint2 &hi, uint2 &lo) {
+    hi.x = cvt_pk_bf16(v[0], v[1]);
+    hi.y = cvt_pk_bf16(v[2], v[3]);
+    const float rx = v[0] - __uint_as_float(hi.x << 16), ry = v[1] - __uint_as_float(hi.x & 0xffff0000u);
+    const float rz = v[2] - __uint_as_float(hi.y << 16), rw = v[3] - __uint_as_float(hi.y & 0xffff0000u);
+    lo.x = cvt_pk_bf16(rx, ry);
+    lo.y = cvt_pk_bf16(rz, rw);
+}
 __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
     hi.x = cvt_pk_bf16(v.x, v.y);
     hi.y = cvt_pk_bf16(v.z, v.w);
@@ -369,6 +379,21 @@ __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
     const float rz = v.z - __uint_as_float(hi.y << 16), rw = v.w - __uint_as_float(hi.y & 0xffff0000u);
     lo.x = cvt_pk_bf16(rx, ry);
     lo.y = cvt_pk_bf16(rz, rw);
+}
+
+// Static operands (weights) are split once: planes (2, N, ldp) bf16 = [hi | lo], rows zero-padded to ldp (multiple of 8).
+// Same rounding as split4, so a pre-split launch is bit-identical to splitting on the fly.
+__global__ void split_planes_kernel(const float *W, int ldw, int N, int K, unsigned *planes, int ldp) {
+    const int hp = ldp >> 1;   // bf16 pairs per row
+    const size_t total = (size_t)N * hp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / hp), k = 2 * (int)(i - (size_t)n * hp);
+        const float a = k < K ? W[(size_t)n * ldw + k] : 0.f, b = k + 1 < K ? W[(size_t)n * ldw + k + 1] : 0.f;
+        const unsigned hi = cvt_pk_bf16(a, b);
+        const unsigned lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+        planes[i] = hi;
+        planes[total + i] = lo;
+    }
 }
 
 // K-tile of 128 per iteration (BK3): at batch 1 most problems give <= 1 workgroup per CU, so the loop is bound by
@@ -381,7 +406,7 @@ __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
 //           accumulators are summed through LDS in a fixed order at the end.  A workgroup that is alone on its CU (small
 //           grids) is bound by the serial chain load -> split -> LDS -> MFMA of ONE wave per SIMD (~2 us per 128-deep tile,
 //           measured); KW waves per SIMD split the conversion work KW ways and overlap each other's phases.
-template <int BM, int BN, int TM, int TN, int BK3, int KW = 1>
+template <int BM, int BN, int TM, int TN, int BK3, int KW = 1, bool WSPLIT = false>
 __global__ __launch_bounds__(256 * KW) void gemm_bf16x3_kernel(GemmArgs g) {
     static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 waves");
     constexpr int NT = 256 * KW;
@@ -390,6 +415,9 @@ __global__ __launch_bounds__(256 * KW) void gemm_bf16x3_kernel(GemmArgs g) {
     constexpr int RPP = NT / LPR;         // rows per staging pass
     constexpr int A_LD4 = BM / RPP, W_LD4 = BN / RPP;            // float4 loads per thread and tile
     static_assert(A_LD4 >= 1 && W_LD4 >= 1 && (BK3 / 16) % KW == 0, "tile too small for this many waves");
+    // pre-split W: 16-B chunks of 8 bf16; chunk c of a plane tile = (row c / CPR, k 8 * (c % CPR))
+    constexpr int CPR = BK3 / 8, W_CH = BN * CPR / NT;
+    static_assert(!WSPLIT || (BN * CPR) % NT == 0, "plane tile must divide over the threads");
     constexpr int TLD = BN + 4;
     constexpr int PLANE_A = BM * BROW3, PLANE_W = BN * BROW3;    // bytes
     constexpr int BUF = 2 * (PLANE_A + PLANE_W);                 // hi+lo of A and W
@@ -404,11 +432,36 @@ __global__ __launch_bounds__(256 * KW) void gemm_bf16x3_kernel(GemmArgs g) {
     const int kend = min(g.K, kbeg + g.kchunk);
     const int ntiles = (kend - kbeg + BK3 - 1) / BK3;
     const int lrow = tid / LPR, lk = (tid % LPR) * 4;            // LPR lanes cover one row slice; RPP rows per pass
-    float4 ra[A_LD4], rw[W_LD4];
+    f32x4 ra[A_LD4];                                             // native vectors: plain 16-B loads, no struct copies
+    f32x4 rw[WSPLIT ? 1 : W_LD4];                                // fp32 W: W_LD4 chunks of 4
+    f32x4 rwh[WSPLIT ? W_CH : 1], rwl[WSPLIT ? W_CH : 1];       // pre-split W: 16-B chunks (8 bf16) of the hi / lo plane, as opaque bits
+    const bool conv = g.cv_ks != 0;
+
+    // Addressing: a workgroup-uniform base (scalar registers, advanced by one K-tile per iteration) plus a per-thread 32-bit
+    // byte offset that never changes -> the loads of a full tile need NO vector arithmetic at all.  Rows past M / N are
+    // clamped to the last row: they only feed output rows / columns that are never stored (MFMA rows and columns are
+    // independent), so they need no zeroing; only K tails (and convolution padding) are zeroed, on the A side.
+    unsigned aoff[A_LD4], woff[WSPLIT ? W_CH : W_LD4];
+#pragma unroll
+    for (int j = 0; j < A_LD4; ++j) aoff[j] = ((unsigned)(min(m0 + lrow + RPP * j, g.M - 1) - m0) * (unsigned)g.lda + lk) * 4u;
+    if constexpr (WSPLIT) {
+#pragma unroll
+        for (int j = 0; j < W_CH; ++j) {
+            const int c = tid + NT * j;
+            woff[j] = ((unsigned)(min(n0 + c / CPR, g.N - 1) - n0) * (unsigned)g.ldw + 8 * (c % CPR)) * 2u;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < W_LD4; ++j) woff[j] = ((unsigned)(min(n0 + lrow + RPP * j, g.N - 1) - n0) * (unsigned)g.ldw + lk) * 4u;
+    }
+    const char *abase = reinterpret_cast<const char *>(g.A + (size_t)m0 * g.lda + kbeg);
+    const char *wbase = WSPLIT ? reinterpret_cast<const char *>(reinterpret_cast<const uint16_t *>(g.W) + (size_t)n0 * g.ldw + kbeg)
+                               : reinterpret_cast<const char *>(g.W + (size_t)n0 * g.ldw + kbeg);
+    const size_t wlo = (size_t)g.w_lo_off * 2;
 
     // conv-mode pixel coordinates of this thread's A rows (row = m0 + lrow + RPP*j)
     int yo[A_LD4], xo[A_LD4], fb[A_LD4];
-    if (g.cv_ks) {
+    if (conv) {
 #pragma unroll
         for (int j = 0; j < A_LD4; ++j) {
             const int r = min(m0 + lrow + RPP * j, g.M - 1);
@@ -418,58 +471,108 @@ __global__ __launch_bounds__(256 * KW) void gemm_bf16x3_kernel(GemmArgs g) {
             xo[j] = pix - yo[j] * g.cv_Wo;
         }
     }
-    // Loads are unconditional on clamped addresses; validity is kept as a bit mask and applied when the registers are
-    // consumed (sstore), so nothing touches a loaded value — and no s_waitcnt is needed — until after the MFMAs.
-    unsigned amask = 0, wmask = 0;
+    // Validity of the A values is kept as a bit mask and applied when the registers are consumed (sstore), so nothing touches
+    // a loaded value - and no s_waitcnt is needed - until after the MFMAs.  Full dense tiles carry no mask at all.
+    unsigned amask = 0;
+    bool afull = false;   // uniform: the A registers hold a full dense tile (no zeroing needed)
     auto gload = [&](int t) {
+        const bool full = kbeg + (t + 1) * BK3 <= kend;   // uniform
         const int k = kbeg + t * BK3 + lk;
         const bool kin = k < kend;
-        const int kc = kin ? k : 0;
-        amask = 0; wmask = 0;
-        if (g.cv_ks == 0) {
+        if (!conv) {
+            afull = full;
+            const char *at = abase + (size_t)t * (BK3 * 4);
+            if (full) {
 #pragma unroll
-            for (int j = 0; j < A_LD4; ++j) {
-                const int r = m0 + lrow + RPP * j;
-                ra[j] = *reinterpret_cast<const float4 *>(g.A + (size_t)min(r, g.M - 1) * g.lda + kc);
-                amask |= (kin && r < g.M) ? (1u << j) : 0u;
+                for (int j = 0; j < A_LD4; ++j) ra[j] = *reinterpret_cast<const f32x4 *>(at + aoff[j]);
+            } else {
+                amask = kin ? ~0u : 0u;   // lanes past the K range re-read the first values of their row (always in range)
+#pragma unroll
+                for (int j = 0; j < A_LD4; ++j) ra[j] = *reinterpret_cast<const f32x4 *>(kin ? at + aoff[j] : abase + (aoff[j] - 4u * lk));
             }
         } else {
+            afull = false;
+            const int kc = kin ? k : 0;
             const int tap = kc / g.cv_Cin, c = kc - tap * g.cv_Cin;
             const int dy = tap / g.cv_ks, dx = tap - dy * g.cv_ks;
+            amask = 0;
 #pragma unroll
             for (int j = 0; j < A_LD4; ++j) {
-                const int r = m0 + lrow + RPP * j;
                 const int yi = yo[j] * g.cv_stride - g.cv_pad + dy, xi = xo[j] * g.cv_stride - g.cv_pad + dx;
-                const bool ok = kin && r < g.M && (unsigned)yi < (unsigned)g.cv_H && (unsigned)xi < (unsigned)g.cv_W;
+                const bool ok = kin && (unsigned)yi < (unsigned)g.cv_H && (unsigned)xi < (unsigned)g.cv_W;
                 const int yc = min(max(yi, 0), g.cv_H - 1), xc = min(max(xi, 0), g.cv_W - 1);
-                ra[j] = *reinterpret_cast<const float4 *>(g.A + ((size_t)fb[j] + (size_t)yc * g.cv_W + xc) * g.lda + c);
+                ra[j] = *reinterpret_cast<const f32x4 *>(g.A + ((size_t)fb[j] + (size_t)yc * g.cv_W + xc) * g.lda + c);
                 amask |= ok ? (1u << j) : 0u;
             }
         }
+        // W: lanes past the K range re-read the start of their row (finite values x zeroed A = 0)
+        if constexpr (WSPLIT) {
+            const char *wt = wbase + (size_t)t * (BK3 * 2);
+            if (full) {
 #pragma unroll
-        for (int j = 0; j < W_LD4; ++j) {
-            const int r = n0 + lrow + RPP * j;
-            rw[j] = *reinterpret_cast<const float4 *>(g.W + (size_t)min(r, g.N - 1) * g.ldw + kc);
-            wmask |= (kin && r < g.N) ? (1u << j) : 0u;
+                for (int j = 0; j < W_CH; ++j) {
+                    rwh[j] = *reinterpret_cast<const f32x4 *>(wt + woff[j]);
+                    rwl[j] = *reinterpret_cast<const f32x4 *>(wt + wlo + woff[j]);
+                }
+            } else {  // chunks that start past the K range re-read the first chunk of their row (plane rows are padded to 8 values)
+#pragma unroll
+                for (int j = 0; j < W_CH; ++j) {
+                    const int c8 = 8 * ((tid + NT * j) % CPR);
+                    const bool cin = kbeg + t * BK3 + c8 < kend;
+                    const char *q = cin ? wt + woff[j] : wbase + (woff[j] - 2u * c8);
+                    rwh[j] = *reinterpret_cast<const f32x4 *>(q);
+                    rwl[j] = *reinterpret_cast<const f32x4 *>(q + wlo);
+                }
+            }
+        } else {
+            const char *wt = wbase + (size_t)t * (BK3 * 4);
+            if (full) {
+#pragma unroll
+                for (int j = 0; j < W_LD4; ++j) rw[j] = *reinterpret_cast<const f32x4 *>(wt + woff[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < W_LD4; ++j) rw[j] = *reinterpret_cast<const f32x4 *>(kin ? wt + woff[j] : wbase + (woff[j] - 4u * lk));
+            }
         }
     };
     auto sstore = [&]() {
-        const float4 zero = make_float4(0, 0, 0, 0);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        if (afull) {
 #pragma unroll
-        for (int j = 0; j < A_LD4; ++j) {
-            uint2 hi, lo;
-            split4(((amask >> j) & 1u) ? ra[j] : zero, hi, lo);
-            unsigned char *p = lds_raw + (lrow + RPP * j) * BROW3 + lk * 2;
-            *reinterpret_cast<uint2 *>(p) = hi;
-            *reinterpret_cast<uint2 *>(p + PLANE_A) = lo;
+            for (int j = 0; j < A_LD4; ++j) {
+                uint2 hi, lo;
+                split4(ra[j], hi, lo);
+                unsigned char *p = lds_raw + (lrow + RPP * j) * BROW3 + lk * 2;
+                *reinterpret_cast<uint2 *>(p) = hi;
+                *reinterpret_cast<uint2 *>(p + PLANE_A) = lo;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < A_LD4; ++j) {
+                uint2 hi, lo;
+                split4(((amask >> j) & 1u) ? ra[j] : zero, hi, lo);
+                unsigned char *p = lds_raw + (lrow + RPP * j) * BROW3 + lk * 2;
+                *reinterpret_cast<uint2 *>(p) = hi;
+                *reinterpret_cast<uint2 *>(p + PLANE_A) = lo;
+            }
         }
+        if constexpr (WSPLIT) {
 #pragma unroll
-        for (int j = 0; j < W_LD4; ++j) {
-            uint2 hi, lo;
-            split4(((wmask >> j) & 1u) ? rw[j] : zero, hi, lo);
-            unsigned char *p = lds_raw + 2 * PLANE_A + (lrow + RPP * j) * BROW3 + lk * 2;
-            *reinterpret_cast<uint2 *>(p) = hi;
-            *reinterpret_cast<uint2 *>(p + PLANE_W) = lo;
+            for (int j = 0; j < W_CH; ++j) {
+                const int c = tid + NT * j;
+                unsigned char *p = lds_raw + 2 * PLANE_A + (c / CPR) * BROW3 + (c % CPR) * 16;
+                *reinterpret_cast<f32x4 *>(p) = rwh[j];
+                *reinterpret_cast<f32x4 *>(p + PLANE_W) = rwl[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < W_LD4; ++j) {
+                uint2 hi, lo;
+                split4(rw[j], hi, lo);
+                unsigned char *p = lds_raw + 2 * PLANE_A + (lrow + RPP * j) * BROW3 + lk * 2;
+                *reinterpret_cast<uint2 *>(p) = hi;
+                *reinterpret_cast<uint2 *>(p + PLANE_W) = lo;
+            }
         }
     };
 
@@ -696,16 +799,25 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
     g.kchunk = p.kchunk;
     dim3 grid(cofi_cdiv(g.N, p.bn), cofi_cdiv(g.M, p.bm), p.ksplit);
     if (g.bf16x3) {
+        const int kw = (p.bm == 64 && p.bn == 64) ? latency_kw(p, g.M, g.N) : 1;
+#define COFI_LAUNCH_BF16X3(BM_, BN_, TM_, TN_, BK_, KW_)                                                                       \
+    do {                                                                                                                       \
+        if (g.wsplit)                                                                                                          \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, true>), grid, dim3(256 * KW_), 0, s, g);      \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, false>), grid, dim3(256 * KW_), 0, s, g);     \
+    } while (0)
         if (p.bm == 128 && p.bn == 128)
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<128, 128, 2, 2, 64>), grid, dim3(256), 0, s, g);
+            COFI_LAUNCH_BF16X3(128, 128, 2, 2, 64, 1);
         else if (p.bm == 64 && p.bn == 128)
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<64, 128, 1, 2, 128>), grid, dim3(256), 0, s, g);
-        else if (int kw = latency_kw(p, g.M, g.N); kw == 4)
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<64, 64, 1, 1, 128, 4>), grid, dim3(1024), 0, s, g);
+            COFI_LAUNCH_BF16X3(64, 128, 1, 2, 128, 1);
+        else if (kw == 4)
+            COFI_LAUNCH_BF16X3(64, 64, 1, 1, 128, 4);
         else if (kw == 2)
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<64, 64, 1, 1, 128, 2>), grid, dim3(512), 0, s, g);
+            COFI_LAUNCH_BF16X3(64, 64, 1, 1, 128, 2);
         else
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<64, 64, 1, 1, 128>), grid, dim3(256), 0, s, g);
+            COFI_LAUNCH_BF16X3(64, 64, 1, 1, 128, 1);
+#undef COFI_LAUNCH_BF16X3
     } else if (p.bm == 128 && p.bn == 128)
         hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, g);
     else if (p.bm == 64 && p.bn == 128)
@@ -753,11 +865,13 @@ extern "C" int cofi_gemm_f32_colstats(const float *A, int lda, const float *W, i
     if (int rc = check_common(A, lda, W, ldw, C, ldc, M, N, K)) return rc;
     if (M == 0) return 0;
     const int bf16x3 = (act & COFI_GEMM_BF16X3) ? 1 : 0;
-    act &= ~COFI_GEMM_BF16X3;
-    if (act < 0 || act > 2) return COFI_EINVAL;
+    const int wsplit = (act & COFI_GEMM_W_SPLIT) ? 1 : 0;
+    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_W_SPLIT);
+    if (act < 0 || act > 2 || (wsplit && (!bf16x3 || (ldw & 7)))) return COFI_EINVAL;
     Plan p = make_plan(M, N, K, false);
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
-    GemmArgs g{A, W, C, bias, rowdiv, (float *)ws, colpart, nullptr, nullptr, nullptr, lda, ldw, ldc, 0, M, N, K, act, 1, 0, 0, 0.f, bf16x3, 0, 0, 0, 0, 0, 0, 0, 1};
+    GemmArgs g{A, W, C, bias, rowdiv, (float *)ws, colpart, nullptr, nullptr, nullptr, lda, ldw, ldc, 0, M, N, K, act, 1, 0, 0, 0.f, bf16x3,
+               wsplit, (long)N * ldw, 0, 0, 0, 0, 0, 0, 0, 1};
     return launch(g, p, cofi_s(stream));
 }
 
@@ -770,8 +884,11 @@ extern "C" int cofi_gemm_f32_layernorm(const float *A, int lda, const float *W, 
     Plan p = make_plan(M, N, K, true);
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
     const int bf16x3 = (relu & COFI_GEMM_BF16X3) ? 1 : 0;
-    relu &= ~COFI_GEMM_BF16X3;
-    GemmArgs g{A, W, C, bias, nullptr, (float *)ws, nullptr, gamma, beta, res, lda, ldw, ldc, ldr, M, N, K, 0, 1, 0, relu, eps, bf16x3, 0, 0, 0, 0, 0, 0, 0, 1};
+    const int wsplit = (relu & COFI_GEMM_W_SPLIT) ? 1 : 0;
+    relu &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_W_SPLIT);
+    if (wsplit && (!bf16x3 || (ldw & 7))) return COFI_EINVAL;
+    GemmArgs g{A, W, C, bias, nullptr, (float *)ws, nullptr, gamma, beta, res, lda, ldw, ldc, ldr, M, N, K, 0, 1, 0, relu, eps, bf16x3,
+               wsplit, (long)N * ldw, 0, 0, 0, 0, 0, 0, 0, 1};
     return launch(g, p, cofi_s(stream));
 }
 
@@ -784,13 +901,23 @@ extern "C" int cofi_conv2d_nhwc(const float *x, int ldx, int H, int W, int Cin, 
     if (frames <= 0) return COFI_EINVAL;
     const int M = Ho * Wo * frames, K = ks * ks * Cin;
     const int bf16x3 = (act & COFI_GEMM_BF16X3) ? 1 : 0;
-    act &= ~COFI_GEMM_BF16X3;
-    if (act < 0 || act > 2) return COFI_EINVAL;
+    const int wsplit = (act & COFI_GEMM_W_SPLIT) ? 1 : 0;
+    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_W_SPLIT);
+    if (act < 0 || act > 2 || (wsplit && !bf16x3)) return COFI_EINVAL;
+    const int ldw = wsplit ? (K + 7) / 8 * 8 : K;   // pre-split planes: rows padded to 8 values
     Plan p = make_plan(M, Cout, K, false);
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * Cout * sizeof(float))) return COFI_EWORKSPACE;
-    GemmArgs g{x, Wt, y, bias, nullptr, (float *)ws, colpart, nullptr, nullptr, res, ldx, K, ldy, ldr, M, Cout, K, act, 1, 0, 0, 0.f, bf16x3,
-               ks, H, W, Cin, Wo, stride, pad, Ho * Wo};
+    GemmArgs g{x, Wt, y, bias, nullptr, (float *)ws, colpart, nullptr, nullptr, res, ldx, ldw, ldy, ldr, M, Cout, K, act, 1, 0, 0, 0.f, bf16x3,
+               wsplit, (long)Cout * ldw, ks, H, W, Cin, Wo, stride, pad, Ho * Wo};
     return launch(g, p, cofi_s(stream));
+}
+
+extern "C" int cofi_split_bf16_planes(const float *W, int ldw, int N, int K, void *planes, int ldp, cofi_stream_t stream) {
+    if (!W || !planes || N <= 0 || K <= 0 || ldw < K || ldp < K || (ldp & 7) || ((uintptr_t)planes & 15)) return COFI_EINVAL;
+    const size_t total = (size_t)N * (ldp >> 1);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, cofi_s(stream),
+                       W, ldw, N, K, (unsigned *)planes, ldp);
+    return cofi_launch_status();
 }
 
 // Tuning hook for tools/tune_gemm.py: force (bm, bn, ksplit) for subsequent plans; (0,0,0) restores the table + heuristic.

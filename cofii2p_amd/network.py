@@ -109,6 +109,15 @@ class CoFiI2P(nn.Module):
                 P["%s.%d.weight" % (head, i)] = w.reshape(w.shape[0], w.shape[1]).contiguous()
         # the last score GEMM has K = 64 -> fine (K % 4 == 0)
         self._layers = [transformer.pack_layer(sd, "transformer.layers.%d." % l) for l in range(N_LAYERS)]
+
+        def gemm_weight(k, v):  # every static GEMM operand: (N, K) fp32 matrices used as `w` of ops.gemm* / conv2d_nhwc
+            return (torch.is_tensor(v) and v.dim() == 2 and v.dtype == torch.float32 and v.shape[1] % 4 == 0
+                    and k.endswith(("weight", "weights", ".nhwc")))
+
+        for d in [P] + self._layers:   # split once into bf16 hi/lo planes (the bf16x3 kernels read those; fp32 mode reads .w)
+            for k in list(d):
+                if gemm_weight(k, d[k]):
+                    d[k] = ops.presplit(d[k])
         self._packed, self._packed_key = P, device
         return P
 

@@ -30,6 +30,44 @@ def _gemm_flag() -> int:
     return GEMM_BF16X3 if GEMM_MODE == "bf16x3" else 0
 
 
+GEMM_W_SPLIT = 0x200
+
+
+class SplitW:
+    """A static GEMM operand (weight) with its bf16 hi/lo planes, split ONCE (cofi_split_bf16_planes).  Accepted wherever a
+    weight matrix is: the bf16x3 kernels read the planes (no on-the-fly conversion of W), the exact-fp32 kernels read `.w`."""
+
+    def __init__(self, w: torch.Tensor):
+        lib = _lib.load()
+        _mat(w, "w")
+        self.w = w
+        self.shape, self.device, self.dtype = w.shape, w.device, w.dtype
+        N, K = w.shape
+        self.ldp = (K + 7) // 8 * 8
+        self.planes = torch.empty((2, N, self.ldp), dtype=torch.int16, device=w.device)
+        _lib.check(lib.cofi_split_bf16_planes(_p(w), _ld(w), N, K, _p(self.planes), self.ldp, _stream()), "cofi_split_bf16_planes")
+
+
+    def numel(self):
+        return self.w.numel()
+
+    def dim(self):
+        return 2
+
+
+def presplit(w):
+    return w if isinstance(w, SplitW) else SplitW(w)
+
+
+def _wargs(w):
+    """(pointer, leading dimension, extra flag) of a weight operand for the current GEMM mode."""
+    if isinstance(w, SplitW):
+        if GEMM_MODE == "bf16x3":
+            return _p(w.planes), w.ldp, GEMM_W_SPLIT
+        w = w.w
+    return _p(w), _ld(w), 0
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -137,7 +175,9 @@ def set_workspace_slot(slot: int):
 def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, bias=None, rowdiv=None, act: int = ACT_NONE):
     """out[m,n] = act( (a @ w.T)[m,n] / rowdiv[m] + bias[n] );  a (M,K), w (N,K)."""
     lib = _lib.load()
-    _mat(a, "a"), _mat(w, "w")
+    _mat(a, "a")
+    if not isinstance(w, SplitW):
+        _mat(w, "w")
     M, K = a.shape
     N = w.shape[0]
     if w.shape[1] != K:
@@ -148,7 +188,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, b
     _vec(bias, "bias", N), _vec(rowdiv, "rowdiv", M)
     nbytes = lib.cofi_gemm_f32_workspace(M, N, K)
     ws = _WS_GEMM.get(nbytes, a.device)
-    rc = lib.cofi_gemm_f32(_p(a), _ld(a), _p(w), _ld(w), _p(out), _ld(out), M, N, K, _p(bias), _p(rowdiv), act | _gemm_flag(), _p(ws),
+    wp, wld, wflag = _wargs(w)
+    rc = lib.cofi_gemm_f32(_p(a), _ld(a), wp, wld, _p(out), _ld(out), M, N, K, _p(bias), _p(rowdiv), act | _gemm_flag() | wflag, _p(ws),
                            0 if ws is None else ws.numel(), _stream())
     _lib.check(rc, "cofi_gemm_f32")
     return out
@@ -157,7 +198,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, b
 def gemm_colstats(a, w, out=None, bias=None, rowdiv=None, act: int = ACT_NONE):
     """gemm() that also returns the fused per-slab column statistics: (out, colpart (nslab,N,2))."""
     lib = _lib.load()
-    _mat(a, "a"), _mat(w, "w")
+    _mat(a, "a")
+    if not isinstance(w, SplitW):
+        _mat(w, "w")
     M, K = a.shape
     N = w.shape[0]
     if w.shape[1] != K:
@@ -169,7 +212,8 @@ def gemm_colstats(a, w, out=None, bias=None, rowdiv=None, act: int = ACT_NONE):
     nslab = lib.cofi_gemm_f32_stat_slabs(M, N, K)
     colpart = torch.empty((nslab, N, 2), dtype=torch.float32, device=a.device)
     ws = _WS_GEMM.get(lib.cofi_gemm_f32_workspace(M, N, K), a.device)
-    rc = lib.cofi_gemm_f32_colstats(_p(a), _ld(a), _p(w), _ld(w), _p(out), _ld(out), M, N, K, _p(bias), _p(rowdiv), act | _gemm_flag(), _p(colpart),
+    wp, wld, wflag = _wargs(w)
+    rc = lib.cofi_gemm_f32_colstats(_p(a), _ld(a), wp, wld, _p(out), _ld(out), M, N, K, _p(bias), _p(rowdiv), act | _gemm_flag() | wflag, _p(colpart),
                                     _p(ws), 0 if ws is None else ws.numel(), _stream())
     _lib.check(rc, "cofi_gemm_f32_colstats")
     return out, colpart
@@ -188,15 +232,18 @@ def colstats_frames_ok(M_total: int, N: int, K: int, frames: int) -> bool:
 def gemm_layernorm(a, w, gamma, beta, bias=None, relu: bool = False, res=None, out=None, eps: float = 1e-5):
     """out = relu?(LayerNorm(a @ w.T + bias) * gamma + beta) + res, one kernel (N <= 128)."""
     lib = _lib.load()
-    _mat(a, "a"), _mat(w, "w")
+    _mat(a, "a")
+    if not isinstance(w, SplitW):
+        _mat(w, "w")
     M, K = a.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     _mat(out, "out")
     ws = _WS_GEMM.get(lib.cofi_gemm_f32_workspace(M, N, K), a.device)
-    rc = lib.cofi_gemm_f32_layernorm(_p(a), _ld(a), _p(w), _ld(w), _p(out), _ld(out), M, N, K, _p(bias), _p(gamma), _p(beta), eps,
-                                     int(relu) | _gemm_flag(), _p(res), 0 if res is None else _ld(res), _p(ws), 0 if ws is None else ws.numel(),
+    wp, wld, wflag = _wargs(w)
+    rc = lib.cofi_gemm_f32_layernorm(_p(a), _ld(a), wp, wld, _p(out), _ld(out), M, N, K, _p(bias), _p(gamma), _p(beta), eps,
+                                     int(relu) | _gemm_flag() | wflag, _p(res), 0 if res is None else _ld(res), _p(ws), 0 if ws is None else ws.numel(),
                                      _stream())
     _lib.check(rc, "cofi_gemm_f32_layernorm")
     return out
@@ -386,7 +433,9 @@ def conv2d_nhwc(x, H: int, W: int, w, ks: int, stride: int = 1, pad: int = 1, bi
     """Implicit-GEMM convolution on an NHWC map x (H*W, Cin) [row-major view, any leading dimension];
     w (Cout, ks*ks*Cin).  -> y (Ho*Wo, Cout) [, colpart]."""
     lib = _lib.load()
-    _mat(x, "x"), _mat(w, "w")
+    _mat(x, "x")
+    if not isinstance(w, SplitW):
+        _mat(w, "w")
     Cin, Cout = x.shape[1], w.shape[0]
     if x.shape[0] != frames * H * W or w.shape[1] != ks * ks * Cin:
         raise _lib.CofiError("conv2d_nhwc: shape mismatch x %s w %s H %d W %d ks %d" % (tuple(x.shape), tuple(w.shape), H, W, ks))
@@ -398,8 +447,9 @@ def conv2d_nhwc(x, H: int, W: int, w, ks: int, stride: int = 1, pad: int = 1, bi
     if colstats:
         part = torch.empty((lib.cofi_gemm_f32_stat_slabs(M, Cout, K), Cout, 2), dtype=torch.float32, device=x.device)
     ws = _WS_GEMM.get(lib.cofi_gemm_f32_workspace(M, Cout, K), x.device)
-    rc = lib.cofi_conv2d_nhwc(_p(x), _ld(x), H, W, Cin, _p(w), Cout, ks, stride, pad, _p(bias), _p(res), 0 if res is None else _ld(res),
-                              act | _gemm_flag(), _p(out), _ld(out), _p(part), _p(ws), 0 if ws is None else ws.numel(), frames, _stream())
+    wp, _wld, wflag = _wargs(w)   # convolution weights are dense (Cout, K) / planes (2, Cout, roundup8(K))
+    rc = lib.cofi_conv2d_nhwc(_p(x), _ld(x), H, W, Cin, wp, Cout, ks, stride, pad, _p(bias), _p(res), 0 if res is None else _ld(res),
+                              act | _gemm_flag() | wflag, _p(out), _ld(out), _p(part), _p(ws), 0 if ws is None else ws.numel(), frames, _stream())
     _lib.check(rc, "cofi_conv2d_nhwc")
     return (out, part, Ho, Wo) if colstats else (out, Ho, Wo)
 

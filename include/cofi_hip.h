@@ -51,6 +51,10 @@ typedef void *cofi_stream_t;
  * (hi*hi + hi*lo + lo*hi, fp32 accumulate) on the bf16 matrix cores instead of the exact fp32 MFMA:
  * ~2^-16 relative error per product, 5.3x the MFMA rate. */
 #define COFI_GEMM_BF16X3 0x100
+/* with COFI_GEMM_BF16X3: W is PRE-SPLIT (cofi_split_bf16_planes): `W` points at the bf16 hi plane, N rows of `ldw` bf16
+ * (ldw % 8 == 0, rows zero-padded past K), immediately followed by the lo plane of the same shape.  Weights are static:
+ * splitting them once removes half of the on-the-fly conversion work of every launch. */
+#define COFI_GEMM_W_SPLIT 0x200
 
 int cofi_abi_version(void);
 /* name of the code object's target, "gfx950" */
@@ -116,6 +120,9 @@ int cofi_gather_rows(const float *x, int ldx, int N, int C, const int32_t *idx, 
 size_t cofi_gemm_f32_workspace(int M, int N, int K);
 int cofi_gemm_f32(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K, const float *bias,
                   const float *rowdiv, int act, void *ws, size_t ws_bytes, cofi_stream_t stream);
+/* Split a static fp32 operand W (N,K) ldw once into bf16 planes for COFI_GEMM_W_SPLIT: planes = (2, N, ldp) bf16,
+ * [hi = bf16(W) RNE | lo = bf16(W - hi)], ldp % 8 == 0, ldp >= K, rows zero-padded; 16-byte aligned. */
+int cofi_split_bf16_planes(const float *W, int ldw, int N, int K, void *planes, int ldp, cofi_stream_t stream);
 /* Tuning hook (tools/tune_gemm.py): force the tile / split-K plan of subsequent calls; (0,0,0) restores the
  * tuned table + heuristic.  Process-global; not used by the product path. */
 int cofi_gemm_debug_force_plan(int bm, int bn, int ksplit);

@@ -283,10 +283,15 @@ def test_gemm_bf16x3_split(ops, M, N, K, monkeypatch):
     w = torch.randn(N, K, generator=g) / K ** 0.5
     bias = torch.randn(N, generator=g)
     ref = a.double() @ w.double().t() + bias.double()
-    out = ops.gemm(G(a), G(w), bias=G(bias)).cpu().double()
+    out_g = ops.gemm(G(a), G(w), bias=G(bias))
+    out = out_g.cpu().double()
     scale = (a.double().abs() @ w.double().abs().t())  # sum of |products|: the natural error scale
     rel = ((out - ref).abs() / scale).max()
     assert rel < 3e-5, float(rel)
+    # weights split once into bf16 planes: same rounding as the on-the-fly split -> bit-identical result
+    if K % 4 == 0:
+        out_s = ops.gemm(G(a), ops.presplit(G(w)), bias=G(bias))
+        assert torch.equal(out_s, out_g)
     y, part = ops.gemm_colstats(G(a), G(w), bias=G(bias))
     st = ops.group_stats_from_colpart(part, M, N).cpu()  # one group per column
     assert float((st[:, 0].double() - ref.mean(0)).abs().max()) < 1e-4
