@@ -28,8 +28,10 @@ struct AttnArgs {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-constexpr int NW = 8;  // waves per workgroup = key splits
-
+// NW = waves per workgroup = key splits.  8 when the grid is small (one frame: 160 workgroups - the split is what fills the
+// chip); fewer when frames are stacked: every wave then runs a longer key loop and the fixed per-workgroup cost (Q load,
+// first K/V round trip, LDS merge) is paid less often.
+template <int NW>
 __global__ __launch_bounds__(64 * NW) void attention_fwd_kernel(AttnArgs a) {
     constexpr int D = 32;
     __shared__ __attribute__((aligned(16))) float s_o[NW][32][D + 4];
@@ -169,8 +171,8 @@ __global__ __launch_bounds__(64 * NW) void attention_fwd_kernel(AttnArgs a) {
         *reinterpret_cast<float4 *>(&s_o[wave][li][d0]) = make_float4(o[4 * rq], o[4 * rq + 1], o[4 * rq + 2], o[4 * rq + 3]);
     }
     __syncthreads();
-    if (threadIdx.x < 256) {
-        const int q = threadIdx.x >> 3, d4 = (threadIdx.x & 7) * 4;
+    for (int e = threadIdx.x; e < 256; e += 64 * NW) {   // 32 queries x 8 float4 columns
+        const int q = e >> 3, d4 = (e & 7) * 4;
         float mm = s_m[0][q];
 #pragma unroll
         for (int w = 1; w < NW; ++w) mm = fmaxf(mm, s_m[w][q]);
@@ -207,6 +209,14 @@ extern "C" int cofi_attention_fwd(const float *Q, int ldq, const float *K, int l
         return COFI_EINVAL;
     AttnArgs a{Q, K, V, q_colscale, O, ldq, ldk, ldv, ldo, L, S, H, scale * 1.4426950408889634f};
     if (frames <= 0) return COFI_EINVAL;
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3(cofi_cdiv(L, 32), H, frames), dim3(64 * NW), 0, cofi_s(stream), a);
+    // >= ~8 waves per CU (2048 in all) with the fewest key splits
+    const long wgs = (long)cofi_cdiv(L, 32) * H * frames;
+    const dim3 grid(cofi_cdiv(L, 32), H, frames);
+    if (wgs * 2 >= 2048 && S >= 64 * 2)
+        hipLaunchKernelGGL(attention_fwd_kernel<2>, grid, dim3(128), 0, cofi_s(stream), a);
+    else if (wgs * 4 >= 2048 && S >= 64 * 4)
+        hipLaunchKernelGGL(attention_fwd_kernel<4>, grid, dim3(256), 0, cofi_s(stream), a);
+    else
+        hipLaunchKernelGGL(attention_fwd_kernel<8>, grid, dim3(512), 0, cofi_s(stream), a);
     return cofi_launch_status();
 }

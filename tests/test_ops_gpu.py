@@ -184,6 +184,19 @@ def test_attention_random(ops, L, S):
     close(ops.attention(G(q), G(k), G(v), q_colscale=G(cs)), ref, 5e-5)
 
 
+@pytest.mark.parametrize("frames,L,S", [(4, 1280, 1280), (8, 1280, 1280), (16, 320, 200)])
+def test_attention_stacked_frames(ops, frames, L, S):
+    """stack mode: frame f attends only to its own keys; large grids run with 4 / 2 key splits per workgroup"""
+    g = torch.Generator().manual_seed(frames * 7 + L)
+    q, k, v = torch.randn(frames * L, 128, generator=g), torch.randn(frames * S, 128, generator=g) * 2, torch.randn(frames * S, 128, generator=g)
+    cs = torch.rand(frames, 128, generator=g) + 0.5
+    out = ops.attention(G(q), G(k), G(v), q_colscale=G(cs), frames=frames).cpu()
+    for f in (0, frames // 2, frames - 1):
+        ref = O.full_attention((q[f * L:(f + 1) * L] * cs[f]).view(L, 4, 32), k[f * S:(f + 1) * S].view(S, 4, 32),
+                               v[f * S:(f + 1) * S].view(S, 4, 32)).reshape(L, 128)
+        close(out[f * L:(f + 1) * L], ref, 5e-5)
+
+
 def test_attention_forced_rescale(ops):
     """a key block arriving late with a much larger score forces the online-softmax rescale branch"""
     L, S = 64, 256
