@@ -13,8 +13,10 @@ namespace {
 constexpr int GS_ROWS = 64;
 
 __global__ __launch_bounds__(256) void group_stats_partial_kernel(const float *x, int ldx, int M, int C, int groups, double *part) {
-    // grid: x = row slab of GS_ROWS rows, y = 64-column tile (cpg < 64) or group (cpg >= 64)
+    // grid: x = row slab of GS_ROWS rows, y = 64-column tile (cpg < 64) or group (cpg >= 64), z = frame (M = rows per frame)
     const int cpg = C / groups;
+    x += (size_t)blockIdx.z * M * ldx;
+    part += (size_t)blockIdx.z * gridDim.x * groups * 2;
     const int r0 = blockIdx.x * GS_ROWS, r1 = min(M, r0 + GS_ROWS);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ double red[4][64][2];
@@ -68,6 +70,8 @@ __global__ __launch_bounds__(256) void group_stats_final_kernel(const double *pa
                                                                 float *stats) {
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= groups) return;
+    part += (size_t)blockIdx.y * nblk * groups * 2;   // grid.y = frame
+    stats += (size_t)blockIdx.y * groups * 2;
     const int lane = threadIdx.x & 63;
     double s = 0.0, q = 0.0;
     for (int b = lane; b < nblk; b += 64) {
@@ -381,23 +385,23 @@ extern "C" int cofi_col_inv_norm_from_colpart(const float *colpart, int nslab, i
     return cofi_launch_status();
 }
 
-extern "C" size_t cofi_group_stats_workspace(int M, int C, int groups) {
-    if (M <= 0 || groups <= 0) return 0;
-    return (size_t)cofi_cdiv(M, GS_ROWS) * groups * 2 * sizeof(double);
+extern "C" size_t cofi_group_stats_workspace(int M, int C, int groups, int frames) {
+    if (M <= 0 || groups <= 0 || frames <= 0 || (M % frames)) return 0;
+    return (size_t)cofi_cdiv(M / frames, GS_ROWS) * frames * groups * 2 * sizeof(double);
 }
 
 extern "C" int cofi_group_stats(const float *x, int ldx, int M, int C, int groups, float eps, float *stats, void *ws,
-                                size_t ws_bytes, cofi_stream_t stream) {
-    if (!x || !stats || M <= 0 || C <= 0 || groups <= 0 || (C % groups) || ldx < C) return COFI_EINVAL;
+                                size_t ws_bytes, int frames, cofi_stream_t stream) {
+    if (!x || !stats || M <= 0 || C <= 0 || groups <= 0 || (C % groups) || ldx < C || frames <= 0 || (M % frames)) return COFI_EINVAL;
     const int cpg = C / groups;
     if (cpg < 64 && (cpg & (cpg - 1))) return COFI_EUNSUPPORTED;  // power-of-two group width below one wave
-    if (!ws || ws_bytes < cofi_group_stats_workspace(M, C, groups)) return COFI_EWORKSPACE;
-    const int nblk = cofi_cdiv(M, GS_ROWS);
+    if (!ws || ws_bytes < cofi_group_stats_workspace(M, C, groups, frames)) return COFI_EWORKSPACE;
+    const int Mf = M / frames, nblk = cofi_cdiv(Mf, GS_ROWS);
     hipStream_t s = cofi_s(stream);
-    hipLaunchKernelGGL(group_stats_partial_kernel, dim3(nblk, cpg < 64 ? cofi_cdiv(C, 64) : groups), dim3(256), 0, s, x, ldx, M, C,
+    hipLaunchKernelGGL(group_stats_partial_kernel, dim3(nblk, cpg < 64 ? cofi_cdiv(C, 64) : groups, frames), dim3(256), 0, s, x, ldx, Mf, C,
                        groups, (double *)ws);
-    hipLaunchKernelGGL(group_stats_final_kernel, dim3(cofi_cdiv(groups, 4)), dim3(256), 0, s, (const double *)ws, nblk, groups,
-                       (double)M * cpg, eps, stats);
+    hipLaunchKernelGGL(group_stats_final_kernel, dim3(cofi_cdiv(groups, 4), frames), dim3(256), 0, s, (const double *)ws, nblk, groups,
+                       (double)Mf * cpg, eps, stats);
     return cofi_launch_status();
 }
 

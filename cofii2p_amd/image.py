@@ -98,17 +98,11 @@ def _in_relu(y, part, res=None, res_part=None, frames: int = 1):
     """relu(InstanceNorm(y) + [res | InstanceNorm(res)]) on (P, C) maps: one group per channel (per frame)."""
     P, C = y.shape
     if not _slabs_ok(y, part, frames) or (res_part is not None and not _slabs_ok(res, res_part, frames)):
-        # tiny maps whose pixel count is not a multiple of the statistics slab (5x16 map of layer4): per-frame statistics the
-        # plain way, one frame at a time
-        Pf = P // frames
-        outs = []
-        for f in range(frames):
-            yf = y[f * Pf:(f + 1) * Pf]
-            st = ops.group_stats(yf, C)
-            rf = None if res is None else res[f * Pf:(f + 1) * Pf]
-            rst = None if res_part is None else ops.group_stats(rf, C)
-            outs.append(ops.group_norm_apply(yf, st, slope=0.0, res=rf, res_stats=rst))
-        return torch.cat(outs, 0)
+        # tiny maps whose pixel count is not a multiple of the statistics slab (5x16 map of layer4): per-frame statistics by a
+        # separate pass over the map (still one launch for all frames)
+        st = ops.group_stats(y, C, frames=frames)
+        rst = None if res_part is None else ops.group_stats(res, C, frames=frames)
+        return ops.group_norm_apply(y, st, slope=0.0, res=res, res_stats=rst, frames=frames)
     st = ops.group_stats_from_colpart(part, P, C, frames=frames)
     rst = None if res_part is None else ops.group_stats_from_colpart(res_part, P, C, frames=frames)
     return ops.group_norm_apply(y, st, slope=0.0, res=res, res_stats=rst, frames=frames)

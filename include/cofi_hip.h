@@ -147,7 +147,7 @@ int cofi_gemm_f32_layernorm(const float *A, int lda, const float *W, int ldw, fl
  * channels, eps 1e-5, biased variance) and, with groups == C and gamma == NULL, the
  * InstanceNorm1d/2d of the score heads (model/network.py:42-43).
  * cofi_group_stats writes stats (groups,2) = {mean, rstd}; deterministic two-level reduction,
- * combined in fp64.  ws: cofi_group_stats_workspace(M, C, groups) bytes.
+ * combined in fp64.  ws: cofi_group_stats_workspace(M, C, groups, frames) bytes.
  * cofi_group_norm_apply:
  *   y = leaky( gn(x; stats, gamma, beta) + R , slope )   with
  *   R = 0                              if res == NULL
@@ -159,9 +159,9 @@ int cofi_group_stats_from_colpart(const float *colpart, int nslab, int M, int C,
                                   cofi_stream_t stream);
 int cofi_col_inv_norm_from_colpart(const float *colpart, int nslab, int ncols, int C, float eps, float *out, int frames,
                                    cofi_stream_t stream);
-size_t cofi_group_stats_workspace(int M, int C, int groups);
-int cofi_group_stats(const float *x, int ldx, int M, int C, int groups, float eps, float *stats, void *ws, size_t ws_bytes,
-                     cofi_stream_t stream);
+size_t cofi_group_stats_workspace(int M, int C, int groups, int frames);
+int cofi_group_stats(const float *x, int ldx, int M, int C, int groups, float eps, float *stats /* (frames, groups, 2) */, void *ws,
+                     size_t ws_bytes, int frames /* stack mode: M = frames * rows-per-frame, statistics per frame */, cofi_stream_t stream);
 int cofi_group_norm_apply(const float *x, int ldx, int M, int C, int groups, const float *stats, const float *gamma,
                           const float *beta, const float *res, int ldr, const float *res_stats, const float *res_gamma,
                           const float *res_beta, float slope, float *y, int ldy, int frames, cofi_stream_t stream);

@@ -24,7 +24,8 @@ def test_library_exports_every_declared_symbol():
     # pure host-side queries are callable without a GPU
     assert lib.cofi_gemm_f32_workspace(1280, 512, 7680) > 0
     assert lib.cofi_gemm_f32_workspace(20480, 128, 64) == 0
-    assert lib.cofi_group_stats_workspace(1280, 2048, 32) == 20 * 32 * 2 * 8
+    assert lib.cofi_group_stats_workspace(1280, 2048, 32, 1) == 20 * 32 * 2 * 8
+    assert lib.cofi_group_stats_workspace(1280, 2048, 32, 16) == 2 * 16 * 32 * 2 * 8  # 16 frames of 80 rows: 2 slabs each
 
 
 def test_code_object_targets_gfx950_only():

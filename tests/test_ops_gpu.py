@@ -153,6 +153,19 @@ def test_group_norm(ops, M, C, groups):
         close(ops.group_norm(G(x), groups, slope=0.0), torch.relu((x - mean) * torch.rsqrt(var + 1e-5)), 2e-5)
 
 
+@pytest.mark.parametrize("frames,Mf,C,groups", [(16, 80, 512, 512), (3, 77, 64, 32), (5, 200, 256, 32)])
+def test_group_stats_stacked_frames(ops, frames, Mf, C, groups):
+    """stack mode with rows-per-frame that are NOT a multiple of any statistics slab (the 5x16 map of ResNet layer4)"""
+    g = torch.Generator().manual_seed(frames + Mf + C)
+    x = torch.randn(frames * Mf, C, generator=g) * 2 + 0.3
+    st = ops.group_stats(G(x), groups, frames=frames)
+    out = ops.group_norm_apply(G(x), st, slope=0.0, frames=frames).cpu()
+    for f in range(frames):
+        xf = x[f * Mf:(f + 1) * Mf]
+        ref = torch.relu(O.group_norm_rows(xf, torch.ones(C), torch.zeros(C), groups))
+        close(out[f * Mf:(f + 1) * Mf], ref, 2e-5)
+
+
 def test_group_norm_golden(ops, mg):
     close(ops.group_norm(G(mg["gn_x"]), 32, G(mg["gn_w"]), G(mg["gn_b"])), mg["gn_out"], 2e-5)
     y = ops.gemm(G(mg["un_x"]), G(mg["un_w"]), bias=G(mg["un_b"]))
