@@ -165,14 +165,26 @@ __global__ __launch_bounds__(256) void nearest_kernel(const float *nodes, int S,
     const float qx = points[3 * row], qy = points[3 * row + 1], qz = points[3 * row + 2];
     const float qq = canon_sqnorm(qx, qy, qz);
     u64 best = KEY_INF;
-    for (int c = lane; c < S; c += 64) {
-        float4 sp;
-        sp.x = nodes[3 * (size_t)c];
-        sp.y = nodes[3 * (size_t)c + 1];
-        sp.z = nodes[3 * (size_t)c + 2];
-        sp.w = canon_sqnorm(sp.x, sp.y, sp.z);
-        const float d = canon_dist(qx, qy, qz, qq, sp);
-        best = umin64(best, ((u64)__float_as_uint(d) << 32) | (unsigned)c);
+    // 4 candidates per lane and round, all 12 loads issued before the first distance: the scan is bound by the L2 round trip
+    // per round, not by arithmetic.  The (distance, index) key makes the result independent of the visiting order.
+    for (int c0 = lane; c0 < S; c0 += 256) {
+        float px[4], py[4], pz[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = min(c0 + 64 * u, S - 1);
+            px[u] = nodes[3 * (size_t)c];
+            py[u] = nodes[3 * (size_t)c + 1];
+            pz[u] = nodes[3 * (size_t)c + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + 64 * u;
+            float4 sp;
+            sp.x = px[u]; sp.y = py[u]; sp.z = pz[u];
+            sp.w = canon_sqnorm(sp.x, sp.y, sp.z);
+            const float d = canon_dist(qx, qy, qz, qq, sp);
+            if (c < S) best = umin64(best, ((u64)__float_as_uint(d) << 32) | (unsigned)c);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) best = umin64(best, shfl_xor_u64(best, o));

@@ -108,8 +108,27 @@ def _in_relu(y, part, res=None, res_part=None, frames: int = 1):
     return ops.group_norm_apply(y, st, slope=0.0, res=res, res_stats=rst, frames=frames)
 
 
-def resnet34_nhwc(P, img: torch.Tensor, full: bool = True):
-    """imagenet.py:196-217 on NHWC maps.  img (1,3,H,W).  Returns ([s2, s4, s8, s16, s32, gap], [(H,W) per map])."""
+def _resnet_layer_nhwc(P, li: int, blocks: int, stride: int, x, H: int, W: int, frames: int):
+    p = "img_encoder.backbone."
+    for b in range(blocks):
+        q = "%slayer%d.%d." % (p, li, b)
+        st = stride if b == 0 else 1
+        y1, part1, Ho, Wo = ops.conv2d_nhwc(x, H, W, P[q + "conv1.weight.nhwc"], 3, st, 1, colstats=True, frames=frames)
+        a = _in_relu(y1, part1, frames=frames)
+        y2, part2, _, _ = ops.conv2d_nhwc(a, Ho, Wo, P[q + "conv2.weight.nhwc"], 3, 1, 1, colstats=True, frames=frames)
+        if (q + "downsample.0.weight.nhwc") in P:
+            d, partd, _, _ = ops.conv2d_nhwc(x, H, W, P[q + "downsample.0.weight.nhwc"], 1, st, 0, colstats=True, frames=frames)
+            x = _in_relu(y2, part2, res=d, res_part=partd, frames=frames)
+        else:
+            x = _in_relu(y2, part2, res=x, frames=frames)
+        H, W = Ho, Wo
+    return x, H, W
+
+
+def resnet34_nhwc(P, img: torch.Tensor, full: bool = True, tail_branch=None):
+    """imagenet.py:196-217 on NHWC maps.  img (frames,3,H,W).  Returns ([s2, s4, s8, s16, s32, gap], [(H,W) per map]).
+    layer3, layer4 and the average pool feed nothing downstream (network.py:87-89 only names them): when the caller hands
+    in a `tail_branch` (ops.Branch) they are enqueued on its side stream and the caller joins it whenever it likes."""
     p = "img_encoder.backbone."
     frames = img.shape[0]
     col, H, W = ops.im2col_stem(img.contiguous())
@@ -117,27 +136,26 @@ def resnet34_nhwc(P, img: torch.Tensor, full: bool = True):
     x = _in_relu(y, part, frames=frames)
     outs, dims = [x], [(H, W)]
     x, H, W = ops.maxpool3x3s2_nhwc(x, H, W, frames)
-    for li, (planes, blocks, stride) in enumerate(RESNET_LAYERS, start=1):
-        if not full and li > 2:
-            outs.append(None)
-            dims.append(None)
-            continue
-        for b in range(blocks):
-            q = "%slayer%d.%d." % (p, li, b)
-            st = stride if b == 0 else 1
-            y1, part1, Ho, Wo = ops.conv2d_nhwc(x, H, W, P[q + "conv1.weight.nhwc"], 3, st, 1, colstats=True, frames=frames)
-            a = _in_relu(y1, part1, frames=frames)
-            y2, part2, _, _ = ops.conv2d_nhwc(a, Ho, Wo, P[q + "conv2.weight.nhwc"], 3, 1, 1, colstats=True, frames=frames)
-            if (q + "downsample.0.weight.nhwc") in P:
-                d, partd, _, _ = ops.conv2d_nhwc(x, H, W, P[q + "downsample.0.weight.nhwc"], 1, st, 0, colstats=True, frames=frames)
-                x = _in_relu(y2, part2, res=d, res_part=partd, frames=frames)
-            else:
-                x = _in_relu(y2, part2, res=x, frames=frames)
-            H, W = Ho, Wo
+    for li, (planes, blocks, stride) in enumerate(RESNET_LAYERS[:2], start=1):
+        x, H, W = _resnet_layer_nhwc(P, li, blocks, stride, x, H, W, frames)
         outs.append(x)
         dims.append((H, W))
-    outs.append(x.reshape(frames, -1, x.shape[1]).mean(1) if full else None)  # AdaptiveAvgPool2d(1): unused downstream (network.py:87)
-    dims.append((1, 1))
+    if not full:
+        return outs + [None, None, None], dims + [None, None, (1, 1)]
+
+    def tail(x, H, W):
+        for li, (planes, blocks, stride) in enumerate(RESNET_LAYERS[2:], start=3):
+            x, H, W = _resnet_layer_nhwc(P, li, blocks, stride, x, H, W, frames)
+            outs.append(x)
+            dims.append((H, W))
+        outs.append(x.reshape(frames, -1, x.shape[1]).mean(1))  # AdaptiveAvgPool2d(1): unused downstream (network.py:87)
+        dims.append((1, 1))
+
+    if tail_branch is not None:
+        with tail_branch:
+            tail(x, H, W)
+    else:
+        tail(x, H, W)
     return outs, dims
 
 

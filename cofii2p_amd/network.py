@@ -74,7 +74,8 @@ class CoFiI2P(nn.Module):
         self._graphs = {}
         import os
 
-        # intra-frame fork/join slots captured by forward_async (bit 0 image branch, 1 residual shortcuts, 2 attention streams)
+        # intra-frame fork/join slots captured by forward_async (bit 0 image branch, 1 residual shortcuts, 2 attention streams,
+        # 3 the ResNet tail nothing reads)
         self.async_branch_mask = int(os.environ.get("COFI_ASYNC_BRANCH_MASK", "0"))
         self.image_backend = os.environ.get("COFI_IMAGE", "nhwc")  # "nhwc": implicit-GEMM HIP convolutions; "miopen": A/B only
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
@@ -166,12 +167,13 @@ class CoFiI2P(nn.Module):
         nhwc = self.image_backend == "nhwc"
         if B != 1 and not nhwc:
             raise ValueError("stack mode needs the NHWC image backend")
+        br_dead = ops.Branch(dev, 3)  # ResNet layer3/layer4/avg-pool: computed (reference parity), read by nothing downstream
         with ops.Branch(dev, 0) as br_img:
             gy, gx = torch.meshgrid(torch.arange(H8, device=dev, dtype=torch.int32), torch.arange(W8, device=dev, dtype=torch.int32),
                                     indexing="ij")
             grid = torch.stack([gy, gx], -1).reshape(T_img, 2).repeat(B, 1).contiguous()
             if nhwc:
-                img_set, dims = image.resnet34_nhwc(P, img, full=self.compute_unused_image_maps)
+                img_set, dims = image.resnet34_nhwc(P, img, full=self.compute_unused_image_maps, tail_branch=br_dead)
                 s2, s4, s8 = img_set[0], img_set[1], img_set[2]  # (B*H*W, C) pixel-major
                 s8n = ops.l2norm_rows(s8)  # the normalised s8 map also feeds the up-sampler (network.py:90,129)
                 ops.l2norm_rows(s8, out=ts.img[0][:, :D_MODEL])
@@ -245,6 +247,7 @@ class CoFiI2P(nn.Module):
                 o["fine_xy"], o["fine_best"] = ops.fine_match(o["patches"], o["fine_pc"], xy, cnt, 4.0)  # eval_all.py:99-105
                 o.update(sel=sel, coarse_xy=xy, count=cnt)
             outs.append(o)
+        br_dead.join()
         return outs
 
     # ------------------------------------------------------------------ hipGraph replay

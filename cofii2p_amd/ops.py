@@ -130,7 +130,8 @@ class Branch:
     _pool = {}
 
     def __init__(self, device, slot: int = 0, enabled: bool = True):
-        # BRANCH_MASK bit i enables fork/join slot i (0: image branch, 1: residual shortcut, 2: self-attention streams)
+        # BRANCH_MASK bit i enables fork/join slot i (0: image branch, 1: residual shortcut, 2: self-attention streams,
+        # 3: ResNet layer3/4 tail that nothing downstream reads)
         self.enabled = enabled and bool((BRANCH_MASK >> slot) & 1)
         enabled = self.enabled
         self.device = device
