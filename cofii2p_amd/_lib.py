@@ -39,7 +39,8 @@ SIGNATURES = {
     "cofi_col_inv_norm_from_colpart": (_I, [_P, _I, _I, _I, _F, _P, _I, _P]),
     "cofi_group_stats_workspace": (_Z, [_I, _I, _I, _I]),
     "cofi_group_stats": (_I, [_P, _I, _I, _I, _I, _F, _P, _P, _Z, _I, _P]),
-    "cofi_group_norm_apply": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _F, _P, _I, _I, _P]),
+    "cofi_group_norm_apply": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _F, _P, _I, _P, _I, _P]),
+    "cofi_group_norm_apply_colpart": (_I, [_P, _I, _I, _I, _I, _P, _I, _F, _P, _P, _P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _I, _P]),
     "cofi_layer_norm": (_I, [_P, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _I, _P]),
     "cofi_loftr_tail_bf16x3": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
     "cofi_attention_workspace": (_Z, [_I, _I, _I, _I]),

@@ -152,6 +152,7 @@ struct GnApplyArgs {
     int ldx, ldr, ldy, M, C, cpg;   // M = rows PER FRAME; grid.y = frame
     float slope;
     int groups;
+    uint8_t *row_pos;   // optional: row_pos[m] = (sum_c y[m,c] > 0) (kpconv.py:113-114 for the next KPConv); needs C <= 256
 };
 
 // Thread = one float4 column chunk (its 4 channels' scale/shift are folded once: y = x*sc + sh), looping over a
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(256) void group_norm_apply_kernel(GnApplyArgs a) {
         a.stats += f * a.groups * 2;
         if (a.res) a.res += f * a.M * a.ldr;
         if (a.res_stats) a.res_stats += f * a.groups * 2;
+        if (a.row_pos) a.row_pos += f * a.M;
     }
     for (int cb = tc; cb < c4n; cb += tpr) {
         const int c = cb * 4;
@@ -201,6 +203,132 @@ __global__ __launch_bounds__(256) void group_norm_apply_kernel(GnApplyArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = v[i] >= 0.f ? v[i] : v[i] * a.slope;
             *reinterpret_cast<float4 *>(a.y + (size_t)m * a.ldy + c) = make_float4(v[0], v[1], v[2], v[3]);
+            if (a.row_pos) {   // host guarantees tpr <= 64 and one column pass: the tpr lanes of a row are adjacent lanes of one wave
+                float rs = (v[0] + v[1]) + (v[2] + v[3]);
+                for (int o = 1; o < tpr; o <<= 1) rs += __shfl_xor(rs, o, 64);
+                if (tc == 0) a.row_pos[m] = rs > 0.0f ? 1 : 0;
+            }
+        }
+    }
+}
+
+// Fused variant for SMALL statistics tables: the apply kernel folds the GEMM's column partials itself (every workgroup
+// repeats the same fixed-order fp64 fold, so all of them see identical statistics) instead of waiting for a separate
+// finalize launch - at one frame a dependent launch costs >= 1.5 us, more than folding a few thousand partials (one or two L2 round trips) per workgroup.
+// Optionally also emits row_pos[m] = (sum_c y[m,c] > 0), the per-row flag of the next KPConv (kpconv.py:113-114).
+struct GnFusedArgs {
+    GnApplyArgs a;
+    const float *colpart, *res_colpart;   // (frames * nslab, C, 2)
+    int nslab, res_nslab;                 // slabs per frame
+    float eps;
+};
+
+__device__ __forceinline__ void fold_colpart(const float *colpart, int nslab, int C, int groups, double count, float eps, double *dred,
+                                             float *sstat) {
+    // thread (ph, c): channel c, slabs ph, ph + PH, ...; then one thread per group folds phases and channels in a fixed order
+    const int cpg = C / groups;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int cw = min(C - c0, 256);          // channels of this pass (power-of-two C: cw divides 256 or equals it)
+        const int PH = 256 / cw;
+        const int c = c0 + threadIdx.x % cw, ph = threadIdx.x / cw;
+        double s = 0.0, q = 0.0;
+        if (ph < PH)
+            for (int b0 = ph; b0 < nslab; b0 += 8 * PH) {   // 8 independent loads per round (the fold is bound by L2 round trips)
+                float2 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int b = b0 + u * PH;
+                    t[u] = *reinterpret_cast<const float2 *>(colpart + ((size_t)(b < nslab ? b : ph) * C + c) * 2);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (b0 + u * PH < nslab) {
+                        s += (double)t[u].x;
+                        q += (double)t[u].y;
+                    }
+            }
+        __syncthreads();   // dred reuse between passes
+        if (ph < PH) {
+            dred[2 * threadIdx.x] = s;
+            dred[2 * threadIdx.x + 1] = q;
+        }
+        __syncthreads();
+        // groups fully inside this pass (cpg <= 256 always: groups >= C / 256 ... cpg divides cw)
+        const int g0 = c0 / cpg, ng = cw / cpg > 0 ? cw / cpg : 0;
+        for (int g = threadIdx.x; g < ng; g += 256) {
+            double ts = 0.0, tq = 0.0;
+            for (int p = 0; p < PH; ++p)
+                for (int i = 0; i < cpg; ++i) {
+                    const int t = p * cw + g * cpg + i;
+                    ts += dred[2 * t];
+                    tq += dred[2 * t + 1];
+                }
+            const double mean = ts / count;
+            double var = tq / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            sstat[2 * (g0 + g)] = (float)mean;
+            sstat[2 * (g0 + g) + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void group_norm_apply_fused_kernel(GnFusedArgs fa) {
+    GnApplyArgs a = fa.a;
+    __shared__ double dred[512];
+    __shared__ float sstat[2 * 1024], rstat[2 * 1024];
+    const int c4n = a.C >> 2;
+    const int tpr = c4n < 256 ? c4n : 256;
+    const int rpb = 256 / tpr;
+    const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    {   // frame blockIdx.y: its rows, its column partials
+        const size_t f = blockIdx.y;
+        a.x += f * a.M * a.ldx;
+        a.y += f * a.M * a.ldy;
+        if (a.res) a.res += f * a.M * a.ldr;
+        fa.colpart += f * fa.nslab * a.C * 2;
+        if (fa.res_colpart) fa.res_colpart += f * fa.res_nslab * a.C * 2;
+        if (a.row_pos) a.row_pos += f * a.M;
+    }
+    const double count = (double)a.M * a.cpg;
+    fold_colpart(fa.colpart, fa.nslab, a.C, a.groups, count, fa.eps, dred, sstat);
+    if (fa.res_colpart) fold_colpart(fa.res_colpart, fa.res_nslab, a.C, a.groups, count, fa.eps, dred, rstat);
+    for (int cb = tc; cb < c4n; cb += tpr) {
+        const int c = cb * 4;
+        float sc[4], sh[4], rsc[4], rsh[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = c + i, g = ch / a.cpg;
+            const float mean = sstat[2 * g], rstd = sstat[2 * g + 1];
+            const float ga = a.gamma ? a.gamma[ch] : 1.f, be = a.gamma ? a.beta[ch] : 0.f;
+            sc[i] = rstd * ga;
+            sh[i] = be - mean * rstd * ga;
+            rsc[i] = 1.f; rsh[i] = 0.f;
+            if (a.res && fa.res_colpart) {
+                const float rm = rstat[2 * g], rr = rstat[2 * g + 1];
+                const float rg = a.res_gamma ? a.res_gamma[ch] : 1.f, rb = a.res_gamma ? a.res_beta[ch] : 0.f;
+                rsc[i] = rr * rg;
+                rsh[i] = rb - rm * rr * rg;
+            }
+        }
+        for (int m = blockIdx.x * rpb + tr; m < a.M; m += gridDim.x * rpb) {
+            const float4 xv = *reinterpret_cast<const float4 *>(a.x + (size_t)m * a.ldx + c);
+            float v[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = v[i] * sc[i] + sh[i];
+            if (a.res) {
+                const float4 rv = *reinterpret_cast<const float4 *>(a.res + (size_t)m * a.ldr + c);
+                v[0] += rv.x * rsc[0] + rsh[0]; v[1] += rv.y * rsc[1] + rsh[1];
+                v[2] += rv.z * rsc[2] + rsh[2]; v[3] += rv.w * rsc[3] + rsh[3];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = v[i] >= 0.f ? v[i] : v[i] * a.slope;
+            *reinterpret_cast<float4 *>(a.y + (size_t)m * a.ldy + c) = make_float4(v[0], v[1], v[2], v[3]);
+            if (a.row_pos) {   // host guarantees tpr <= 64 and one column pass: the tpr lanes of a row are adjacent lanes of one wave
+                float rs = (v[0] + v[1]) + (v[2] + v[3]);
+                for (int o = 1; o < tpr; o <<= 1) rs += __shfl_xor(rs, o, 64);
+                if (tc == 0) a.row_pos[m] = rs > 0.0f ? 1 : 0;
+            }
         }
     }
 }
@@ -407,19 +535,41 @@ extern "C" int cofi_group_stats(const float *x, int ldx, int M, int C, int group
 
 extern "C" int cofi_group_norm_apply(const float *x, int ldx, int M, int C, int groups, const float *stats, const float *gamma,
                                      const float *beta, const float *res, int ldr, const float *res_stats,
-                                     const float *res_gamma, const float *res_beta, float slope, float *y, int ldy, int frames,
-                                     cofi_stream_t stream) {
+                                     const float *res_gamma, const float *res_beta, float slope, float *y, int ldy, uint8_t *row_pos,
+                                     int frames, cofi_stream_t stream) {
     if (!x || !stats || !y || M <= 0 || C <= 0 || groups <= 0 || (C % groups) || (C & 3) || (ldx & 3) || (ldy & 3)) return COFI_EINVAL;
     if ((gamma == nullptr) != (beta == nullptr) || (res_gamma == nullptr) != (res_beta == nullptr)) return COFI_EINVAL;
     if (res && (ldr & 3)) return COFI_EINVAL;
     if (frames <= 0 || (M % frames)) return COFI_EINVAL;
     const int Mf = M / frames;
-    GnApplyArgs a{x, stats, gamma, beta, res, res_stats, res_gamma, res_beta, y, ldx, ldr, ldy, Mf, C, C / groups, slope, groups};
+    GnApplyArgs a{x, stats, gamma, beta, res, res_stats, res_gamma, res_beta, y, ldx, ldr, ldy, Mf, C, C / groups, slope, groups, row_pos};
     const int c4n = C >> 2, tpr = c4n < 256 ? c4n : 256, rpb = 256 / tpr;
+    if (row_pos && (tpr > 64 || (64 % tpr))) return COFI_EUNSUPPORTED;
     int nb = cofi_cdiv(Mf, rpb * 4);  // ~4 rows per thread
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(group_norm_apply_kernel, dim3(nb, frames), dim3(256), 0, cofi_s(stream), a);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_group_norm_apply_colpart(const float *x, int ldx, int M, int C, int groups, const float *colpart, int nslab, float eps,
+                                             const float *gamma, const float *beta, const float *res, int ldr, const float *res_colpart,
+                                             int res_nslab, const float *res_gamma, const float *res_beta, float slope, float *y, int ldy,
+                                             uint8_t *row_pos, int frames, cofi_stream_t stream) {
+    if (!x || !colpart || !y || M <= 0 || C <= 0 || groups <= 0 || (C % groups) || (C & 3) || (ldx & 3) || (ldy & 3)) return COFI_EINVAL;
+    if ((gamma == nullptr) != (beta == nullptr) || (res_gamma == nullptr) != (res_beta == nullptr)) return COFI_EINVAL;
+    if (res && (ldr & 3)) return COFI_EINVAL;
+    if (frames <= 0 || (M % frames) || nslab <= 0 || (nslab % frames) || (res_colpart && (!res || res_nslab <= 0 || (res_nslab % frames)))) return COFI_EINVAL;
+    // in-kernel fold: power-of-two C <= 1024 (thread = channel), a bounded number of partials per workgroup
+    if ((C & (C - 1)) || C > 1024 || groups > 1024 || C / groups > 256) return COFI_EUNSUPPORTED;
+    const int Mf = M / frames, c4n = C >> 2, tpr = c4n < 256 ? c4n : 256, rpb = 256 / tpr;
+    if (row_pos && tpr > 64) return COFI_EUNSUPPORTED;
+    GnFusedArgs fa{{x, nullptr, gamma, beta, res, nullptr, res_gamma, res_beta, y, ldx, ldr, ldy, Mf, C, C / groups, slope, groups, row_pos},
+                   colpart, res_colpart, nslab / frames, res_colpart ? res_nslab / frames : 0, eps};
+    int nb = cofi_cdiv(Mf, rpb * 4);
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(group_norm_apply_fused_kernel, dim3(nb, frames), dim3(256), 0, cofi_s(stream), fa);
     return cofi_launch_status();
 }
 

@@ -103,8 +103,8 @@ def _in_relu(y, part, res=None, res_part=None, frames: int = 1):
         st = ops.group_stats(y, C, frames=frames)
         rst = None if res_part is None else ops.group_stats(res, C, frames=frames)
         return ops.group_norm_apply(y, st, slope=0.0, res=res, res_stats=rst, frames=frames)
-    st = ops.group_stats_from_colpart(part, P, C, frames=frames)
-    rst = None if res_part is None else ops.group_stats_from_colpart(res_part, P, C, frames=frames)
+    st = ops.ColStats(part, P, C, frames)
+    rst = None if res_part is None else ops.ColStats(res_part, P, C, frames)
     return ops.group_norm_apply(y, st, slope=0.0, res=res, res_stats=rst, frames=frames)
 
 

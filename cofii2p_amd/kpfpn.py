@@ -29,7 +29,7 @@ def _stats(y, part, frames: int):
     if frames > 1 and (part.shape[0] % frames or (y.shape[0] // frames) % (y.shape[0] // part.shape[0])):
         raise ops._lib.CofiError("stack mode needs per-frame row counts that are multiples of the statistics slab (%d rows, %d slabs, %d frames)"
                                  % (y.shape[0], part.shape[0], frames))
-    return ops.group_stats_from_colpart(part, y.shape[0], GN_GROUPS, frames=frames)
+    return ops.ColStats(part, y.shape[0], GN_GROUPS, frames)
 
 
 def _kpconv(P, p: str, feats, q_pts, s_pts, idx, sigma: float, frames: int = 1, order=None):
@@ -45,9 +45,10 @@ def _unary_raw(P, p: str, x, frames: int = 1):
     return y, _stats(y, part, frames)
 
 
-def _unary(P, p: str, x, slope: float, out=None, frames: int = 1):
+def _unary(P, p: str, x, slope: float, out=None, frames: int = 1, want_row_pos: bool = False):
     y, st = _unary_raw(P, p, x, frames)
-    return ops.group_norm_apply(y, st, P[p + "norm.norm.weight"], P[p + "norm.norm.bias"], slope=slope, out=out, frames=frames)
+    return ops.group_norm_apply(y, st, P[p + "norm.norm.weight"], P[p + "norm.norm.bias"], slope=slope, out=out, frames=frames,
+                                want_row_pos=want_row_pos)
 
 
 def run_block(P, blk: KPBlock, feats, q_pts, s_pts, idx, out=None, concurrent: bool = True, frames: int = 1, order=None):
@@ -63,11 +64,12 @@ def run_block(P, blk: KPBlock, feats, q_pts, s_pts, idx, out=None, concurrent: b
         ys = sts = None
         if blk.has_shortcut_unary:
             ys, sts = _unary_raw(P, p + "unary_shortcut.", sc, frames)
-    x = _unary(P, p + "unary1.", feats, LRELU, frames=frames) if blk.cin != blk.mid else feats
+    # unary1 feeds the KPConv: its apply kernel also emits the per-row flag the aggregation needs
+    x = _unary(P, p + "unary1.", feats, LRELU, frames=frames, want_row_pos=True) if blk.cin != blk.mid else feats
     y, st = _kpconv(P, p, x, q_pts, s_pts, idx, blk.sigma, frames, order)
     x = ops.group_norm_apply(y, st, P[p + "norm_conv.norm.weight"], P[p + "norm_conv.norm.bias"], slope=LRELU, frames=frames)
     y2, st2 = _unary_raw(P, p + "unary2.", x, frames)
-    br.join(sc, ys, sts)
+    br.join(sc, ys, None if sts is None else sts.part)
     g2, b2 = P[p + "unary2.norm.norm.weight"], P[p + "unary2.norm.norm.bias"]
     if blk.has_shortcut_unary:
         return ops.group_norm_apply(y2, st2, g2, b2, slope=LRELU, res=ys, res_stats=sts,

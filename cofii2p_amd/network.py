@@ -132,9 +132,9 @@ class CoFiI2P(nn.Module):
         per-column normalisation (group width 1), ReLU = slope 0."""
         T = tokens.shape[0]
         y, part = ops.gemm_colstats(tokens, P[head + ".0.weight"])
-        y = ops.group_norm_apply(y, ops.group_stats_from_colpart(part, T, y.shape[1], frames=frames), slope=0.0, frames=frames)
+        y = ops.group_norm_apply(y, ops.ColStats(part, T, y.shape[1], frames), slope=0.0, frames=frames)
         y, part = ops.gemm_colstats(y, P[head + ".3.weight"])
-        y = ops.group_norm_apply(y, ops.group_stats_from_colpart(part, T, y.shape[1], frames=frames), slope=0.0, frames=frames)
+        y = ops.group_norm_apply(y, ops.ColStats(part, T, y.shape[1], frames), slope=0.0, frames=frames)
         return ops.gemm(y, P[head + ".6.weight"], act=ops.ACT_SIGMOID)  # (T,1)
 
     def _pc_feature_mlp(self, P, x: torch.Tensor) -> torch.Tensor:

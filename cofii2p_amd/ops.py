@@ -290,6 +290,8 @@ def kpconv_aggregate(feats, q_pts, s_pts, idx, kernel_points, sigma: float, row_
     if s_pts.shape != (N, 3) or q_pts.shape != (M, 3) or kernel_points.shape != (15, 3) or N % frames or M % frames:
         raise _lib.CofiError("kpconv_aggregate: shape mismatch")
     if row_pos is None:
+        row_pos = getattr(feats, "cofi_row_pos", None)   # left there by the group_norm_apply that produced feats
+    if row_pos is None:
         row_pos = row_sum_positive(feats)
     agg = torch.empty((M, 15 * C), dtype=torch.float32, device=feats.device)
     cnt = torch.empty((M,), dtype=torch.float32, device=feats.device)
@@ -337,18 +339,55 @@ def group_stats(x, groups: int, eps: float = 1e-5, frames: int = 1):
     return stats
 
 
+class ColStats:
+    """GroupNorm / InstanceNorm statistics still in the form the GEMM epilogue left them: per-slab column partials
+    (nslab, C, 2) of an (M, C) activation.  `group_norm_apply` folds small tables inside its own kernel
+    (cofi_group_norm_apply_colpart); large ones are finalised by cofi_group_stats_from_colpart first."""
+    FUSE_MAX_PARTIALS = int(os.environ.get("COFI_GN_FUSE_MAX", "2048"))  # per frame: nslab * C partial pairs = 8 loads per thread, one L2 round trip
+
+    def __init__(self, part: torch.Tensor, M: int, groups: int, frames: int = 1, eps: float = 1e-5):
+        self.part, self.M, self.groups, self.frames, self.eps = part, M, groups, frames, eps
+
+    def fusable(self) -> bool:
+        nslab, C, _ = self.part.shape
+        return (C & (C - 1)) == 0 and C <= 1024 and C // self.groups <= 256 and (nslab // self.frames) * C <= self.FUSE_MAX_PARTIALS
+
+    def finalize(self) -> torch.Tensor:
+        return group_stats_from_colpart(self.part, self.M, self.groups, self.eps, self.frames)
+
+
 def group_norm_apply(x, stats, gamma=None, beta=None, slope: float = 1.0, res=None, res_stats=None, res_gamma=None, res_beta=None,
-                     out=None, frames: int = 1):
-    """stats (groups,2) or, in stack mode, (frames, groups, 2)."""
+                     out=None, frames: int = 1, want_row_pos: bool = False):
+    """stats: (groups,2) / stack mode (frames, groups, 2) tensor, or ColStats (column partials, folded in-kernel when small).
+    want_row_pos (activation at most 256 wide): the kernel also emits row_pos = (row sum > 0), attached to the result as
+    `out.cofi_row_pos` for the KPConv that consumes it (kpconv.py:113-114)."""
     lib = _lib.load()
     _mat(x, "x")
     M, C = x.shape
-    groups = stats.shape[-2]
     if out is None:
         out = torch.empty((M, C), dtype=torch.float32, device=x.device)
-    rc = lib.cofi_group_norm_apply(_p(x), _ld(x), M, C, groups, _p(stats), _p(gamma), _p(beta), _p(res), 0 if res is None else _ld(res),
-                                   _p(res_stats), _p(res_gamma), _p(res_beta), float(slope), _p(out), _ld(out), frames, _stream())
-    _lib.check(rc, "cofi_group_norm_apply")
+    c4n = C // 4
+    row_pos = torch.empty((M,), dtype=torch.uint8, device=x.device) if (want_row_pos and C % 4 == 0 and c4n <= 64 and 64 % c4n == 0) else None
+    fused = isinstance(stats, ColStats) and stats.fusable() and (res_stats is None or (isinstance(res_stats, ColStats) and res_stats.fusable()))
+    if fused:
+        rc = lib.cofi_group_norm_apply_colpart(_p(x), _ld(x), M, C, stats.groups, _p(stats.part), stats.part.shape[0], stats.eps, _p(gamma),
+                                               _p(beta), _p(res), 0 if res is None else _ld(res),
+                                               None if res_stats is None else _p(res_stats.part),
+                                               0 if res_stats is None else res_stats.part.shape[0], _p(res_gamma), _p(res_beta),
+                                               float(slope), _p(out), _ld(out), _p(row_pos), frames, _stream())
+        _lib.check(rc, "cofi_group_norm_apply_colpart")
+    else:
+        if isinstance(stats, ColStats):
+            stats = stats.finalize()
+        if isinstance(res_stats, ColStats):
+            res_stats = res_stats.finalize()
+        groups = stats.shape[-2]
+        rc = lib.cofi_group_norm_apply(_p(x), _ld(x), M, C, groups, _p(stats), _p(gamma), _p(beta), _p(res), 0 if res is None else _ld(res),
+                                       _p(res_stats), _p(res_gamma), _p(res_beta), float(slope), _p(out), _ld(out), _p(row_pos), frames,
+                                       _stream())
+        _lib.check(rc, "cofi_group_norm_apply")
+    if row_pos is not None:
+        out.cofi_row_pos = row_pos
     return out
 
 

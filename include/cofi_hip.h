@@ -164,7 +164,17 @@ int cofi_group_stats(const float *x, int ldx, int M, int C, int groups, float ep
                      size_t ws_bytes, int frames /* stack mode: M = frames * rows-per-frame, statistics per frame */, cofi_stream_t stream);
 int cofi_group_norm_apply(const float *x, int ldx, int M, int C, int groups, const float *stats, const float *gamma,
                           const float *beta, const float *res, int ldr, const float *res_stats, const float *res_gamma,
-                          const float *res_beta, float slope, float *y, int ldy, int frames, cofi_stream_t stream);
+                          const float *res_beta, float slope, float *y, int ldy,
+                          uint8_t *row_pos /* optional (M): row_pos[m] = (sum_c y[m,c] > 0), C <= 256 (kpconv.py:113-114) */, int frames, cofi_stream_t stream);
+
+/* cofi_group_norm_apply with the statistics folded in-kernel from the GEMM's column partials (colpart (nslab, C, 2),
+ * res_colpart for the shortcut's own GroupNorm): saves the separate cofi_group_stats_from_colpart launch when the table is
+ * small (every workgroup repeats the fixed-order fp64 fold).  C a power of two <= 1024.  row_pos (optional, M bytes):
+ * row_pos[m] = (sum_c y[m,c] > 0), the per-row flag cofi_kpconv_aggregate takes (kpconv.py:113-114); needs C <= 256. */
+int cofi_group_norm_apply_colpart(const float *x, int ldx, int M, int C, int groups, const float *colpart, int nslab, float eps,
+                                  const float *gamma, const float *beta, const float *res, int ldr, const float *res_colpart, int res_nslab,
+                                  const float *res_gamma, const float *res_beta, float slope, float *y, int ldy, uint8_t *row_pos,
+                                  int frames, cofi_stream_t stream);
 
 /* Row LayerNorm: y = act(LN(x) * gamma + beta) (+ res).  Replaces nn.LayerNorm at
  * model/transformer/transformer.py:40-41,58,62 and model/network.py:29.  C <= 2048, C % 4 == 0. */

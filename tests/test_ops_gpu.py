@@ -166,6 +166,35 @@ def test_group_stats_stacked_frames(ops, frames, Mf, C, groups):
         close(out[f * Mf:(f + 1) * Mf], ref, 2e-5)
 
 
+@pytest.mark.parametrize("frames,Mf,C,groups,K", [(1, 1280, 128, 32, 128), (1, 320, 256, 256, 64), (4, 640, 64, 32, 96), (2, 1280, 512, 32, 64),
+                                                  (1, 20480, 64, 32, 64)])
+def test_group_norm_apply_from_column_partials(ops, frames, Mf, C, groups, K):
+    """statistics folded inside the apply kernel (small tables) or by the finalize kernel (large): both equal the oracle's
+    GroupNorm of the GEMM output; row_pos = (row sum > 0) comes out of the same kernel"""
+    g = torch.Generator().manual_seed(frames * 131 + Mf + C)
+    a, w = torch.randn(frames * Mf, K, generator=g), torch.randn(C, K, generator=g) / K ** 0.5
+    r = torch.randn(frames * Mf, C, generator=g)
+    ga, be = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    y, part = ops.gemm_colstats(G(a), G(w))
+    yr, rpart = ops.gemm_colstats(G(r), G(torch.eye(C)))          # the residual with its own statistics
+    st, rst = ops.ColStats(part, frames * Mf, groups, frames), ops.ColStats(rpart, frames * Mf, groups, frames)
+    out = ops.group_norm_apply(y, st, G(ga), G(be), slope=0.1, res=yr, res_stats=rst, res_gamma=G(be), res_beta=G(ga), frames=frames,
+                               want_row_pos=True)
+    yc, outc = y.cpu(), out.cpu()
+    for f in range(frames):
+        sl = slice(f * Mf, (f + 1) * Mf)
+        ref = O.leaky(O.group_norm_rows(yc[sl], ga, be, groups) + O.group_norm_rows(r[sl], be, ga, groups))
+        close(outc[sl], ref, 3e-5)
+    if C <= 256:
+        rp = out.cofi_row_pos.cpu().bool()
+        s = outc.double().sum(1)
+        firm = s.abs() > 1e-4                                        # rows whose sum is not within rounding of zero
+        assert torch.equal(rp[firm], (s > 0)[firm])
+        assert torch.equal(out.cofi_row_pos, ops.row_sum_positive(out)) or (rp != ops.row_sum_positive(out).cpu().bool()).sum() <= 2
+    else:
+        assert not hasattr(out, "cofi_row_pos")
+
+
 def test_group_norm_golden(ops, mg):
     close(ops.group_norm(G(mg["gn_x"]), 32, G(mg["gn_w"]), G(mg["gn_b"])), mg["gn_out"], 2e-5)
     y = ops.gemm(G(mg["un_x"]), G(mg["un_w"]), bias=G(mg["un_b"]))
