@@ -10,7 +10,8 @@
 //   S^T[key, q] = K_blk . Q^T    16 MFMA, A = K straight from L2 (float4 per lane), B = Q registers
 //   online softmax, per lane = per query column (q = lane&31), 16 keys per lane, halves joined by
 //   one __shfl_xor(.., 32)
-//   O^T[d, q] += V_blk^T . P^T   16 MFMA, A = V[key, d = lane&31] (128-B coalesced rows), B = P
+//   O^T[d, q] += V_blk^T . P^T   16 MFMA, A = V[key, d = lane&31] (block fetched as 16-B loads, transposed through a
+//                                wave-private LDS tile), B = P
 // The MFMA D layout of S^T (lane (q,h) holds keys (r&3)+8(r>>2)+4h) is exactly the B-operand layout
 // the second chain needs once the contraction index is allowed to run in that (permuted) key order,
 // so P never moves between lanes and O^T keeps "one query per lane": the softmax rescale and the
@@ -36,6 +37,11 @@ __global__ __launch_bounds__(64 * NW) void attention_fwd_kernel(AttnArgs a) {
     constexpr int D = 32;
     __shared__ __attribute__((aligned(16))) float s_o[NW][32][D + 4];
     __shared__ float s_m[NW][32], s_l[NW][32];
+    // wave-private transposition buffer for V: a block is fetched as 4 coalesced 16-B loads per lane (32 rows x 128 B) and
+    // read back as the MFMA A operand (lane = column d, 16 key rows).  Fetching the operand layout directly takes 16 dword
+    // loads per block, and the CU's texture-address unit (~16 cycles per wave-wide load, shared by the 4 SIMDs) then costs
+    // as much time as the MFMA chains themselves.
+    __shared__ __attribute__((aligned(16))) float s_v[NW][32][D + 4];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -79,12 +85,18 @@ __global__ __launch_bounds__(64 * NW) void attention_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) kf[c] = *reinterpret_cast<const float4 *>(kp + 8 * c);
     };
-    auto load_v = [&](int b, float(&vf)[16]) {
+    auto load_v = [&](int b, float4(&vr)[4]) {   // raw rows: lane l holds float4 #(l & 7) of key rows (l >> 3) + 8j
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {  // lane (d = li, h) needs V[k0 + keyrow(r,h)][d]
-            const int kr = min(b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, a.S - 1);
-            vf[r] = a.V[(size_t)kr * a.ldv + hc + li];
+        for (int j = 0; j < 4; ++j) {
+            const int kr = min(b * 32 + (lane >> 3) + 8 * j, a.S - 1);
+            vr[j] = *reinterpret_cast<const float4 *>(a.V + (size_t)kr * a.ldv + hc + 4 * (lane & 7));
         }
+    };
+    auto transpose_v = [&](const float4(&vr)[4], float(&vf)[16]) {   // -> lane (d = li, h): V[keyrow(r, h)][d]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(&s_v[wave][(lane >> 3) + 8 * j][4 * (lane & 7)]) = vr[j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vf[r] = s_v[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li];
     };
     auto qk = [&](const float4(&kf)[4]) {  // S^T = K . Q^T, 16 chained MFMAs
         f32x16 s;
@@ -134,21 +146,21 @@ __global__ __launch_bounds__(64 * NW) void attention_fwd_kernel(AttnArgs a) {
     {
         int b = wave;
         if (b < nblk) {
-            float4 kC[4], kN[4], kN2[4];
-            float vC[16], vN[16];
+            float4 kC[4], kN[4], kN2[4], vR[4];
+            float vC[16];
             load_k(b, kC);
-            load_v(b, vC);
+            load_v(b, vR);
             load_k(min(b + NW, nblk - 1), kN);
             f32x16 sC = qk(kC);
+            transpose_v(vR, vC);
             while (b + NW < nblk) {
-                load_v(b + NW, vN);
                 load_k(min(b + 2 * NW, nblk - 1), kN2);
+                load_v(b + NW, vR);                 // raw rows of the next block fly under this block's MFMA chains ...
                 f32x16 sN = qk(kN);
                 softmax(b, sC);
                 pv(sC, vC);
+                transpose_v(vR, vC);                // ... and go through LDS once the PV chain has read the current ones
                 sC = sN;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) vC[r] = vN[r];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) kN[c] = kN2[c];
                 b += NW;
@@ -205,7 +217,7 @@ extern "C" int cofi_attention_fwd(const float *Q, int ldq, const float *K, int l
     if (!Q || !K || !V || !O || L <= 0 || S <= 0 || H <= 0) return COFI_EINVAL;
     if (D != 32) return COFI_EUNSUPPORTED;
     if ((ldq & 3) || (ldk & 3) || (ldo & 3) || ldq < H * D || ldk < H * D || ldv < H * D || ldo < H * D) return COFI_EINVAL;
-    if (((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)O & 15) || (q_colscale && ((uintptr_t)q_colscale & 15)))
+    if ((ldv & 3) || ((uintptr_t)V & 15) || ((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)O & 15) || (q_colscale && ((uintptr_t)q_colscale & 15)))
         return COFI_EINVAL;
     AttnArgs a{Q, K, V, q_colscale, O, ldq, ldk, ldv, ldo, L, S, H, scale * 1.4426950408889634f};
     if (frames <= 0) return COFI_EINVAL;
