@@ -56,13 +56,17 @@ __device__ __forceinline__ void split_store1(float v, unsigned char *hi_ptr, uns
 }
 
 // One GEMM stage of a wave: acc[t] (32 rows x 32 cols, t < NT) += A(32 x K, bf16 planes in LDS) . W[nbase + 32t + (0..31), 0..K)^T.
-// W planes are (N, K) bf16 row-major in global memory.  KSTEPS = K / 16.  B fragments are loaded CH steps ahead.
-template <int NT, int KSTEPS>
+// W planes are (N, K) bf16 row-major in global memory.  KSTEPS = K / 16, in chunks of CH = 4 steps; PF chunks of B fragments
+// are in flight ahead of the one being multiplied.  The workgroup is alone on its CU (40-80 workgroups per launch) and a
+// chunk is only ~0.2 us of MFMA work, so the stage is a chain of L2 round trips: PF = all chunks (one round trip per stage)
+// where the registers allow it - one wave per SIMD may use the whole 512-entry register file.
+template <int NT, int KSTEPS, int PF>
 __device__ __forceinline__ void gemm_stage(f32x16 (&acc)[NT], const unsigned char *a_hi, const unsigned char *a_lo, int a_stride,
                                            const unsigned short *w_hi, const unsigned short *w_lo, int K, int nbase, int li, int lh) {
     constexpr int CH = 4;
     constexpr int NCH = KSTEPS / CH;
-    Frag bh[2][NT][CH], bl[2][NT][CH];
+    constexpr int SLOTS = PF + 1 < NCH ? PF + 1 : NCH;
+    Frag bh[SLOTS][NT][CH], bl[SLOTS][NT][CH];
     auto loadw = [&](int c, int slot) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -75,11 +79,20 @@ __device__ __forceinline__ void gemm_stage(f32x16 (&acc)[NT], const unsigned cha
             }
         }
     };
-    loadw(0, 0);
-    const unsigned char *ah = a_hi + li * a_stride + lh * 16, *al = a_lo + li * a_stride + lh * 16;
+#pragma unroll
+    for (int c = 0; c < PF && c < NCH; ++c) loadw(c, c % SLOTS);
+    // `aoff` (the lane's byte offset into the A planes) doubles as the anchor of compiler-level barriers: every A-fragment
+    // read below depends on it, and no load above an anchor may sink below it.  Without the anchors the scheduler moves each
+    // weight load down to the MFMA that consumes it (less register pressure) - a chain of exposed L2 round trips.
+    unsigned aoff = li * a_stride + lh * 16;
+    asm volatile("" : "+v"(aoff) : : "memory");
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        if (c + 1 < NCH) loadw(c + 1, (c + 1) & 1);
+        if (c + PF < NCH) {
+            loadw(c + PF, (c + PF) % SLOTS);
+            asm volatile("" : "+v"(aoff) : : "memory");
+        }
+        const unsigned char *ah = a_hi + aoff, *al = a_lo + aoff;
 #pragma unroll
         for (int s = 0; s < CH; ++s) {
             Frag fa_h, fa_l;
@@ -87,9 +100,9 @@ __device__ __forceinline__ void gemm_stage(f32x16 (&acc)[NT], const unsigned cha
             fa_l.u = *reinterpret_cast<const uint4 *>(al + (c * CH + s) * 32);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_l.v, bh[c & 1][t][s].v, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_h.v, bl[c & 1][t][s].v, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_h.v, bh[c & 1][t][s].v, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_l.v, bh[c % SLOTS][t][s].v, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_h.v, bl[c % SLOTS][t][s].v, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_h.v, bh[c % SLOTS][t][s].v, acc[t], 0, 0, 0);
             }
         }
     }
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailArgs a) {
         f32x16 acc[1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-        gemm_stage<1, 8>(acc, msg_hi, msg_lo, S128, a.wm_hi, a.wm_lo, C, wave * 32, li, lh);
+        gemm_stage<1, 8, 2>(acc, msg_hi, msg_lo, S128, a.wm_hi, a.wm_lo, C, wave * 32, li, lh);
         acc_to_stage(acc[0], wave * 32);
     }
     __syncthreads();
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailArgs a) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        gemm_stage<2, 16>(acc, cat_hi, cat_lo, S256, a.w0_hi, a.w0_lo, 2 * C, wave * 64, li, lh);
+        gemm_stage<2, 16, 2>(acc, cat_hi, cat_lo, S256, a.w0_hi, a.w0_lo, 2 * C, wave * 64, li, lh);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailArgs a) {
         f32x16 acc[1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-        gemm_stage<1, 16>(acc, h_hi, h_lo, S256, a.w2_hi, a.w2_lo, 2 * C, wave * 32, li, lh);
+        gemm_stage<1, 16, 4>(acc, h_hi, h_lo, S256, a.w2_hi, a.w2_lo, 2 * C, wave * 32, li, lh);
         acc_to_stage(acc[0], wave * 32);
     }
     __syncthreads();
