@@ -289,6 +289,22 @@ int cofi_gather_rows_sel(const float *x, int ldx, int C, const int32_t *row_idx,
 int cofi_fine_match(const float *patches, const float *pc_feats, int ldp, int C, const float *coarse_xy, int ldxy,
                     float center_scale, const int32_t *count_dev, int cap, float *fine_xy, int32_t *best, cofi_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Row f1: camera pose from the fine matches, replacing the reference's
+ *   cv2.solvePnPRansac(cameraMatrix=K, imagePoints=fine_xy.T, objectPoints=coarse_pc_points, iterationsCount=10000,
+ *                      distCoeffs=None)                                   (evaluation/eval_all.py:107)
+ * = RANSAC over minimal-set hypotheses scored by reprojection error (threshold `reproj_err`, OpenCV default 8 px), best
+ * consensus set, Levenberg-Marquardt refit on its inliers.  Here: `iterations` P3P hypotheses evaluated in parallel (4 sampled
+ * correspondences each; counter-based sampling from `seed`, reproducible), winner = most inliers (lowest id on ties), LM refit
+ * (`refine_iters` steps) in one workgroup.  Everything stays on the device: obj (n,3), img (n,2) are read up to
+ * count_dev[0] rows (or n_max if count_dev == NULL).  Outputs: pose[12] = R row-major | t with x_cam = R X + t;
+ * result[3] = {success, inliers of the RANSAC model, winning hypothesis id}; inlier_mask (n_max bytes).
+ * OpenCV is absent from this image: parity with it is unpinned; oracle/pnp_oracle.py is the restatement it is tested against. */
+size_t cofi_pnp_ransac_workspace(int iterations);
+int cofi_pnp_ransac(const float *obj, const float *img, const int32_t *count_dev, int n_max, float fx, float fy, float cx, float cy,
+                    int iterations, float reproj_err, unsigned seed, int refine_iters, void *ws, size_t ws_bytes, float *pose,
+                    int32_t *result, uint8_t *inlier_mask, cofi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
