@@ -7,6 +7,7 @@ forward enqueues hand-written gfx950 kernels through the C ABI of libcofi_hip.so
 (include/cofi_hip.h).  Inference only (`torch.no_grad()` semantics): there is no autograd and no
 CPU path — the module raises if the HIP library is missing or a tensor is not on the GPU.
 """
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -72,7 +73,6 @@ class CoFiI2P(nn.Module):
         self.compute_unused_image_maps = True  # layer3/layer4/avg-pool of the ResNet (network.py:87-89)
         self._use_graphs = False
         self._graphs = {}
-        import os
 
         # intra-frame fork/join slots captured by forward_async (bit 0 image branch, 1 residual shortcuts, 2 attention streams,
         # 3 the ResNet tail nothing reads)
@@ -336,7 +336,8 @@ class CoFiI2P(nn.Module):
         # submissions in flight fill the GPU by themselves: the per-submission graph is a linear chain (intra-frame
         # fork/join only adds join latency then — measured 306 vs 250 frames/s)
         outs = self._graph_forward(P, points, tabs[0], tabs[1], tabs[2], pc_data_dict["feats"].contiguous(), img.contiguous(), mode, None,
-                                   None, slot=slot, branch_mask=self.async_branch_mask, order=pc_data_dict.get("order"))
+                                   None, slot=slot, branch_mask=self.async_branch_mask,
+                                   order=None if os.environ.get("COFI_NO_ORDER") else pc_data_dict.get("order"))
         host = torch.empty((len(outs), 2), dtype=torch.int32, pin_memory=True)
         for f, o in enumerate(outs):
             host[f].copy_(o["count"], non_blocking=True)
