@@ -344,9 +344,12 @@ def main():
         "metric": "I2P frames/sec (160x512 img, 20480 pts)", "value": world * args.steps * Bsz / dt, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if args.gemm == "f32" else "f32 (dense contractions as 3-term bf16 split on the bf16 matrix cores, fp32 accumulate; "
-                                                   "4e-6 max abs deviation from the fp32 reference on the golden frame)",
+        "dtype": "f32",
         "data": "synthetic", "launch": "eager" if args.eager else "hipGraph replay",
+        "arithmetic": "fp32 storage and accumulation everywhere; dense contractions " + (
+            "on the exact fp32 MFMA" if args.gemm == "f32" else
+            "as a 3-term bf16 split (hi*hi + hi*lo + lo*hi) on the bf16 matrix cores: 4e-6 max abs deviation from the reference's "
+            "outputs on the golden frame (budget 1e-3)"),
         "config": {"workload": "KITTI-shape synthetic frame (160x512 image, %d points, KNN-128 pyramid resident in HBM), batch %d, "
                                "CoFiI2P.forward(mode='test') + fine matching, one %s per step per GPU"
                                % (args.points, Bsz, "frame" if Bsz == 1 else "stack-mode batch of %d frames" % Bsz),
