@@ -63,6 +63,7 @@ SIGNATURES = {
     "cofi_gather_points_sel": (_I, [_P, _P, _P, _I, _P, _P]),
     "cofi_extract_patches": (_I, [_P, _I, _I, _I, _P, _I, _F, _P, _I, _P, _P]),
     "cofi_gather_rows_sel": (_I, [_P, _I, _I, _P, _P, _I, _P, _I, _P]),
+    "cofi_multi_copy": (_I, [_P, _I, _I, _P]),
     "cofi_pnp_ransac_workspace": (_Z, [_I]),
     "cofi_pnp_ransac": (_I, [_P, _P, _P, _I, _F, _F, _F, _F, _I, _F, ctypes.c_uint, _I, _P, _Z, _P, _P, _P, _P]),
     "cofi_fine_match": (_I, [_P, _P, _I, _I, _P, _I, _F, _P, _I, _P, _P, _P]),

@@ -73,6 +73,7 @@ class CoFiI2P(nn.Module):
         self.compute_unused_image_maps = True  # layer3/layer4/avg-pool of the ResNet (network.py:87-89)
         self._use_graphs = False
         self._graphs = {}
+        self._multicopy = {}
 
         # intra-frame fork/join slots captured by forward_async (bit 0 image branch, 1 residual shortcuts, 2 attention streams,
         # 3 the ResNet tail nothing reads)
@@ -259,6 +260,7 @@ class CoFiI2P(nn.Module):
         self._use_graphs = bool(flag)
         if not flag:
             self._graphs = {}
+            self._multicopy = {}
         return self
 
     def _graph_forward(self, P, points, neighbors, subsampling, upsampling, feats, img, mode, kpt, inl, slot: int = 0,
@@ -298,9 +300,11 @@ class CoFiI2P(nn.Module):
             ent = (graph, static, outs)
             self._graphs[key] = ent
         graph, static, outs = ent
-        for s_, t in zip(static, tensors):
-            if t is not None:
-                s_.copy_(t, non_blocking=True)
+        # per-frame inputs -> the static buffers the graph reads: one batched copy launch (20+ tensors)
+        mc = self._multicopy.get(key)
+        if mc is None:
+            mc = self._multicopy[key] = ops.MultiCopy(img.device)
+        mc.run([None if t is None else t.contiguous() for t in tensors], static)
         graph.replay()
         ops.set_workspace_slot(0)
         ops.BRANCH_MASK = saved_mask

@@ -606,6 +606,35 @@ def loftr_tail(msg, x, w, out, eps: float = 1e-5):
     return out
 
 
+class MultiCopy:
+    """One-launch copy of a list of (src -> dst) tensor pairs (cofi_multi_copy).  The descriptor table of an address set is
+    built once (pinned host buffer -> device) and cached: a stream of frames that recycles its buffers pays one kernel launch."""
+    MAX_TABLES = 32
+
+    def __init__(self, device):
+        self.device = device
+        self.tables = {}
+
+    def run(self, srcs, dsts):
+        lib = _lib.load()
+        pairs = [(s, d) for s, d in zip(srcs, dsts) if s is not None]
+        if not pairs:
+            return
+        key = tuple((s.data_ptr(), d.data_ptr(), s.numel() * s.element_size()) for s, d in pairs)
+        table = self.tables.get(key)
+        if table is None:
+            for s, d in pairs:
+                if not (s.is_contiguous() and d.is_contiguous() and s.shape == d.shape and s.dtype == d.dtype and s.is_cuda and d.is_cuda):
+                    raise _lib.CofiError("multi_copy: contiguous CUDA tensors of equal shape / dtype expected")
+            host = torch.tensor([v for k in key for v in k], dtype=torch.int64).pin_memory()
+            table = torch.empty(3 * len(pairs), dtype=torch.int64, device=self.device)
+            table.copy_(host, non_blocking=True)   # the pinned allocator keeps `host` alive until the copy has run
+            if len(self.tables) >= self.MAX_TABLES:
+                self.tables.pop(next(iter(self.tables)))
+            self.tables[key] = table
+        _lib.check(lib.cofi_multi_copy(_p(table), len(pairs), 64, _stream()), "cofi_multi_copy")
+
+
 # ------------------------------------------------------------------------------------------ KNN / indices
 def knn(support, query, k: int, return_dist: bool = False):
     lib = _lib.load()

@@ -305,6 +305,10 @@ int cofi_pnp_ransac(const float *obj, const float *img, const int32_t *count_dev
                     int iterations, float reproj_err, unsigned seed, int refine_iters, void *ws, size_t ws_bytes, float *pose,
                     int32_t *result, uint8_t *inlier_mask, cofi_stream_t stream);
 
+/* Batched device-to-device copy in one launch: descs_dev = n records {const void *src; void *dst; uint64 bytes} in device
+ * memory (e.g. the per-frame inputs -> the static buffers of a captured forward graph); blocks_per_copy workgroups per record. */
+int cofi_multi_copy(const void *descs_dev, int n, int blocks_per_copy, cofi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -435,3 +435,21 @@ def test_loftr_layer_fused_tail_bf16x3(ops, mg, monkeypatch):
     x, src = torch.randn(1280, 128, generator=g), torch.randn(300, 128, generator=g)
     sd = {k: v.cpu() for k, v in w.items()}
     close(loftr_layer(w, G(x), G(src)), O.loftr_layer({"l." + k: v for k, v in sd.items()}, "l.", x, src), 1e-4)
+
+
+def test_multi_copy(ops):
+    """batched device-to-device copy: mixed dtypes, odd byte counts, unaligned views, cached descriptor tables"""
+    g = torch.Generator().manual_seed(5)
+    srcs = [G(torch.randn(1000, 3, generator=g)), G(torch.randint(0, 100, (77, 128), generator=g, dtype=torch.int32)),
+            G(torch.randint(0, 255, (13,), generator=g, dtype=torch.uint8)), G(torch.randn(4097, generator=g))[1:], None]
+    dsts = [torch.empty_like(s) if s is not None else None for s in srcs]
+    mc = ops.MultiCopy(torch.device(DEV))
+    for _ in range(2):  # second round: cached table
+        for d in dsts:
+            if d is not None:
+                d.zero_()
+        mc.run(srcs, dsts)
+        for s_, d in zip(srcs, dsts):
+            if s_ is not None:
+                assert torch.equal(s_, d)
+    assert len(mc.tables) == 1
