@@ -45,6 +45,7 @@ SIGNATURES = {
     "cofi_loftr_tail_bf16x3": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
     "cofi_attention_workspace": (_Z, [_I, _I, _I, _I]),
     "cofi_attention_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P, _Z, _I, _P]),
+    "cofi_attention_fwd_colpart": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _F, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "cofi_col_inv_norm": (_I, [_P, _I, _I, _I, _F, _P, _P]),
     "cofi_pos_sine": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _P, _I, _P]),
     "cofi_l2norm_rows": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),

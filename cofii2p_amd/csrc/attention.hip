@@ -25,6 +25,11 @@ struct AttnArgs {
     float *O;
     int ldq, ldk, ldv, ldo, L, S, H;
     float scale_log2e;
+    // alternative to qs: the column partials of the projection that produced Q (cofi_gemm_f32_colstats: (frames*nslab, ncols, 2)
+    // {sum, sum of squares}); the kernel folds them into 1 / max(||Q[:, c]||, eps) itself (transformer.py:53)
+    const float *q_colpart;
+    int q_nslab, q_ncols;
+    float q_eps;
 };
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -56,6 +61,26 @@ __global__ __launch_bounds__(64 * NW) void attention_fwd_kernel(AttnArgs a) {
         if (a.qs) a.qs += f * a.H * D;
     }
 
+    // token-axis norm of this head's 32 Q columns from the projection's column partials: thread (phase, column) sums the
+    // squares of slabs phase, phase + NPH, ...; column threads fold the phases in a fixed order (deterministic)
+    __shared__ __attribute__((aligned(16))) float s_qs[D];
+    if (a.q_colpart) {
+        constexpr int NPH = 2 * NW;   // 64 * NW threads = NPH phases x 32 columns
+        __shared__ float s_part[NPH][D];
+        const int col = threadIdx.x & 31, ph = threadIdx.x >> 5;
+        const float *cp = a.q_colpart + ((size_t)blockIdx.z * a.q_nslab * a.q_ncols + hc + col) * 2 + 1;
+        float acc = 0.f;
+        for (int b = ph; b < a.q_nslab; b += NPH) acc += cp[(size_t)b * a.q_ncols * 2];
+        s_part[ph][col] = acc;
+        __syncthreads();
+        if (threadIdx.x < D) {
+            float t = 0.f;
+#pragma unroll
+            for (int p = 0; p < NPH; ++p) t += s_part[p][threadIdx.x];
+            s_qs[threadIdx.x] = 1.0f / fmaxf(sqrtf(t), a.q_eps);
+        }
+        __syncthreads();
+    }
     // Q fragment: lane (q = li, h) holds Q[q][8c+4h+e], pre-multiplied by colscale * scale * log2(e)
     float qf[16];
     {
@@ -65,7 +90,8 @@ __global__ __launch_bounds__(64 * NW) void attention_fwd_kernel(AttnArgs a) {
         for (int c = 0; c < 4; ++c) {
             const float4 v = *reinterpret_cast<const float4 *>(qp + 8 * c);
             float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (a.qs) sc = *reinterpret_cast<const float4 *>(a.qs + hc + 4 * lh + 8 * c);
+            if (a.q_colpart) sc = *reinterpret_cast<const float4 *>(&s_qs[4 * lh + 8 * c]);
+            else if (a.qs) sc = *reinterpret_cast<const float4 *>(a.qs + hc + 4 * lh + 8 * c);
             qf[4 * c + 0] = (v.x * sc.x) * a.scale_log2e;
             qf[4 * c + 1] = (v.y * sc.y) * a.scale_log2e;
             qf[4 * c + 2] = (v.z * sc.z) * a.scale_log2e;
@@ -210,25 +236,43 @@ extern "C" size_t cofi_attention_workspace(int L, int S, int H, int D) {
     return 0;  // split-KV partials are merged in LDS
 }
 
+static int attention_launch(AttnArgs a, int frames, hipStream_t stream) {
+    // >= ~8 waves per CU (2048 in all) with the fewest key splits
+    const long wgs = (long)cofi_cdiv(a.L, 32) * a.H * frames;
+    const dim3 grid(cofi_cdiv(a.L, 32), a.H, frames);
+    if (wgs * 2 >= 2048 && a.S >= 64 * 2)
+        hipLaunchKernelGGL(attention_fwd_kernel<2>, grid, dim3(128), 0, stream, a);
+    else if (wgs * 4 >= 2048 && a.S >= 64 * 4)
+        hipLaunchKernelGGL(attention_fwd_kernel<4>, grid, dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(attention_fwd_kernel<8>, grid, dim3(512), 0, stream, a);
+    return cofi_launch_status();
+}
+
+static int attention_check(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, float *O, int ldo, int L, int S, int H,
+                           int D, int frames) {
+    if (!Q || !K || !V || !O || L <= 0 || S <= 0 || H <= 0 || frames <= 0) return COFI_EINVAL;
+    if (D != 32) return COFI_EUNSUPPORTED;
+    if ((ldq & 3) || (ldk & 3) || (ldo & 3) || ldq < H * D || ldk < H * D || ldv < H * D || ldo < H * D) return COFI_EINVAL;
+    if ((ldv & 3) || ((uintptr_t)V & 15) || ((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)O & 15)) return COFI_EINVAL;
+    return 0;
+}
+
 extern "C" int cofi_attention_fwd(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, const float *q_colscale,
                                   float *O, int ldo, int L, int S, int H, int D, float scale, void *ws, size_t ws_bytes, int frames,
                                   cofi_stream_t stream) {
     (void)ws; (void)ws_bytes;
-    if (!Q || !K || !V || !O || L <= 0 || S <= 0 || H <= 0) return COFI_EINVAL;
-    if (D != 32) return COFI_EUNSUPPORTED;
-    if ((ldq & 3) || (ldk & 3) || (ldo & 3) || ldq < H * D || ldk < H * D || ldv < H * D || ldo < H * D) return COFI_EINVAL;
-    if ((ldv & 3) || ((uintptr_t)V & 15) || ((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)O & 15) || (q_colscale && ((uintptr_t)q_colscale & 15)))
-        return COFI_EINVAL;
-    AttnArgs a{Q, K, V, q_colscale, O, ldq, ldk, ldv, ldo, L, S, H, scale * 1.4426950408889634f};
-    if (frames <= 0) return COFI_EINVAL;
-    // >= ~8 waves per CU (2048 in all) with the fewest key splits
-    const long wgs = (long)cofi_cdiv(L, 32) * H * frames;
-    const dim3 grid(cofi_cdiv(L, 32), H, frames);
-    if (wgs * 2 >= 2048 && S >= 64 * 2)
-        hipLaunchKernelGGL(attention_fwd_kernel<2>, grid, dim3(128), 0, cofi_s(stream), a);
-    else if (wgs * 4 >= 2048 && S >= 64 * 4)
-        hipLaunchKernelGGL(attention_fwd_kernel<4>, grid, dim3(256), 0, cofi_s(stream), a);
-    else
-        hipLaunchKernelGGL(attention_fwd_kernel<8>, grid, dim3(512), 0, cofi_s(stream), a);
-    return cofi_launch_status();
+    if (int rc = attention_check(Q, ldq, K, ldk, V, ldv, O, ldo, L, S, H, D, frames)) return rc;
+    if (q_colscale && ((uintptr_t)q_colscale & 15)) return COFI_EINVAL;
+    AttnArgs a{Q, K, V, q_colscale, O, ldq, ldk, ldv, ldo, L, S, H, scale * 1.4426950408889634f, nullptr, 0, 0, 0.f};
+    return attention_launch(a, frames, cofi_s(stream));
+}
+
+extern "C" int cofi_attention_fwd_colpart(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, const float *q_colpart,
+                                          int q_nslab, int q_ncols, float q_eps, float *O, int ldo, int L, int S, int H, int D,
+                                          float scale, int frames, cofi_stream_t stream) {
+    if (int rc = attention_check(Q, ldq, K, ldk, V, ldv, O, ldo, L, S, H, D, frames)) return rc;
+    if (!q_colpart || q_nslab <= 0 || (q_nslab % frames) || q_ncols < H * D) return COFI_EINVAL;
+    AttnArgs a{Q, K, V, nullptr, O, ldq, ldk, ldv, ldo, L, S, H, scale * 1.4426950408889634f, q_colpart, q_nslab / frames, q_ncols, q_eps};
+    return attention_launch(a, frames, cofi_s(stream));
 }

@@ -74,6 +74,7 @@ class CoFiI2P(nn.Module):
         self._use_graphs = False
         self._graphs = {}
         self._multicopy = {}
+        self._grid_cache = {}
 
         # intra-frame fork/join slots captured by forward_async (bit 0 image branch, 1 residual shortcuts, 2 attention streams,
         # 3 the ResNet tail nothing reads)
@@ -124,6 +125,15 @@ class CoFiI2P(nn.Module):
         return P
 
     # ------------------------------------------------------------------ forward pieces
+    def _pixel_grid(self, H8: int, W8: int, B: int, dev) -> torch.Tensor:
+        key = (H8, W8, B, str(dev))
+        g = self._grid_cache.get(key)
+        if g is None:
+            gy, gx = torch.meshgrid(torch.arange(H8, device=dev, dtype=torch.int32), torch.arange(W8, device=dev, dtype=torch.int32),
+                                    indexing="ij")
+            g = self._grid_cache[key] = torch.stack([gy, gx], -1).reshape(H8 * W8, 2).repeat(B, 1).contiguous()
+        return g
+
     @staticmethod
     def _as_idx32(t: torch.Tensor) -> torch.Tensor:
         return ops.idx_to_int32(t) if t.dtype != torch.int32 else t.contiguous()
@@ -170,9 +180,7 @@ class CoFiI2P(nn.Module):
             raise ValueError("stack mode needs the NHWC image backend")
         br_dead = ops.Branch(dev, 3)  # ResNet layer3/layer4/avg-pool: computed (reference parity), read by nothing downstream
         with ops.Branch(dev, 0) as br_img:
-            gy, gx = torch.meshgrid(torch.arange(H8, device=dev, dtype=torch.int32), torch.arange(W8, device=dev, dtype=torch.int32),
-                                    indexing="ij")
-            grid = torch.stack([gy, gx], -1).reshape(T_img, 2).repeat(B, 1).contiguous()
+            grid = self._pixel_grid(H8, W8, B, dev)   # (y, x) of every token of the 1/8 map: a constant, built once
             if nhwc:
                 img_set, dims = image.resnet34_nhwc(P, img, full=self.compute_unused_image_maps, tail_branch=br_dead)
                 s2, s4, s8 = img_set[0], img_set[1], img_set[2]  # (B*H*W, C) pixel-major

@@ -572,8 +572,9 @@ def upsample2x_cat(low, skip):
 
 
 # ------------------------------------------------------------------------------------------ attention
-def attention(q, k, v, q_colscale=None, nhead: int = 4, out=None, frames: int = 1):
-    """Stack mode: q (frames*L, HD), k/v (frames*S, HD), q_colscale (frames, HD)."""
+def attention(q, k, v, q_colscale=None, nhead: int = 4, out=None, frames: int = 1, q_colpart=None, q_eps: float = 1e-12):
+    """Stack mode: q (frames*L, HD), k/v (frames*S, HD), q_colscale (frames, HD).  q_colpart (nslab, ncols, 2): the column
+    partials of the GEMM that produced q (its first HD columns) - the token-axis norm of Q is then folded inside the kernel."""
     lib = _lib.load()
     _mat(q, "q"), _mat(k, "k"), _mat(v, "v")
     L, HD = q.shape
@@ -581,6 +582,11 @@ def attention(q, k, v, q_colscale=None, nhead: int = 4, out=None, frames: int = 
     D = HD // nhead
     if out is None:
         out = torch.empty((L, HD), dtype=torch.float32, device=q.device)
+    if q_colpart is not None:
+        rc = lib.cofi_attention_fwd_colpart(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(q_colpart), q_colpart.shape[0], q_colpart.shape[1],
+                                            q_eps, _p(out), _ld(out), L // frames, S // frames, nhead, D, 1.0 / math.sqrt(D), frames, _stream())
+        _lib.check(rc, "cofi_attention_fwd_colpart")
+        return out
     rc = lib.cofi_attention_fwd(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(q_colscale), _p(out), _ld(out), L // frames, S // frames,
                                 nhead, D, 1.0 / math.sqrt(D), None, 0, frames, _stream())
     _lib.check(rc, "cofi_attention_fwd")

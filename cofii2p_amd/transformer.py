@@ -49,8 +49,8 @@ def _layer(w, xcat: torch.Tensor, src: torch.Tensor, out: torch.Tensor, self_att
         q, part = ops.gemm_colstats(x, w["q_proj.weight"])
         kv = ops.gemm(src, w["kv.weight"])
         k, v = kv[:, :C], kv[:, C:]
-    qscale = ops.col_inv_norm_from_colpart(part, C, frames=frames)  # per frame: the token axis of ONE frame
-    msg = ops.attention(q, k, v, q_colscale=qscale, nhead=nhead, frames=frames)
+    # the attention kernel folds the partials into the per-frame token-axis norm of Q itself
+    msg = ops.attention(q, k, v, q_colpart=part, nhead=nhead, frames=frames)
     if ops.GEMM_MODE == "bf16x3" and C == 128:
         # merge + LN1 + concat + MLP + LN2 + residual: one kernel, intermediates stay in LDS
         return ops.loftr_tail(msg, x, w, out)

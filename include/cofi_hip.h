@@ -194,6 +194,12 @@ size_t cofi_attention_workspace(int L, int S, int H, int D);
 int cofi_attention_fwd(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, const float *q_colscale,
                        float *O, int ldo, int L, int S, int H, int D, float scale, void *ws, size_t ws_bytes, int frames,
                        cofi_stream_t stream);
+/* Same, with the token-axis norm of Q folded in-kernel from the column partials of the projection that produced Q
+ * (cofi_gemm_f32_colstats: q_colpart (q_nslab, q_ncols, 2), Q = the first H*D columns; per frame in stack mode): saves the
+ * cofi_col_inv_norm_from_colpart launch in front of every attention call. */
+int cofi_attention_fwd_colpart(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, const float *q_colpart,
+                               int q_nslab, int q_ncols, float q_eps, float *O, int ldo, int L, int S, int H, int D, float scale,
+                               int frames, cofi_stream_t stream);
 int cofi_col_inv_norm(const float *x, int ldx, int M, int C, float eps, float *out, cofi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -239,6 +239,26 @@ def test_attention_stacked_frames(ops, frames, L, S):
         close(out[f * L:(f + 1) * L], ref, 5e-5)
 
 
+@pytest.mark.parametrize("frames,L", [(1, 1280), (2, 1280), (8, 640)])
+def test_attention_q_norm_from_column_partials(ops, frames, L):
+    """the token-axis norm of Q folded inside the attention kernel from the projection's column partials == the explicit
+    per-frame column scale"""
+    g = torch.Generator().manual_seed(frames + L)
+    x, w = torch.randn(frames * L, 128, generator=g), torch.randn(384, 128, generator=g) / 11.0
+    qkv, part = ops.gemm_colstats(G(x), G(w))
+    q, k, v = qkv[:, :128], qkv[:, 128:256], qkv[:, 256:]
+    cs = ops.col_inv_norm_from_colpart(part, 128, frames=frames)
+    a = ops.attention(q, k, v, q_colscale=cs, frames=frames)
+    b = ops.attention(q, k, v, q_colpart=part, frames=frames)
+    close(b, a.cpu(), 1e-5)
+    qc = qkv.cpu()
+    f = frames - 1
+    sl = slice(f * L, (f + 1) * L)
+    qn = qc[sl, :128] / qc[sl, :128].norm(dim=0).clamp_min(1e-12)
+    ref = O.full_attention(qn.reshape(L, 4, 32), qc[sl, 128:256].reshape(L, 4, 32), qc[sl, 256:].reshape(L, 4, 32)).reshape(L, 128)
+    close(b[sl], ref, 5e-5)
+
+
 def test_attention_forced_rescale(ops):
     """a key block arriving late with a much larger score forces the online-softmax rescale branch"""
     L, S = 64, 256
