@@ -64,6 +64,29 @@ def record_kernel_calls(model, dev, points=20480, batch=1):
     return kt
 
 
+def make_streams(dev, n, cu_split=None):
+    """n HIP streams; cu_split = "even" | "halves": experiment - each stream gets a disjoint CU mask (hipExtStreamCreateWithCUMask)."""
+    if not cu_split or n != 2:
+        return [torch.cuda.Stream(device=dev) for _ in range(n)]
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    streams = []
+    for i in range(2):
+        words = (ctypes.c_uint32 * 8)()
+        for w in range(8):
+            if cu_split == "halves":
+                words[w] = 0xFFFFFFFF if (w < 4) == (i == 0) else 0
+            else:  # alternate CUs
+                words[w] = 0x55555555 if i == 0 else 0xAAAAAAAA
+        st = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
+        if rc != 0:
+            raise SystemExit("hipExtStreamCreateWithCUMask failed: %d" % rc)
+        streams.append(torch.cuda.ExternalStream(st.value, device=dev))
+    return streams
+
+
 def one_step(model, frame):
     """forward(mode='test') computes the coarse matches, the 4x4 patches AND (in the same hipGraph) the
     caller-side fine matching of eval_all.py:99-105; the returned tuple is the reference's 8-tuple."""
@@ -227,6 +250,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the hipGraph")
     ap.add_argument("--inflight", type=int, default=2, help="frames in flight per GPU (each on its own HIP stream + hipGraph slot)")
+    ap.add_argument("--cu-split", default=None, choices=[None, "even", "halves"], help="experiment: the two frame streams get disjoint CU masks")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the extra stack-mode batch-4/16 measurements")
     ap.add_argument("--batch", type=int, default=1, help="frames per submission in stack mode (BASELINE configs[2] uses 16); a step is then one batch")
     ap.add_argument("--gemm", default=os.environ.get("COFI_GEMM", "bf16x3"), choices=["f32", "bf16x3"],
@@ -312,7 +336,7 @@ def main():
         # software pipeline over S frame slots: frame i is enqueued on stream i % S while the previous S-1 frames
         # are still executing; a slot's result (incl. the host read of the match count) is collected just before
         # the slot is reused.  Every step is still ONE frame through the complete forward.
-        streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+        streams = make_streams(dev, S, args.cu_split)
         pending = [None] * S
 
         def run(nsteps, base):
