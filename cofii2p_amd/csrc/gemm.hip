@@ -354,10 +354,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 // bf16x3 variant: every fp32 operand x is split on the fly into hi = bf16(x), lo = bf16(x - hi) and the product
 // is formed as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: ~2^-16 relative
 // error per product (the dropped lo*lo term) at 16/3 = 5.3x the fp32 MFMA rate.  Same tiling, staging map,
-// split-K and epilogue as the fp32 kernel; LDS holds a hi and a lo plane per operand, rows of 32 bf16 padded
-// to 80 B (conflict-free 16-B fragment reads).  Selected with COFI_GEMM_BF16X3 in `act`.
+// split-K and epilogue as the fp32 kernel; LDS holds a hi and a lo plane per operand, rows of BK3 bf16 padded
+// by 16 B (conflict-free 16-B fragment reads).  Selected with COFI_GEMM_BF16X3 in `act`; static operands (weights) may arrive
+// pre-split (COFI_GEMM_W_SPLIT, cofi_split_bf16_planes).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int BROW = 80;  // bytes per LDS row (64 B of bf16 + 16 B pad)
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {  // RNE, a -> low half
     unsigned r;

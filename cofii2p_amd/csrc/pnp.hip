@@ -390,7 +390,7 @@ extern "C" int cofi_pnp_ransac(const float *obj, const float *img, const int32_t
     hipStream_t s = cofi_s(stream);
     unsigned long long *key = (unsigned long long *)ws;
     float *poses = (float *)((char *)ws + 64);
-    hipMemsetAsync(key, 0, 8, s);
+    if (hipError_t e = hipMemsetAsync(key, 0, 8, s); e != hipSuccess) return (int)e;
     const Cam cam{fx, fy, cx, cy};
     hipLaunchKernelGGL(pnp_hypotheses_kernel, dim3(cofi_cdiv(iterations, HPW)), dim3(64), 0, s, obj, img, count_dev, n_max, cam, iterations,
                        reproj_err * reproj_err, seed, poses, key);
