@@ -473,3 +473,34 @@ def test_multi_copy(ops):
             if s_ is not None:
                 assert torch.equal(s_, d)
     assert len(mc.tables) == 1
+
+
+def test_attention_stress_size_sampled_rows(ops):
+    """BASELINE configs[4] (896x1600 image: 22 400 tokens): the L x S score matrix (8 GB per call in the reference) cannot be
+    checked whole; a random sample of query rows is compared with an exact fp64 softmax of those rows"""
+    L = S = 22400
+    g = torch.Generator().manual_seed(77)
+    q, k, v = torch.randn(L, 128, generator=g), torch.randn(S, 128, generator=g), torch.randn(S, 128, generator=g)
+    out = ops.attention(G(q), G(k), G(v)).cpu()
+    rows = torch.randperm(L, generator=g)[:192]
+    qs = q[rows].double().view(-1, 4, 32)
+    kd, vd = k.double().view(S, 4, 32), v.double().view(S, 4, 32)
+    att = torch.softmax(torch.einsum("lhd,shd->hls", qs, kd) / 32 ** 0.5, dim=-1)
+    ref = torch.einsum("hls,shd->lhd", att, vd).reshape(-1, 128)
+    close(out[rows], ref.float(), 5e-5)
+    assert torch.isfinite(out).all()
+
+
+def test_knn_stress_size_properties(ops):
+    """40 960 points, k = 128 (BASELINE configs[4]): sorted ascending, self first, and a sample of rows bit-equal to the oracle"""
+    from cofii2p_amd.synth import make_frame
+
+    pts = make_frame(11, 40960).points
+    idx, dist = ops.knn(G(pts), G(pts), 128, return_dist=True)
+    d = dist.cpu().numpy()
+    assert (np.diff(d, axis=1) >= 0).all()                                   # sortedness
+    i = idx.cpu().numpy().astype(np.int64)
+    assert (d[:, 0] == d.min(1)).all() and (np.sort(i, 1)[:, 1:] != np.sort(i, 1)[:, :-1]).all()   # no duplicates in a row
+    rows = np.random.RandomState(0).choice(40960, 256, replace=False)
+    ic, dc = knn_c.knn(pts, pts[rows], 128, True)
+    assert np.array_equal(i[rows], ic) and np.array_equal(d[rows], dc)
