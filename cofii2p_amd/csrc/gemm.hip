@@ -421,8 +421,11 @@ __global__ __launch_bounds__(256 * KW) void gemm_bf16x3_kernel(GemmArgs g) {
     constexpr int TLD = BN + 4;
     constexpr int PLANE_A = BM * BROW3, PLANE_W = BN * BROW3;    // bytes
     constexpr int BUF = 2 * (PLANE_A + PLANE_W);                 // hi+lo of A and W
-    static_assert(BM * TLD * 4 <= BUF && (NT / (BN / 4)) * BN * 2 * 4 <= BUF, "epilogue tile must fit in the operand buffer");
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[BUF];
+    // the epilogue re-uses the operand buffer as a row-major fp32 tile (+ the column-statistics scratch behind it when KW > 1)
+    constexpr int EPI = BM * TLD * 4 + (KW > 1 ? (NT / (BN / 4)) * BN * 2 * 4 : 0);
+    constexpr int LDS_BYTES = BUF > EPI ? BUF : EPI;
+    static_assert((NT / (BN / 4)) * BN * 2 * 4 <= LDS_BYTES, "column-statistics scratch must fit");
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = wave >> 2, wq = wave & 3;   // K share, position in the 2x2 wave grid
@@ -662,7 +665,6 @@ __global__ __launch_bounds__(256 * KW) void gemm_bf16x3_kernel(GemmArgs g) {
             return;
         }
         // `red` of the epilogue aliases the tile: park it behind the tile instead (BUF >= tile + red, checked below)
-        static_assert(BM * TLD * 4 + (NT / (BN / 4)) * BN * 2 * 4 <= BUF, "tile + reduction scratch must fit in the operand buffer");
         rowwise_epilogue<BM, BN, false, NT>(g, lds, TLD, m0, n0, blockIdx.y, lds + BM * TLD);
         return;
     }
@@ -807,16 +809,19 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
         else                                                                                                                   \
             hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, false>), grid, dim3(256 * KW_), 0, s, g);     \
     } while (0)
+        // K-tile depth per tile shape (measured): the 128x128 tile is register-bound at 2 waves per SIMD either way; the 64x128 and
+        // the throughput 64x64 tile run 1.4x / 1.05x faster with 64-deep K-tiles (2-3 workgroups per CU instead of 1-2) than with
+        // 128-deep ones; the small-grid 8/16-wave configurations keep 128 (fewer barriers for a lone workgroup).
         if (p.bm == 128 && p.bn == 128)
             COFI_LAUNCH_BF16X3(128, 128, 2, 2, 64, 1);
         else if (p.bm == 64 && p.bn == 128)
-            COFI_LAUNCH_BF16X3(64, 128, 1, 2, 128, 1);
+            COFI_LAUNCH_BF16X3(64, 128, 1, 2, 64, 1);
         else if (kw == 4)
             COFI_LAUNCH_BF16X3(64, 64, 1, 1, 128, 4);
         else if (kw == 2)
             COFI_LAUNCH_BF16X3(64, 64, 1, 1, 128, 2);
         else
-            COFI_LAUNCH_BF16X3(64, 64, 1, 1, 128, 1);
+            COFI_LAUNCH_BF16X3(64, 64, 1, 1, 64, 1);
 #undef COFI_LAUNCH_BF16X3
     } else if (p.bm == 128 && p.bn == 128)
         hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, g);
