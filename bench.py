@@ -453,6 +453,32 @@ def main():
             sweep["batch_%d" % bsz] = {"frames_per_s": nst * bsz / dtb, "ms_per_frame": 1e3 * dtb / (nst * bsz), "submissions_in_flight": 2}
             del pyr_b, img_b
         result["stack_mode_batches"] = sweep
+        # additional information, NOT the headline: the reference computes ResNet layer3, layer4 and the average pool and never reads
+        # them (model/network.py:87-89 only names them); `value` above includes them.  Without that dead branch:
+        model.compute_unused_image_maps = False
+        model.enable_graphs(False)
+        model.enable_graphs(True)
+        st = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        pend = [None, None]
+        for phase in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                sl = i % 2
+                if pend[sl] is not None:
+                    model.finish(pend[sl])
+                pyr, img, _ = frames[i % len(frames)]
+                with torch.cuda.stream(st[sl]):
+                    pend[sl] = model.forward_async(20 + sl, pyr, img)
+            for sl in range(2):
+                if pend[sl] is not None:
+                    model.finish(pend[sl])
+                    pend[sl] = None
+            torch.cuda.synchronize()
+            dtb = time.perf_counter() - t0
+        model.compute_unused_image_maps = True
+        result["without_unread_resnet_maps"] = {"frames_per_s": args.steps / dtb, "ms_per_frame": 1e3 * dtb / args.steps,
+                                                "note": "batch 1; layer3/layer4/avg-pool of the image encoder skipped (outputs identical: nothing reads them)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(frames[0])
     if rank == 0:
