@@ -336,6 +336,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             }
         return;
     }
+    if constexpr (BM == 128) {
+        // two 64-row halves: the statistics slabs are 64 rows for every tile shape (see the bf16x3 kernel)
+        for (int half = 0; half < 2; ++half) {
+            if (wm == half) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            lds[rl * TLD + wn * 32 * TN + j * 32 + li] = acc[i][j][r];
+                        }
+            }
+            __syncthreads();
+            rowwise_epilogue<64, BN, false>(g, lds, TLD, m0 + 64 * half, n0, 2 * blockIdx.y + half, lds);
+            __syncthreads();
+        }
+        return;
+    }
     // accumulators -> row-major LDS tile (the operand buffers are dead: the loop ended on a barrier)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -406,8 +426,8 @@ __global__ void split_planes_kernel(const float *W, int ldw, int N, int K, unsig
 //           accumulators are summed through LDS in a fixed order at the end.  A workgroup that is alone on its CU (small
 //           grids) is bound by the serial chain load -> split -> LDS -> MFMA of ONE wave per SIMD (~2 us per 128-deep tile,
 //           measured); KW waves per SIMD split the conversion work KW ways and overlap each other's phases.
-template <int BM, int BN, int TM, int TN, int BK3, int KW = 1, bool WSPLIT = false>
-__global__ __launch_bounds__(256 * KW) void gemm_bf16x3_kernel(GemmArgs g) {
+template <int BM, int BN, int TM, int TN, int BK3, int KW = 1, bool WSPLIT = false, int WPE = 1>
+__global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
     static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 waves");
     constexpr int NT = 256 * KW;
     constexpr int BROW3 = BK3 * 2 + 16;   // bytes per LDS row: bf16 values + 16 B pad (68 / 36 dwords: conflict-free b128 reads)
@@ -422,7 +442,7 @@ __global__ __launch_bounds__(256 * KW) void gemm_bf16x3_kernel(GemmArgs g) {
     constexpr int PLANE_A = BM * BROW3, PLANE_W = BN * BROW3;    // bytes
     constexpr int BUF = 2 * (PLANE_A + PLANE_W);                 // hi+lo of A and W
     // the epilogue re-uses the operand buffer as a row-major fp32 tile (+ the column-statistics scratch behind it when KW > 1)
-    constexpr int EPI = BM * TLD * 4 + (KW > 1 ? (NT / (BN / 4)) * BN * 2 * 4 : 0);
+    constexpr int EPI = (BM == 128 ? 64 : BM) * TLD * 4 + (KW > 1 ? (NT / (BN / 4)) * BN * 2 * 4 : 0);   // BM = 128: two 64-row halves
     constexpr int LDS_BYTES = BUF > EPI ? BUF : EPI;
     static_assert((NT / (BN / 4)) * BN * 2 * 4 <= LDS_BYTES, "column-statistics scratch must fit");
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
@@ -682,6 +702,27 @@ __global__ __launch_bounds__(256 * KW) void gemm_bf16x3_kernel(GemmArgs g) {
             }
         return;
     }
+    if constexpr (BM == 128) {
+        // epilogue in two 64-row halves (statistics slabs of 64 rows): half the LDS tile, so the operand buffer - not the epilogue -
+        // sizes the workgroup's LDS and a third workgroup fits on the CU
+        for (int half = 0; half < 2; ++half) {
+            if (wm == half) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            lds[rl * TLD + wn * 32 * TN + j * 32 + li] = acc[i][j][r];
+                        }
+            }
+            __syncthreads();
+            rowwise_epilogue<64, BN, false>(g, lds, TLD, m0 + 64 * half, n0, 2 * blockIdx.y + half, lds);
+            __syncthreads();
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -802,18 +843,19 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
     dim3 grid(cofi_cdiv(g.N, p.bn), cofi_cdiv(g.M, p.bm), p.ksplit);
     if (g.bf16x3) {
         const int kw = (p.bm == 64 && p.bn == 64) ? latency_kw(p, g.M, g.N) : 1;
-#define COFI_LAUNCH_BF16X3(BM_, BN_, TM_, TN_, BK_, KW_)                                                                       \
-    do {                                                                                                                       \
-        if (g.wsplit)                                                                                                          \
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, true>), grid, dim3(256 * KW_), 0, s, g);      \
-        else                                                                                                                   \
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, false>), grid, dim3(256 * KW_), 0, s, g);     \
+#define COFI_LAUNCH_BF16X3_W(BM_, BN_, TM_, TN_, BK_, KW_, WPE_)                                                                     \
+    do {                                                                                                                           \
+        if (g.wsplit)                                                                                                              \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, true, WPE_>), grid, dim3(256 * KW_), 0, s, g);    \
+        else                                                                                                                       \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, false, WPE_>), grid, dim3(256 * KW_), 0, s, g);   \
     } while (0)
+#define COFI_LAUNCH_BF16X3(BM_, BN_, TM_, TN_, BK_, KW_) COFI_LAUNCH_BF16X3_W(BM_, BN_, TM_, TN_, BK_, KW_, 1)
         // K-tile depth per tile shape (measured): the 128x128 tile is register-bound at 2 waves per SIMD either way; the 64x128 and
         // the throughput 64x64 tile run 1.4x / 1.05x faster with 64-deep K-tiles (2-3 workgroups per CU instead of 1-2) than with
         // 128-deep ones; the small-grid 8/16-wave configurations keep 128 (fewer barriers for a lone workgroup).
         if (p.bm == 128 && p.bn == 128)
-            COFI_LAUNCH_BF16X3(128, 128, 2, 2, 64, 1);
+            COFI_LAUNCH_BF16X3(128, 128, 2, 2, 64, 1);   // (32-deep K-tiles at 3 waves per SIMD, 168 VGPRs with spills: no faster)
         else if (p.bm == 64 && p.bn == 128)
             COFI_LAUNCH_BF16X3(64, 128, 1, 2, 64, 1);
         else if (kw == 4)
@@ -823,6 +865,7 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
         else
             COFI_LAUNCH_BF16X3(64, 64, 1, 1, 64, 1);
 #undef COFI_LAUNCH_BF16X3
+#undef COFI_LAUNCH_BF16X3_W
     } else if (p.bm == 128 && p.bn == 128)
         hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, g);
     else if (p.bm == 64 && p.bn == 128)
@@ -856,7 +899,8 @@ extern "C" size_t cofi_gemm_f32_workspace(int M, int N, int K) {
 extern "C" int cofi_gemm_f32_stat_slabs(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     Plan p = make_plan(M, N, K, false);
-    return cofi_cdiv(M, p.ksplit > 1 ? SK_ROWS : p.bm);
+    (void)p;
+    return cofi_cdiv(M, 64);   // every path (64-row tiles, 128-row tiles in two halves, split-K reduction) emits 64-row slabs
 }
 
 extern "C" int cofi_gemm_f32(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K,
