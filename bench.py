@@ -19,6 +19,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, shared with the null and capture streams): with the default
+# the third frame stream lands on an occupied queue and frames serialise (326 f/s); with 8 queues three frames in flight run
+# 447 f/s (two: 371, four: 318 - measured on MI355X).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -249,7 +253,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the hipGraph")
-    ap.add_argument("--inflight", type=int, default=2, help="frames in flight per GPU (each on its own HIP stream + hipGraph slot)")
+    ap.add_argument("--inflight", type=int, default=3, help="frames in flight per GPU (each on its own HIP stream + hipGraph slot)")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for single-GPU tests of the N > 1 path)")
+    ap.add_argument("--share-device", action="store_true", help="test aid: all ranks use cuda:0")
     ap.add_argument("--cu-split", default=None, choices=[None, "even", "halves"], help="experiment: the two frame streams get disjoint CU masks")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the extra stack-mode batch-4/16 measurements")
     ap.add_argument("--batch", type=int, default=1, help="frames per submission in stack mode (BASELINE configs[2] uses 16); a step is then one batch")
@@ -267,7 +273,9 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    if args.share_device:  # test aid: every rank on cuda:0 (with --dist-backend gloo; RCCL refuses two ranks on one GPU)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -432,25 +440,25 @@ def main():
         for bsz in (4, 16):
             grp = [frames[i % len(frames)] for i in range(bsz)]
             pyr_b, img_b = CoFiI2P.stack_frames([g[0] for g in grp], [g[1] for g in grp])
-            st = [torch.cuda.Stream(device=dev) for _ in range(2)]
-            pend = [None, None]
-            nst = max(6, args.steps // bsz)
+            st = [torch.cuda.Stream(device=dev) for _ in range(S)]
+            pend = [None] * S
+            nst = max(2 * S, args.steps // bsz)
             for phase in range(2):  # 0 = warm-up (captures the graphs), 1 = timed
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for i in range(nst):
-                    sl = i % 2
+                    sl = i % S
                     if pend[sl] is not None:
                         model.finish(pend[sl])
                     with torch.cuda.stream(st[sl]):
                         pend[sl] = model.forward_async(10 + sl, pyr_b, img_b)
-                for sl in range(2):
+                for sl in range(S):
                     if pend[sl] is not None:
                         model.finish(pend[sl])
                         pend[sl] = None
                 torch.cuda.synchronize()
                 dtb = time.perf_counter() - t0
-            sweep["batch_%d" % bsz] = {"frames_per_s": nst * bsz / dtb, "ms_per_frame": 1e3 * dtb / (nst * bsz), "submissions_in_flight": 2}
+            sweep["batch_%d" % bsz] = {"frames_per_s": nst * bsz / dtb, "ms_per_frame": 1e3 * dtb / (nst * bsz), "submissions_in_flight": S}
             del pyr_b, img_b
         result["stack_mode_batches"] = sweep
         # additional information, NOT the headline: the reference computes ResNet layer3, layer4 and the average pool and never reads
@@ -458,19 +466,19 @@ def main():
         model.compute_unused_image_maps = False
         model.enable_graphs(False)
         model.enable_graphs(True)
-        st = [torch.cuda.Stream(device=dev) for _ in range(2)]
-        pend = [None, None]
+        st = [torch.cuda.Stream(device=dev) for _ in range(S)]
+        pend = [None] * S
         for phase in range(2):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(args.steps):
-                sl = i % 2
+                sl = i % S
                 if pend[sl] is not None:
                     model.finish(pend[sl])
                 pyr, img, _ = frames[i % len(frames)]
                 with torch.cuda.stream(st[sl]):
                     pend[sl] = model.forward_async(20 + sl, pyr, img)
-            for sl in range(2):
+            for sl in range(S):
                 if pend[sl] is not None:
                     model.finish(pend[sl])
                     pend[sl] = None

@@ -19,7 +19,7 @@ run_pmc() {  # name, counters
   python $R/tools/rocpd_pmc_summary.py $(find /tmp/prof_$1 -name '*_results.db' | head -1) > $OUT/$1_pmc.md 2>&1
   rm -rf /tmp/prof_$1
 }
-run_trace inflight2 ""
+run_trace inflight3 ""
 run_trace inflight1 "--inflight 1"
 run_pmc fetch "FETCH_SIZE"
 run_pmc write "WRITE_SIZE"
