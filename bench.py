@@ -19,10 +19,21 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, shared with the null and capture streams): with the default
-# the third frame stream lands on an occupied queue and frames serialise (326 f/s); with 8 queues three frames in flight run
-# 447 f/s (two: 371, four: 318 - measured on MI355X).  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, shared with the null and capture streams).  Measured on
+# MI355X (frames/s at 1 / 2 / 3 / 4 frames in flight): 4 queues 264 / 371 / 326 / 371; 5-8 queues 96-148 / 371 / 444 / 305-367.
+# Three frames in flight need their own queues; a single stream is slower when the command processor polls more queues.
+# Must be set before the HIP runtime initialises, hence the early look at --inflight.
+def _inflight_from_argv(default=3):
+    for i, a in enumerate(sys.argv):
+        if a == "--inflight" and i + 1 < len(sys.argv):
+            return int(sys.argv[i + 1])
+        if a.startswith("--inflight="):
+            return int(a.split("=", 1)[1])
+    return default
+
+
+if _inflight_from_argv() >= 3:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
