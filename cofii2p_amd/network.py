@@ -346,7 +346,7 @@ class CoFiI2P(nn.Module):
         points = [p.contiguous() for p in pc_data_dict["points"]]
         tabs = [[self._as_idx32(t) for t in pc_data_dict[k]] for k in ("neighbors", "subsampling", "upsampling")]
         # submissions in flight fill the GPU by themselves: the per-submission graph is a linear chain (intra-frame
-        # fork/join only adds join latency then — measured 306 vs 250 frames/s)
+        # fork/join only adds join latency then — measured 254 vs 331 frames/s at two frames in flight)
         outs = self._graph_forward(P, points, tabs[0], tabs[1], tabs[2], pc_data_dict["feats"].contiguous(), img.contiguous(), mode, None,
                                    None, slot=slot, branch_mask=self.async_branch_mask,
                                    order=None if os.environ.get("COFI_NO_ORDER") else pc_data_dict.get("order"))
