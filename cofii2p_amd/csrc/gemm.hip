@@ -46,7 +46,27 @@ struct GemmArgs {
     // output pixel (m / Wo, m % Wo), column k is (tap = k / Cin, channel = k % Cin); K = ks*ks*Cin
     int cv_ks, cv_H, cv_W, cv_Cin, cv_Wo, cv_stride, cv_pad;
     int cv_Pout;  // output pixels per frame (stack mode: GEMM row m is frame m / cv_Pout, pixel m % cv_Pout)
+    int xcd;      // 0: hardware tile order; 1 + log2(gridDim.x): XCD-contiguous tile order (gemm_block_id)
+    unsigned xcd_rcp_gy;
 };
+
+// Tile coordinates of this workgroup.  The dispatcher hands workgroup L (x fastest, then y, then the K-split slice z) to XCD
+// L % 8, so with e.g. 8 column tiles every XCD owns ONE column of tiles and pulls the whole A operand through its private L2
+// (8x the algorithmic traffic).  xcd = 1 + log2(gridDim.x) re-numbers the workgroups so that each XCD works through one
+// CONTIGUOUS eighth of that order: the column tiles of a row panel of A run on the same XCD at the same time and A crosses the
+// fabric once; with split-K an XCD works on (part of) ONE K-slice and reads only that slice of W.
+// Power-of-two gridDim.x and an exact multiply-high reciprocal of gridDim.y: no division in the prologue of latency-bound launches.
+struct BlockId { int x, y, z; };
+__device__ __forceinline__ BlockId gemm_block_id(const GemmArgs &g) {
+    if (!g.xcd) return {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+    const int sh = g.xcd - 1, gy = gridDim.y, nblk = (gy * (int)gridDim.z) << sh;
+    const int l = ((blockIdx.z * gy + blockIdx.y) << sh) + blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, c = l & 7, i = l >> 3;   // bijective for any block count
+    const int t = (c < r ? c * (q + 1) : r * (q + 1) + (c - r) * q) + i;
+    const int yz = t >> sh;
+    const int z = g.xcd_rcp_gy ? (int)__umulhi((unsigned)yz, g.xcd_rcp_gy) : yz;   // rcp = ceil(2^32 / gy), exact for yz, gy < 2^16; 0: gy = 1
+    return {t & ((1 << sh) - 1), yz - z * gy, z};
+}
 
 // A-operand tile loader shared by both MFMA kernels: float4 number j of this thread covers row m0 + lrow + 32j,
 // k .. k+3.  Dense: A[row, k].  Convolution: the input pixel under tap k / Cin of output pixel `row`, zero
@@ -251,8 +271,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * g.kchunk;
+    const BlockId bid = gemm_block_id(g);
+    const int m0 = bid.y * BM, n0 = bid.x * BN;
+    const int kbeg = bid.z * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     const int ntiles = (kend - kbeg + BK - 1) / BK;
 
@@ -331,7 +352,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (row < g.M && col < g.N) g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = acc[i][j][r];
+                    if (row < g.M && col < g.N) g.ws[((size_t)bid.z * g.M + row) * g.N + col] = acc[i][j][r];
                 }
             }
         return;
@@ -351,7 +372,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                         }
             }
             __syncthreads();
-            rowwise_epilogue<64, BN, false>(g, lds, TLD, m0 + 64 * half, n0, 2 * blockIdx.y + half, lds);
+            rowwise_epilogue<64, BN, false>(g, lds, TLD, m0 + 64 * half, n0, 2 * bid.y + half, lds);
             __syncthreads();
         }
         return;
@@ -367,7 +388,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 lds[rl * TLD + wn * 32 * TN + j * 32 + li] = acc[i][j][r];
             }
     __syncthreads();
-    rowwise_epilogue<BM, BN, false>(g, lds, TLD, m0, n0, blockIdx.y, lds);  // `red` aliases the tile: it is written after a barrier
+    rowwise_epilogue<BM, BN, false>(g, lds, TLD, m0, n0, bid.y, lds);  // `red` aliases the tile: it is written after a barrier
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -450,8 +471,9 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = wave >> 2, wq = wave & 3;   // K share, position in the 2x2 wave grid
     const int wm = wq >> 1, wn = wq & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * g.kchunk;
+    const BlockId bid = gemm_block_id(g);
+    const int m0 = bid.y * BM, n0 = bid.x * BN;
+    const int kbeg = bid.z * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     const int ntiles = (kend - kbeg + BK3 - 1) / BK3;
     const int lrow = tid / LPR, lk = (tid % LPR) * 4;            // LPR lanes cover one row slice; RPP rows per pass
@@ -680,12 +702,12 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
             for (int e = tid; e < BM * BN; e += NT) {
                 const int rl = e / BN, cl = e - rl * BN;
                 const int row = m0 + rl, col = n0 + cl;
-                if (row < g.M && col < g.N) g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = lds[rl * TLD + cl];
+                if (row < g.M && col < g.N) g.ws[((size_t)bid.z * g.M + row) * g.N + col] = lds[rl * TLD + cl];
             }
             return;
         }
         // `red` of the epilogue aliases the tile: park it behind the tile instead (BUF >= tile + red, checked below)
-        rowwise_epilogue<BM, BN, false, NT>(g, lds, TLD, m0, n0, blockIdx.y, lds + BM * TLD);
+        rowwise_epilogue<BM, BN, false, NT>(g, lds, TLD, m0, n0, bid.y, lds + BM * TLD);
         return;
     }
     if (g.ksplit > 1) {
@@ -697,7 +719,7 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (row < g.M && col < g.N) g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = acc[i][j][r];
+                    if (row < g.M && col < g.N) g.ws[((size_t)bid.z * g.M + row) * g.N + col] = acc[i][j][r];
                 }
             }
         return;
@@ -718,7 +740,7 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
                         }
             }
             __syncthreads();
-            rowwise_epilogue<64, BN, false>(g, lds, TLD, m0 + 64 * half, n0, 2 * blockIdx.y + half, lds);
+            rowwise_epilogue<64, BN, false>(g, lds, TLD, m0 + 64 * half, n0, 2 * bid.y + half, lds);
             __syncthreads();
         }
         return;
@@ -733,7 +755,7 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
                 lds[rl * TLD + wn * 32 * TN + j * 32 + li] = acc[i][j][r];
             }
     __syncthreads();
-    rowwise_epilogue<BM, BN, false>(g, lds, TLD, m0, n0, blockIdx.y, lds);
+    rowwise_epilogue<BM, BN, false>(g, lds, TLD, m0, n0, bid.y, lds);
 }
 
 // split-K tail, same row-wise epilogue reading the partial sums.  Two tilings:
@@ -836,11 +858,35 @@ int latency_kw(const Plan &p, int M, int N) {
     return cfg.kw ? cfg.kw : (p.kchunk >= 4 * 128 ? 4 : 2);
 }
 
+// Tile order (GemmArgs::xcd): estimate the bytes both orders pull over the fabric — every XCD that touches a row panel of A
+// or a column panel of W reads it through its own L2 — and take the cheaper one.  COFI_GEMM_XCD = 0 / 1 forces hardware /
+// XCD-contiguous order for A/B runs.
+int xcd_order(const GemmArgs &g, const dim3 &grid) {
+    static const int mode = [] {
+        const char *e = getenv("COFI_GEMM_XCD");
+        return e ? atoi(e) : 2;
+    }();
+    const long gx = grid.x, gy = grid.y, gz = grid.z, nblk = gx * gy * gz;
+    if (mode == 0 || (gx & (gx - 1)) || nblk < 16 || gy * gz >= 65536) return 0;
+    const int enc = 1 + __builtin_ctzl(gx);
+    if (mode == 1) return enc;
+    auto gcd = [](long a, long b) { while (b) { long t = a % b; a = b; b = t; } return a; };
+    const double abytes = (double)g.M * g.K, wbytes = (double)g.N * g.K;
+    // hardware order: workgroup L -> XCD L % 8, L = (z*gy + y)*gx + x
+    const double rr = abytes * std::min(gx, 8L) + wbytes * std::min(gy, 8 / gcd(gx % 8 ? gx % 8 : 8, 8));
+    // contiguous order: XCD c owns workgroups [c*nblk/8, (c+1)*nblk/8) -> a K-slice of W is shared by ceil(8/gz) XCDs
+    const double a_rep = std::min(8.0, std::max(1.0, 8.0 * gx / nblk));
+    const double ct = abytes * a_rep + wbytes * std::min(std::min(gy, 8L), (8 + gz - 1) / gz);
+    return ct < rr ? enc : 0;
+}
+
 int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
     GemmArgs g = g0;
     g.ksplit = p.ksplit;
     g.kchunk = p.kchunk;
     dim3 grid(cofi_cdiv(g.N, p.bn), cofi_cdiv(g.M, p.bm), p.ksplit);
+    g.xcd = xcd_order(g, grid);
+    g.xcd_rcp_gy = grid.y > 1 ? (unsigned)((0x100000000ULL + grid.y - 1) / grid.y) : 0u;   // 0: gy = 1
     if (g.bf16x3) {
         const int kw = (p.bm == 64 && p.bn == 64) ? latency_kw(p, g.M, g.N) : 1;
 #define COFI_LAUNCH_BF16X3_W(BM_, BN_, TM_, TN_, BK_, KW_, WPE_)                                                                     \

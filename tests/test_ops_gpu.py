@@ -40,7 +40,9 @@ def close(a, b, tol=1e-4):
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 64, 32), (128, 128, 128), (1280, 512, 7680), (77, 33, 60), (1280, 1, 64), (2560, 1024, 3072),
-                                   (20480, 32, 64), (300, 200, 36), (5, 7, 4)])
+                                   (20480, 32, 64), (300, 200, 36), (5, 7, 4),
+                                   # XCD-contiguous tile order: 2 / 4 / 8 / 16 column tiles x a row-tile count that is not a multiple of 8
+                                   (2400, 256, 128), (4700, 512, 64), (1350, 1024, 256), (2368 + 13, 2048, 64)])
 def test_gemm(ops, M, N, K):
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     a = torch.randn(M, K, generator=g)
@@ -53,7 +55,8 @@ def test_gemm(ops, M, N, K):
     close(ops.gemm(G(a), G(w), bias=G(bias), act=ops.ACT_SIGMOID), torch.sigmoid(ref + bias.double()).float(), 2e-4)
 
 
-@pytest.mark.parametrize("M,N,K,groups", [(1280, 128, 128, 128), (1000, 64, 480, 32), (1280, 2048, 512, 32), (20480, 32, 128, 32), (77, 96, 36, 96)])
+@pytest.mark.parametrize("M,N,K,groups", [(1280, 128, 128, 128), (1000, 64, 480, 32), (1280, 2048, 512, 32), (20480, 32, 128, 32), (77, 96, 36, 96),
+                                          (4700, 512, 64, 32), (1350, 1024, 256, 32)])  # re-numbered tiles: slab id = remapped row tile
 def test_gemm_fused_column_statistics(ops, M, N, K, groups):
     g = torch.Generator().manual_seed(M + N)
     a, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
@@ -349,7 +352,8 @@ def test_matching_chain(ops, mg):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 128), (1280, 512, 7680), (77, 33, 60), (2560, 1024, 3072), (1280, 128, 256), (20480, 32, 64),
                                    # small grids with >= 3 K-tiles per workgroup: the two-tiles-in-flight configuration (odd / even / ragged tile counts)
-                                   (320, 256, 2304), (80, 512, 4608), (1280, 128, 1152), (100, 64, 1000), (64, 64, 384), (130, 60, 516)])
+                                   (320, 256, 2304), (80, 512, 4608), (1280, 128, 1152), (100, 64, 1000), (64, 64, 384), (130, 60, 516),
+                                   (2400, 256, 128), (4700, 512, 64), (1350, 1024, 256), (2381, 2048, 64)])  # XCD-contiguous tile order
 def test_gemm_bf16x3_split(ops, M, N, K, monkeypatch):
     """3-term bf16 split with fp32 accumulation: error ~2^-16 per product, i.e. well inside the 1e-3 budget"""
     monkeypatch.setattr(ops, "GEMM_MODE", "bf16x3")
