@@ -99,12 +99,14 @@ def _vec(t: Optional[torch.Tensor], name: str, n: int, dtype=torch.float32):
 class Workspace:
     """Grow-only device scratch, one per (purpose, device, stream).  Kernels are stream ordered, so reuse by
     consecutive calls on ONE stream is safe; concurrent streams (forked branches of the forward graph) each
-    get their own buffer."""
+    get their own buffer.  Growing never frees the old buffer: a hipGraph captured earlier (another input shape on the same
+    slot) keeps replaying with the address it recorded."""
 
     slot = 0  # frames-in-flight slot: concurrently replayed graphs must not share scratch (set_workspace_slot)
 
     def __init__(self):
         self.bufs = {}
+        self.retired = []   # outgrown buffers stay alive: a captured hipGraph may still hold their address
 
     def get(self, nbytes: int, device) -> Optional[torch.Tensor]:
         if nbytes == 0:
@@ -112,6 +114,8 @@ class Workspace:
         key = (device, torch.cuda.current_stream(device).cuda_stream, Workspace.slot)
         buf = self.bufs.get(key)
         if buf is None or buf.numel() < nbytes:
+            if buf is not None:
+                self.retired.append(buf)
             buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
             self.bufs[key] = buf
         return buf

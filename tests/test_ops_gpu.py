@@ -461,6 +461,18 @@ def test_loftr_layer_fused_tail_bf16x3(ops, mg, monkeypatch):
     close(loftr_layer(w, G(x), G(src)), O.loftr_layer({"l." + k: v for k, v in sd.items()}, "l.", x, src), 1e-4)
 
 
+def test_workspace_growth_keeps_captured_addresses(ops):
+    """a hipGraph captured on a slot records the scratch address; a later, larger request on the same slot must not free it"""
+    ws = ops.Workspace()
+    small = ws.get(1000, torch.device(DEV))
+    addr = small.data_ptr()
+    del small
+    big = ws.get(50_000_000, torch.device(DEV))
+    assert big.numel() >= 50_000_000 and big.data_ptr() != addr
+    assert any(r.data_ptr() == addr for r in ws.retired)
+    assert ws.get(2000, torch.device(DEV)).data_ptr() == big.data_ptr()   # grow-only: later small requests reuse the big buffer
+
+
 def test_multi_copy(ops):
     """batched device-to-device copy: mixed dtypes, odd byte counts, unaligned views, cached descriptor tables"""
     g = torch.Generator().manual_seed(5)
