@@ -16,59 +16,11 @@
 // a full buffer is bitonic-sorted across the wave and bitonic-merged into the list.  After the first
 // few hundred candidates almost nothing passes the threshold, so the stream runs at ~10 VALU
 // instructions per 64 distances.
-#include "common.h"
+#include "knn_common.h"
 
 namespace {
 
-typedef unsigned long long u64;
-constexpr u64 KEY_INF = 0x7f8000007fffffffull;  // (+inf, INT_MAX)
 constexpr int TILE = 1024;
-
-__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
-    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    lo = __shfl_xor(lo, m, 64);
-    hi = __shfl_xor(hi, m, 64);
-    return ((u64)hi << 32) | lo;
-}
-__device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
-    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    lo = __shfl(lo, src, 64);
-    hi = __shfl(hi, src, 64);
-    return ((u64)hi << 32) | lo;
-}
-__device__ __forceinline__ u64 umin64(u64 a, u64 b) { return a < b ? a : b; }
-__device__ __forceinline__ u64 umax64(u64 a, u64 b) { return a < b ? b : a; }
-
-// ascending bitonic sort of one key per lane
-__device__ __forceinline__ u64 wave_sort(u64 v, int lane) {
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const u64 p = shfl_xor_u64(v, j);
-            const bool up = (lane & k) == 0;
-            const bool lower = (lane & j) == 0;
-            v = (lower == up) ? umin64(v, p) : umax64(v, p);
-        }
-    }
-    return v;
-}
-// sorts a bitonic sequence held one key per lane into ascending order
-__device__ __forceinline__ u64 wave_bitonic_merge(u64 v, int lane) {
-#pragma unroll
-    for (int j = 32; j > 0; j >>= 1) {
-        const u64 p = shfl_xor_u64(v, j);
-        v = ((lane & j) == 0) ? umin64(v, p) : umax64(v, p);
-    }
-    return v;
-}
-
-__device__ __forceinline__ float canon_sqnorm(float x, float y, float z) { return (x * x + y * y) + z * z; }
-__device__ __forceinline__ float canon_dist(float qx, float qy, float qz, float qq, float4 s) {
-    const float dot = fmaf(qz, s.z, fmaf(qy, s.y, qx * s.x));
-    const float d = ((-2.0f * dot) + qq) + s.w;
-    return d < 1e-12f ? 1e-12f : d;
-}
 
 __global__ __launch_bounds__(1024) void knn_topk_kernel(const float *support, int S, const float *query, int Q, int k,
                                                         int32_t *out_idx, float *out_dist) {
@@ -84,23 +36,12 @@ __global__ __launch_bounds__(1024) void knn_topk_kernel(const float *support, in
         qz = query[3 * (size_t)q + 2];
     }
     const float qq = canon_sqnorm(qx, qy, qz);
-    u64 l0 = KEY_INF, l1 = KEY_INF;  // sorted best-128: rank lane (l0) and 64+lane (l1)
-    u64 tau = KEY_INF;
-    int nstage = 0;  // wave-uniform fill of stage[wave]
+    Best128 best;        // sorted best-128 of the query, admission threshold best.tau
+    int nstage = 0;      // wave-uniform fill of stage[wave]
 
     auto flush = [&]() {
-        u64 b = lane < nstage ? stage[wave][lane] : KEY_INF;
+        best.merge(lane < nstage ? stage[wave][lane] : KEY_INF, lane);
         nstage = 0;
-        b = wave_sort(b, lane);
-        // 64 smallest of (l1 U b): min(l1[i], b[63-i]) is bitonic
-        u64 t = umin64(l1, shfl_u64(b, 63 - lane));
-        t = wave_bitonic_merge(t, lane);
-        // merge sorted l0 with sorted t (128 keys): low/high halves are each bitonic
-        const u64 tr = shfl_u64(t, 63 - lane);
-        const u64 lo = umin64(l0, tr), hi = umax64(l0, tr);
-        l0 = wave_bitonic_merge(lo, lane);
-        l1 = wave_bitonic_merge(hi, lane);
-        tau = shfl_u64(l1, 63);
     };
 
     for (int t0 = 0; t0 < S; t0 += TILE) {
@@ -122,9 +63,9 @@ __global__ __launch_bounds__(1024) void knn_topk_kernel(const float *support, in
         for (int i = 0; i < nt; i += 64) {
             const int c = i + lane;
             const float4 sp = tile[c];
-            const float d = canon_dist(qx, qy, qz, qq, sp);
+            const float d = canon_dist(qx, qy, qz, qq, sp.x, sp.y, sp.z, sp.w);
             const u64 key = ((u64)__float_as_uint(d) << 32) | (unsigned)(t0 + c);
-            const bool pass = (c < nt) && key < tau;
+            const bool pass = (c < nt) && key < best.tau;
             const u64 mask = __ballot(pass);
             if (mask == 0) continue;
             const int n = __popcll(mask);
@@ -140,17 +81,7 @@ __global__ __launch_bounds__(1024) void knn_topk_kernel(const float *support, in
     }
     if (!active) return;
     if (nstage > 0) flush();
-    // emit ranks lane and 64+lane
-    if (lane < k) {
-        const int id = (int)(unsigned)(l0 & 0xffffffffu);
-        out_idx[(size_t)q * k + lane] = id == 0x7fffffff ? S : id;
-        if (out_dist) out_dist[(size_t)q * k + lane] = __uint_as_float((unsigned)(l0 >> 32));
-    }
-    if (64 + lane < k) {
-        const int id = (int)(unsigned)(l1 & 0xffffffffu);
-        out_idx[(size_t)q * k + 64 + lane] = id == 0x7fffffff ? S : id;
-        if (out_dist) out_dist[(size_t)q * k + 64 + lane] = __uint_as_float((unsigned)(l1 >> 32));
-    }
+    best.emit(q, k, S, lane, out_idx, out_dist);
 }
 
 // k = 1: nearest support row per query, lowest index on ties.  One wave per query; if sel != NULL
@@ -182,12 +113,16 @@ __global__ __launch_bounds__(256) void nearest_kernel(const float *nodes, int S,
             float4 sp;
             sp.x = px[u]; sp.y = py[u]; sp.z = pz[u];
             sp.w = canon_sqnorm(sp.x, sp.y, sp.z);
-            const float d = canon_dist(qx, qy, qz, qq, sp);
+            const float d = canon_dist(qx, qy, qz, qq, sp.x, sp.y, sp.z, sp.w);
             if (c < S) best = umin64(best, ((u64)__float_as_uint(d) << 32) | (unsigned)c);
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) best = umin64(best, shfl_xor_u64(best, o));
+    best = umin64(best, lane_xor64<32>(best, lane));
+    best = umin64(best, lane_xor64<16>(best, lane));
+    best = umin64(best, lane_xor64<8>(best, lane));
+    best = umin64(best, lane_xor64<4>(best, lane));
+    best = umin64(best, lane_xor64<2>(best, lane));
+    best = umin64(best, lane_xor64<1>(best, lane));
     if (lane == 0) out_idx[q] = (int)(unsigned)(best & 0xffffffffu);
 }
 

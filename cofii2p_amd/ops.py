@@ -646,11 +646,49 @@ class MultiCopy:
 
 
 # ------------------------------------------------------------------------------------------ KNN / indices
-def knn(support, query, k: int, return_dist: bool = False):
+KNN_GRID_MIN_SUPPORT = int(os.environ.get("COFI_KNN_GRID_MIN", "4096"))   # smaller support sets: brute force (a query needs a tenth of them anyway)
+
+
+def _check_xyz(t, name):
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.shape[1] != 3 or not t.is_contiguous():
+        raise _lib.CofiError("knn: %s must be contiguous CUDA float32 (n,3)" % name)
+
+
+class KnnGrid:
+    """Cell grid over one support set (cofi_knn_grid_build): build once, search it with any number of query sets.
+    `order` = the support indices in cell order (int32), a spatially coherent processing order for a self search."""
+
+    def __init__(self, support: torch.Tensor, want_order: bool = True):
+        lib = _lib.load()
+        _check_xyz(support, "support")
+        self.support, self.S = support, support.shape[0]
+        self.ws = torch.empty(lib.cofi_knn_grid_workspace(self.S), dtype=torch.uint8, device=support.device)
+        self.order = torch.empty((self.S,), dtype=torch.int32, device=support.device) if want_order else None
+        _lib.check(lib.cofi_knn_grid_build(_p(support), self.S, _p(self.ws), self.ws.numel(), _p(self.order), _stream()), "cofi_knn_grid_build")
+
+    def search(self, query: torch.Tensor, k: int, return_dist: bool = False, qorder: Optional[torch.Tensor] = None):
+        lib = _lib.load()
+        _check_xyz(query, "query")
+        Q = query.shape[0]
+        if qorder is not None and (qorder.dtype != torch.int32 or qorder.numel() != Q or not qorder.is_contiguous() or not qorder.is_cuda):
+            raise _lib.CofiError("knn: qorder must be a contiguous CUDA int32 permutation of the queries")
+        idx = torch.empty((Q, k), dtype=torch.int32, device=query.device)
+        dist = torch.empty((Q, k), dtype=torch.float32, device=query.device) if return_dist else None
+        _lib.check(lib.cofi_knn_topk_grid(_p(self.ws), self.ws.numel(), self.S, _p(query), _p(qorder), Q, k, _p(idx), _p(dist), _stream()),
+                   "cofi_knn_topk_grid")
+        return (idx, dist) if return_dist else idx
+
+
+def knn(support, query, k: int, return_dist: bool = False, grid=None, qorder=None):
+    """k nearest support rows per query row, ascending (distance, index).  grid: a KnnGrid of `support` (same results, fewer
+    distance evaluations); None = brute force (cofi_knn_topk)."""
+    if grid is not None:
+        if grid.support is not support and (grid.S != support.shape[0] or grid.support.data_ptr() != support.data_ptr()):
+            raise _lib.CofiError("knn: the grid was built over another support set")
+        return grid.search(query, k, return_dist, qorder)
     lib = _lib.load()
-    for t, n in ((support, "support"), (query, "query")):
-        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.shape[1] != 3 or not t.is_contiguous():
-            raise _lib.CofiError("knn: %s must be contiguous CUDA float32 (n,3)" % n)
+    _check_xyz(support, "support")
+    _check_xyz(query, "query")
     Q = query.shape[0]
     idx = torch.empty((Q, k), dtype=torch.int32, device=query.device)
     dist = torch.empty((Q, k), dtype=torch.float32, device=query.device) if return_dist else None

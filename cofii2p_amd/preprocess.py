@@ -35,16 +35,22 @@ def build_pyramid(points: torch.Tensor, subsample: List[torch.Tensor], k: int = 
     pts = [points.contiguous()]
     for sel in subsample:
         pts.append(pts[-1][sel.long()].contiguous())
+    # one cell grid per large stage, shared by the (up to three) searches against it; queries are processed in their own
+    # stage's cell order when it has one (neighbouring waves then read the same cells).  Small stages: brute force.
+    grids = [ops.KnnGrid(p) if p.shape[0] >= ops.KNN_GRID_MIN_SUPPORT else None for p in pts]
+    qord = [None if g is None else g.order for g in grids]
     neighbors, subsampling, upsampling = [], [], []
     for i in range(len(pts)):
-        neighbors.append(ops.knn(pts[i], pts[i], k))
+        neighbors.append(ops.knn(pts[i], pts[i], k, grid=grids[i], qorder=qord[i] if grids[i] is not None else None))
         if i < len(pts) - 1:
-            subsampling.append(ops.knn(pts[i], pts[i + 1], k))
-            upsampling.append(ops.knn(pts[i + 1], pts[i], k))
+            subsampling.append(ops.knn(pts[i], pts[i + 1], k, grid=grids[i], qorder=qord[i + 1] if grids[i] is not None else None))
+            upsampling.append(ops.knn(pts[i + 1], pts[i], k, grid=grids[i + 1], qorder=qord[i] if grids[i + 1] is not None else None))
     conv = ops.idx_to_int64 if int64 else (lambda t: t)
     return {"points": pts, "lengths": [int(p.shape[0]) for p in pts], "neighbors": [conv(t) for t in neighbors],
             "subsampling": [conv(t) for t in subsampling], "upsampling": [conv(t) for t in upsampling],
-            "order": [morton_order(p) for p in pts]}  # optional extra key: processing order of the gather kernels
+            # optional extra key: a spatially coherent processing order for the gather kernels (results do not depend on it) —
+            # the cell order of the stage's grid where there is one; the few thousand points of the small stages stay as they are
+            "order": [g.order if g is not None else torch.arange(p.shape[0], dtype=torch.int32, device=p.device) for g, p in zip(grids, pts)]}
 
 
 def precompute_point_cloud_stack_mode(points, intensity, normals, lengths, num_stages, device="cuda", rng: Optional[np.random.RandomState] = None):

@@ -72,6 +72,19 @@ const char *cofi_target_arch(void);
  */
 int cofi_knn_topk(const float *support, int S, const float *query, int Q, int k, int32_t *out_idx, float *out_dist,
                   cofi_stream_t stream);
+/* The same search (identical out_idx / out_dist, bit for bit) over a uniform 2-D cell grid of the support set: a query
+ * visits only the cells that can hold one of its k nearest (cofii2p_amd/csrc/knn_grid.hip states the pruning bound).
+ *   cofi_knn_grid_workspace(S)   bytes of `ws` (16-byte aligned device memory)
+ *   cofi_knn_grid_build(...)     bounding box, <= 128 x 128 cells of about 8 points, counting sort into cell order; optional
+ *                                order_out (S) int32 = the support indices in cell order (a spatially coherent query order
+ *                                for a self search)
+ *   cofi_knn_topk_grid(...)      wave per query against a built grid; qorder (Q) optional: wave w handles query qorder[w]
+ * One grid serves every search against that support set (neighbors[i], subsampling[i], upsampling[i-1] of
+ * preprocess_data.py:60-99 share stage i).  Worth it from a few thousand support points on; below that cofi_knn_topk. */
+size_t cofi_knn_grid_workspace(int S);
+int cofi_knn_grid_build(const float *support, int S, void *ws, size_t ws_bytes, int32_t *order_out, cofi_stream_t stream);
+int cofi_knn_topk_grid(const void *ws, size_t ws_bytes, int S, const float *query, const int32_t *qorder, int Q, int k,
+                       int32_t *out_idx, float *out_dist, cofi_stream_t stream);
 int cofi_nearest_node(const float *nodes, int S, const float *points, int Q, int32_t *out_idx, cofi_stream_t stream);
 /* like cofi_nearest_node, but the query rows are points_all[sel[i]] for i < *count_dev (count read
  * on the device: no host sync).  Used by the test-mode matching chain (network.py:152-153). */

@@ -317,6 +317,65 @@ def test_knn_bit_exact(ops, S, Q, k):
     assert np.array_equal(ops.nearest_node(G(sup), G(qry)).cpu().numpy().astype(np.int64), knn_c.nearest(sup, qry))
 
 
+def _knn_cases():
+    from cofii2p_amd.synth import make_frame
+
+    rs = np.random.RandomState(5)
+    kitti = make_frame(9, 20480).points
+    cube = rs.uniform(-20, 20, (8192, 3)).astype(np.float32)                                   # no thin axis: cells are columns
+    lattice = np.round(rs.uniform(-15, 15, (6000, 3)) * 2).astype(np.float32) / 2              # snapped: thousands of exact ties
+    line = np.zeros((5000, 3), np.float32); line[:, 0] = rs.uniform(-100, 100, 5000)           # two degenerate axes
+    same = np.tile(np.array([[3.0, -1.0, 7.0]], np.float32), (4200, 1))                        # all points identical: order by index
+    cluster = np.concatenate([rs.normal(0, 0.3, (6000, 3)), rs.uniform(-500, 500, (300, 3))]).astype(np.float32)
+    far_q = np.concatenate([kitti[:200], kitti[:200] + np.float32(400.0), kitti[:100] * np.float32(-3.0)])   # queries outside the box
+    return [("kitti self", kitti, kitti, 128), ("kitti sub", kitti, kitti[rs.choice(20480, 10240)], 128), ("kitti far", kitti, far_q, 128),
+            ("cube", cube, cube[:3000] + np.float32(0.01), 128), ("lattice", lattice, lattice, 128), ("line", line, line[:1500], 128),
+            ("same", same, same[:300], 128), ("cluster", cluster, cluster[::3], 128), ("k1", kitti[:5000], kitti[:700], 1),
+            ("k64", cube, cube[:999], 64), ("k65", cube, cube[:999], 65), ("tiny", kitti[:50], kitti[:64], 128),
+            ("one", kitti[:1], kitti[:5], 16)]
+
+
+def test_knn_grid_equals_brute_force(ops):
+    """the cell-grid search returns the brute-force kernel's rows bit for bit — indices and distances — on every geometry"""
+    for name, sup, qry, k in _knn_cases():
+        S, Q = G(sup), G(qry)
+        ib, db = ops.knn(S, Q, k, return_dist=True)
+        grid = ops.KnnGrid(S)
+        assert sorted(grid.order.cpu().tolist()) == list(range(sup.shape[0])), name        # cell order is a permutation
+        ig, dg = ops.knn(S, Q, k, return_dist=True, grid=grid)
+        assert torch.equal(ig, ib), name
+        assert torch.equal(dg, db), name
+        if qry.shape[0] == sup.shape[0]:                                                    # self search in cell order
+            io, do = ops.knn(S, Q, k, return_dist=True, grid=grid, qorder=grid.order)
+            assert torch.equal(io, ib) and torch.equal(do, db), name
+    with pytest.raises(Exception):
+        ops.knn(G(_knn_cases()[3][1]), G(_knn_cases()[3][2]), 16, grid=grid)               # grid of another support set
+
+
+def test_knn_grid_vs_c_oracle_and_pyramid(ops):
+    """grid search against oracle/knn_oracle.c directly, and build_pyramid (grids on the large stages) against the brute-force pyramid"""
+    from cofii2p_amd import preprocess
+    from cofii2p_amd.synth import make_frame, subsample_indices
+
+    pts = make_frame(13, 8192).points
+    rows = np.random.RandomState(1).choice(8192, 400, replace=False)
+    ic, dc = knn_c.knn(pts, pts[rows], 128, True)
+    sup = G(pts)
+    ig, dg = ops.knn(sup, G(pts[rows]), 128, return_dist=True, grid=ops.KnnGrid(sup))
+    assert np.array_equal(ig.cpu().numpy().astype(np.int64), ic) and np.array_equal(dg.cpu().numpy(), dc)
+    sub = [torch.from_numpy(s_).to(DEV) for s_ in subsample_indices(20480, 5, seed=3)]
+    p0 = G(make_frame(14, 20480).points)
+    got = preprocess.build_pyramid(p0, sub)
+    saved, ops.KNN_GRID_MIN_SUPPORT = ops.KNN_GRID_MIN_SUPPORT, 1 << 30
+    try:
+        want = preprocess.build_pyramid(p0, sub)
+    finally:
+        ops.KNN_GRID_MIN_SUPPORT = saved
+    for key in ("neighbors", "subsampling", "upsampling"):
+        for a, b in zip(got[key], want[key]):
+            assert torch.equal(a, b), key
+
+
 def test_idx_convert(ops):
     a = torch.randint(0, 20481, (1000, 128))
     assert torch.equal(ops.idx_to_int64(ops.idx_to_int32(G(a))).cpu(), a)
