@@ -500,6 +500,33 @@ def main():
         model.compute_unused_image_maps = True
         result["without_unread_resnet_maps"] = {"frames_per_s": args.steps / dtb, "ms_per_frame": 1e3 * dtb / args.steps,
                                                 "note": "batch 1; layer3/layer4/avg-pool of the image encoder skipped (outputs identical: nothing reads them)"}
+    if rank == 0 and world == 1 and Bsz == 1 and not args.no_batch_sweep:
+        # additional information, outside `value` (the reference's DataLoader builds the pyramid, preprocess_data.py:36-107): the 13
+        # KNN-128 searches of one frame's pyramid on this GPU, cell-grid search vs the brute-force kernel (identical tables)
+        from cofii2p_amd import ops as _ops
+        from cofii2p_amd.preprocess import build_pyramid
+        from cofii2p_amd.synth import subsample_indices
+
+        p0 = frames[0][0]["points"][0]
+        sub = [torch.from_numpy(s_).to(dev) for s_ in subsample_indices(args.points, 5, seed=1000)]
+
+        def pyramid_ms(n=20):
+            for _ in range(3):
+                build_pyramid(p0, sub)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                build_pyramid(p0, sub)
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t0) / n
+
+        saved = _ops.KNN_GRID_MIN_SUPPORT
+        grid_ms = pyramid_ms()
+        _ops.KNN_GRID_MIN_SUPPORT = 1 << 30
+        brute_ms = pyramid_ms()
+        _ops.KNN_GRID_MIN_SUPPORT = saved
+        result["knn_pyramid"] = {"ms_per_frame": grid_ms, "brute_force_ms_per_frame": brute_ms,
+                                 "note": "build_pyramid (5 stages, 13 searches, k = 128) as called from Python, one stream; not part of `value`"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(frames[0])
     if rank == 0:

@@ -3,7 +3,7 @@
 // but a query only visits the cells that can hold one of its k nearest.  Reference: model/kpconv/preprocess_data.py:109-143.
 //
 // Build (cofi_knn_grid_build): bounding box -> the two axes with the largest extent span a grid of <= 128 x 128 square cells
-// (about 8 points per cell) -> counting sort of the support into cell order as (x, y, z, original index) records.
+// (about 12 points per cell) -> counting sort of the support into cell order as (x, y, z, original index) records.
 //
 // Search (cofi_knn_topk_grid), one wave per query: stream the records of a block of cells around the query through the same
 // threshold filter / 64-key staging / wave-bitonic merge as the brute-force kernel (best 128 keys sorted across the wave), then
@@ -16,18 +16,20 @@
 // delta covers the rounding of the cell binning.  Skipped points therefore have keys strictly above the k-th key, and the keys
 // of visited points are computed by the same instructions as in the brute-force kernel: identical output.
 #include "knn_common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int GRID_MAX_DIM = 128;
 constexpr int GRID_MAX_CELLS = GRID_MAX_DIM * GRID_MAX_DIM;
-constexpr float GRID_TARGET_OCC = 8.0f;
 
 struct GridHeader {       // 64 bytes at the start of the workspace
     unsigned lo[3], hi[3];   // bounding box as order-preserving uints (atomicMin / atomicMax)
     unsigned ss_max;         // max |s|^2 (non-negative floats order like their bits)
     int S;
-    int pad[8];
+    float target_occ;        // points per cell the cell size aims at
+    float first_block;       // the first block of a query holds about first_block * k points
+    int pad[6];
 };
 static_assert(sizeof(GridHeader) == 64, "header layout");
 
@@ -38,7 +40,8 @@ struct GridParams {
 
 __host__ __device__ inline size_t grid_off_start() { return sizeof(GridHeader); }
 __host__ __device__ inline size_t grid_off_cursor() { return grid_off_start() + sizeof(int) * (GRID_MAX_CELLS + 4); }
-__host__ __device__ inline size_t grid_off_sorted() { return grid_off_cursor() + sizeof(int) * GRID_MAX_CELLS; }
+__host__ __device__ inline size_t grid_off_sorted() { return grid_off_cursor() + sizeof(int) * (GRID_MAX_CELLS + 4); }
+static_assert((sizeof(GridHeader) + 2 * sizeof(int) * (GRID_MAX_CELLS + 4)) % 16 == 0, "records are 16-byte aligned");
 
 __device__ __forceinline__ unsigned f2ord(float f) {
     const unsigned b = __float_as_uint(f);
@@ -65,7 +68,7 @@ __device__ __forceinline__ GridParams grid_params(const GridHeader *hd) {
     g.a0 = drop == 0 ? 1 : 0;
     g.a1 = drop == 2 ? 1 : 2;
     const float e0 = fmaxf(ext[g.a0], 1e-6f), e1 = fmaxf(ext[g.a1], 1e-6f);
-    float h = sqrtf(e0 * e1 * GRID_TARGET_OCC / (float)max(hd->S, 1));
+    float h = sqrtf(e0 * e1 * hd->target_occ / (float)max(hd->S, 1));
     h = fmaxf(h, fmaxf(e0, e1) / (float)(GRID_MAX_DIM - 1));   // at most GRID_MAX_DIM cells per axis
     h = fmaxf(h, 1e-6f);
     g.h = h;
@@ -87,7 +90,7 @@ __device__ __forceinline__ int grid_cell(const GridParams &g, float a, float b) 
 __device__ __forceinline__ float pick(float x, float y, float z, int a) { return a == 0 ? x : (a == 1 ? y : z); }
 
 // ------------------------------------------------------------------------------------------------ build
-__global__ void grid_init_kernel(GridHeader *hd, int *counts, int S) {
+__global__ void grid_init_kernel(GridHeader *hd, int *counts, int S, float target_occ, float first_block) {
     for (int i = threadIdx.x; i < GRID_MAX_CELLS + 4; i += blockDim.x) counts[i] = 0;
     if (threadIdx.x < 3) {
         hd->lo[threadIdx.x] = 0xffffffffu;
@@ -96,6 +99,8 @@ __global__ void grid_init_kernel(GridHeader *hd, int *counts, int S) {
     if (threadIdx.x == 3) {
         hd->ss_max = 0u;
         hd->S = S;
+        hd->target_occ = target_occ;
+        hd->first_block = first_block;
     }
 }
 
@@ -118,13 +123,24 @@ __global__ __launch_bounds__(256) void grid_bbox_kernel(const float *support, in
         }
         ssm = max(ssm, (unsigned)__shfl_xor((int)ssm, o, 64));
     }
+    __shared__ unsigned red[4][7];
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            atomicMin(&hd->lo[a], lo[a]);
-            atomicMax(&hd->hi[a], hi[a]);
+            red[wave][a] = lo[a];
+            red[wave][3 + a] = hi[a];
         }
-        atomicMax(&hd->ss_max, ssm);
+        red[wave][6] = ssm;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {   // 7 atomics per workgroup
+        const int c = threadIdx.x;
+        unsigned v = red[0][c];
+        for (int w = 1; w < 4; ++w) v = c < 3 ? min(v, red[w][c]) : max(v, red[w][c]);
+        if (c < 3) atomicMin(&hd->lo[c], v);
+        else if (c < 6) atomicMax(&hd->hi[c - 3], v);
+        else atomicMax(&hd->ss_max, v);
     }
 }
 
@@ -136,37 +152,31 @@ __global__ __launch_bounds__(256) void grid_count_kernel(const float *support, i
     }
 }
 
-// exclusive scan of the GRID_MAX_CELLS counts in place (-> cell_start, with cell_start[ncells..] = S) + a copy as scatter cursors
-__global__ __launch_bounds__(1024) void grid_scan_kernel(int *start, int *cursor) {
-    constexpr int PER = GRID_MAX_CELLS / 1024;
+// exclusive scan of the grid's cell counts in place (-> cell_start[0 .. ncells], cell_start[ncells] = S) + a copy as scatter cursors
+__global__ __launch_bounds__(1024) void grid_scan_kernel(const GridHeader *hd, int *start, int *cursor) {
     __shared__ int wsum[16];
+    const GridParams g = grid_params(hd);
+    const int n = g.nx * g.nz + 1;                 // the entry behind the last cell holds a zero count: it becomes S
+    const int per = (n + 1023) / 1024;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    int v[PER], sum = 0;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        v[j] = start[t * PER + j];
-        sum += v[j];
-    }
+    const int b = t * per, e = min(b + per, n);
+    int sum = 0;
+    for (int i = b; i < e; ++i) sum += start[i];
     int inc = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const int n = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += n;
+        const int v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
     }
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += wsum[w];
-    int run = base + inc - sum;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        start[t * PER + j] = run;
-        cursor[t * PER + j] = run;
-        run += v[j];
-    }
-    if (t == 1023) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) start[GRID_MAX_CELLS + j] = run;
+    int run = inc - sum;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    for (int i = b; i < e; ++i) {
+        const int c = start[i];
+        start[i] = run;
+        cursor[i] = run;
+        run += c;
     }
 }
 
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(64 * GW) void knn_grid_kernel(const GridHeader *__r
     const int cu = __builtin_amdgcn_readfirstlane(min(max((int)floorf((qa - g.x0) * g.inv_h), 0), nx - 1));
     const int cv = __builtin_amdgcn_readfirstlane(min(max((int)floorf((qb - g.z0) * g.inv_h), 0), nz - 1));
     const float occ = (float)S / (float)(nx * nz);
-    int r = max(1, (int)ceilf(0.5f * (sqrtf(1.5f * (float)k / fmaxf(occ, 1e-3f)) - 1.0f)));   // first block: about 1.5 k points
+    int r = max(1, (int)ceilf(0.5f * (sqrtf(hd->first_block * (float)k / fmaxf(occ, 1e-3f)) - 1.0f)));
     int ulo = max(cu - r, 0), uhi = min(cu + r, nx - 1), vlo = max(cv - r, 0), vhi = min(cv + r, nz - 1);
     int pulo = 1, puhi = 0, pvlo = 1, pvhi = 0;   // empty
     for (;;) {
@@ -307,11 +317,14 @@ extern "C" int cofi_knn_grid_build(const float *support, int S, void *ws, size_t
     GridHeader *hd = (GridHeader *)base;
     int *start = (int *)(base + grid_off_start()), *cursor = (int *)(base + grid_off_cursor());
     float4 *sorted = (float4 *)(base + grid_off_sorted());
-    const int nb = min(cofi_cdiv(S, 256), 1024);
-    hipLaunchKernelGGL(grid_init_kernel, dim3(1), dim3(1024), 0, s, hd, start, S);
-    hipLaunchKernelGGL(grid_bbox_kernel, dim3(nb), dim3(256), 0, s, support, S, hd);
+    const int nb = min(cofi_cdiv(S, 256), 1024), nb_box = min(cofi_cdiv(S, 1024), 64);
+    // tuning knobs (results never depend on them): points per cell, size of a query's first block in units of k
+    static const float target_occ = [] { const char *e = getenv("COFI_KNN_OCC"); return e ? fmaxf((float)atof(e), 0.5f) : 12.0f; }();
+    static const float first_block = [] { const char *e = getenv("COFI_KNN_FIRST"); return e ? fmaxf((float)atof(e), 0.1f) : 0.8f; }();
+    hipLaunchKernelGGL(grid_init_kernel, dim3(1), dim3(1024), 0, s, hd, start, S, target_occ, first_block);
+    hipLaunchKernelGGL(grid_bbox_kernel, dim3(nb_box), dim3(256), 0, s, support, S, hd);
     hipLaunchKernelGGL(grid_count_kernel, dim3(nb), dim3(256), 0, s, support, S, hd, start);
-    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, s, start, cursor);
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, s, (const GridHeader *)hd, start, cursor);
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(nb), dim3(256), 0, s, support, S, hd, cursor, sorted);
     if (order_out) hipLaunchKernelGGL(grid_order_kernel, dim3(nb), dim3(256), 0, s, sorted, S, order_out);
     return cofi_launch_status();

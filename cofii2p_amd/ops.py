@@ -646,7 +646,7 @@ class MultiCopy:
 
 
 # ------------------------------------------------------------------------------------------ KNN / indices
-KNN_GRID_MIN_SUPPORT = int(os.environ.get("COFI_KNN_GRID_MIN", "4096"))   # smaller support sets: brute force (a query needs a tenth of them anyway)
+KNN_GRID_MIN_SUPPORT = int(os.environ.get("COFI_KNN_GRID_MIN", "1024"))   # smaller support sets: brute force
 
 
 def _check_xyz(t, name):

@@ -75,7 +75,7 @@ int cofi_knn_topk(const float *support, int S, const float *query, int Q, int k,
 /* The same search (identical out_idx / out_dist, bit for bit) over a uniform 2-D cell grid of the support set: a query
  * visits only the cells that can hold one of its k nearest (cofii2p_amd/csrc/knn_grid.hip states the pruning bound).
  *   cofi_knn_grid_workspace(S)   bytes of `ws` (16-byte aligned device memory)
- *   cofi_knn_grid_build(...)     bounding box, <= 128 x 128 cells of about 8 points, counting sort into cell order; optional
+ *   cofi_knn_grid_build(...)     bounding box, <= 128 x 128 cells of about 12 points, counting sort into cell order; optional
  *                                order_out (S) int32 = the support indices in cell order (a spatially coherent query order
  *                                for a self search)
  *   cofi_knn_topk_grid(...)      wave per query against a built grid; qorder (Q) optional: wave w handles query qorder[w]

@@ -16,7 +16,7 @@ def timed(fn, n=10):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
 
-for name, thr in (("grid", 4096), ("grid>=2048", 2048), ("brute", 1 << 30)):
+for name, thr in (("grid", 4096), ("grid>=2048", 2048), ("grid>=1024", 1024), ("brute", 1 << 30)):
     ops.KNN_GRID_MIN_SUPPORT = thr
     print("%-12s pyramid %.3f ms/frame" % (name, timed(lambda: preprocess.build_pyramid(p0, sub))))
 pts = [p0]
@@ -29,7 +29,8 @@ for i in (0, 1, 2):
         timed(lambda: ops.knn(S, S, 128, grid=g, qorder=g.order)), timed(lambda: ops.knn(S, S, 128))))
 print("per search (ms): grid | brute")
 tot_g = tot_b = 0.0
-grids = [ops.KnnGrid(p) if p.shape[0] >= 4096 else None for p in pts]
+GMIN = int(os.environ.get("GMIN", "4096"))
+grids = [ops.KnnGrid(p) if p.shape[0] >= GMIN else None for p in pts]
 for i in range(len(pts)):
     todo = [("self%d" % i, pts[i], pts[i], grids[i])]
     if i < len(pts) - 1:
