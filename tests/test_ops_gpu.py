@@ -352,6 +352,34 @@ def test_knn_grid_equals_brute_force(ops):
         ops.knn(G(_knn_cases()[3][1]), G(_knn_cases()[3][2]), 16, grid=grid)               # grid of another support set
 
 
+def test_knn_grid_random_geometries(ops):
+    """randomised differential test of the pruning bound: anisotropic boxes, clusters, large offsets (where the canonical fp32
+    distance is dominated by rounding and the bound has to widen the search), lattices; every row bit-equal to brute force"""
+    rs = np.random.RandomState(77)
+    for case in range(40):
+        S = int(rs.choice([300, 1500, 4000, 9000]))
+        Q = int(rs.choice([64, 500, 1500]))
+        k = int(rs.choice([1, 7, 64, 100, 128]))
+        scale = rs.uniform(0.05, 60.0, 3) * rs.choice([1.0, 1e-3, 1.0, 1.0], 3)         # thin or flat boxes now and then
+        offset = rs.choice([0.0, 0.0, 50.0, 3000.0, -20000.0]) * rs.uniform(0.5, 1.0, 3)
+        kind = case % 4
+        if kind == 0:
+            sup = rs.uniform(-1, 1, (S, 3))
+        elif kind == 1:
+            sup = rs.normal(0, 0.2, (S, 3)) + rs.choice([-1.0, 0.0, 1.0], (S, 1))
+        elif kind == 2:
+            sup = np.round(rs.uniform(-1, 1, (S, 3)) * 6) / 6
+        else:
+            sup = np.concatenate([rs.uniform(-1, 1, (S - S // 8, 3)), rs.normal(0, 1e-3, (S // 8, 3))])
+        sup = (sup * scale + offset).astype(np.float32)
+        qry = sup[rs.choice(S, Q)] + (rs.normal(0, 1, (Q, 3)) * scale * rs.choice([0.0, 0.01, 0.5, 3.0])).astype(np.float32)
+        qry = qry.astype(np.float32)
+        Sg, Qg = G(sup), G(qry)
+        ib, db = ops.knn(Sg, Qg, k, return_dist=True)
+        ig, dg = ops.knn(Sg, Qg, k, return_dist=True, grid=ops.KnnGrid(Sg))
+        assert torch.equal(ig, ib) and torch.equal(dg, db), (case, S, Q, k, scale, offset)
+
+
 def test_knn_grid_vs_c_oracle_and_pyramid(ops):
     """grid search against oracle/knn_oracle.c directly, and build_pyramid (grids on the large stages) against the brute-force pyramid"""
     from cofii2p_amd import preprocess
