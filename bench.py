@@ -527,6 +527,32 @@ def main():
         _ops.KNN_GRID_MIN_SUPPORT = saved
         result["knn_pyramid"] = {"ms_per_frame": grid_ms, "brute_force_ms_per_frame": brute_ms,
                                  "note": "build_pyramid (5 stages, 13 searches, k = 128) as called from Python, one stream; not part of `value`"}
+        if S > 1 and not args.eager:
+            # ... and the whole chain on this GPU: every frame's pyramid is built on its frame stream right before its forward
+            model.enable_graphs(True)
+            st = [torch.cuda.Stream(device=dev) for _ in range(S)]
+            pend = [None] * S
+            feats0, img0 = frames[0][0]["feats"], frames[0][1]
+            for phase in range(2):
+                nfr = max(args.steps // 2, 2 * S)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(nfr):
+                    sl = i % S
+                    if pend[sl] is not None:
+                        model.finish(pend[sl])
+                    with torch.cuda.stream(st[sl]):
+                        pyr = build_pyramid(p0, sub)
+                        pyr["feats"] = feats0
+                        pend[sl] = model.forward_async(30 + sl, pyr, img0)
+                for sl in range(S):
+                    if pend[sl] is not None:
+                        model.finish(pend[sl])
+                        pend[sl] = None
+                torch.cuda.synchronize()
+                dte = time.perf_counter() - t0
+            result["with_pyramid_build"] = {"frames_per_s": nfr / dte, "ms_per_frame": 1e3 * dte / nfr,
+                                            "note": "pyramid construction (KNN) + forward + fine matching per frame on the same GPU; not the headline"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(frames[0])
     if rank == 0:
