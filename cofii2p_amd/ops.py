@@ -191,6 +191,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, b
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     _mat(out, "out")
     _vec(bias, "bias", N), _vec(rowdiv, "rowdiv", M)
+    if M == 0:   # zero rows: nothing to launch (torch hands out a null pointer for an empty tensor, which the C ABI rejects)
+        return out
     nbytes = lib.cofi_gemm_f32_workspace(M, N, K)
     ws = _WS_GEMM.get(nbytes, a.device)
     wp, wld, wflag = _wargs(w)
@@ -311,6 +313,8 @@ def neighbor_maxpool(x, idx, out=None, frames: int = 1, order=None):
     M, H = idx.shape
     if out is None:
         out = torch.empty((M, x.shape[1]), dtype=torch.float32, device=x.device)
+    if M == 0:
+        return out
     _lib.check(lib.cofi_neighbor_maxpool(_p(x), _ld(x), x.shape[0] // frames, x.shape[1], _p(idx), M // frames, H, _p(out), _ld(out),
                                          frames, _p(order), _stream()), "cofi_neighbor_maxpool")
     return out
@@ -326,6 +330,8 @@ def gather_rows(x, idx, out=None, frames: int = 1):
     stride = idx.stride(0) if idx.dim() == 2 else 1
     if out is None:
         out = torch.empty((M, x.shape[1]), dtype=torch.float32, device=x.device)
+    if M == 0:
+        return out
     _lib.check(lib.cofi_gather_rows(_p(x), _ld(x), x.shape[0] // frames, x.shape[1], _p(idx), stride, M // frames, _p(out), _ld(out),
                                     frames, _stream()), "cofi_gather_rows")
     return out
@@ -405,6 +411,8 @@ def layer_norm(x, gamma, beta, relu: bool = False, res=None, out=None, eps: floa
     M, C = x.shape
     if out is None:
         out = torch.empty((M, C), dtype=torch.float32, device=x.device)
+    if M == 0:
+        return out
     rc = lib.cofi_layer_norm(_p(x), _ld(x), M, C, _p(gamma), _p(beta), eps, int(relu), _p(res), 0 if res is None else _ld(res), _p(out),
                              _ld(out), _stream())
     _lib.check(rc, "cofi_layer_norm")
@@ -425,6 +433,8 @@ def l2norm_rows(x, out=None, transpose: bool = False):
     M, C = x.shape
     if out is None:
         out = torch.empty((C, M) if transpose else (M, C), dtype=torch.float32, device=x.device)
+    if M == 0:
+        return out
     _lib.check(lib.cofi_l2norm_rows(_p(x), _ld(x), M, C, _p(out), _ld(out), int(transpose), _stream()), "cofi_l2norm_rows")
     return out
 
@@ -674,6 +684,8 @@ class KnnGrid:
             raise _lib.CofiError("knn: qorder must be a contiguous CUDA int32 permutation of the queries")
         idx = torch.empty((Q, k), dtype=torch.int32, device=query.device)
         dist = torch.empty((Q, k), dtype=torch.float32, device=query.device) if return_dist else None
+        if Q == 0:
+            return (idx, dist) if return_dist else idx
         _lib.check(lib.cofi_knn_topk_grid(_p(self.ws), self.ws.numel(), self.S, _p(query), _p(qorder), Q, k, _p(idx), _p(dist), _stream()),
                    "cofi_knn_topk_grid")
         return (idx, dist) if return_dist else idx
@@ -692,6 +704,10 @@ def knn(support, query, k: int, return_dist: bool = False, grid=None, qorder=Non
     Q = query.shape[0]
     idx = torch.empty((Q, k), dtype=torch.int32, device=query.device)
     dist = torch.empty((Q, k), dtype=torch.float32, device=query.device) if return_dist else None
+    if Q == 0:
+        return (idx, dist) if return_dist else idx
+    if support.shape[0] == 0:
+        raise _lib.CofiError("knn: empty support set")
     _lib.check(lib.cofi_knn_topk(_p(support), support.shape[0], _p(query), Q, k, _p(idx), _p(dist), _stream()), "cofi_knn_topk")
     return (idx, dist) if return_dist else idx
 
@@ -699,6 +715,10 @@ def knn(support, query, k: int, return_dist: bool = False, grid=None, qorder=Non
 def nearest_node(nodes, points):
     lib = _lib.load()
     out = torch.empty((points.shape[0],), dtype=torch.int32, device=points.device)
+    if points.shape[0] == 0:
+        return out
+    if nodes.shape[0] == 0:
+        raise _lib.CofiError("nearest_node: empty node set")
     _lib.check(lib.cofi_nearest_node(_p(nodes.contiguous()), nodes.shape[0], _p(points.contiguous()), points.shape[0], _p(out), _stream()),
                "cofi_nearest_node")
     return out

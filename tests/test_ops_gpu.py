@@ -404,6 +404,28 @@ def test_knn_grid_vs_c_oracle_and_pyramid(ops):
             assert torch.equal(a, b), key
 
 
+def test_zero_row_inputs(ops):
+    """zero query / activation rows are no-ops that return correctly shaped empty results; empty support sets are errors"""
+    z = lambda *shape, dt=torch.float32: torch.zeros(*shape, dtype=dt, device=DEV)
+    sup = G(np.random.RandomState(0).normal(size=(2000, 3)).astype(np.float32))
+    assert ops.knn(sup, z(0, 3), 16).shape == (0, 16)
+    i0, d0 = ops.knn(sup, z(0, 3), 16, return_dist=True, grid=ops.KnnGrid(sup))
+    assert i0.shape == (0, 16) and d0.shape == (0, 16) and i0.dtype == torch.int32
+    assert ops.nearest_node(sup, z(0, 3)).shape == (0,)
+    assert ops.gemm(z(0, 64), G(torch.randn(32, 64))).shape == (0, 32)
+    assert ops.gather_rows(sup, z(0, dt=torch.int32)).shape == (0, 3)
+    assert ops.neighbor_maxpool(G(torch.randn(10, 32)), z(0, 128, dt=torch.int32)).shape == (0, 32)
+    assert ops.l2norm_rows(z(0, 64)).shape == (0, 64) and ops.l2norm_rows(z(0, 64), transpose=True).shape == (64, 0)
+    assert ops.layer_norm(z(0, 64), G(torch.ones(64)), G(torch.zeros(64))).shape == (0, 64)
+    cnt = torch.zeros(2, dtype=torch.int32, device=DEV)                       # a frame with no accepted match: kernels read count = 0
+    fxy, best = ops.fine_match(z(8, 64, 16), z(8, 64), z(2, 8), cnt, 1.0)
+    assert fxy.shape == (2, 8) and best.shape == (8,)
+    for bad in (lambda: ops.knn(z(0, 3), sup[:5].contiguous(), 16), lambda: ops.KnnGrid(z(0, 3)), lambda: ops.nearest_node(z(0, 3), sup[:5].contiguous())):
+        with pytest.raises(Exception):
+            bad()
+    torch.cuda.synchronize()
+
+
 def test_idx_convert(ops):
     a = torch.randint(0, 20481, (1000, 128))
     assert torch.equal(ops.idx_to_int64(ops.idx_to_int32(G(a))).cpu(), a)
