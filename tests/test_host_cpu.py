@@ -99,3 +99,17 @@ def test_spec_tables():
     assert abs(spec.ENCODER[-1].sigma - 3.2) < 1e-6 and spec.stage_sizes(20480) == [20480, 10240, 5120, 2560, 1280]
     kp = spec.synth_state_dict()["pc_encoder.encoder3_2.KPConv.kernel_points"]
     assert kp.shape == (15, 3) and np.allclose(kp[0], 0) and abs(np.linalg.norm(kp[1]) - 0.66 * 0.425 * 4) < 1e-5
+
+
+def test_integration_md_ctypes_example_matches_the_abi():
+    """the binding stub INTEGRATION.md shows a maintainer must declare as many arguments as the header / binding table"""
+    import re
+
+    from cofii2p_amd import _lib
+
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    found = re.findall(r"_lib\.(cofi_\w+)\.argtypes = \[(.*?)\]", text, re.S)
+    assert len(found) >= 3
+    for name, body in found:
+        n = len([x for x in body.replace("\n", " ").split(",") if x.strip()])
+        assert n == len(_lib.SIGNATURES[name][1]), name
