@@ -393,6 +393,10 @@ def main():
             "on the exact fp32 MFMA" if args.gemm == "f32" else
             "as a 3-term bf16 split (hi*hi + hi*lo + lo*hi) on the bf16 matrix cores: 4e-6 max abs deviation from the reference's "
             "outputs on the golden frame (budget 1e-3)"),
+        # north star / SURVEY.md 8(d): throughput as a fraction of the attention roofline = frames/s x 13.42 GFLOP of attention per
+        # frame (4 self + 4 cross layers over both token streams: 4 * 512 * (1280 + 1280)^2) / the fp32 MFMA peak of the GPUs used (attention runs on v_mfma_f32_16x16x4_f32)
+        "attention_roofline_frac": (world * args.steps * Bsz / dt) * 4 * 512 * ((Opt.img_H // 8) * (Opt.img_W // 8) + args.points // 16) ** 2
+                                   / (world * FP32_MFMA_PEAK_TF * 1e12),
         "config": {"workload": "KITTI-shape synthetic frame (160x512 image, %d points, KNN-128 pyramid resident in HBM), batch %d, "
                                "CoFiI2P.forward(mode='test') + fine matching, one %s per step per GPU"
                                % (args.points, Bsz, "frame" if Bsz == 1 else "stack-mode batch of %d frames" % Bsz),
