@@ -15,6 +15,15 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cofi_hip.h")
 c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 _P, _I, _F, _Z = c_void_p, c_int, c_float, c_size_t
 
+
+class NormDesc(ctypes.Structure):
+    """cofi_norm_desc_t (include/cofi_hip.h): a pending GroupNorm / InstanceNorm described by its statistics partials."""
+    _fields_ = [("partials", c_void_p), ("nslab", c_int), ("width", c_int), ("channels", c_int), ("groups", c_int),
+                ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("slope", c_float)]
+
+
+_N = ctypes.POINTER(NormDesc)
+
 # name -> (restype, argtypes); mirrors include/cofi_hip.h declaration by declaration
 SIGNATURES = {
     "cofi_abi_version": (_I, []),
@@ -33,39 +42,39 @@ SIGNATURES = {
     "cofi_gather_rows": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P]),
     "cofi_gemm_f32_workspace": (_Z, [_I, _I, _I]),
     "cofi_gemm_f32": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _Z, _P]),
-    "cofi_gemm_debug_force_plan": (_I, [_I, _I, _I]),
     "cofi_split_bf16_planes": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "cofi_gemm_f32_stat_slabs": (_I, [_I, _I, _I]),
     "cofi_gemm_f32_colstats": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _Z, _P]),
+    "cofi_gemm_f32_fused": (_I, [_P, _I, _N, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _Z, _I, _P]),
     "cofi_gemm_f32_layernorm": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _F, _I, _P, _I, _P, _Z, _P]),
     "cofi_group_stats_from_colpart": (_I, [_P, _I, _I, _I, _I, _F, _P, _I, _P]),
-    "cofi_col_inv_norm_from_colpart": (_I, [_P, _I, _I, _I, _F, _P, _I, _P]),
+    "cofi_col_inv_norm_from_colpart": (_I, [_P, _I, _I, _I, _I, _F, _P, _I, _P]),
     "cofi_group_stats_workspace": (_Z, [_I, _I, _I, _I]),
     "cofi_group_stats": (_I, [_P, _I, _I, _I, _I, _F, _P, _P, _Z, _I, _P]),
     "cofi_group_norm_apply": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _F, _P, _I, _P, _I, _P]),
-    "cofi_group_norm_apply_colpart": (_I, [_P, _I, _I, _I, _I, _P, _I, _F, _P, _P, _P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _I, _P]),
+    "cofi_group_norm_apply_partials": (_I, [_P, _I, _I, _I, _N, _P, _I, _N, _P, _I, _P, _I, _P]),
     "cofi_layer_norm": (_I, [_P, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _I, _P]),
     "cofi_loftr_tail_bf16x3": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
-    "cofi_attention_workspace": (_Z, [_I, _I, _I, _I]),
+    "cofi_loftr_tail_parts_bf16x3": (_I, [_P, _Z, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P]),
+    "cofi_attention_workspace": (_Z, [_I, _I, _I, _I, _I]),
+    "cofi_attention_parts": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _F, _I, _I, _I, _I, _F, _I, _P, _Z, _P]),
+    "cofi_attention_merge": (_I, [_P, _Z, _I, _I, _I, _I, _I, _P, _I, _P]),
     "cofi_attention_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P, _Z, _I, _P]),
-    "cofi_attention_fwd_colpart": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _F, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
+    "cofi_attention_fwd_colpart": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _F, _P, _I, _I, _I, _I, _I, _F, _P, _Z, _I, _P]),
     "cofi_col_inv_norm": (_I, [_P, _I, _I, _I, _F, _P, _P]),
     "cofi_pos_sine": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _P, _I, _P]),
     "cofi_l2norm_rows": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
     "cofi_transpose": (_I, [_P, _I, _I, _I, _P, _I, _P]),
-    "cofi_l2norm_cols": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P]),
+    "cofi_col_mean": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "cofi_conv2d_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _Z, _I, _P]),
+    "cofi_conv2d_nhwc_fused": (_I, [_P, _I, _N, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P, _Z, _I, _P]),
     "cofi_im2col_stem": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "cofi_maxpool3x3s2_nhwc": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "cofi_upsample2x_cat_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P]),
     "cofi_extract_patches_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _F, _P, _I, _P, _P]),
-    "cofi_instance_norm_nchw": (_I, [_P, _I, _I, _F, _P, _I, _I, _P, _P]),
-    "cofi_bias_act_nchw": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
-    "cofi_upsample2x_cat": (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
     "cofi_row_argmin_1m": (_I, [_P, _I, _I, _I, _P, _P]),
-    "cofi_select_matches": (_I, [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P]),
+    "cofi_select_matches": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P]),
     "cofi_gather_points_sel": (_I, [_P, _P, _P, _I, _P, _P]),
-    "cofi_extract_patches": (_I, [_P, _I, _I, _I, _P, _I, _F, _P, _I, _P, _P]),
     "cofi_gather_rows_sel": (_I, [_P, _I, _I, _P, _P, _I, _P, _I, _P]),
     "cofi_multi_copy": (_I, [_P, _I, _I, _P]),
     "cofi_pnp_ransac_workspace": (_Z, [_I]),

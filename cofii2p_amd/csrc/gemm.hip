@@ -21,6 +21,7 @@
 // Deep-K / small-MN problems are split over K (gridDim.z) into a workspace and reduced in fixed
 // order by splitk_epilogue_kernel (same row-wise epilogue): deterministic, no float atomics.
 #include "common.h"
+#include "stat_fold.h"
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -48,6 +49,12 @@ struct GemmArgs {
     int cv_Pout;  // output pixels per frame (stack mode: GEMM row m is frame m / cv_Pout, pixel m % cv_Pout)
     int xcd;      // 0: hardware tile order; 1 + log2(gridDim.x): XCD-contiguous tile order (gemm_block_id)
     unsigned xcd_rcp_gy;
+    int stat_shift;   // colpart holds one entry per 2^stat_shift adjacent columns: (nslab, N >> stat_shift, 2)
+    // pending normalisation of the A operand (stat_fold.h): the loader applies  a -> leaky(a * sc[c] + sh[c])  to every element
+    // it stages, c = column of a dense A / input channel of a convolution; an.part == nullptr: none.  an_rows = GEMM rows per
+    // frame (tiles never straddle frames: host-checked).
+    NormSrc an;
+    int an_rows;
 };
 
 // Tile coordinates of this workgroup.  The dispatcher hands workgroup L (x fastest, then y, then the K-split slice z) to XCD
@@ -253,9 +260,24 @@ __device__ __forceinline__ void rowwise_epilogue(const GemmArgs &g, const float 
                 s += red[(p * BN + threadIdx.x) * 2 + 0];
                 q += red[(p * BN + threadIdx.x) * 2 + 1];
             }
-            float *o = g.colpart + ((size_t)slab * g.N + n0 + threadIdx.x) * 2;
-            o[0] = s;
-            o[1] = q;
+            if (g.stat_shift) {
+                // one table entry per 2^stat_shift adjacent columns (<= BN, aligned: a group never leaves the tile, and N is a
+                // multiple of the width, so the lanes of a group are all active): fp64 butterfly, fixed order
+                double ds = s, dq = q;
+                for (int o = 1; o < (1 << g.stat_shift); o <<= 1) {
+                    ds += __shfl_xor(ds, o, 64);
+                    dq += __shfl_xor(dq, o, 64);
+                }
+                if ((threadIdx.x & ((1u << g.stat_shift) - 1)) == 0) {
+                    float *o = g.colpart + ((size_t)slab * (g.N >> g.stat_shift) + ((n0 + threadIdx.x) >> g.stat_shift)) * 2;
+                    o[0] = (float)ds;
+                    o[1] = (float)dq;
+                }
+            } else {
+                float *o = g.colpart + ((size_t)slab * g.N + n0 + threadIdx.x) * 2;
+                o[0] = s;
+                o[1] = q;
+            }
         }
     }
 }
@@ -447,7 +469,11 @@ __global__ void split_planes_kernel(const float *W, int ldw, int N, int K, unsig
 //           accumulators are summed through LDS in a fixed order at the end.  A workgroup that is alone on its CU (small
 //           grids) is bound by the serial chain load -> split -> LDS -> MFMA of ONE wave per SIMD (~2 us per 128-deep tile,
 //           measured); KW waves per SIMD split the conversion work KW ways and overlap each other's phases.
-template <int BM, int BN, int TM, int TN, int BK3, int KW = 1, bool WSPLIT = false, int WPE = 1>
+// ANORM: the A operand carries a pending GroupNorm / InstanceNorm (+ affine + LeakyReLU) of the producing layer (GemmArgs::an):
+//        the workgroup folds the producer's statistics partials itself while its first tile is in flight, keeps the per-channel
+//        scale / shift in LDS and normalises every A element on its way into the bf16 planes - the stand-alone normalisation
+//        kernel, its statistics kernel and one round trip of the activation through HBM disappear.
+template <int BM, int BN, int TM, int TN, int BK3, int KW = 1, bool WSPLIT = false, int WPE = 1, bool ANORM = false>
 __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
     static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 waves");
     constexpr int NT = 256 * KW;
@@ -466,7 +492,10 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
     constexpr int EPI = (BM == 128 ? 64 : BM) * TLD * 4 + (KW > 1 ? (NT / (BN / 4)) * BN * 2 * 4 : 0);   // BM = 128: two 64-row halves
     constexpr int LDS_BYTES = BUF > EPI ? BUF : EPI;
     static_assert((NT / (BN / 4)) * BN * 2 * 4 <= LDS_BYTES, "column-statistics scratch must fit");
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    constexpr int AN_MAXC = 512;                                 // channels of a normalised A operand (scale + shift table behind the buffers)
+    static_assert(!ANORM || (NT * 16 + AN_MAXC * 8 <= LDS_BYTES), "statistics fold scratch must fit in the operand buffer");
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES + (ANORM ? AN_MAXC * 8 : 0)];
+    float *nsc = reinterpret_cast<float *>(lds_raw + LDS_BYTES), *nsh = nsc + AN_MAXC;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = wave >> 2, wq = wave & 3;   // K share, position in the 2x2 wave grid
@@ -520,11 +549,13 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
     // a loaded value - and no s_waitcnt is needed - until after the MFMAs.  Full dense tiles carry no mask at all.
     unsigned amask = 0;
     bool afull = false;   // uniform: the A registers hold a full dense tile (no zeroing needed)
+    int achan = 0;        // ANORM: first of the 4 channels the staged float4s of this thread belong to
     auto gload = [&](int t) {
         const bool full = kbeg + (t + 1) * BK3 <= kend;   // uniform
         const int k = kbeg + t * BK3 + lk;
         const bool kin = k < kend;
         if (!conv) {
+            if constexpr (ANORM) achan = kin ? k : 0;
             afull = full;
             const char *at = abase + (size_t)t * (BK3 * 4);
             if (full) {
@@ -540,6 +571,7 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
             const int kc = kin ? k : 0;
             const int tap = kc / g.cv_Cin, c = kc - tap * g.cv_Cin;
             const int dy = tap / g.cv_ks, dx = tap - dy * g.cv_ks;
+            if constexpr (ANORM) achan = c;
             amask = 0;
 #pragma unroll
             for (int j = 0; j < A_LD4; ++j) {
@@ -582,6 +614,18 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
     };
     auto sstore = [&]() {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (ANORM) {
+            // the pending normalisation of the producer: y * sc + sh, LeakyReLU as max(v, v * slope) (0 <= slope <= 1) - the
+            // same operations in the same order as the stand-alone apply kernel.  Zero padding / K tails are masked afterwards.
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(nsc + achan), sh = *reinterpret_cast<const f32x4 *>(nsh + achan);
+#pragma unroll
+            for (int j = 0; j < A_LD4; ++j) {
+                f32x4 v = ra[j] * sc + sh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * g.an.slope;
+                ra[j] = v;
+            }
+        }
         if (afull) {
 #pragma unroll
             for (int j = 0; j < A_LD4; ++j) {
@@ -662,10 +706,18 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
     // tile t+1 -> barrier.  (Measured on MI355X: deeper register prefetch (2-3 tiles in flight, exact vmcnt) and a second LDS
     // buffer do NOT shorten the ~1 us a lone workgroup spends per 64 KB tile - that is the CU's L2 fill rate; only spreading
     // the tiles over more CUs does, which is what split-K is tuned for.)
-    if (ntiles > 0) {
-        gload(0);
-        sstore();
+    if (ntiles > 0) gload(0);
+    if constexpr (ANORM) {
+        // statistics of this tile's frame -> scale / shift table (fold scratch lives in the still unused operand buffer)
+        const int f = g.an_rows > 0 ? m0 / g.an_rows : 0;
+        double *dred = reinterpret_cast<double *>(lds_raw);
+        float *sstat = reinterpret_cast<float *>(lds_raw + NT * 16);
+        fold_stat_table<NT>(g.an.part + (size_t)f * g.an.nslab * g.an.tcols * 2, g.an.nslab, g.an.tcols, g.an.groups, g.an.count, g.an.eps,
+                            dred, sstat);
+        norm_scale_shift<NT>(g.an, sstat, nsc, nsh);
+        __syncthreads();
     }
+    if (ntiles > 0) sstore();
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles) gload(t + 1);
@@ -763,9 +815,10 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
 //                          even M = 1280, N = 256 still gives 160 workgroups;
 //   16 rows x 128 columns (fused LayerNorm): a tile spans whole rows (N <= 128).
 constexpr int SK_ROWS = 64, SK_COLS = 32, SKLN_ROWS = 16;
+template <int COLS>   // 32; 64 when a statistics table entry spans 64 columns
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs g) {
-    __shared__ float red[32 * SK_COLS * 2];
-    rowwise_epilogue<SK_ROWS, SK_COLS, true>(g, nullptr, 0, blockIdx.y * SK_ROWS, blockIdx.x * SK_COLS, blockIdx.y, red);
+    __shared__ float red[(256 / (COLS / 4)) * COLS * 2];
+    rowwise_epilogue<SK_ROWS, COLS, true>(g, nullptr, 0, blockIdx.y * SK_ROWS, blockIdx.x * COLS, blockIdx.y, red);
 }
 __global__ __launch_bounds__(256) void splitk_epilogue_ln_kernel(GemmArgs g) {
     rowwise_epilogue<SKLN_ROWS, 128, true>(g, nullptr, 0, blockIdx.y * SKLN_ROWS, blockIdx.x * 128, blockIdx.y, nullptr);
@@ -889,12 +942,14 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
     g.xcd_rcp_gy = grid.y > 1 ? (unsigned)((0x100000000ULL + grid.y - 1) / grid.y) : 0u;   // 0: gy = 1
     if (g.bf16x3) {
         const int kw = (p.bm == 64 && p.bn == 64) ? latency_kw(p, g.M, g.N) : 1;
-#define COFI_LAUNCH_BF16X3_W(BM_, BN_, TM_, TN_, BK_, KW_, WPE_)                                                                     \
-    do {                                                                                                                           \
-        if (g.wsplit)                                                                                                              \
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, true, WPE_>), grid, dim3(256 * KW_), 0, s, g);    \
-        else                                                                                                                       \
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, false, WPE_>), grid, dim3(256 * KW_), 0, s, g);   \
+#define COFI_LAUNCH_BF16X3_W(BM_, BN_, TM_, TN_, BK_, KW_, WPE_)                                                                            \
+    do {                                                                                                                                  \
+        if (g.an.part)                                                                                                                    \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, true, WPE_, true>), grid, dim3(256 * KW_), 0, s, g);     \
+        else if (g.wsplit)                                                                                                                \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, true, WPE_, false>), grid, dim3(256 * KW_), 0, s, g);    \
+        else                                                                                                                              \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, false, WPE_, false>), grid, dim3(256 * KW_), 0, s, g);   \
     } while (0)
 #define COFI_LAUNCH_BF16X3(BM_, BN_, TM_, TN_, BK_, KW_) COFI_LAUNCH_BF16X3_W(BM_, BN_, TM_, TN_, BK_, KW_, 1)
         // K-tile depth per tile shape (measured): the 128x128 tile is register-bound at 2 waves per SIMD either way; the 64x128 and
@@ -921,8 +976,10 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
     if (p.ksplit > 1) {
         if (g.ln_gamma)
             hipLaunchKernelGGL(splitk_epilogue_ln_kernel, dim3(1, cofi_cdiv(g.M, SKLN_ROWS)), dim3(256), 0, s, g);
+        else if (g.colpart && g.stat_shift > 5)
+            hipLaunchKernelGGL(splitk_epilogue_kernel<64>, dim3(cofi_cdiv(g.N, 64), cofi_cdiv(g.M, SK_ROWS)), dim3(256), 0, s, g);
         else
-            hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(cofi_cdiv(g.N, SK_COLS), cofi_cdiv(g.M, SK_ROWS)), dim3(256), 0, s, g);
+            hipLaunchKernelGGL(splitk_epilogue_kernel<SK_COLS>, dim3(cofi_cdiv(g.N, SK_COLS), cofi_cdiv(g.M, SK_ROWS)), dim3(256), 0, s, g);
     }
     return cofi_launch_status();
 }
@@ -932,6 +989,76 @@ int check_common(const float *A, int lda, const float *W, int ldw, float *C, int
     if ((K & 3) || (lda & 3) || (ldw & 3) || lda < K || ldw < K || ldc < N) return COFI_EINVAL;
     if (((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return COFI_EINVAL;
     return 0;
+}
+
+// log2 of the statistics table width, or -1 if it cannot be used with N columns
+int stat_shift_of(int width, int N) {
+    if (width <= 0 || width > 64 || (width & (width - 1)) || (N % width)) return -1;
+    int sh = 0;
+    while ((1 << sh) < width) ++sh;
+    return sh;
+}
+
+// the pending normalisation of the A operand; channels = columns of a dense A / input channels of a convolution.
+// Runs on the bf16x3 kernels with pre-split weights only.
+int set_a_norm(GemmArgs &g, const cofi_norm_desc_t *a_norm, int channels, int a_rows_per_frame, int frames, const Plan &p) {
+    if (!a_norm) return 0;
+    if (!g.bf16x3 || !g.wsplit) return COFI_EUNSUPPORTED;
+    if (a_norm->channels != channels) return COFI_EINVAL;
+    if (int rc = make_norm_src(a_norm, a_rows_per_frame, frames, 512, &g.an)) return rc;
+    if (!(g.an.slope >= 0.f && g.an.slope <= 1.f)) return COFI_EINVAL;
+    // a tile of GEMM rows must lie inside one frame
+    g.an_rows = g.M / frames;
+    if (frames > 1 && (g.M % frames || (g.an_rows % p.bm))) return COFI_EUNSUPPORTED;
+    return 0;
+}
+
+int gemm_entry(const float *A, int lda, const cofi_norm_desc_t *a_norm, const float *W, int ldw, float *C, int ldc, int M, int N, int K,
+               const float *bias, const float *rowdiv, int act, float *colpart, int stat_width, void *ws, size_t ws_bytes, int frames,
+               cofi_stream_t stream) {
+    if (int rc = check_common(A, lda, W, ldw, C, ldc, M, N, K)) return rc;
+    if (M == 0) return 0;
+    const int bf16x3 = (act & COFI_GEMM_BF16X3) ? 1 : 0;
+    const int wsplit = (act & COFI_GEMM_W_SPLIT) ? 1 : 0;
+    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_W_SPLIT);
+    if (act < 0 || act > 2 || (wsplit && (!bf16x3 || (ldw & 7))) || frames <= 0) return COFI_EINVAL;
+    const int sshift = colpart ? stat_shift_of(stat_width, N) : 0;
+    if (sshift < 0) return COFI_EINVAL;
+    Plan p = make_plan(M, N, K, false);
+    if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
+    GemmArgs g{};
+    g.A = A; g.W = W; g.C = C; g.bias = bias; g.rowdiv = rowdiv; g.ws = (float *)ws; g.colpart = colpart;
+    g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.act = act; g.ksplit = 1;
+    g.bf16x3 = bf16x3; g.wsplit = wsplit; g.w_lo_off = (long)N * ldw; g.cv_Pout = 1; g.stat_shift = sshift;
+    if (int rc = set_a_norm(g, a_norm, K, M / frames, frames, p)) return rc;
+    return launch(g, p, cofi_s(stream));
+}
+
+int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, int W, int Cin, const float *Wt, int Cout, int ks, int stride,
+               int pad, const float *bias, const float *res, int ldr, int act, float *y, int ldy, float *colpart, int stat_width, void *ws,
+               size_t ws_bytes, int frames, cofi_stream_t stream) {
+    if (!x || !Wt || !y || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ks != 1 && ks != 3) || stride <= 0 || pad < 0) return COFI_EINVAL;
+    if ((Cin & 3) || (ldx & 3) || ldx < Cin || ldy < Cout || (res && ldr < Cout) || ((uintptr_t)x & 15) || ((uintptr_t)Wt & 15)) return COFI_EINVAL;
+    const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
+    if (frames <= 0) return COFI_EINVAL;
+    const int M = Ho * Wo * frames, K = ks * ks * Cin;
+    const int bf16x3 = (act & COFI_GEMM_BF16X3) ? 1 : 0;
+    const int wsplit = (act & COFI_GEMM_W_SPLIT) ? 1 : 0;
+    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_W_SPLIT);
+    if (act < 0 || act > 2 || (wsplit && !bf16x3)) return COFI_EINVAL;
+    const int sshift = colpart ? stat_shift_of(stat_width, Cout) : 0;
+    if (sshift < 0) return COFI_EINVAL;
+    const int ldw = wsplit ? (K + 7) / 8 * 8 : K;   // pre-split planes: rows padded to 8 values
+    Plan p = make_plan(M, Cout, K, false);
+    if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * Cout * sizeof(float))) return COFI_EWORKSPACE;
+    GemmArgs g{};
+    g.A = x; g.W = Wt; g.C = y; g.bias = bias; g.ws = (float *)ws; g.colpart = colpart; g.res = res;
+    g.lda = ldx; g.ldw = ldw; g.ldc = ldy; g.ldr = ldr; g.M = M; g.N = Cout; g.K = K; g.act = act; g.ksplit = 1;
+    g.bf16x3 = bf16x3; g.wsplit = wsplit; g.w_lo_off = (long)Cout * ldw;
+    g.cv_ks = ks; g.cv_H = H; g.cv_W = W; g.cv_Cin = Cin; g.cv_Wo = Wo; g.cv_stride = stride; g.cv_pad = pad; g.cv_Pout = Ho * Wo;
+    g.stat_shift = sshift;
+    if (int rc = set_a_norm(g, x_norm, Cin, H * W, frames, p)) return rc;   // statistics of the INPUT map: H * W rows per frame
+    return launch(g, p, cofi_s(stream));
 }
 
 }  // namespace
@@ -944,30 +1071,24 @@ extern "C" size_t cofi_gemm_f32_workspace(int M, int N, int K) {
 
 extern "C" int cofi_gemm_f32_stat_slabs(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    Plan p = make_plan(M, N, K, false);
-    (void)p;
     return cofi_cdiv(M, 64);   // every path (64-row tiles, 128-row tiles in two halves, split-K reduction) emits 64-row slabs
 }
 
 extern "C" int cofi_gemm_f32(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K,
                              const float *bias, const float *rowdiv, int act, void *ws, size_t ws_bytes, cofi_stream_t stream) {
-    return cofi_gemm_f32_colstats(A, lda, W, ldw, C, ldc, M, N, K, bias, rowdiv, act, nullptr, ws, ws_bytes, stream);
+    return gemm_entry(A, lda, nullptr, W, ldw, C, ldc, M, N, K, bias, rowdiv, act, nullptr, 1, ws, ws_bytes, 1, stream);
 }
 
 extern "C" int cofi_gemm_f32_colstats(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K,
                                       const float *bias, const float *rowdiv, int act, float *colpart, void *ws, size_t ws_bytes,
                                       cofi_stream_t stream) {
-    if (int rc = check_common(A, lda, W, ldw, C, ldc, M, N, K)) return rc;
-    if (M == 0) return 0;
-    const int bf16x3 = (act & COFI_GEMM_BF16X3) ? 1 : 0;
-    const int wsplit = (act & COFI_GEMM_W_SPLIT) ? 1 : 0;
-    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_W_SPLIT);
-    if (act < 0 || act > 2 || (wsplit && (!bf16x3 || (ldw & 7)))) return COFI_EINVAL;
-    Plan p = make_plan(M, N, K, false);
-    if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
-    GemmArgs g{A, W, C, bias, rowdiv, (float *)ws, colpart, nullptr, nullptr, nullptr, lda, ldw, ldc, 0, M, N, K, act, 1, 0, 0, 0.f, bf16x3,
-               wsplit, (long)N * ldw, 0, 0, 0, 0, 0, 0, 0, 1};
-    return launch(g, p, cofi_s(stream));
+    return gemm_entry(A, lda, nullptr, W, ldw, C, ldc, M, N, K, bias, rowdiv, act, colpart, 1, ws, ws_bytes, 1, stream);
+}
+
+extern "C" int cofi_gemm_f32_fused(const float *A, int lda, const cofi_norm_desc_t *a_norm, const float *W, int ldw, float *C, int ldc,
+                                   int M, int N, int K, const float *bias, const float *rowdiv, int act, float *colpart, int stat_width,
+                                   void *ws, size_t ws_bytes, int frames, cofi_stream_t stream) {
+    return gemm_entry(A, lda, a_norm, W, ldw, C, ldc, M, N, K, bias, rowdiv, act, colpart, stat_width, ws, ws_bytes, frames, stream);
 }
 
 extern "C" int cofi_gemm_f32_layernorm(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K,
@@ -982,29 +1103,24 @@ extern "C" int cofi_gemm_f32_layernorm(const float *A, int lda, const float *W, 
     const int wsplit = (relu & COFI_GEMM_W_SPLIT) ? 1 : 0;
     relu &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_W_SPLIT);
     if (wsplit && (!bf16x3 || (ldw & 7))) return COFI_EINVAL;
-    GemmArgs g{A, W, C, bias, nullptr, (float *)ws, nullptr, gamma, beta, res, lda, ldw, ldc, ldr, M, N, K, 0, 1, 0, relu, eps, bf16x3,
-               wsplit, (long)N * ldw, 0, 0, 0, 0, 0, 0, 0, 1};
+    GemmArgs g{};
+    g.A = A; g.W = W; g.C = C; g.bias = bias; g.ws = (float *)ws; g.ln_gamma = gamma; g.ln_beta = beta; g.res = res;
+    g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr; g.M = M; g.N = N; g.K = K; g.ksplit = 1; g.ln_relu = relu; g.ln_eps = eps;
+    g.bf16x3 = bf16x3; g.wsplit = wsplit; g.w_lo_off = (long)N * ldw; g.cv_Pout = 1;
     return launch(g, p, cofi_s(stream));
 }
 
 extern "C" int cofi_conv2d_nhwc(const float *x, int ldx, int H, int W, int Cin, const float *Wt, int Cout, int ks, int stride, int pad,
                                 const float *bias, const float *res, int ldr, int act, float *y, int ldy, float *colpart, void *ws,
                                 size_t ws_bytes, int frames, cofi_stream_t stream) {
-    if (!x || !Wt || !y || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ks != 1 && ks != 3) || stride <= 0 || pad < 0) return COFI_EINVAL;
-    if ((Cin & 3) || (ldx & 3) || ldx < Cin || ldy < Cout || (res && ldr < Cout) || ((uintptr_t)x & 15) || ((uintptr_t)Wt & 15)) return COFI_EINVAL;
-    const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
-    if (frames <= 0) return COFI_EINVAL;
-    const int M = Ho * Wo * frames, K = ks * ks * Cin;
-    const int bf16x3 = (act & COFI_GEMM_BF16X3) ? 1 : 0;
-    const int wsplit = (act & COFI_GEMM_W_SPLIT) ? 1 : 0;
-    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_W_SPLIT);
-    if (act < 0 || act > 2 || (wsplit && !bf16x3)) return COFI_EINVAL;
-    const int ldw = wsplit ? (K + 7) / 8 * 8 : K;   // pre-split planes: rows padded to 8 values
-    Plan p = make_plan(M, Cout, K, false);
-    if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * Cout * sizeof(float))) return COFI_EWORKSPACE;
-    GemmArgs g{x, Wt, y, bias, nullptr, (float *)ws, colpart, nullptr, nullptr, res, ldx, ldw, ldy, ldr, M, Cout, K, act, 1, 0, 0, 0.f, bf16x3,
-               wsplit, (long)Cout * ldw, ks, H, W, Cin, Wo, stride, pad, Ho * Wo};
-    return launch(g, p, cofi_s(stream));
+    return conv_entry(x, ldx, nullptr, H, W, Cin, Wt, Cout, ks, stride, pad, bias, res, ldr, act, y, ldy, colpart, 1, ws, ws_bytes, frames, stream);
+}
+
+extern "C" int cofi_conv2d_nhwc_fused(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, int W, int Cin, const float *Wt, int Cout,
+                                      int ks, int stride, int pad, const float *bias, const float *res, int ldr, int act, float *y, int ldy,
+                                      float *colpart, int stat_width, void *ws, size_t ws_bytes, int frames, cofi_stream_t stream) {
+    return conv_entry(x, ldx, x_norm, H, W, Cin, Wt, Cout, ks, stride, pad, bias, res, ldr, act, y, ldy, colpart, stat_width, ws, ws_bytes,
+                      frames, stream);
 }
 
 extern "C" int cofi_split_bf16_planes(const float *W, int ldw, int N, int K, void *planes, int ldp, cofi_stream_t stream) {
@@ -1015,8 +1131,9 @@ extern "C" int cofi_split_bf16_planes(const float *W, int ldw, int N, int K, voi
     return cofi_launch_status();
 }
 
-// Tuning hook for tools/tune_gemm.py: force (bm, bn, ksplit) for subsequent plans; (0,0,0) restores the table + heuristic.
-extern "C" int cofi_gemm_debug_force_plan(int bm, int bn, int ksplit) {
+// Plan override for tools/tune_gemm.py (not declared in the public header, not used by the product path): force (bm, bn, ksplit)
+// for subsequent plans; (0,0,0) restores the table + heuristic.
+extern "C" int cofi_tune_force_plan(int bm, int bn, int ksplit) {
     const bool ok = (bm == 0 && bn == 0) || ((bm == 64 || bm == 128) && (bn == 64 || bn == 128) && !(bm == 128 && bn == 64));
     if (!ok || ksplit < 0) return COFI_EINVAL;
     g_force_bm = bm; g_force_bn = bn; g_force_ks = ksplit;

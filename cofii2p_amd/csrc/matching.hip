@@ -32,7 +32,7 @@ struct SelArgs {
     const int32_t *pix;
     int32_t *sel, *count;
     float *xy;
-    int N, W8, H8, n_thr, min_matches;
+    int N, W8, H8, n_thr, min_matches, xmax, ymax;
     float thr[64];
 };
 
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(1024) void select_matches_kernel(SelArgs a) {
         for (int n = tid; n < a.N; n += 1024) {
             const int p = a.pix[n];
             const int x = p % a.W8, y = p / a.W8;
-            const bool ok = a.score[n] >= a.thr[t] && x >= 2 && x <= a.W8 - 2 && y >= 2 && y <= a.H8 - 2;
+            const bool ok = a.score[n] >= a.thr[t] && x >= 2 && x <= a.xmax && y >= 2 && y <= a.ymax;
             c += ok ? 1 : 0;
         }
 #pragma unroll
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(1024) void select_matches_kernel(SelArgs a) {
         if (n < a.N) {
             const int p = a.pix[n];
             x = p % a.W8; y = p / a.W8;
-            ok = a.score[n] >= thr && x >= 2 && x <= a.W8 - 2 && y >= 2 && y <= a.H8 - 2;
+            ok = a.score[n] >= thr && x >= 2 && x <= a.xmax && y >= 2 && y <= a.ymax;
         }
         const unsigned long long m = __ballot(ok);
         if (lane == 0) s_cnt[wave] = __popcll(m);
@@ -108,22 +108,7 @@ __global__ void gather_points_sel_kernel(const float *pts, const int32_t *sel, c
     out[i] = pts[3 * (size_t)sel[i / 3] + (i % 3)];
 }
 
-// patches[i, c, r*4 + w] = fmap[c, 4*y - 2 + r, 4*x - 2 + w]
-__global__ void extract_patches_kernel(const float *fmap, int C, int H2, int W2, const float *xy, int ldxy, float cscale,
-                                       const int32_t *count_dev, int cap, float *patches) {
-    const int i = blockIdx.x;
-    if (i >= min(*count_dev, cap)) return;
-    const int left = (int)floorf(xy[i] * cscale - 2.0f), top = (int)floorf(xy[ldxy + i] * cscale - 2.0f);
-    for (int e = threadIdx.x; e < C * 16; e += blockDim.x) {
-        const int c = e >> 4, r = (e >> 2) & 3, w = e & 3;
-        const int yy = top + r, xx = left + w;
-        float v = 0.f;
-        if (yy >= 0 && yy < H2 && xx >= 0 && xx < W2) v = fmap[((size_t)c * H2 + yy) * W2 + xx];
-        patches[((size_t)i * C + c) * 16 + (r * 4 + w)] = v;
-    }
-}
-
-// NHWC variant: fmap row (y*W2 + x) holds the C channels of a pixel
+// patches[i, c, r*4 + w] = fmap[(4*y - 2 + r) * W2 + 4*x - 2 + w, c]: fmap row (y*W2 + x) holds the C channels of a pixel
 __global__ void extract_patches_nhwc_kernel(const float *fmap, int ldf, int C, int H2, int W2, const float *xy, int ldxy, float cscale,
                                             const int32_t *count_dev, int cap, float *patches) {
     const int i = blockIdx.x;
@@ -189,13 +174,13 @@ extern "C" int cofi_row_argmin_1m(const float *sim, int lds, int N, int P, int32
     return cofi_launch_status();
 }
 
-extern "C" int cofi_select_matches(const float *score, const int32_t *pix, int N, int W8, int H8, const float *thr_host, int n_thr,
-                                   int min_matches, int32_t *sel, float *coarse_xy, int32_t *count_dev, cofi_stream_t stream) {
-    if (!score || !pix || !thr_host || !sel || !coarse_xy || !count_dev || N <= 0 || W8 <= 4 || H8 <= 4 || n_thr <= 0 || n_thr > 64)
+extern "C" int cofi_select_matches(const float *score, const int32_t *pix, int N, int W8, int H8, int x_max, int y_max, const float *thr_host,
+                                   int n_thr, int min_matches, int32_t *sel, float *coarse_xy, int32_t *count_dev, cofi_stream_t stream) {
+    if (!score || !pix || !thr_host || !sel || !coarse_xy || !count_dev || N <= 0 || W8 <= 0 || H8 <= 0 || n_thr <= 0 || n_thr > 64)
         return COFI_EINVAL;
     SelArgs a;
     a.score = score; a.pix = pix; a.sel = sel; a.count = count_dev; a.xy = coarse_xy;
-    a.N = N; a.W8 = W8; a.H8 = H8; a.n_thr = n_thr; a.min_matches = min_matches;
+    a.N = N; a.W8 = W8; a.H8 = H8; a.n_thr = n_thr; a.min_matches = min_matches; a.xmax = x_max; a.ymax = y_max;
     for (int i = 0; i < 64; ++i) a.thr[i] = i < n_thr ? thr_host[i] : 0.f;
     hipLaunchKernelGGL(select_matches_kernel, dim3(1), dim3(1024), 0, cofi_s(stream), a);
     return cofi_launch_status();
@@ -206,14 +191,6 @@ extern "C" int cofi_gather_points_sel(const float *pts, const int32_t *sel, cons
     if (!pts || !sel || !count_dev || !out || cap <= 0) return COFI_EINVAL;
     hipLaunchKernelGGL(gather_points_sel_kernel, dim3(cofi_cdiv(cap * 3, 256)), dim3(256), 0, cofi_s(stream), pts, sel, count_dev, cap,
                        out);
-    return cofi_launch_status();
-}
-
-extern "C" int cofi_extract_patches(const float *fmap, int C, int H2, int W2, const float *coarse_xy, int ldxy, float center_scale,
-                                    const int32_t *count_dev, int cap, float *patches, cofi_stream_t stream) {
-    if (!fmap || !coarse_xy || !count_dev || !patches || C <= 0 || H2 <= 0 || W2 <= 0 || cap <= 0) return COFI_EINVAL;
-    hipLaunchKernelGGL(extract_patches_kernel, dim3(cap), dim3(256), 0, cofi_s(stream), fmap, C, H2, W2, coarse_xy, ldxy, center_scale,
-                       count_dev, cap, patches);
     return cofi_launch_status();
 }
 

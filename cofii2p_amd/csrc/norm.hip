@@ -3,6 +3,7 @@
 // and the sine position embedding.  All HBM/L2-bound streaming kernels: float4 accesses where the
 // layout allows, one pass over the data per kernel.
 #include "common.h"
+#include "stat_fold.h"
 
 namespace {
 
@@ -212,66 +213,13 @@ __global__ __launch_bounds__(256) void group_norm_apply_kernel(GnApplyArgs a) {
     }
 }
 
-// Fused variant for SMALL statistics tables: the apply kernel folds the GEMM's column partials itself (every workgroup
-// repeats the same fixed-order fp64 fold, so all of them see identical statistics) instead of waiting for a separate
-// finalize launch - at one frame a dependent launch costs >= 1.5 us, more than folding a few thousand partials (one or two L2 round trips) per workgroup.
+// Variant that folds the statistics partials of the producing GEMM itself (stat_fold.h: every workgroup repeats the same
+// fixed-order fp64 fold, so all of them see identical statistics) instead of waiting for a separate finalize launch.
 // Optionally also emits row_pos[m] = (sum_c y[m,c] > 0), the per-row flag of the next KPConv (kpconv.py:113-114).
 struct GnFusedArgs {
     GnApplyArgs a;
-    const float *colpart, *res_colpart;   // (frames * nslab, C, 2)
-    int nslab, res_nslab;                 // slabs per frame
-    float eps;
+    NormSrc n, rn;   // statistics source of x / of the shortcut (rn.part == nullptr: none); gamma / beta live in `a`
 };
-
-__device__ __forceinline__ void fold_colpart(const float *colpart, int nslab, int C, int groups, double count, float eps, double *dred,
-                                             float *sstat) {
-    // thread (ph, c): channel c, slabs ph, ph + PH, ...; then one thread per group folds phases and channels in a fixed order
-    const int cpg = C / groups;
-    for (int c0 = 0; c0 < C; c0 += 256) {
-        const int cw = min(C - c0, 256);          // channels of this pass (power-of-two C: cw divides 256 or equals it)
-        const int PH = 256 / cw;
-        const int c = c0 + threadIdx.x % cw, ph = threadIdx.x / cw;
-        double s = 0.0, q = 0.0;
-        if (ph < PH)
-            for (int b0 = ph; b0 < nslab; b0 += 8 * PH) {   // 8 independent loads per round (the fold is bound by L2 round trips)
-                float2 t[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int b = b0 + u * PH;
-                    t[u] = *reinterpret_cast<const float2 *>(colpart + ((size_t)(b < nslab ? b : ph) * C + c) * 2);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (b0 + u * PH < nslab) {
-                        s += (double)t[u].x;
-                        q += (double)t[u].y;
-                    }
-            }
-        __syncthreads();   // dred reuse between passes
-        if (ph < PH) {
-            dred[2 * threadIdx.x] = s;
-            dred[2 * threadIdx.x + 1] = q;
-        }
-        __syncthreads();
-        // groups fully inside this pass (cpg <= 256 always: groups >= C / 256 ... cpg divides cw)
-        const int g0 = c0 / cpg, ng = cw / cpg > 0 ? cw / cpg : 0;
-        for (int g = threadIdx.x; g < ng; g += 256) {
-            double ts = 0.0, tq = 0.0;
-            for (int p = 0; p < PH; ++p)
-                for (int i = 0; i < cpg; ++i) {
-                    const int t = p * cw + g * cpg + i;
-                    ts += dred[2 * t];
-                    tq += dred[2 * t + 1];
-                }
-            const double mean = ts / count;
-            double var = tq / count - mean * mean;
-            if (var < 0.0) var = 0.0;
-            sstat[2 * (g0 + g)] = (float)mean;
-            sstat[2 * (g0 + g) + 1] = (float)(1.0 / sqrt(var + (double)eps));
-        }
-    }
-    __syncthreads();
-}
 
 __global__ __launch_bounds__(256) void group_norm_apply_fused_kernel(GnFusedArgs fa) {
     GnApplyArgs a = fa.a;
@@ -281,18 +229,17 @@ __global__ __launch_bounds__(256) void group_norm_apply_fused_kernel(GnFusedArgs
     const int tpr = c4n < 256 ? c4n : 256;
     const int rpb = 256 / tpr;
     const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
-    {   // frame blockIdx.y: its rows, its column partials
+    {   // frame blockIdx.y: its rows, its statistics partials
         const size_t f = blockIdx.y;
         a.x += f * a.M * a.ldx;
         a.y += f * a.M * a.ldy;
         if (a.res) a.res += f * a.M * a.ldr;
-        fa.colpart += f * fa.nslab * a.C * 2;
-        if (fa.res_colpart) fa.res_colpart += f * fa.res_nslab * a.C * 2;
+        fa.n.part += f * fa.n.nslab * fa.n.tcols * 2;
+        if (fa.rn.part) fa.rn.part += f * fa.rn.nslab * fa.rn.tcols * 2;
         if (a.row_pos) a.row_pos += f * a.M;
     }
-    const double count = (double)a.M * a.cpg;
-    fold_colpart(fa.colpart, fa.nslab, a.C, a.groups, count, fa.eps, dred, sstat);
-    if (fa.res_colpart) fold_colpart(fa.res_colpart, fa.res_nslab, a.C, a.groups, count, fa.eps, dred, rstat);
+    fold_stat_table<256>(fa.n.part, fa.n.nslab, fa.n.tcols, fa.n.groups, fa.n.count, fa.n.eps, dred, sstat);
+    if (fa.rn.part) fold_stat_table<256>(fa.rn.part, fa.rn.nslab, fa.rn.tcols, fa.rn.groups, fa.rn.count, fa.rn.eps, dred, rstat);
     for (int cb = tc; cb < c4n; cb += tpr) {
         const int c = cb * 4;
         float sc[4], sh[4], rsc[4], rsh[4];
@@ -304,7 +251,7 @@ __global__ __launch_bounds__(256) void group_norm_apply_fused_kernel(GnFusedArgs
             sc[i] = rstd * ga;
             sh[i] = be - mean * rstd * ga;
             rsc[i] = 1.f; rsh[i] = 0.f;
-            if (a.res && fa.res_colpart) {
+            if (a.res && fa.rn.part) {
                 const float rm = rstat[2 * g], rr = rstat[2 * g + 1];
                 const float rg = a.res_gamma ? a.res_gamma[ch] : 1.f, rb = a.res_gamma ? a.res_beta[ch] : 0.f;
                 rsc[i] = rr * rg;
@@ -428,28 +375,19 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float *x, int ld
     }
 }
 
-// (C,P) channel-major map: normalise every pixel's C-vector.  Block = 64 pixels x 4 channel phases (lanes =
-// consecutive pixels: coalesced rows of the map), phases folded through LDS in a fixed order.
-__global__ __launch_bounds__(256) void l2norm_cols_kernel(const float *x, int ldx, int C, int P, float *y_cp, int ldy, float *y_pc,
-                                                          int ldt) {
+// out[f, c] = mean over the M rows of frame f of x[:, c]: nn.AdaptiveAvgPool2d(1) on an NHWC map (imagenet.py:145,215).
+// Block = 64 columns x 4 row phases, fp32 per thread, fixed-order fold (deterministic).
+__global__ __launch_bounds__(256) void col_mean_kernel(const float *x, int ldx, int M, int C, float *out) {
     __shared__ float red[4][64];
-    const int pl = threadIdx.x & 63, ph = threadIdx.x >> 6;
-    const int p = blockIdx.x * 64 + pl;
-    float q = 0.f;
-    if (p < P)
-        for (int c = ph; c < C; c += 4) {
-            const float v = x[(size_t)c * ldx + p];
-            q += v * v;
-        }
-    red[ph][pl] = q;
+    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    x += (size_t)blockIdx.y * M * ldx;
+    float s = 0.f;
+    if (c < C)
+        for (int m = ph; m < M; m += 4) s += x[(size_t)m * ldx + c];
+    red[ph][cl] = s;
     __syncthreads();
-    const float inv = 1.0f / fmaxf(sqrtf((red[0][pl] + red[1][pl]) + (red[2][pl] + red[3][pl])), 1e-12f);
-    if (p < P)
-        for (int c = ph; c < C; c += 4) {
-            const float v = x[(size_t)c * ldx + p] * inv;
-            if (y_cp) y_cp[(size_t)c * ldy + p] = v;
-            if (y_pc) y_pc[(size_t)p * ldt + c] = v;
-        }
+    if (ph == 0 && c < C) out[(size_t)blockIdx.y * C + c] = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)M;
 }
 
 __global__ void transpose_kernel(const float *x, int ldx, int M, int C, float *y, int ldy) {
@@ -499,15 +437,19 @@ __global__ void pos_sine_kernel(PosArgs a) {
 extern "C" int cofi_group_stats_from_colpart(const float *colpart, int nslab, int M, int C, int groups, float eps, float *stats,
                                              int frames, cofi_stream_t stream) {
     if (!colpart || !stats || nslab <= 0 || M <= 0 || C <= 0 || groups <= 0 || (C % groups) || frames <= 0) return COFI_EINVAL;
-    if ((nslab % frames) || (M % frames)) return COFI_EINVAL;  // slabs must not straddle frames
+    if ((nslab % frames) || (M % frames)) return COFI_EINVAL;
+    if (frames > 1 && ((M / frames) % 64)) return COFI_EINVAL;   // the producer's 64-row slabs must not straddle frames
+    if (nslab / frames != cofi_cdiv(M / frames, 64)) return COFI_EINVAL;
     hipLaunchKernelGGL(group_stats_from_colpart_kernel, dim3(groups, frames), dim3(256), 0, cofi_s(stream), colpart, nslab / frames, C,
                        groups, (double)(M / frames) * (C / groups), eps, stats);
     return cofi_launch_status();
 }
 
-extern "C" int cofi_col_inv_norm_from_colpart(const float *colpart, int nslab, int ncols, int C, float eps, float *out, int frames,
+extern "C" int cofi_col_inv_norm_from_colpart(const float *colpart, int nslab, int M, int ncols, int C, float eps, float *out, int frames,
                                               cofi_stream_t stream) {
-    if (!colpart || !out || nslab <= 0 || C <= 0 || ncols < C || frames <= 0 || (nslab % frames)) return COFI_EINVAL;
+    if (!colpart || !out || nslab <= 0 || M <= 0 || C <= 0 || ncols < C || frames <= 0 || (nslab % frames) || (M % frames)) return COFI_EINVAL;
+    if (frames > 1 && ((M / frames) % 64)) return COFI_EINVAL;   // the producer's 64-row slabs must not straddle frames
+    if (nslab / frames != cofi_cdiv(M / frames, 64)) return COFI_EINVAL;
     hipLaunchKernelGGL(col_inv_norm_from_colpart_kernel, dim3(cofi_cdiv(C, 64), frames), dim3(256), 0, cofi_s(stream), colpart,
                        nslab / frames, ncols, C, eps, out);
     return cofi_launch_status();
@@ -552,20 +494,22 @@ extern "C" int cofi_group_norm_apply(const float *x, int ldx, int M, int C, int 
     return cofi_launch_status();
 }
 
-extern "C" int cofi_group_norm_apply_colpart(const float *x, int ldx, int M, int C, int groups, const float *colpart, int nslab, float eps,
-                                             const float *gamma, const float *beta, const float *res, int ldr, const float *res_colpart,
-                                             int res_nslab, const float *res_gamma, const float *res_beta, float slope, float *y, int ldy,
-                                             uint8_t *row_pos, int frames, cofi_stream_t stream) {
-    if (!x || !colpart || !y || M <= 0 || C <= 0 || groups <= 0 || (C % groups) || (C & 3) || (ldx & 3) || (ldy & 3)) return COFI_EINVAL;
-    if ((gamma == nullptr) != (beta == nullptr) || (res_gamma == nullptr) != (res_beta == nullptr)) return COFI_EINVAL;
-    if (res && (ldr & 3)) return COFI_EINVAL;
-    if (frames <= 0 || (M % frames) || nslab <= 0 || (nslab % frames) || (res_colpart && (!res || res_nslab <= 0 || (res_nslab % frames)))) return COFI_EINVAL;
-    // in-kernel fold: power-of-two C <= 1024 (thread = channel), a bounded number of partials per workgroup
-    if ((C & (C - 1)) || C > 1024 || groups > 1024 || C / groups > 256) return COFI_EUNSUPPORTED;
+extern "C" int cofi_group_norm_apply_partials(const float *x, int ldx, int M, int C, const cofi_norm_desc_t *norm, const float *res, int ldr,
+                                              const cofi_norm_desc_t *res_norm, float *y, int ldy, uint8_t *row_pos, int frames,
+                                              cofi_stream_t stream) {
+    if (!x || !norm || !y || M <= 0 || C <= 0 || (C & 3) || (ldx & 3) || (ldy & 3) || ldx < C || ldy < C) return COFI_EINVAL;
+    if (res && ((ldr & 3) || ldr < C)) return COFI_EINVAL;
+    if (frames <= 0 || (M % frames) || (res_norm && !res)) return COFI_EINVAL;
+    if (norm->channels != C || (res_norm && res_norm->channels != C) || (res_norm && res_norm->groups != norm->groups)) return COFI_EINVAL;
     const int Mf = M / frames, c4n = C >> 2, tpr = c4n < 256 ? c4n : 256, rpb = 256 / tpr;
-    if (row_pos && tpr > 64) return COFI_EUNSUPPORTED;
-    GnFusedArgs fa{{x, nullptr, gamma, beta, res, nullptr, res_gamma, res_beta, y, ldx, ldr, ldy, Mf, C, C / groups, slope, groups, row_pos},
-                   colpart, res_colpart, nslab / frames, res_colpart ? res_nslab / frames : 0, eps};
+    if (row_pos && (tpr > 64 || (64 % tpr))) return COFI_EUNSUPPORTED;
+    GnFusedArgs fa{};
+    if (int rc = make_norm_src(norm, Mf, frames, 1 << 20, &fa.n)) return rc;
+    if (res_norm)
+        if (int rc = make_norm_src(res_norm, Mf, frames, 1 << 20, &fa.rn)) return rc;
+    if (fa.n.groups > 1024) return COFI_EUNSUPPORTED;   // LDS statistics table
+    fa.a = GnApplyArgs{x, nullptr, norm->gamma, norm->beta, res, nullptr, res_norm ? res_norm->gamma : nullptr, res_norm ? res_norm->beta : nullptr,
+                       y, ldx, ldr, ldy, Mf, C, C / norm->groups, norm->slope, norm->groups, row_pos};
     int nb = cofi_cdiv(Mf, rpb * 4);
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
@@ -594,10 +538,9 @@ extern "C" int cofi_l2norm_rows(const float *x, int ldx, int M, int C, float *y,
     return cofi_launch_status();
 }
 
-extern "C" int cofi_l2norm_cols(const float *x, int ldx, int C, int P, float *y_cp, int ldy, float *y_pc, int ldt,
-                                cofi_stream_t stream) {
-    if (!x || C <= 0 || P <= 0 || ldx < P || (y_cp && ldy < P) || (y_pc && ldt < C)) return COFI_EINVAL;
-    hipLaunchKernelGGL(l2norm_cols_kernel, dim3(cofi_cdiv(P, 64)), dim3(256), 0, cofi_s(stream), x, ldx, C, P, y_cp, ldy, y_pc, ldt);
+extern "C" int cofi_col_mean(const float *x, int ldx, int M, int C, float *out, int frames, cofi_stream_t stream) {
+    if (!x || !out || M <= 0 || C <= 0 || ldx < C || frames <= 0 || (M % frames)) return COFI_EINVAL;
+    hipLaunchKernelGGL(col_mean_kernel, dim3(cofi_cdiv(C, 64), frames), dim3(256), 0, cofi_s(stream), x, ldx, M / frames, C, out);
     return cofi_launch_status();
 }
 

@@ -12,6 +12,7 @@
 // load time), so a wave streams its B fragments straight from L2 into registers (each wave owns distinct weight
 // rows: nothing to share through LDS) one 4-step chunk ahead of the MFMAs; activations are split once when they
 // enter LDS and are shared by the four waves as A fragments.
+#include "attention_parts.h"
 #include "common.h"
 
 namespace {
@@ -32,6 +33,11 @@ struct TailArgs {
     float *out;
     int ldm, ldx, ldo, L;
     float eps;
+    // msg == nullptr: the attention output is still in the form the attention kernel left it - per-pair partial slots
+    // (attention_parts.h) - and the loader below merges + normalises them on the fly (L = frames * Lf rows, H heads of 32)
+    const float *parts;
+    AttnLayout lay;
+    int Lf, H;
 };
 
 __device__ __forceinline__ unsigned cvt_pk(float a, float b) {  // RNE, a -> low half
@@ -127,7 +133,13 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailArgs a) {
 #pragma unroll
         for (int p = 0; p < R / 8; ++p) {
             const int rl = lr + 8 * p, row = min(r0 + rl, a.L - 1);
-            const float4 mv = *reinterpret_cast<const float4 *>(a.msg + (size_t)row * a.ldm + lk);
+            float4 mv;
+            if (a.parts) {
+                const int f = row / a.Lf;
+                mv = attn_merged_chunk(a.parts, a.lay, f, a.H, lk >> 5, row - f * a.Lf, (lk & 31) >> 2);
+            } else {
+                mv = *reinterpret_cast<const float4 *>(a.msg + (size_t)row * a.ldm + lk);
+            }
             const float4 xv = *reinterpret_cast<const float4 *>(a.x + (size_t)row * a.ldx + lk);
             split_store4(mv, msg_hi + rl * S128 + lk * 2, msg_lo + rl * S128 + lk * 2);
             split_store4(xv, cat_hi + rl * S256 + lk * 2, cat_lo + rl * S256 + lk * 2);
@@ -220,7 +232,24 @@ extern "C" int cofi_loftr_tail_bf16x3(const float *msg, int ldm, const float *x,
         return COFI_EINVAL;
     if (L <= 0 || (ldm & 3) || (ldx & 3) || ldm < C || ldx < C || ldo < C || ((uintptr_t)msg & 15) || ((uintptr_t)x & 15)) return COFI_EINVAL;
     if (((uintptr_t)wm_hi | (uintptr_t)wm_lo | (uintptr_t)w0_hi | (uintptr_t)w0_lo | (uintptr_t)w2_hi | (uintptr_t)w2_lo) & 15) return COFI_EINVAL;
-    TailArgs a{msg, x, wm_hi, wm_lo, w0_hi, w0_lo, w2_hi, w2_lo, n1_gamma, n1_beta, n2_gamma, n2_beta, out, ldm, ldx, ldo, L, eps};
+    TailArgs a{msg, x, wm_hi, wm_lo, w0_hi, w0_lo, w2_hi, w2_lo, n1_gamma, n1_beta, n2_gamma, n2_beta, out, ldm, ldx, ldo, L, eps, nullptr, {}, 0, 0};
     hipLaunchKernelGGL(loftr_tail_kernel, dim3(cofi_cdiv(L, R)), dim3(256), 0, cofi_s(stream), a);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_loftr_tail_parts_bf16x3(const void *parts, size_t parts_bytes, int L, int S, int H, int frames, const float *x, int ldx,
+                                            const uint16_t *wm_hi, const uint16_t *wm_lo, const float *n1_gamma, const float *n1_beta,
+                                            const uint16_t *w0_hi, const uint16_t *w0_lo, const uint16_t *w2_hi, const uint16_t *w2_lo,
+                                            const float *n2_gamma, const float *n2_beta, float eps, float *out, int ldo, cofi_stream_t stream) {
+    if (!parts || !x || !wm_hi || !wm_lo || !w0_hi || !w0_lo || !w2_hi || !w2_lo || !n1_gamma || !n1_beta || !n2_gamma || !n2_beta || !out)
+        return COFI_EINVAL;
+    if (L <= 0 || S <= 0 || frames <= 0 || H * 32 != C || (ldx & 3) || ldx < C || ldo < C || ((uintptr_t)x & 15) || ((uintptr_t)parts & 15)) return COFI_EINVAL;
+    if (((uintptr_t)wm_hi | (uintptr_t)wm_lo | (uintptr_t)w0_hi | (uintptr_t)w0_lo | (uintptr_t)w2_hi | (uintptr_t)w2_lo) & 15) return COFI_EINVAL;
+    const AttnLayout lay = attn_layout(L, S, H, frames);
+    if (parts_bytes < lay.bytes) return COFI_EWORKSPACE;
+    const int rows = L * frames;
+    TailArgs a{nullptr, x, wm_hi, wm_lo, w0_hi, w0_lo, w2_hi, w2_lo, n1_gamma, n1_beta, n2_gamma, n2_beta, out, 0, ldx, ldo, rows, eps,
+               (const float *)parts, lay, L, H};
+    hipLaunchKernelGGL(loftr_tail_kernel, dim3(cofi_cdiv(rows, R)), dim3(256), 0, cofi_s(stream), a);
     return cofi_launch_status();
 }

@@ -1,19 +1,16 @@
 """Image branch: ResNet-34 (affine-less InstanceNorm) + two bilinear up-sample / ResidualConv stages
 (reference: model/imagenet.py:119-217, 377-444).
 
-Default path (`*_nhwc`): feature maps are NHWC = pixel-major (H*W, C) matrices like every other activation
-of the network; a convolution is an implicit GEMM on the MFMA kernel (`cofi_conv2d_nhwc`), whose epilogue
-emits the per-channel column statistics InstanceNorm needs (or fuses the folded-BatchNorm bias, ReLU and the
-skip convolution of a ResidualConv); InstanceNorm + ReLU + residual is the stack-mode GroupNorm apply kernel
-with one group per channel.  No MIOpen, no layout transposes, bit-reproducible.
-
-`resnet34` / `upsample_stage` (NCHW) keep the MIOpen convolutions with HIP glue; they are selected with
-COFI_IMAGE=miopen for A/B measurements only.
+Feature maps are NHWC = pixel-major (H*W, C) matrices like every other activation of the network; a convolution is an
+implicit GEMM on the MFMA kernel (`cofi_conv2d_nhwc_fused`), whose epilogue emits the per-channel statistics partials
+InstanceNorm needs (or fuses the folded-BatchNorm bias, ReLU and the skip convolution of a ResidualConv).  The
+InstanceNorm + ReLU between the two convolutions of a BasicBlock is applied by the second convolution's operand loader
+(ops.Normed); InstanceNorm + ReLU + residual at the end of a block is the GroupNorm apply kernel with one group per
+channel.  No vendor library, no layout transposes, bit-reproducible.
 """
 from typing import Dict, List
 
 import torch
-import torch.nn.functional as F
 
 from . import ops
 from .spec import RESNET_LAYERS
@@ -32,9 +29,6 @@ def pack_image(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     for k, v in sd.items():
         if k.startswith("img_encoder.backbone.") and k.endswith("weight") and v.dim() == 4:
             out[k + ".nhwc"] = _nhwc_weight(v, 160 if k.endswith("backbone.conv1.weight") else 0)
-    for k, v in sd.items():
-        if k.startswith("img_encoder.backbone.") and k.endswith("weight") and v.dim() == 4:
-            out[k] = v.contiguous()
     eps = 1e-5
     for name in ("img_upsample_1", "img_upsample_2"):
         for j in (0, 1):
@@ -42,56 +36,14 @@ def pack_image(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
             for conv, bn in (("conv1", "bn1"), ("conv2", "bn2"), ("conv_skip.0", "conv_skip.1")):
                 w = sd[p + conv + ".weight"]
                 scale = sd[p + bn + ".weight"] * torch.rsqrt(sd[p + bn + ".running_var"] + eps)
-                out[p + conv + ".w"] = (w * scale[:, None, None, None]).contiguous()
                 out[p + conv + ".w.nhwc"] = _nhwc_weight(w * scale[:, None, None, None])
                 out[p + conv + ".b"] = (sd[p + bn + ".bias"] - sd[p + bn + ".running_mean"] * scale).contiguous()
     return out
 
 
-def resnet34(P, img: torch.Tensor, full: bool = True) -> List[torch.Tensor]:
-    """imagenet.py:196-217.  Returns [s2, s4, s8, s16, s32, gap]; with full=False the maps nothing
-    downstream reads (layer3, layer4, avg-pool: network.py:87-89) are skipped and returned as None.
-    Convolutions / max-pool: MIOpen; InstanceNorm + ReLU + residual tails: one HIP kernel each."""
-    p = "img_encoder.backbone."
-    x = ops.instance_norm_nchw(F.conv2d(img, P[p + "conv1.weight"], stride=2, padding=3), relu=True)
-    outs = [x]
-    x = F.max_pool2d(x, 3, 2, 1)
-    for li, (planes, blocks, stride) in enumerate(RESNET_LAYERS, start=1):
-        if not full and li > 2:
-            outs.append(None)
-            continue
-        for b in range(blocks):
-            q = "%slayer%d.%d." % (p, li, b)
-            st = stride if b == 0 else 1
-            y = ops.instance_norm_nchw(F.conv2d(x, P[q + "conv1.weight"], stride=st, padding=1), relu=True)
-            y = F.conv2d(y, P[q + "conv2.weight"], padding=1)
-            if (q + "downsample.0.weight") in P:  # relu(IN(y) + IN(downsample(x)))
-                x = ops.instance_norm_nchw(y, relu=True, res=F.conv2d(x, P[q + "downsample.0.weight"], stride=st), res_norm=True)
-            else:  # relu(IN(y) + x)
-                x = ops.instance_norm_nchw(y, relu=True, res=x)
-        outs.append(x)
-    outs.append(F.adaptive_avg_pool2d(x, 1) if full else None)
-    return outs
-
-
-def _residual_conv(P, p: str, x):
-    """imagenet.py:397-411 with the eval-mode BatchNorms folded into the convolutions (pack_image)."""
-    skip = F.conv2d(x, P[p + "conv_skip.0.w"], padding=1)
-    y = ops.bias_act_nchw(F.conv2d(x, P[p + "conv1.w"], padding=1), P[p + "conv1.b"], relu=True)
-    y = F.conv2d(y, P[p + "conv2.w"], padding=1)
-    return ops.bias_act_nchw(y, P[p + "conv2.b"], res=skip, res_bias=P[p + "conv_skip.0.b"], relu=True)
-
-
-def upsample_stage(P, name: str, low, skip):
-    """imagenet.py:431-444."""
-    x = ops.upsample2x_cat(low, skip)
-    return _residual_conv(P, name + ".conv.1.", _residual_conv(P, name + ".conv.0.", x))
-
-
-# ---------------------------------------------------------------------------------------------- NHWC path
 def _slabs_ok(y, part, frames):
-    return frames == 1 or (part.shape[0] % frames == 0 and y.shape[0] % part.shape[0] == 0
-                           and (y.shape[0] // frames) % (y.shape[0] // part.shape[0]) == 0)
+    """the 64-row statistics slabs of the producing convolution do not straddle frames"""
+    return frames == 1 or (part.shape[0] % frames == 0 and (y.shape[0] // frames) % 64 == 0)
 
 
 def _in_relu(y, part, res=None, res_part=None, frames: int = 1):
@@ -114,7 +66,11 @@ def _resnet_layer_nhwc(P, li: int, blocks: int, stride: int, x, H: int, W: int, 
         q = "%slayer%d.%d." % (p, li, b)
         st = stride if b == 0 else 1
         y1, part1, Ho, Wo = ops.conv2d_nhwc(x, H, W, P[q + "conv1.weight.nhwc"], 3, st, 1, colstats=True, frames=frames)
-        a = _in_relu(y1, part1, frames=frames)
+        if _slabs_ok(y1, part1, frames):
+            # relu(IN(y1)) is read by conv2 only (imagenet.py:60-64): its operand loader applies it
+            a = ops.Normed(y1, ops.ColStats(part1, y1.shape[0], y1.shape[1], frames), slope=0.0)
+        else:
+            a = _in_relu(y1, part1, frames=frames)
         y2, part2, _, _ = ops.conv2d_nhwc(a, Ho, Wo, P[q + "conv2.weight.nhwc"], 3, 1, 1, colstats=True, frames=frames)
         if (q + "downsample.0.weight.nhwc") in P:
             d, partd, _, _ = ops.conv2d_nhwc(x, H, W, P[q + "downsample.0.weight.nhwc"], 1, st, 0, colstats=True, frames=frames)
@@ -148,7 +104,7 @@ def resnet34_nhwc(P, img: torch.Tensor, full: bool = True, tail_branch=None):
             x, H, W = _resnet_layer_nhwc(P, li, blocks, stride, x, H, W, frames)
             outs.append(x)
             dims.append((H, W))
-        outs.append(x.reshape(frames, -1, x.shape[1]).mean(1))  # AdaptiveAvgPool2d(1): unused downstream (network.py:87)
+        outs.append(ops.col_mean(x, frames))  # AdaptiveAvgPool2d(1): unused downstream (network.py:87)
         dims.append((1, 1))
 
     if tail_branch is not None:

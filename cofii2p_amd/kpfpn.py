@@ -24,25 +24,38 @@ def pack_encoder(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     return out
 
 
-def _stats(y, part, frames: int):
-    """GroupNorm statistics per frame from the GEMM's column partials (stack mode: (frames, groups, 2))."""
-    if frames > 1 and (part.shape[0] % frames or (y.shape[0] // frames) % (y.shape[0] // part.shape[0])):
-        raise ops._lib.CofiError("stack mode needs per-frame row counts that are multiples of the statistics slab (%d rows, %d slabs, %d frames)"
-                                 % (y.shape[0], part.shape[0], frames))
-    return ops.ColStats(part, y.shape[0], GN_GROUPS, frames)
+def _gn_width(C: int) -> int:
+    """Statistics table width for a GroupNorm(32, C) output: one entry per group and slab (256 bytes per slab) when the group
+    width is a power of two the GEMM epilogue can fold (<= 64 columns), else per column."""
+    cpg = C // GN_GROUPS
+    return cpg if (C % GN_GROUPS == 0 and 1 <= cpg <= 64 and (cpg & (cpg - 1)) == 0) else 1
+
+
+def _stats(y, part, frames: int, width: int = 1):
+    """GroupNorm statistics per frame, still as the GEMM's statistics partials (stack mode: slabs must not straddle frames)."""
+    if frames > 1 and (part.shape[0] % frames or (y.shape[0] // frames) % 64):
+        raise ops._lib.CofiError("stack mode needs per-frame row counts that are multiples of the 64-row statistics slab (%d rows, %d frames)"
+                                 % (y.shape[0], frames))
+    return ops.ColStats(part, y.shape[0], GN_GROUPS, frames, width=width)
 
 
 def _kpconv(P, p: str, feats, q_pts, s_pts, idx, sigma: float, frames: int = 1, order=None):
-    """-> (KPConv output, its GroupNorm statistics).  The statistics come out of the GEMM epilogue (column
-    partials) instead of another pass over the activation."""
+    """-> (KPConv output, its GroupNorm statistics).  The statistics come out of the GEMM epilogue (partials per
+    slab and group) instead of another pass over the activation."""
     agg, cnt = ops.kpconv_aggregate(feats, q_pts, s_pts, idx, P[p + "KPConv.kernel_points"], sigma, frames=frames, order=order)
-    y, part = ops.gemm_colstats(agg, P[p + "KPConv.weights"], bias=P[p + "KPConv.bias"], rowdiv=cnt)
-    return y, _stats(y, part, frames)
+    w = P[p + "KPConv.weights"]
+    sw = _gn_width(w.shape[0])
+    y, part = ops.gemm_colstats(agg, w, bias=P[p + "KPConv.bias"], rowdiv=cnt, stat_width=sw)
+    return y, _stats(y, part, frames, sw)
 
 
 def _unary_raw(P, p: str, x, frames: int = 1):
-    y, part = ops.gemm_colstats(x, P[p + "mlp.weight"], bias=P[p + "mlp.bias"])
-    return y, _stats(y, part, frames)
+    """Linear of a UnaryBlock (modules.py:76,89) -> (raw output, GroupNorm statistics).  `x` may be an ops.Normed: the
+    previous layer's GroupNorm + LeakyReLU is then applied by this GEMM's operand loader."""
+    w = P[p + "mlp.weight"]
+    sw = _gn_width(w.shape[0])
+    y, part = ops.gemm_colstats(x, w, bias=P[p + "mlp.bias"], stat_width=sw, frames=frames)
+    return y, _stats(y, part, frames, sw)
 
 
 def _unary(P, p: str, x, slope: float, out=None, frames: int = 1, want_row_pos: bool = False):
@@ -64,10 +77,12 @@ def run_block(P, blk: KPBlock, feats, q_pts, s_pts, idx, out=None, concurrent: b
         ys = sts = None
         if blk.has_shortcut_unary:
             ys, sts = _unary_raw(P, p + "unary_shortcut.", sc, frames)
-    # unary1 feeds the KPConv: its apply kernel also emits the per-row flag the aggregation needs
+    # unary1 feeds the KPConv gather: its normalisation is materialised, and the apply kernel also emits the per-row flag
+    # the aggregation needs
     x = _unary(P, p + "unary1.", feats, LRELU, frames=frames, want_row_pos=True) if blk.cin != blk.mid else feats
     y, st = _kpconv(P, p, x, q_pts, s_pts, idx, blk.sigma, frames, order)
-    x = ops.group_norm_apply(y, st, P[p + "norm_conv.norm.weight"], P[p + "norm_conv.norm.bias"], slope=LRELU, frames=frames)
+    # norm_conv + LeakyReLU (modules.py:232-233) is consumed by unary2's Linear only: applied by that GEMM's operand loader
+    x = ops.Normed(y, st, P[p + "norm_conv.norm.weight"], P[p + "norm_conv.norm.bias"], LRELU)
     y2, st2 = _unary_raw(P, p + "unary2.", x, frames)
     br.join(sc, ys, None if sts is None else sts.part)
     g2, b2 = P[p + "unary2.norm.norm.weight"], P[p + "unary2.norm.norm.bias"]

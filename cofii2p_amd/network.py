@@ -4,8 +4,8 @@
 layout (model/network.py:14-164; 430 tensors, strict-loadable: evaluation/eval_all.py:49), so it
 drops into `evaluation/eval_all.py` / `train.py`-style callers under PyTorch-ROCm.  Underneath,
 forward enqueues hand-written gfx950 kernels through the C ABI of libcofi_hip.so
-(include/cofi_hip.h).  Inference only (`torch.no_grad()` semantics): there is no autograd and no
-CPU path — the module raises if the HIP library is missing or a tensor is not on the GPU.
+(include/cofi_hip.h).  Inference only (`torch.no_grad()` semantics): there is no autograd (mode='train' with
+gradients enabled raises) and no CPU path — the module raises if the HIP library is missing or a tensor is not on the GPU.
 """
 import os
 from typing import Dict, List, Optional
@@ -79,7 +79,6 @@ class CoFiI2P(nn.Module):
         # intra-frame fork/join slots captured by forward_async (bit 0 image branch, 1 residual shortcuts, 2 attention streams,
         # 3 the ResNet tail nothing reads)
         self.async_branch_mask = int(os.environ.get("COFI_ASYNC_BRANCH_MASK", "0"))
-        self.image_backend = os.environ.get("COFI_IMAGE", "nhwc")  # "nhwc": implicit-GEMM HIP convolutions; "miopen": A/B only
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
         self.eval()
 
@@ -139,14 +138,19 @@ class CoFiI2P(nn.Module):
         return ops.idx_to_int32(t) if t.dtype != torch.int32 else t.contiguous()
 
     def _score_head(self, P, head: str, tokens: torch.Tensor, frames: int = 1) -> torch.Tensor:
-        """network.py:42-43 on token-major data: 1x1 conv = GEMM, InstanceNorm over positions =
-        per-column normalisation (group width 1), ReLU = slope 0."""
+        """network.py:42-43 on token-major data: 1x1 conv = GEMM, InstanceNorm over positions = per-column
+        normalisation (group width 1), ReLU = slope 0; each InstanceNorm + ReLU is applied by the operand loader of the
+        next GEMM (ops.Normed), falling back to the stand-alone kernels where the 64-row statistics slabs straddle frames."""
         T = tokens.shape[0]
+
+        def in_relu(y, part):
+            if frames > 1 and (T // frames) % 64:   # slabs straddle frames: statistics by a separate pass over the rows
+                return ops.group_norm_apply(y, ops.group_stats(y, y.shape[1], frames=frames), slope=0.0, frames=frames)
+            return ops.Normed(y, ops.ColStats(part, T, y.shape[1], frames), slope=0.0)
+
         y, part = ops.gemm_colstats(tokens, P[head + ".0.weight"])
-        y = ops.group_norm_apply(y, ops.ColStats(part, T, y.shape[1], frames), slope=0.0, frames=frames)
-        y, part = ops.gemm_colstats(y, P[head + ".3.weight"])
-        y = ops.group_norm_apply(y, ops.ColStats(part, T, y.shape[1], frames), slope=0.0, frames=frames)
-        return ops.gemm(y, P[head + ".6.weight"], act=ops.ACT_SIGMOID)  # (T,1)
+        y, part = ops.gemm_colstats(in_relu(y, part), P[head + ".3.weight"], frames=frames)
+        return ops.gemm(in_relu(y, part), P[head + ".6.weight"], act=ops.ACT_SIGMOID, frames=frames)  # (T,1)
 
     def _pc_feature_mlp(self, P, x: torch.Tensor) -> torch.Tensor:
         """network.py:29."""
@@ -175,21 +179,13 @@ class CoFiI2P(nn.Module):
         T_img, C = H8 * W8, D_MODEL
         ts = transformer.TokenStreams(B * T_img, B * N4, D_MODEL, dev)
         # ---- image branch (network.py:77,90,104-106,110) on a side stream, concurrent with the point encoder
-        nhwc = self.image_backend == "nhwc"
-        if B != 1 and not nhwc:
-            raise ValueError("stack mode needs the NHWC image backend")
         br_dead = ops.Branch(dev, 3)  # ResNet layer3/layer4/avg-pool: computed (reference parity), read by nothing downstream
         with ops.Branch(dev, 0) as br_img:
             grid = self._pixel_grid(H8, W8, B, dev)   # (y, x) of every token of the 1/8 map: a constant, built once
-            if nhwc:
-                img_set, dims = image.resnet34_nhwc(P, img, full=self.compute_unused_image_maps, tail_branch=br_dead)
-                s2, s4, s8 = img_set[0], img_set[1], img_set[2]  # (B*H*W, C) pixel-major
-                s8n = ops.l2norm_rows(s8)  # the normalised s8 map also feeds the up-sampler (network.py:90,129)
-                ops.l2norm_rows(s8, out=ts.img[0][:, :D_MODEL])
-            else:
-                img_set = image.resnet34(P, img, full=self.compute_unused_image_maps)
-                s2, s4, s8 = img_set[0], img_set[1], img_set[2]
-                s8n, _ = ops.l2norm_cols(s8[0].reshape(C, T_img), tokens_out=ts.img[0][:, :D_MODEL])
+            img_set, dims = image.resnet34_nhwc(P, img, full=self.compute_unused_image_maps, tail_branch=br_dead)
+            s2, s4, s8 = img_set[0], img_set[1], img_set[2]  # (B*H*W, C) pixel-major
+            s8n = ops.l2norm_rows(s8)  # the normalised s8 map also feeds the up-sampler (network.py:90,129)
+            ops.l2norm_rows(s8, out=ts.img[0][:, :D_MODEL])
             ops.pos_sine(grid, ts.img[0], accumulate=True)
         # ---- point branch (network.py:76,83-84,107,111)
         pc_set = kpfpn.run_fpn(P, points, neighbors, subsampling, upsampling, feats, taps=taps, frames=B, order=order)
@@ -202,17 +198,10 @@ class CoFiI2P(nn.Module):
 
         # ---- fine image descriptors (network.py:129-130): only image data -> side stream, under the transformer
         with ops.Branch(dev, 0) as br_up:
-            if nhwc:
-                up4 = image.upsample_stage_nhwc(P, "img_upsample_1", s8n, H8, W8, s4, frames=B)
-                up2_raw = image.upsample_stage_nhwc(P, "img_upsample_2", up4, 2 * H8, 2 * W8, s2, frames=B)
-                H2, W2, C2 = 4 * H8, 4 * W8, up2_raw.shape[1]
-                up2 = ops.l2norm_rows(up2_raw)  # (B*H2*W2, C2) pixel-major fine image descriptors
-            else:
-                up4 = image.upsample_stage(P, "img_upsample_1", s8n.reshape(1, C, H8, W8), s4)
-                up2_raw = image.upsample_stage(P, "img_upsample_2", up4, s2)
-                C2, H2, W2 = up2_raw.shape[1:]
-                up2, _ = ops.l2norm_cols(up2_raw[0].reshape(C2, H2 * W2), want_tokens=False)
-                up2 = up2.reshape(C2, H2, W2)
+            up4 = image.upsample_stage_nhwc(P, "img_upsample_1", s8n, H8, W8, s4, frames=B)
+            up2_raw = image.upsample_stage_nhwc(P, "img_upsample_2", up4, 2 * H8, 2 * W8, s2, frames=B)
+            H2, W2, C2 = 4 * H8, 4 * W8, up2_raw.shape[1]
+            up2 = ops.l2norm_rows(up2_raw)  # (B*H2*W2, C2) pixel-major fine image descriptors
 
         # ---- transformer (network.py:113-115)
         tok_img, tok_pc = transformer.run_transformer(self._layers, LAYER_KINDS, ts, N_HEAD, frames=B)
@@ -233,13 +222,13 @@ class CoFiI2P(nn.Module):
             o = {"img_desc": ops.transpose(idt).reshape(1, C, H8, W8), "pc_desc": ops.transpose(pdt),
                  "img_score": img_score[f * T_img:(f + 1) * T_img].reshape(1, 1, H8, W8), "pc_score": pc_score[f * N4:(f + 1) * N4].reshape(1, 1, N4)}
             fpc = fine_pc[f * N1:(f + 1) * N1]
-            up2_f = up2[f * P2:(f + 1) * P2] if nhwc else up2
+            up2_f = up2[f * P2:(f + 1) * P2]
             if mode in ("train", "val"):
                 K = fine_center_kpt_coors.shape[1]
                 cnt = torch.zeros((2,), dtype=torch.int32, device=dev)
                 cnt[0] = K
                 ctr = fine_center_kpt_coors.to(torch.float32).contiguous()
-                pat = ops.extract_patches_nhwc(up2_f, H2, W2, ctr, cnt, K, 1.0) if nhwc else ops.extract_patches(up2_f, ctr, cnt, K, 1.0)
+                pat = ops.extract_patches_nhwc(up2_f, H2, W2, ctr, cnt, K, 1.0)
                 o["patches"] = pat.reshape(K, C2, 4, 4)
                 o["fine_pc"] = ops.gather_rows(fpc, self._as_idx32(fine_pc_inline_index.reshape(-1)))
             else:
@@ -250,8 +239,7 @@ class CoFiI2P(nn.Module):
                 sel, xy, cnt = ops.select_matches(o["pc_score"].reshape(-1), pix, W8, H8, score_thresholds(), 4)
                 o["coarse_pts"] = ops.gather_points_sel(pts4, sel, cnt)
                 node = ops.nearest_node_sel(pts1, pts4, sel, cnt)
-                o["patches"] = (ops.extract_patches_nhwc(up2_f, H2, W2, xy, cnt, N4, 4.0) if nhwc
-                                else ops.extract_patches(up2_f, xy, cnt, N4, 4.0))
+                o["patches"] = ops.extract_patches_nhwc(up2_f, H2, W2, xy, cnt, N4, 4.0)
                 o["fine_pc"] = ops.gather_rows_sel(fpc, node, cnt, N4)
                 o["fine_xy"], o["fine_best"] = ops.fine_match(o["patches"], o["fine_pc"], xy, cnt, 4.0)  # eval_all.py:99-105
                 o.update(sel=sel, coarse_xy=xy, count=cnt)
@@ -278,44 +266,49 @@ class CoFiI2P(nn.Module):
 
         order = [] if order is None else list(order)
         tensors = list(points) + list(neighbors) + list(subsampling) + list(upsampling) + order + [feats, img, kpt, inl]
-        key = (mode, str(img.device), slot, branch_mask) + tuple(sig(t) for t in tensors)
+        # everything a captured launch sequence depends on besides the tensor signature: arithmetic, optional branches
+        key = (mode, str(img.device), slot, branch_mask, ops.GEMM_MODE, self.compute_unused_image_maps, transformer.JOINT_SELF) \
+            + tuple(sig(t) for t in tensors)
+        saved_mask, saved_slot = ops.BRANCH_MASK, ops.Workspace.slot
         ops.set_workspace_slot(slot)
-        saved_mask, ops.BRANCH_MASK = ops.BRANCH_MASK, branch_mask  # which intra-frame forks the capture records
-        ent = self._graphs.get(key)
-        if ent is None:
-            static = [None if t is None else torch.empty_like(t) for t in tensors]
-            for s_, t in zip(static, tensors):
-                if t is not None:
-                    s_.copy_(t)
-            n = [len(points), len(neighbors), len(subsampling), len(upsampling), len(order)]
-            o = [0, n[0], n[0] + n[1], n[0] + n[1] + n[2], n[0] + n[1] + n[2] + n[3], sum(n)]
-            args = (static[o[0]:o[1]], static[o[1]:o[2]], static[o[2]:o[3]], static[o[3]:o[4]], static[o[5]], static[o[5] + 1], mode,
-                    static[o[5] + 2], static[o[5] + 3], None, (static[o[4]:o[5]] or None))
-            # warm-up AND capture run on one persistent stream, so every per-stream workspace is grown (in the
-            # ordinary allocator pool) before the capture starts and nothing is allocated for it inside
-            if getattr(self, "_capture_stream", None) is None or self._capture_stream.device != img.device:
-                self._capture_stream = torch.cuda.Stream(device=img.device)
-            cap = self._capture_stream
-            cap.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(cap):
-                for _ in range(2):
-                    self._run_device(P, *args)
-            torch.cuda.current_stream().wait_stream(cap)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=cap):
-                outs = self._run_device(P, *args)
-            ent = (graph, static, outs)
-            self._graphs[key] = ent
-        graph, static, outs = ent
-        # per-frame inputs -> the static buffers the graph reads: one batched copy launch (20+ tensors)
-        mc = self._multicopy.get(key)
-        if mc is None:
-            mc = self._multicopy[key] = ops.MultiCopy(img.device)
-        mc.run([None if t is None else t.contiguous() for t in tensors], static)
-        graph.replay()
-        ops.set_workspace_slot(0)
-        ops.BRANCH_MASK = saved_mask
+        ops.BRANCH_MASK = branch_mask  # which intra-frame forks the capture records
+        try:
+            ent = self._graphs.get(key)
+            if ent is None:
+                static = [None if t is None else torch.empty_like(t) for t in tensors]
+                for s_, t in zip(static, tensors):
+                    if t is not None:
+                        s_.copy_(t)
+                n = [len(points), len(neighbors), len(subsampling), len(upsampling), len(order)]
+                o = [0, n[0], n[0] + n[1], n[0] + n[1] + n[2], n[0] + n[1] + n[2] + n[3], sum(n)]
+                args = (static[o[0]:o[1]], static[o[1]:o[2]], static[o[2]:o[3]], static[o[3]:o[4]], static[o[5]], static[o[5] + 1], mode,
+                        static[o[5] + 2], static[o[5] + 3], None, (static[o[4]:o[5]] or None))
+                # warm-up AND capture run on one persistent stream, so every per-stream workspace is grown (in the
+                # ordinary allocator pool) before the capture starts and nothing is allocated for it inside
+                if getattr(self, "_capture_stream", None) is None or self._capture_stream.device != img.device:
+                    self._capture_stream = torch.cuda.Stream(device=img.device)
+                cap = self._capture_stream
+                cap.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(cap):
+                    for _ in range(2):
+                        self._run_device(P, *args)
+                torch.cuda.current_stream().wait_stream(cap)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=cap):
+                    outs = self._run_device(P, *args)
+                ent = (graph, static, outs)
+                self._graphs[key] = ent
+            graph, static, outs = ent
+            # per-frame inputs -> the static buffers the graph reads: one batched copy launch (20+ tensors)
+            mc = self._multicopy.get(key)
+            if mc is None:
+                mc = self._multicopy[key] = ops.MultiCopy(img.device)
+            mc.run([None if t is None else t.contiguous() for t in tensors], static)
+            graph.replay()
+        finally:   # an exception during warm-up / capture must not leave later eager forwards in this slot's scratch namespace
+            ops.set_workspace_slot(saved_slot)
+            ops.BRANCH_MASK = saved_mask
         return outs
 
     # ------------------------------------------------------------------ frames in flight / stack-mode batches
@@ -376,9 +369,20 @@ class CoFiI2P(nn.Module):
         handle["fine_xy"] = fine
         return res[0] if len(res) == 1 else res
 
-    @torch.no_grad()
     def forward(self, pc_data_dict, img, fine_center_kpt_coors, fine_xy, fine_pc_inline_index, mode, taps=None):
-        """model/network.py:74-164.  ``fine_xy`` is unused (as in the reference)."""
+        """model/network.py:74-164.  ``fine_xy`` is unused (as in the reference).
+
+        Inference only: the HIP kernels have no backward (SURVEY.md §8 row f3 is not built).  A caller that expects a graph -
+        mode='train' with autograd enabled (train.py:224-226 followed by loss.backward(), train.py:285), or any input that
+        requires grad - gets an error instead of tensors that silently carry no gradient; train.py's validation pass
+        (mode='val' under torch.no_grad(), train.py:66-70) and evaluation/eval_all.py are served."""
+        if torch.is_grad_enabled() and (mode == "train" or img.requires_grad or pc_data_dict["feats"].requires_grad):
+            raise NotImplementedError("cofii2p_amd.CoFiI2P is forward-only (no autograd through the HIP kernels): call it under "
+                                      "torch.no_grad() for inference / validation; training needs the reference's PyTorch model")
+        with torch.no_grad():
+            return self._forward(pc_data_dict, img, fine_center_kpt_coors, fine_pc_inline_index, mode, taps)
+
+    def _forward(self, pc_data_dict, img, fine_center_kpt_coors, fine_pc_inline_index, mode, taps=None):
         if mode not in ("train", "val", "test"):
             raise ValueError("mode must be 'train', 'val' or 'test'")
         if not img.is_cuda:
@@ -454,9 +458,13 @@ def extract_patch(feature_map, center_points, size: int = 4):
     if size != 4:
         raise NotImplementedError("the reference asserts 4x4 patches (network.py:222)")
     n = center_points.shape[1]
+    B, C, H2, W2 = feature_map.shape
     cnt = torch.tensor([n, 0], dtype=torch.int32, device=feature_map.device)
-    out = [ops.extract_patches(feature_map[b].contiguous(), center_points.to(torch.float32).contiguous(), cnt, n, 1.0)
-           .reshape(n, feature_map.shape[1], 4, 4) for b in range(feature_map.shape[0])]
+    ctr = center_points.to(torch.float32).contiguous()
+    out = []
+    for b in range(B):
+        nhwc = ops.transpose(feature_map[b].reshape(C, H2 * W2).contiguous())   # (H2*W2, C) pixel-major, as the forward keeps its maps
+        out.append(ops.extract_patches_nhwc(nhwc, H2, W2, ctr, cnt, n, 1.0).reshape(n, C, 4, 4))
     return torch.stack(out, 1)
 
 

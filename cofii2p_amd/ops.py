@@ -17,8 +17,9 @@ import os
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 GEMM_BF16X3 = 0x100
-# arithmetic of the dense contractions: "f32" = exact fp32 MFMA, "bf16x3" = 3-term bf16 split with fp32 accumulation
-GEMM_MODE = os.environ.get("COFI_GEMM", "f32")
+# arithmetic of the dense contractions: "bf16x3" (default) = 3-term bf16 split (hi*hi + hi*lo + lo*hi) on the bf16 matrix cores
+# with fp32 accumulation, ~2^-16 relative error per product; "f32" = exact fp32 MFMA (COFI_GEMM=f32)
+GEMM_MODE = os.environ.get("COFI_GEMM", "bf16x3")
 
 
 # Which intra-frame fork/join branches are taken (see Branch).  With >= 2 frames in flight the frames themselves fill
@@ -177,9 +178,83 @@ def set_workspace_slot(slot: int):
 
 
 # ------------------------------------------------------------------------------------------ dense
-def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, bias=None, rowdiv=None, act: int = ACT_NONE):
-    """out[m,n] = act( (a @ w.T)[m,n] / rowdiv[m] + bias[n] );  a (M,K), w (N,K)."""
+class ColStats:
+    """Statistics partials a GEMM / convolution epilogue left behind for its (M, C) output: part (nslab, C // width, 2)
+    = {sum, sum of squares} per 64-row slab and per `width` adjacent columns (include/cofi_hip.h: cofi_norm_desc_t).
+    Consumers fold them in-kernel; `finalize()` (separate launch, width 1 only) is the fallback for layouts the in-kernel
+    fold does not take."""
+
+    def __init__(self, part: torch.Tensor, M: int, groups: int, frames: int = 1, eps: float = 1e-5, width: int = 1):
+        self.part, self.M, self.groups, self.frames, self.eps, self.width = part, M, groups, frames, eps, width
+
+    @property
+    def C(self) -> int:
+        return self.part.shape[1] * self.width
+
+    def fusable(self) -> bool:
+        C, tc, G = self.C, self.part.shape[1], self.groups
+        cpg = C // G
+        rows = self.M // self.frames
+        return ((tc & (tc - 1)) == 0 and (G & (G - 1)) == 0 and cpg % self.width == 0 and G <= 1024
+                and (self.frames == 1 or rows % 64 == 0) and self.part.shape[0] == self.frames * ((rows + 63) // 64))
+
+    def finalize(self) -> torch.Tensor:
+        if self.width != 1:
+            raise _lib.CofiError("ColStats.finalize needs per-column partials (width 1)")
+        return group_stats_from_colpart(self.part, self.M, self.groups, self.eps, self.frames)
+
+    def desc(self, gamma=None, beta=None, slope: float = 1.0) -> "_lib.NormDesc":
+        d = _lib.NormDesc()
+        d.partials = self.part.data_ptr()
+        d.nslab, d.width, d.channels, d.groups = self.part.shape[0], self.width, self.C, self.groups
+        d.gamma = None if gamma is None else gamma.data_ptr()
+        d.beta = None if beta is None else beta.data_ptr()
+        d.eps, d.slope = self.eps, slope
+        return d
+
+
+class Normed:
+    """A raw layer output `y` whose GroupNorm / InstanceNorm (+ affine + LeakyReLU) is still pending:
+         value = leaky(gn(y; stats) * gamma + beta, slope).
+    A GEMM / convolution that consumes it applies the normalisation in its operand loader (cofi_gemm_f32_fused); anything
+    else calls `materialize()` (the stand-alone apply kernel)."""
+    MAX_FUSED_CHANNELS = 512
+
+    def __init__(self, y: torch.Tensor, stats: ColStats, gamma=None, beta=None, slope: float = 1.0):
+        self.y, self.stats, self.gamma, self.beta, self.slope = y, stats, gamma, beta, slope
+        self.shape, self.device, self.dtype = y.shape, y.device, y.dtype
+
+    def numel(self):
+        return self.y.numel()
+
+    def fusable(self, tile_rows_ok: bool = True) -> bool:
+        return (GEMM_MODE == "bf16x3" and self.stats.fusable() and self.y.shape[1] <= self.MAX_FUSED_CHANNELS and 0.0 <= self.slope <= 1.0
+                and tile_rows_ok)
+
+    def desc(self):
+        return self.stats.desc(self.gamma, self.beta, self.slope)
+
+    def materialize(self, out=None, want_row_pos: bool = False):
+        return group_norm_apply(self.y, self.stats, self.gamma, self.beta, slope=self.slope, out=out, frames=self.stats.frames,
+                                want_row_pos=want_row_pos)
+
+
+def _a_operand(a, M_rows: int, frames: int):
+    """-> (raw matrix, NormDesc or None) for a GEMM A operand that may carry a pending normalisation."""
+    if not isinstance(a, Normed):
+        return a, None
+    # a tile of GEMM rows must lie inside one frame: 128-row tiles are the largest
+    if a.fusable(frames == 1 or (M_rows // frames) % 128 == 0):
+        return a.y, a.desc()
+    return a.materialize(), None
+
+
+def _gemm_impl(a, w, out, bias, rowdiv, act, stat_width, frames):
     lib = _lib.load()
+    if isinstance(a, Normed) and not isinstance(w, SplitW) and a.fusable():
+        w = SplitW(w)   # the normalising loader lives in the pre-split-weight kernels
+    M0 = a.shape[0]
+    a, nd = _a_operand(a, M0, frames)
     _mat(a, "a")
     if not isinstance(w, SplitW):
         _mat(w, "w")
@@ -191,39 +266,30 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, b
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     _mat(out, "out")
     _vec(bias, "bias", N), _vec(rowdiv, "rowdiv", M)
+    colpart = None
+    if stat_width:
+        if N % stat_width:
+            raise _lib.CofiError("gemm: %d columns are not a multiple of the statistics width %d" % (N, stat_width))
+        colpart = torch.empty((lib.cofi_gemm_f32_stat_slabs(M, N, K), N // stat_width, 2), dtype=torch.float32, device=a.device)
     if M == 0:   # zero rows: nothing to launch (torch hands out a null pointer for an empty tensor, which the C ABI rejects)
-        return out
-    nbytes = lib.cofi_gemm_f32_workspace(M, N, K)
-    ws = _WS_GEMM.get(nbytes, a.device)
-    wp, wld, wflag = _wargs(w)
-    rc = lib.cofi_gemm_f32(_p(a), _ld(a), wp, wld, _p(out), _ld(out), M, N, K, _p(bias), _p(rowdiv), act | _gemm_flag() | wflag, _p(ws),
-                           0 if ws is None else ws.numel(), _stream())
-    _lib.check(rc, "cofi_gemm_f32")
-    return out
-
-
-def gemm_colstats(a, w, out=None, bias=None, rowdiv=None, act: int = ACT_NONE):
-    """gemm() that also returns the fused per-slab column statistics: (out, colpart (nslab,N,2))."""
-    lib = _lib.load()
-    _mat(a, "a")
-    if not isinstance(w, SplitW):
-        _mat(w, "w")
-    M, K = a.shape
-    N = w.shape[0]
-    if w.shape[1] != K:
-        raise _lib.CofiError("gemm: K mismatch %s vs %s" % (tuple(a.shape), tuple(w.shape)))
-    if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    _mat(out, "out")
-    _vec(bias, "bias", N), _vec(rowdiv, "rowdiv", M)
-    nslab = lib.cofi_gemm_f32_stat_slabs(M, N, K)
-    colpart = torch.empty((nslab, N, 2), dtype=torch.float32, device=a.device)
+        return out, colpart
     ws = _WS_GEMM.get(lib.cofi_gemm_f32_workspace(M, N, K), a.device)
     wp, wld, wflag = _wargs(w)
-    rc = lib.cofi_gemm_f32_colstats(_p(a), _ld(a), wp, wld, _p(out), _ld(out), M, N, K, _p(bias), _p(rowdiv), act | _gemm_flag() | wflag, _p(colpart),
-                                    _p(ws), 0 if ws is None else ws.numel(), _stream())
-    _lib.check(rc, "cofi_gemm_f32_colstats")
+    rc = lib.cofi_gemm_f32_fused(_p(a), _ld(a), None if nd is None else ctypes.byref(nd), wp, wld, _p(out), _ld(out), M, N, K, _p(bias),
+                                 _p(rowdiv), act | _gemm_flag() | wflag, _p(colpart), max(stat_width, 1), _p(ws), 0 if ws is None else ws.numel(),
+                                 frames, _stream())
+    _lib.check(rc, "cofi_gemm_f32_fused")
     return out, colpart
+
+
+def gemm(a, w, out: Optional[torch.Tensor] = None, bias=None, rowdiv=None, act: int = ACT_NONE, frames: int = 1):
+    """out[m,n] = act( (a @ w.T)[m,n] / rowdiv[m] + bias[n] );  a (M,K) [or a Normed: normalised on the fly], w (N,K)."""
+    return _gemm_impl(a, w, out, bias, rowdiv, act, 0, frames)[0]
+
+
+def gemm_colstats(a, w, out=None, bias=None, rowdiv=None, act: int = ACT_NONE, stat_width: int = 1, frames: int = 1):
+    """gemm() that also returns the fused statistics partials: (out, colpart (nslab, N // stat_width, 2))."""
+    return _gemm_impl(a, w, out, bias, rowdiv, act, stat_width, frames)
 
 
 def colstats_frames_ok(M_total: int, N: int, K: int, frames: int) -> bool:
@@ -266,11 +332,12 @@ def group_stats_from_colpart(colpart, M: int, groups: int, eps: float = 1e-5, fr
     return stats
 
 
-def col_inv_norm_from_colpart(colpart, C: int, eps: float = 1e-12, frames: int = 1):
+def col_inv_norm_from_colpart(colpart, M: int, C: int, eps: float = 1e-12, frames: int = 1):
+    """M = rows of the activation (all frames) the per-column partials were taken over."""
     lib = _lib.load()
     nslab, ncols, _ = colpart.shape
     out = torch.empty((C,) if frames == 1 else (frames, C), dtype=torch.float32, device=colpart.device)
-    _lib.check(lib.cofi_col_inv_norm_from_colpart(_p(colpart), nslab, ncols, C, eps, _p(out), frames, _stream()),
+    _lib.check(lib.cofi_col_inv_norm_from_colpart(_p(colpart), nslab, M, ncols, C, eps, _p(out), frames, _stream()),
                "cofi_col_inv_norm_from_colpart")
     return out
 
@@ -349,26 +416,9 @@ def group_stats(x, groups: int, eps: float = 1e-5, frames: int = 1):
     return stats
 
 
-class ColStats:
-    """GroupNorm / InstanceNorm statistics still in the form the GEMM epilogue left them: per-slab column partials
-    (nslab, C, 2) of an (M, C) activation.  `group_norm_apply` folds small tables inside its own kernel
-    (cofi_group_norm_apply_colpart); large ones are finalised by cofi_group_stats_from_colpart first."""
-    FUSE_MAX_PARTIALS = int(os.environ.get("COFI_GN_FUSE_MAX", "2048"))  # per frame: nslab * C partial pairs = 8 loads per thread, one L2 round trip
-
-    def __init__(self, part: torch.Tensor, M: int, groups: int, frames: int = 1, eps: float = 1e-5):
-        self.part, self.M, self.groups, self.frames, self.eps = part, M, groups, frames, eps
-
-    def fusable(self) -> bool:
-        nslab, C, _ = self.part.shape
-        return (C & (C - 1)) == 0 and C <= 1024 and C // self.groups <= 256 and (nslab // self.frames) * C <= self.FUSE_MAX_PARTIALS
-
-    def finalize(self) -> torch.Tensor:
-        return group_stats_from_colpart(self.part, self.M, self.groups, self.eps, self.frames)
-
-
 def group_norm_apply(x, stats, gamma=None, beta=None, slope: float = 1.0, res=None, res_stats=None, res_gamma=None, res_beta=None,
                      out=None, frames: int = 1, want_row_pos: bool = False):
-    """stats: (groups,2) / stack mode (frames, groups, 2) tensor, or ColStats (column partials, folded in-kernel when small).
+    """stats: (groups,2) / stack mode (frames, groups, 2) tensor, or ColStats (statistics partials, folded in-kernel).
     want_row_pos (activation at most 256 wide): the kernel also emits row_pos = (row sum > 0), attached to the result as
     `out.cofi_row_pos` for the KPConv that consumes it (kpconv.py:113-114)."""
     lib = _lib.load()
@@ -380,12 +430,11 @@ def group_norm_apply(x, stats, gamma=None, beta=None, slope: float = 1.0, res=No
     row_pos = torch.empty((M,), dtype=torch.uint8, device=x.device) if (want_row_pos and C % 4 == 0 and c4n <= 64 and 64 % c4n == 0) else None
     fused = isinstance(stats, ColStats) and stats.fusable() and (res_stats is None or (isinstance(res_stats, ColStats) and res_stats.fusable()))
     if fused:
-        rc = lib.cofi_group_norm_apply_colpart(_p(x), _ld(x), M, C, stats.groups, _p(stats.part), stats.part.shape[0], stats.eps, _p(gamma),
-                                               _p(beta), _p(res), 0 if res is None else _ld(res),
-                                               None if res_stats is None else _p(res_stats.part),
-                                               0 if res_stats is None else res_stats.part.shape[0], _p(res_gamma), _p(res_beta),
-                                               float(slope), _p(out), _ld(out), _p(row_pos), frames, _stream())
-        _lib.check(rc, "cofi_group_norm_apply_colpart")
+        nd = stats.desc(gamma, beta, slope)
+        rnd = None if res_stats is None else res_stats.desc(res_gamma, res_beta, 1.0)
+        rc = lib.cofi_group_norm_apply_partials(_p(x), _ld(x), M, C, ctypes.byref(nd), _p(res), 0 if res is None else _ld(res),
+                                                None if rnd is None else ctypes.byref(rnd), _p(out), _ld(out), _p(row_pos), frames, _stream())
+        _lib.check(rc, "cofi_group_norm_apply_partials")
     else:
         if isinstance(stats, ColStats):
             stats = stats.finalize()
@@ -439,17 +488,13 @@ def l2norm_rows(x, out=None, transpose: bool = False):
     return out
 
 
-def l2norm_cols(x_cp, want_map: bool = True, want_tokens: bool = True, tokens_out=None):
-    """x (C,P) channel-major -> (normalised (C,P) map, token-major (P,C) copy)."""
+def col_mean(x, frames: int = 1):
+    """(frames * rows, C) -> (frames, C) column means per frame (AdaptiveAvgPool2d(1) of an NHWC map)."""
     lib = _lib.load()
-    _mat(x_cp, "x")
-    C, P = x_cp.shape
-    y_cp = torch.empty((C, P), dtype=torch.float32, device=x_cp.device) if want_map else None
-    y_pc = tokens_out if tokens_out is not None else (torch.empty((P, C), dtype=torch.float32, device=x_cp.device) if want_tokens else None)
-    rc = lib.cofi_l2norm_cols(_p(x_cp), _ld(x_cp), C, P, _p(y_cp), 0 if y_cp is None else _ld(y_cp), _p(y_pc),
-                              0 if y_pc is None else _ld(y_pc), _stream())
-    _lib.check(rc, "cofi_l2norm_cols")
-    return y_cp, y_pc
+    _mat(x, "x")
+    out = torch.empty((frames, x.shape[1]), dtype=torch.float32, device=x.device)
+    _lib.check(lib.cofi_col_mean(_p(x), _ld(x), x.shape[0], x.shape[1], _p(out), frames, _stream()), "cofi_col_mean")
+    return out
 
 
 def transpose(x, out=None):
@@ -484,28 +529,36 @@ def pos_sine(coords, out, accumulate: bool, d_model: int = 128):
 
 # ------------------------------------------------------------------------------------------ image branch, NHWC
 def conv2d_nhwc(x, H: int, W: int, w, ks: int, stride: int = 1, pad: int = 1, bias=None, res=None, act: int = ACT_NONE,
-                colstats: bool = False, out=None, frames: int = 1):
-    """Implicit-GEMM convolution on an NHWC map x (H*W, Cin) [row-major view, any leading dimension];
-    w (Cout, ks*ks*Cin).  -> y (Ho*Wo, Cout) [, colpart]."""
+                colstats: bool = False, out=None, frames: int = 1, stat_width: int = 1):
+    """Implicit-GEMM convolution on an NHWC map x (H*W, Cin) [row-major view, any leading dimension; or a Normed: the pending
+    InstanceNorm + ReLU of the previous convolution is applied by the operand loader]; w (Cout, ks*ks*Cin).
+    -> y (Ho*Wo, Cout) [, colpart]."""
     lib = _lib.load()
+    Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    nd = None
+    if isinstance(x, Normed):
+        if isinstance(w, SplitW) and x.fusable(frames == 1 or (Ho * Wo) % 128 == 0):
+            x, nd = x.y, x.desc()
+        else:
+            x = x.materialize()
     _mat(x, "x")
     if not isinstance(w, SplitW):
         _mat(w, "w")
     Cin, Cout = x.shape[1], w.shape[0]
     if x.shape[0] != frames * H * W or w.shape[1] != ks * ks * Cin:
         raise _lib.CofiError("conv2d_nhwc: shape mismatch x %s w %s H %d W %d ks %d" % (tuple(x.shape), tuple(w.shape), H, W, ks))
-    Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
     M, K = frames * Ho * Wo, ks * ks * Cin
     if out is None:
         out = torch.empty((M, Cout), dtype=torch.float32, device=x.device)
     part = None
     if colstats:
-        part = torch.empty((lib.cofi_gemm_f32_stat_slabs(M, Cout, K), Cout, 2), dtype=torch.float32, device=x.device)
+        part = torch.empty((lib.cofi_gemm_f32_stat_slabs(M, Cout, K), Cout // stat_width, 2), dtype=torch.float32, device=x.device)
     ws = _WS_GEMM.get(lib.cofi_gemm_f32_workspace(M, Cout, K), x.device)
     wp, _wld, wflag = _wargs(w)   # convolution weights are dense (Cout, K) / planes (2, Cout, roundup8(K))
-    rc = lib.cofi_conv2d_nhwc(_p(x), _ld(x), H, W, Cin, wp, Cout, ks, stride, pad, _p(bias), _p(res), 0 if res is None else _ld(res),
-                              act | _gemm_flag() | wflag, _p(out), _ld(out), _p(part), _p(ws), 0 if ws is None else ws.numel(), frames, _stream())
-    _lib.check(rc, "cofi_conv2d_nhwc")
+    rc = lib.cofi_conv2d_nhwc_fused(_p(x), _ld(x), None if nd is None else ctypes.byref(nd), H, W, Cin, wp, Cout, ks, stride, pad, _p(bias),
+                                    _p(res), 0 if res is None else _ld(res), act | _gemm_flag() | wflag, _p(out), _ld(out), _p(part), stat_width,
+                                    _p(ws), 0 if ws is None else ws.numel(), frames, _stream())
+    _lib.check(rc, "cofi_conv2d_nhwc_fused")
     return (out, part, Ho, Wo) if colstats else (out, Ho, Wo)
 
 
@@ -554,57 +607,52 @@ def extract_patches_nhwc(fmap, H2: int, W2: int, xy, cnt, cap: int, center_scale
     return out
 
 
-# ------------------------------------------------------------------------------------------ image-branch glue (NCHW / MIOpen variant)
-def instance_norm_nchw(x, relu: bool = False, res=None, res_norm: bool = False, eps: float = 1e-5):
-    """x (1,C,H,W) contiguous -> relu?(IN(x) + [res | IN(res)])."""
-    lib = _lib.load()
-    if not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous() or x.shape[0] != 1:
-        raise _lib.CofiError("instance_norm_nchw: contiguous CUDA fp32 (1,C,H,W) expected")
-    _, C, H, W = x.shape
-    y = torch.empty_like(x)
-    mode = 0 if res is None else (2 if res_norm else 1)
-    _lib.check(lib.cofi_instance_norm_nchw(_p(x), C, H * W, eps, _p(res), mode, int(relu), _p(y), _stream()), "cofi_instance_norm_nchw")
-    return y
-
-
-def bias_act_nchw(x, bias=None, res=None, res_bias=None, relu: bool = True):
-    lib = _lib.load()
-    _, C, H, W = x.shape
-    y = torch.empty_like(x)
-    _lib.check(lib.cofi_bias_act_nchw(_p(x), _p(bias), _p(res), _p(res_bias), C, H * W, int(relu), _p(y), _stream()), "cofi_bias_act_nchw")
-    return y
-
-
-def upsample2x_cat(low, skip):
-    """(1,C1,h,w), (1,C2,2h,2w) -> (1,C1+C2,2h,2w): bilinear x2 (align_corners=False) + channel concat."""
-    lib = _lib.load()
-    _, C1, h, w = low.shape
-    C2 = skip.shape[1]
-    out = torch.empty((1, C1 + C2, 2 * h, 2 * w), dtype=torch.float32, device=low.device)
-    _lib.check(lib.cofi_upsample2x_cat(_p(low.contiguous()), C1, h, w, _p(skip.contiguous()), C2, _p(out), _stream()), "cofi_upsample2x_cat")
-    return out
-
-
 # ------------------------------------------------------------------------------------------ attention
-def attention(q, k, v, q_colscale=None, nhead: int = 4, out=None, frames: int = 1, q_colpart=None, q_eps: float = 1e-12):
+_WS_ATTN = Workspace()
+
+
+class AttnParts:
+    """Output of the attention kernel in its native form: per (frame, head, 32-query block) partial slots
+    (csrc/attention_parts.h).  `ops.loftr_tail` merges them in its loader; `merge()` writes the plain (frames*L, H*D) matrix."""
+
+    def __init__(self, buf, L: int, S: int, H: int, D: int, frames: int):
+        self.buf, self.L, self.S, self.H, self.D, self.frames = buf, L, S, H, D, frames
+        self.shape = (frames * L, H * D)
+
+    def merge(self, out=None):
+        lib = _lib.load()
+        if out is None:
+            out = torch.empty(self.shape, dtype=torch.float32, device=self.buf.device)
+        _mat(out, "out")
+        _lib.check(lib.cofi_attention_merge(_p(self.buf), self.buf.numel(), self.L, self.S, self.H, self.D, self.frames, _p(out), _ld(out),
+                                            _stream()), "cofi_attention_merge")
+        return out
+
+
+def attention(q, k, v, q_colscale=None, nhead: int = 4, out=None, frames: int = 1, q_colpart=None, q_eps: float = 1e-12,
+              parts: bool = False):
     """Stack mode: q (frames*L, HD), k/v (frames*S, HD), q_colscale (frames, HD).  q_colpart (nslab, ncols, 2): the column
-    partials of the GEMM that produced q (its first HD columns) - the token-axis norm of Q is then folded inside the kernel."""
+    partials of the GEMM that produced q (its first HD columns) - the token-axis norm of Q is then folded inside the kernel.
+    parts=True: return the kernel's partial slots (AttnParts) instead of the merged matrix."""
     lib = _lib.load()
     _mat(q, "q"), _mat(k, "k"), _mat(v, "v")
     L, HD = q.shape
     S = k.shape[0]
     D = HD // nhead
-    if out is None:
-        out = torch.empty((L, HD), dtype=torch.float32, device=q.device)
-    if q_colpart is not None:
-        rc = lib.cofi_attention_fwd_colpart(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(q_colpart), q_colpart.shape[0], q_colpart.shape[1],
-                                            q_eps, _p(out), _ld(out), L // frames, S // frames, nhead, D, 1.0 / math.sqrt(D), frames, _stream())
-        _lib.check(rc, "cofi_attention_fwd_colpart")
-        return out
-    rc = lib.cofi_attention_fwd(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(q_colscale), _p(out), _ld(out), L // frames, S // frames,
-                                nhead, D, 1.0 / math.sqrt(D), None, 0, frames, _stream())
-    _lib.check(rc, "cofi_attention_fwd")
-    return out
+    if L % frames or S % frames:
+        raise _lib.CofiError("attention: rows are not a multiple of the frame count")
+    L, S = L // frames, S // frames
+    nbytes = lib.cofi_attention_workspace(L, S, nhead, D, frames)
+    if nbytes == 0:
+        raise _lib.CofiError("attention: unsupported shape (head dimension must be 32)")
+    # the slot table outlives this call when it is handed to the consumer: a per-stream workspace is safe (stream ordered)
+    ws = _WS_ATTN.get(nbytes, q.device)
+    rc = lib.cofi_attention_parts(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(q_colscale), _p(q_colpart),
+                                  0 if q_colpart is None else q_colpart.shape[0], 0 if q_colpart is None else q_colpart.shape[1], q_eps,
+                                  L, S, nhead, D, 1.0 / math.sqrt(D), frames, _p(ws), ws.numel(), _stream())
+    _lib.check(rc, "cofi_attention_parts")
+    res = AttnParts(ws, L, S, nhead, D, frames)
+    return res if parts else res.merge(out)
 
 
 def split_bf16(w: torch.Tensor):
@@ -615,9 +663,18 @@ def split_bf16(w: torch.Tensor):
 
 
 def loftr_tail(msg, x, w, out, eps: float = 1e-5):
-    """out = x + LN2(relu([x | LN1(msg Wm^T)] W0^T) W2^T) in one kernel; `w` holds the pre-split planes."""
+    """out = x + LN2(relu([x | LN1(msg Wm^T)] W0^T) W2^T) in one kernel; `w` holds the pre-split planes.  msg: the attention
+    output as a matrix or as AttnParts (merged by the kernel's loader)."""
     lib = _lib.load()
-    _mat(msg, "msg"), _mat(x, "x"), _mat(out, "out")
+    _mat(x, "x"), _mat(out, "out")
+    if isinstance(msg, AttnParts):
+        rc = lib.cofi_loftr_tail_parts_bf16x3(_p(msg.buf), msg.buf.numel(), msg.L, msg.S, msg.H, msg.frames, _p(x), _ld(x), _p(w["merge.hi"]),
+                                              _p(w["merge.lo"]), _p(w["norm1.weight"]), _p(w["norm1.bias"]), _p(w["mlp.0.hi"]), _p(w["mlp.0.lo"]),
+                                              _p(w["mlp.2.hi"]), _p(w["mlp.2.lo"]), _p(w["norm2.weight"]), _p(w["norm2.bias"]), eps, _p(out),
+                                              _ld(out), _stream())
+        _lib.check(rc, "cofi_loftr_tail_parts_bf16x3")
+        return out
+    _mat(msg, "msg")
     L = msg.shape[0]
     rc = lib.cofi_loftr_tail_bf16x3(_p(msg), _ld(msg), _p(x), _ld(x), _p(w["merge.hi"]), _p(w["merge.lo"]), _p(w["norm1.weight"]),
                                     _p(w["norm1.bias"]), _p(w["mlp.0.hi"]), _p(w["mlp.0.lo"]), _p(w["mlp.2.hi"]), _p(w["mlp.2.lo"]),
@@ -753,16 +810,17 @@ def row_argmin_1m(sim):
     return out
 
 
-def select_matches(score, pix, W8: int, H8: int, thresholds: np.ndarray, min_matches: int = 4):
-    """-> sel (N,) int32, coarse_xy (2,N) float32, count_dev (2,) int32 [n, threshold index]."""
+def select_matches(score, pix, W8: int, H8: int, thresholds: np.ndarray, min_matches: int = 4, x_max: int = 62, y_max: int = 18):
+    """-> sel (N,) int32, coarse_xy (2,N) float32, count_dev (2,) int32 [n, threshold index].  Border rule of the reference
+    (model/network.py:184): 2 <= x <= 62, 2 <= y <= 18 - hard-coded there for the KITTI 64x20 map and kept for every image size."""
     lib = _lib.load()
     N = score.numel()
     sel = torch.empty((N,), dtype=torch.int32, device=score.device)
     xy = torch.empty((2, N), dtype=torch.float32, device=score.device)
     cnt = torch.empty((2,), dtype=torch.int32, device=score.device)
     thr = np.ascontiguousarray(thresholds, dtype=np.float32)
-    rc = lib.cofi_select_matches(_p(score), _p(pix), N, W8, H8, thr.ctypes.data_as(ctypes.c_void_p), len(thr), min_matches, _p(sel),
-                                 _p(xy), _p(cnt), _stream())
+    rc = lib.cofi_select_matches(_p(score), _p(pix), N, W8, H8, x_max, y_max, thr.ctypes.data_as(ctypes.c_void_p), len(thr), min_matches,
+                                 _p(sel), _p(xy), _p(cnt), _stream())
     _lib.check(rc, "cofi_select_matches")
     return sel, xy, cnt
 
@@ -781,15 +839,6 @@ def nearest_node_sel(nodes, points_all, sel, cnt):
     out = torch.empty((cap,), dtype=torch.int32, device=nodes.device)
     rc = lib.cofi_nearest_node_sel(_p(nodes), nodes.shape[0], _p(points_all), _p(sel), _p(cnt), cap, _p(out), _stream())
     _lib.check(rc, "cofi_nearest_node_sel")
-    return out
-
-
-def extract_patches(fmap_chw, xy, cnt, cap: int, center_scale: float):
-    lib = _lib.load()
-    C, H2, W2 = fmap_chw.shape
-    out = torch.empty((cap, C, 16), dtype=torch.float32, device=fmap_chw.device)
-    rc = lib.cofi_extract_patches(_p(fmap_chw), C, H2, W2, _p(xy), xy.stride(0), float(center_scale), _p(cnt), cap, _p(out), _stream())
-    _lib.check(rc, "cofi_extract_patches")
     return out
 
 

@@ -50,9 +50,16 @@ def _layer(w, xcat: torch.Tensor, src: torch.Tensor, out: torch.Tensor, self_att
         kv = ops.gemm(src, w["kv.weight"])
         k, v = kv[:, :C], kv[:, C:]
     # the attention kernel folds the partials into the per-frame token-axis norm of Q itself
-    msg = ops.attention(q, k, v, q_colpart=part, nhead=nhead, frames=frames)
-    if ops.GEMM_MODE == "bf16x3" and C == 128:
-        # merge + LN1 + concat + MLP + LN2 + residual: one kernel, intermediates stay in LDS
+    fused_tail = ops.GEMM_MODE == "bf16x3" and C == 128
+    rows_q = x.shape[0] // frames
+    if frames > 1 and rows_q % 64:   # the projection's 64-row statistics slabs straddle frames: explicit per-frame column norms
+        qs = torch.stack([ops.col_inv_norm(q[f * rows_q:(f + 1) * rows_q]) for f in range(frames)])
+        msg = ops.attention(q, k, v, q_colscale=qs, nhead=nhead, frames=frames, parts=fused_tail)
+    else:
+        msg = ops.attention(q, k, v, q_colpart=part, nhead=nhead, frames=frames, parts=fused_tail)
+    if fused_tail:
+        # merge + LN1 + concat + MLP + LN2 + residual: one kernel, intermediates stay in LDS; its loader also combines the
+        # attention kernel's partial slots
         return ops.loftr_tail(msg, x, w, out)
     # merge Linear + LayerNorm1 in one kernel, written into the right half of the concat buffer
     ops.gemm_layernorm(msg, w["merge.weight"], w["norm1.weight"], w["norm1.bias"], out=xcat[:, C:])

@@ -43,6 +43,26 @@ extern "C" {
 
 typedef void *cofi_stream_t;
 
+/* A PENDING normalisation: an activation y (rows, channels) whose GroupNorm / InstanceNorm (+ affine + LeakyReLU) has not been
+ * applied yet, described by the statistics partials its producer left behind.  Producers (cofi_gemm_f32_colstats / _fused,
+ * cofi_conv2d_nhwc / _fused) write, per 64-row slab and per `width` adjacent output columns, {sum, sum of squares}:
+ *   partials (nslab, channels / width, 2) fp32, nslab = frames * ceil(rows_per_frame / 64).
+ * Consumers (cofi_gemm_f32_fused, cofi_conv2d_nhwc_fused, cofi_group_norm_apply_partials) fold the table themselves
+ * (fixed order, fp64) and evaluate   leaky( (y - mean_g) * rstd_g * gamma[c] + beta[c], slope ),  g = c / (channels / groups),
+ * i.e. nn.GroupNorm(groups, channels) over ALL rows of the frame (model/kpconv/modules.py:45-48) or, with groups == channels and
+ * gamma == NULL, the affine-less InstanceNorm of model/imagenet.py:123 / model/network.py:42-43.
+ * width, channels / width and groups are powers of two; width divides channels / groups. */
+typedef struct cofi_norm_desc {
+    const float *partials;
+    int nslab;    /* all frames */
+    int width;    /* output columns per table entry */
+    int channels;
+    int groups;
+    const float *gamma, *beta; /* (channels) or both NULL */
+    float eps;
+    float slope;  /* LeakyReLU slope in [0, 1]: 1 = identity, 0 = ReLU, 0.1 = the reference's LeakyReLU */
+} cofi_norm_desc_t;
+
 /* activation codes of the GEMM epilogue */
 #define COFI_ACT_NONE 0
 #define COFI_ACT_RELU 1
@@ -136,9 +156,6 @@ int cofi_gemm_f32(const float *A, int lda, const float *W, int ldw, float *C, in
 /* Split a static fp32 operand W (N,K) ldw once into bf16 planes for COFI_GEMM_W_SPLIT: planes = (2, N, ldp) bf16,
  * [hi = bf16(W) RNE | lo = bf16(W - hi)], ldp % 8 == 0, ldp >= K, rows zero-padded; 16-byte aligned. */
 int cofi_split_bf16_planes(const float *W, int ldw, int N, int K, void *planes, int ldp, cofi_stream_t stream);
-/* Tuning hook (tools/tune_gemm.py): force the tile / split-K plan of subsequent calls; (0,0,0) restores the
- * tuned table + heuristic.  Process-global; not used by the product path. */
-int cofi_gemm_debug_force_plan(int bm, int bn, int ksplit);
 /* Same contraction with fused COLUMN STATISTICS: colpart (nslab, N, 2) receives, per row slab, the sum and
  * the sum of squares of every output column (after bias / rowdiv / act), nslab =
  * cofi_gemm_f32_stat_slabs(M,N,K).  cofi_group_stats_from_colpart / cofi_col_inv_norm_from_colpart turn
@@ -148,6 +165,16 @@ int cofi_gemm_f32_stat_slabs(int M, int N, int K);
 int cofi_gemm_f32_colstats(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K,
                            const float *bias, const float *rowdiv, int act, float *colpart, void *ws, size_t ws_bytes,
                            cofi_stream_t stream);
+/* The general form.  a_norm != NULL: A is the RAW output of the previous layer and its pending normalisation (see
+ * cofi_norm_desc_t; channels == K) is applied by the operand loader - the normalised activation never exists in memory
+ * (replaces the GroupNorm + LeakyReLU between two Linear layers, modules.py:45-49,89-94,232-236).  Needs COFI_GEMM_BF16X3 |
+ * COFI_GEMM_W_SPLIT, K <= 512; in stack mode M / frames must be a multiple of 128.  COFI_EUNSUPPORTED otherwise (apply the
+ * normalisation with cofi_group_norm_apply_partials first).
+ * colpart != NULL: statistics partials of C with one entry per `stat_width` adjacent columns, (nslab, N / stat_width, 2);
+ * stat_width a power of two <= 64 dividing N (the GroupNorm group width C/32 keeps the table at 256 bytes per slab). */
+int cofi_gemm_f32_fused(const float *A, int lda, const cofi_norm_desc_t *a_norm, const float *W, int ldw, float *C, int ldc, int M, int N,
+                        int K, const float *bias, const float *rowdiv, int act, float *colpart, int stat_width, void *ws, size_t ws_bytes,
+                        int frames, cofi_stream_t stream);
 /* Contraction with fused row LayerNorm (N <= 128): C = relu?(LN(A W^T + bias) * gamma + beta) + res.
  * Replaces Linear + nn.LayerNorm (+ residual) of model/transformer/transformer.py:57-58,61-64. */
 int cofi_gemm_f32_layernorm(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K,
@@ -170,8 +197,8 @@ int cofi_gemm_f32_layernorm(const float *A, int lda, const float *W, int ldw, fl
  */
 int cofi_group_stats_from_colpart(const float *colpart, int nslab, int M, int C, int groups, float eps, float *stats, int frames,
                                   cofi_stream_t stream);
-int cofi_col_inv_norm_from_colpart(const float *colpart, int nslab, int ncols, int C, float eps, float *out, int frames,
-                                   cofi_stream_t stream);
+int cofi_col_inv_norm_from_colpart(const float *colpart, int nslab, int M /* rows, all frames */, int ncols, int C, float eps, float *out,
+                                   int frames, cofi_stream_t stream);
 size_t cofi_group_stats_workspace(int M, int C, int groups, int frames);
 int cofi_group_stats(const float *x, int ldx, int M, int C, int groups, float eps, float *stats /* (frames, groups, 2) */, void *ws,
                      size_t ws_bytes, int frames /* stack mode: M = frames * rows-per-frame, statistics per frame */, cofi_stream_t stream);
@@ -180,14 +207,12 @@ int cofi_group_norm_apply(const float *x, int ldx, int M, int C, int groups, con
                           const float *res_beta, float slope, float *y, int ldy,
                           uint8_t *row_pos /* optional (M): row_pos[m] = (sum_c y[m,c] > 0), C <= 256 (kpconv.py:113-114) */, int frames, cofi_stream_t stream);
 
-/* cofi_group_norm_apply with the statistics folded in-kernel from the GEMM's column partials (colpart (nslab, C, 2),
- * res_colpart for the shortcut's own GroupNorm): saves the separate cofi_group_stats_from_colpart launch when the table is
- * small (every workgroup repeats the fixed-order fp64 fold).  C a power of two <= 1024.  row_pos (optional, M bytes):
+/* cofi_group_norm_apply with the statistics folded in-kernel from the producer's partials (cofi_norm_desc_t; `res_norm` = the
+ * shortcut's own GroupNorm, same group count): no separate statistics launch.  row_pos (optional, M bytes):
  * row_pos[m] = (sum_c y[m,c] > 0), the per-row flag cofi_kpconv_aggregate takes (kpconv.py:113-114); needs C <= 256. */
-int cofi_group_norm_apply_colpart(const float *x, int ldx, int M, int C, int groups, const float *colpart, int nslab, float eps,
-                                  const float *gamma, const float *beta, const float *res, int ldr, const float *res_colpart, int res_nslab,
-                                  const float *res_gamma, const float *res_beta, float slope, float *y, int ldy, uint8_t *row_pos,
-                                  int frames, cofi_stream_t stream);
+int cofi_group_norm_apply_partials(const float *x, int ldx, int M, int C, const cofi_norm_desc_t *norm, const float *res, int ldr,
+                                   const cofi_norm_desc_t *res_norm, float *y, int ldy, uint8_t *row_pos, int frames,
+                                   cofi_stream_t stream);
 
 /* Row LayerNorm: y = act(LN(x) * gamma + beta) (+ res).  Replaces nn.LayerNorm at
  * model/transformer/transformer.py:40-41,58,62 and model/network.py:29.  C <= 2048, C % 4 == 0. */
@@ -200,19 +225,33 @@ int cofi_layer_norm(const float *x, int ldx, int M, int C, const float *gamma, c
  * the per-channel query scaling of model/transformer/transformer.py:53
  * (F.normalize over the TOKEN axis): q'[l,c] = q[l,c] * q_colscale[c].
  *   O[l, h*D + d] = sum_s softmax_s( scale * <q'[l,h,:], k[s,h,:]> ) * v[s,h,d]
- * Q (L, H*D) ldq; K,V (S, H*D) ldk/ldv; O (L, H*D) ldo.  D == 32.  q_colscale (H*D) may be NULL.
+ * Q (frames*L, H*D) ldq; K,V (frames*S, H*D) ldk/ldv; O (frames*L, H*D) ldo.  D == 32.  q_colscale (frames, H*D) may be NULL.
+ *
+ * The work of a launch - (frame, head, 32-query block, 32-key block) units - is dealt out in equal contiguous ranges to about
+ * one workgroup per CU whatever L, S and H are (one KITTI call is 160 query-block x head pairs of 40 units: whole pairs would
+ * fill 160 of 256 CUs); a pair that is spread over several workgroups leaves one partial result per workgroup.
+ *   cofi_attention_workspace  bytes of the partial-slot table `ws` (16-byte aligned device memory) for (L, S, H, frames)
+ *   cofi_attention_parts      the attention kernel: fills `parts`.  Exactly one of q_colscale / q_colpart may be given;
+ *                             q_colpart (q_nslab, q_ncols, 2) = the column partials of the projection that produced Q
+ *                             (cofi_gemm_f32_colstats, Q = its first H*D columns; q_nslab = frames * ceil(L/64), L % 64 == 0
+ *                             when frames > 1): the token-axis norm of Q is then folded inside the kernel
+ *   cofi_attention_merge      combines the slots of every query row into O (fixed order)
+ *   cofi_attention_fwd, cofi_attention_fwd_colpart   = parts + merge
+ * cofi_loftr_tail_parts_bf16x3 (K7) consumes `parts` directly: no merge launch, O never exists in memory.
  * cofi_col_inv_norm: out[c] = 1 / max(sqrt(sum_m x[m,c]^2), eps)  (F.normalize, eps 1e-12).
  */
-size_t cofi_attention_workspace(int L, int S, int H, int D);
+size_t cofi_attention_workspace(int L, int S, int H, int D, int frames);
+int cofi_attention_parts(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, const float *q_colscale,
+                         const float *q_colpart, int q_nslab, int q_ncols, float q_eps, int L, int S, int H, int D, float scale, int frames,
+                         void *parts, size_t parts_bytes, cofi_stream_t stream);
+int cofi_attention_merge(const void *parts, size_t parts_bytes, int L, int S, int H, int D, int frames, float *O, int ldo,
+                         cofi_stream_t stream);
 int cofi_attention_fwd(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, const float *q_colscale,
                        float *O, int ldo, int L, int S, int H, int D, float scale, void *ws, size_t ws_bytes, int frames,
                        cofi_stream_t stream);
-/* Same, with the token-axis norm of Q folded in-kernel from the column partials of the projection that produced Q
- * (cofi_gemm_f32_colstats: q_colpart (q_nslab, q_ncols, 2), Q = the first H*D columns; per frame in stack mode): saves the
- * cofi_col_inv_norm_from_colpart launch in front of every attention call. */
 int cofi_attention_fwd_colpart(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, const float *q_colpart,
                                int q_nslab, int q_ncols, float q_eps, float *O, int ldo, int L, int S, int H, int D, float scale,
-                               int frames, cofi_stream_t stream);
+                               void *ws, size_t ws_bytes, int frames, cofi_stream_t stream);
 int cofi_col_inv_norm(const float *x, int ldx, int M, int C, float eps, float *out, cofi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -225,6 +264,12 @@ int cofi_loftr_tail_bf16x3(const float *msg, int ldm, const float *x, int ldx, c
                            const float *n1_gamma, const float *n1_beta, const uint16_t *w0_hi, const uint16_t *w0_lo,
                            const uint16_t *w2_hi, const uint16_t *w2_lo, const float *n2_gamma, const float *n2_beta, float eps,
                            float *out, int ldo, int L, cofi_stream_t stream);
+/* The same with msg still in the attention kernel's partial-slot form (cofi_attention_parts over (L, S, H, frames), H * 32 == 128):
+ * the loader merges and normalises the slots of its rows; x / out hold frames * L rows. */
+int cofi_loftr_tail_parts_bf16x3(const void *parts, size_t parts_bytes, int L, int S, int H, int frames, const float *x, int ldx,
+                                 const uint16_t *wm_hi, const uint16_t *wm_lo, const float *n1_gamma, const float *n1_beta,
+                                 const uint16_t *w0_hi, const uint16_t *w0_lo, const uint16_t *w2_hi, const uint16_t *w2_lo,
+                                 const float *n2_gamma, const float *n2_beta, float eps, float *out, int ldo, cofi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K8 / glue.
@@ -239,10 +284,9 @@ int cofi_pos_sine(const void *coords, int coords_are_int, int T, int n_dim, cons
                   int accumulate, float *out, int ldo, cofi_stream_t stream);
 int cofi_l2norm_rows(const float *x, int ldx, int M, int C, float *y, int ldy, int transpose, cofi_stream_t stream);
 int cofi_transpose(const float *x, int ldx, int M, int C, float *y, int ldy, cofi_stream_t stream);
-/* channel-major (C, P) map -> L2-normalised over C; writes the normalised map (C,P) and/or the
- * token-major (P, C) copy (model/network.py:90,110).  Either output may be NULL. */
-int cofi_l2norm_cols(const float *x, int ldx, int C, int P, float *y_cp, int ldy, float *y_pc, int ldt, cofi_stream_t stream);
-
+/* out (frames, C) = column means over the M / frames rows of each frame: nn.AdaptiveAvgPool2d(1) on an NHWC map
+ * (model/imagenet.py:145,215). */
+int cofi_col_mean(const float *x, int ldx, int M, int C, float *out, int frames, cofi_stream_t stream);
 /* ---------------------------------------------------------------------------------------------
  * K13  image convolutions as implicit GEMM on the same MFMA kernel (no im2col buffer): x is an NHWC map
  * (H*W rows, ldx floats per pixel: a channel-concatenation is just a wider row), Wt is (Cout, ks*ks*Cin) with
@@ -259,24 +303,16 @@ int cofi_l2norm_cols(const float *x, int ldx, int C, int P, float *y_cp, int ldy
 int cofi_conv2d_nhwc(const float *x, int ldx, int H, int W, int Cin, const float *Wt, int Cout, int ks, int stride, int pad,
                      const float *bias, const float *res, int ldr, int act, float *y, int ldy, float *colpart, void *ws, size_t ws_bytes,
                      int frames, cofi_stream_t stream);
+/* cofi_conv2d_nhwc with a pending normalisation of the INPUT map (x_norm, channels == Cin <= 512: the InstanceNorm + ReLU between
+ * the two convolutions of a BasicBlock, imagenet.py:58-66; zero padding is applied after the normalisation, as nn.Conv2d pads the
+ * normalised map) and a statistics table of width `stat_width`; see cofi_gemm_f32_fused. */
+int cofi_conv2d_nhwc_fused(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, int W, int Cin, const float *Wt, int Cout, int ks,
+                           int stride, int pad, const float *bias, const float *res, int ldr, int act, float *y, int ldy, float *colpart,
+                           int stat_width, void *ws, size_t ws_bytes, int frames, cofi_stream_t stream);
 int cofi_im2col_stem(const float *img_chw, int H, int W, int Kpad, float *out, int frames, cofi_stream_t stream);
 int cofi_maxpool3x3s2_nhwc(const float *x, int H, int W, int C, float *y, int frames, cofi_stream_t stream);
 int cofi_upsample2x_cat_nhwc(const float *low, int ldl, int C1, int h, int w, const float *skip, int lds, int C2, float *out, int ldo,
                              int frames, cofi_stream_t stream);
-
-/* K13 glue, channel-major (C, P = H*W) variants (used when the convolutions run through MIOpen instead).
- * cofi_instance_norm_nchw: y[c,:] = relu?( IN(x[c,:]) + R ), IN = affine-less InstanceNorm2d (eps, biased
- *   variance; model/imagenet.py:123), R = 0 (res_mode 0) | res[c,:] (1) | IN(res[c,:]) (2): the BasicBlock tail of
- *   model/imagenet.py:58-73.  P % 4 == 0.
- * cofi_bias_act_nchw: y = relu?( x + bias[c] + res + res_bias[c] ): ResidualConv with eval-mode BatchNorm folded
- *   into the convolutions (model/imagenet.py:397-411).
- * cofi_upsample2x_cat: out[:C1] = bilinear x2 of low (align_corners=False), out[C1:] = skip
- *   (model/imagenet.py:433,441-443: nn.Upsample + torch.cat). */
-int cofi_instance_norm_nchw(const float *x, int C, int P, float eps, const float *res, int res_mode, int relu, float *y,
-                            cofi_stream_t stream);
-int cofi_bias_act_nchw(const float *x, const float *bias, const float *res, const float *res_bias, int C, int P, int relu, float *y,
-                       cofi_stream_t stream);
-int cofi_upsample2x_cat(const float *low, int C1, int h, int w, const float *skip, int C2, float *out, cofi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K10-K12  coarse + fine matching without host round trips (model/network.py:145-161,167-226,
@@ -284,23 +320,20 @@ int cofi_upsample2x_cat(const float *low, int C1, int h, int w, const float *ski
  * cofi_row_argmin_1m: pix[n] = argmin_p (1 - sim[n,p]) with the lowest index on ties
  *   (network.py:176-180); sim (N,P) comes from cofi_gemm_f32 on the two descriptor sets.
  * cofi_select_matches: tries thresholds thr_host[0..n_thr) in order until at least `min_matches`
- *   super-points satisfy score >= thr AND 2 <= x <= W8-2 AND 2 <= y <= H8-2 (network.py:147-151,184;
- *   x = pix % W8, y = pix / W8).  Writes (ascending point index) sel (cap N), coarse_xy (2, N) with
+ *   super-points satisfy score >= thr AND 2 <= x <= x_max AND 2 <= y <= y_max (network.py:147-151; x = pix % W8,
+ *   y = pix / W8; the reference hard-codes x_max = 62, y_max = 18 whatever the image size, network.py:184).  Writes (ascending point index) sel (cap N), coarse_xy (2, N) with
  *   leading dimension N, count_dev[0] = n, count_dev[1] = index of the threshold used (or -1).
- * cofi_extract_patches: 4x4 windows [4*xy - 2, 4*xy + 2) of the (C,H2,W2) map -> (n, C, 16)
+ * cofi_extract_patches_nhwc: 4x4 windows [4*xy - 2, 4*xy + 2) of the NHWC map (H2*W2 rows of ldf floats) -> (n, C, 16)
  *   (network.py:206-226,156-158).
  * cofi_fine_match: cosine similarity of the 16 patch pixels against the point descriptor, argmax
  *   (first index on ties), fine_xy = 4*xy - 2 + (idx / 4, idx % 4)  [sic: x gets idx/4]
  *   (eval_all.py:99-105).  fine_xy (2, cap) with leading dimension `cap`.
  */
 int cofi_row_argmin_1m(const float *sim, int lds, int N, int P, int32_t *pix, cofi_stream_t stream);
-int cofi_select_matches(const float *score, const int32_t *pix, int N, int W8, int H8, const float *thr_host, int n_thr,
-                        int min_matches, int32_t *sel, float *coarse_xy, int32_t *count_dev, cofi_stream_t stream);
+int cofi_select_matches(const float *score, const int32_t *pix, int N, int W8, int H8, int x_max, int y_max, const float *thr_host,
+                        int n_thr, int min_matches, int32_t *sel, float *coarse_xy, int32_t *count_dev, cofi_stream_t stream);
 int cofi_gather_points_sel(const float *pts, const int32_t *sel, const int32_t *count_dev, int cap, float *out,
                            cofi_stream_t stream);
-int cofi_extract_patches(const float *fmap, int C, int H2, int W2, const float *coarse_xy, int ldxy, float center_scale,
-                         const int32_t *count_dev, int cap, float *patches, cofi_stream_t stream);
-/* same, reading an NHWC map (H2*W2 rows of ldf floats) */
 int cofi_extract_patches_nhwc(const float *fmap, int ldf, int C, int H2, int W2, const float *coarse_xy, int ldxy, float center_scale,
                               const int32_t *count_dev, int cap, float *patches, cofi_stream_t stream);
 int cofi_gather_rows_sel(const float *x, int ldx, int C, const int32_t *row_idx, const int32_t *count_dev, int cap, float *out,

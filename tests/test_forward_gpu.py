@@ -20,9 +20,14 @@ class Opt:
 
 @pytest.fixture(scope="module")
 def model():
+    """Tests without an explicit arithmetic run the exact-fp32 GEMMs (tight drift bounds against the fp32 oracle); the library
+    default, the 3-term bf16 split with its fused normalising loaders / layer tail, is selected per test (monkeypatch)."""
+    from cofii2p_amd import ops
     from cofii2p_amd.network import CoFiI2P
 
-    return CoFiI2P(Opt()).to(DEV)
+    saved, ops.GEMM_MODE = ops.GEMM_MODE, "f32"
+    yield CoFiI2P(Opt()).to(DEV)
+    ops.GEMM_MODE = saved
 
 
 def to_dev(data):

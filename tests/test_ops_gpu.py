@@ -15,10 +15,14 @@ DEV = "cuda:0"
 
 @pytest.fixture(scope="module")
 def ops():
+    """The kernel tests of this file compare against fp64 / reference values at fp32 tolerances: they run the exact-fp32 GEMM
+    arithmetic unless a test selects "bf16x3" (the library default) itself."""
     from cofii2p_amd import ops as _ops
 
     assert torch.cuda.is_available()
-    return _ops
+    saved, _ops.GEMM_MODE = _ops.GEMM_MODE, "f32"
+    yield _ops
+    _ops.GEMM_MODE = saved
 
 
 @pytest.fixture(scope="module")
@@ -69,7 +73,7 @@ def test_gemm_fused_column_statistics(ops, M, N, K, groups):
     mean, var = gr.mean((0, 2)), gr.var((0, 2), unbiased=False)
     close(st[:, 0], mean.float(), 1e-4)
     close(st[:, 1], torch.rsqrt(var + 1e-5).float(), 1e-4)
-    close(ops.col_inv_norm_from_colpart(part, min(N, 32)), (1.0 / ref[:, : min(N, 32)].norm(dim=0)).float(), 1e-4)
+    close(ops.col_inv_norm_from_colpart(part, M, min(N, 32)), (1.0 / ref[:, : min(N, 32)].norm(dim=0)).float(), 1e-4)
 
 
 @pytest.mark.parametrize("M,N,K", [(1280, 128, 128), (1280, 128, 256), (100, 64, 64), (33, 100, 36)])
@@ -250,7 +254,7 @@ def test_attention_q_norm_from_column_partials(ops, frames, L):
     x, w = torch.randn(frames * L, 128, generator=g), torch.randn(384, 128, generator=g) / 11.0
     qkv, part = ops.gemm_colstats(G(x), G(w))
     q, k, v = qkv[:, :128], qkv[:, 128:256], qkv[:, 256:]
-    cs = ops.col_inv_norm_from_colpart(part, 128, frames=frames)
+    cs = ops.col_inv_norm_from_colpart(part, frames * L, 128, frames=frames)
     a = ops.attention(q, k, v, q_colscale=cs, frames=frames)
     b = ops.attention(q, k, v, q_colpart=part, frames=frames)
     close(b, a.cpu(), 1e-5)
@@ -289,10 +293,7 @@ def test_small_glue(ops, mg):
     close(ops.l2norm_rows(G(x)), torch.nn.functional.normalize(x, dim=1), 1e-6)
     close(ops.l2norm_rows(G(x), transpose=True), torch.nn.functional.normalize(x, dim=1).t(), 1e-6)
     close(ops.transpose(G(x)), x.t(), 0)
-    m = torch.randn(128, 20 * 64, generator=g)
-    y_cp, y_pc = ops.l2norm_cols(G(m))
-    close(y_cp, torch.nn.functional.normalize(m, dim=0), 1e-6)
-    close(y_pc, torch.nn.functional.normalize(m, dim=0).t(), 1e-6)
+    close(ops.col_mean(G(x), 4), x.reshape(4, 320, 128).mean(1), 1e-6)
     out = torch.zeros(1280, 128, device=DEV)
     ops.pos_sine(G(mg["pe_grid"], torch.int32), out, accumulate=False)
     close(out, mg["pe_grid_out"], 1e-5)
@@ -452,8 +453,13 @@ def test_matching_chain(ops, mg):
     # patches: val-style centres at scale 1
     ctr = G(mg["ep_ctr"])
     c12 = torch.tensor([12, 0], dtype=torch.int32, device=DEV)
-    pat = ops.extract_patches(G(mg["ep_fmap"]), ctr, c12, 12, 1.0)
+    fmap = G(mg["ep_fmap"])   # (C, H2, W2) as the reference holds it; the product keeps maps pixel-major (NHWC)
+    Cc, H2, W2 = fmap.shape
+    pat = ops.extract_patches_nhwc(ops.transpose(fmap.reshape(Cc, H2 * W2)), H2, W2, ctr, c12, 12, 1.0)
     close(pat.reshape(12, 8, 4, 4), mg["ep_out"], 0)
+    from cofii2p_amd.network import extract_patch
+
+    close(extract_patch(fmap[None], ctr)[:, 0], mg["ep_out"], 0)   # the reference's free function, (B,C,H,W) in
     fxy, best = ops.fine_match(G(mg["fm_patches"]), G(mg["fm_pc"]), ctr, c12, 1.0)
     assert np.array_equal(best.cpu().numpy(), mg["fm_pred"])
     assert np.array_equal(fxy.cpu().numpy(), mg["fm_xy"])
@@ -487,22 +493,6 @@ def test_gemm_bf16x3_split(ops, M, N, K, monkeypatch):
         ga, be = torch.ones(N), torch.zeros(N)
         ln = ops.gemm_layernorm(G(a), G(w), G(ga), G(be), bias=G(bias))
         close(ln, torch.nn.functional.layer_norm(ref.float(), (N,)), 2e-4)
-
-
-def test_image_glue_kernels(ops):
-    import torch.nn.functional as F
-
-    g = torch.Generator().manual_seed(9)
-    for (C, H, W) in ((64, 80, 256), (128, 20, 64), (512, 5, 16)):
-        x, r = torch.randn(1, C, H, W, generator=g) * 2 + 0.3, torch.randn(1, C, H, W, generator=g)
-        close(ops.instance_norm_nchw(G(x), relu=True), F.relu(F.instance_norm(x)), 2e-5)
-        close(ops.instance_norm_nchw(G(x), relu=True, res=G(r)), F.relu(F.instance_norm(x) + r), 2e-5)
-        close(ops.instance_norm_nchw(G(x), relu=True, res=G(r), res_norm=True), F.relu(F.instance_norm(x) + F.instance_norm(r)), 2e-5)
-        b, b2 = torch.randn(C, generator=g), torch.randn(C, generator=g)
-        close(ops.bias_act_nchw(G(x), G(b), res=G(r), res_bias=G(b2)), F.relu(x + b[None, :, None, None] + r + b2[None, :, None, None]), 1e-6)
-    low, skip = torch.randn(1, 128, 20, 64, generator=g), torch.randn(1, 64, 40, 128, generator=g)
-    ref = torch.cat([F.interpolate(low, scale_factor=2, mode="bilinear", align_corners=False), skip], 1)
-    close(ops.upsample2x_cat(G(low), G(skip)), ref, 1e-6)
 
 
 def _nhwc(t):  # (1,C,H,W) -> (H*W, C)
@@ -554,6 +544,103 @@ def test_image_nhwc_glue(ops):
     yv, part = ops.gemm_colstats(G(xm), G(torch.eye(64)))
     out = ops.group_norm_apply(yv, ops.group_stats_from_colpart(part, xm.shape[0], 64), slope=0.0, res=G(xm))
     close(out, _nhwc(F.relu(F.instance_norm(x) + x)), 2e-5)
+
+
+@pytest.mark.parametrize("frames,Mf,Kc,N,groups,affine,slope", [
+    (1, 1280, 128, 512, 32, True, 0.1),      # unary2 of a deep block: K = mid
+    (1, 20480, 32, 128, 32, True, 0.1),      # encoder1_2: 320 slabs, group width 1
+    (1, 5120, 64, 256, 32, True, 0.1),
+    (1, 1000, 256, 96, 32, True, 0.1),       # ragged rows (last slab / tile partial)
+    (1, 1280, 128, 64, 128, False, 0.0),     # score head: InstanceNorm (one group per column) + ReLU
+    (1, 2560, 512, 2048, 32, True, 0.1),     # K = 512 (largest table), 64-wide statistics groups downstream
+    (3, 1280, 128, 128, 32, True, 0.1),      # stack mode: per-frame statistics
+    (2, 640, 64, 1, 64, False, 0.0),         # N = 1 (last score layer)
+])
+def test_gemm_normalising_loader(ops, monkeypatch, frames, Mf, Kc, N, groups, affine, slope):
+    """cofi_gemm_f32_fused with a pending GroupNorm / InstanceNorm on A == stand-alone apply kernel followed by the same GEMM,
+    bit for bit (same operations in the same order), and the apply kernel itself against torch's group_norm"""
+    import torch.nn.functional as F
+
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x3")
+    g = torch.Generator().manual_seed(Mf + Kc + N)
+    M = frames * Mf
+    x0 = torch.randn(M, 96, generator=g) * 1.5 + 0.2
+    w0 = torch.randn(Kc, 96, generator=g) / 9.0
+    w1 = torch.randn(N, Kc, generator=g) / Kc ** 0.5
+    b1 = torch.randn(N, generator=g)
+    ga = (1 + 0.2 * torch.randn(Kc, generator=g)) if affine else None
+    be = (0.3 * torch.randn(Kc, generator=g)) if affine else None
+    cpg = Kc // groups
+    for sw in sorted({1, cpg}):
+        y, part = ops.gemm_colstats(G(x0), ops.presplit(G(w0)), stat_width=sw)
+        assert part.shape == (frames * ((Mf + 63) // 64), Kc // sw, 2)
+        st = ops.ColStats(part, M, groups, frames, width=sw)
+        assert st.fusable()
+        nm = ops.Normed(y, st, None if ga is None else G(ga), None if be is None else G(be), slope)
+        mat = nm.materialize()
+        yc = y.cpu()
+        ref = torch.cat([F.leaky_relu(F.group_norm(yc[f * Mf:(f + 1) * Mf].t()[None], groups, ga, be, 1e-5)[0].t(), slope) for f in range(frames)])
+        close(mat, ref, 3e-5)
+        w1s = ops.presplit(G(w1))
+        fused, fpart = ops.gemm_colstats(nm, w1s, bias=G(b1), frames=frames)
+        plain, ppart = ops.gemm_colstats(mat, w1s, bias=G(b1))
+        assert torch.equal(fused, plain)
+        assert torch.equal(fpart, ppart)
+        close(plain, (ref.double() @ w1.double().t() + b1.double()).float(), 2e-4)
+    if cpg > 1:   # the group-wide table is the per-column table summed over the group's columns
+        _, p1 = ops.gemm_colstats(G(x0), ops.presplit(G(w0)), stat_width=1)
+        close(part, p1.reshape(p1.shape[0], Kc // cpg, cpg, 2).sum(2), 2e-5 * float(p1.abs().max()))
+
+
+@pytest.mark.parametrize("frames,Cin,Cout,H,W,stride", [(1, 64, 64, 40, 128, 1), (1, 128, 128, 20, 64, 1), (1, 256, 256, 10, 32, 1), (2, 64, 64, 16, 16, 1),
+                                                        (1, 64, 128, 40, 128, 2)])
+def test_conv2d_normalising_loader(ops, monkeypatch, frames, Cin, Cout, H, W, stride):
+    """second convolution of a BasicBlock (imagenet.py:58-66): InstanceNorm + ReLU of the first convolution's output applied by the
+    implicit-GEMM loader (zero padding AFTER the normalisation) == apply kernel + plain convolution, and against torch"""
+    import torch.nn.functional as F
+
+    from cofii2p_amd.image import _nhwc_weight
+
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x3")
+    g = torch.Generator().manual_seed(Cin + H)
+    x = torch.randn(frames, Cin, H, W, generator=g)
+    wa = torch.randn(Cin, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    wb = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    xm = torch.cat([_nhwc(x[f:f + 1]) for f in range(frames)])
+    y1, part1, _, _ = ops.conv2d_nhwc(G(xm), H, W, ops.presplit(G(_nhwc_weight(wa))), 3, 1, 1, colstats=True, frames=frames)
+    nm = ops.Normed(y1, ops.ColStats(part1, y1.shape[0], Cin, frames), slope=0.0)
+    wbs = ops.presplit(G(_nhwc_weight(wb)))
+    fused, fp, Ho, Wo = ops.conv2d_nhwc(nm, H, W, wbs, 3, stride, 1, colstats=True, frames=frames)
+    plain, pp, _, _ = ops.conv2d_nhwc(nm.materialize(), H, W, wbs, 3, stride, 1, colstats=True, frames=frames)
+    assert torch.equal(fused, plain) and torch.equal(fp, pp)
+    ref = F.conv2d(F.relu(F.instance_norm(F.conv2d(x, wa, padding=1))), wb, stride=stride, padding=1)
+    close(fused, torch.cat([_nhwc(ref[f:f + 1]) for f in range(frames)]), 3e-4)
+
+
+def test_statistics_slabs_must_not_straddle_frames(ops):
+    """2 frames of 112 rows give 4 slabs of 64 rows, divisible by the frame count although slab 1 mixes both frames:
+    the per-frame folds must refuse such tables instead of silently mixing rows"""
+    from cofii2p_amd._lib import CofiError
+
+    g = torch.Generator().manual_seed(1)
+    x, w = torch.randn(224, 64, generator=g), torch.randn(128, 64, generator=g)
+    y, part = ops.gemm_colstats(G(x), G(w))
+    assert part.shape[0] == 4
+    st = ops.ColStats(part, 224, 32, frames=2)
+    assert not st.fusable()
+    with pytest.raises(CofiError):
+        st.finalize()
+    with pytest.raises(CofiError):
+        ops.col_inv_norm_from_colpart(part, 224, 128, frames=2)
+    with pytest.raises(CofiError):
+        ops.attention(y[:, :128], y[:, :128], y[:, :128], q_colpart=part, frames=2)
+    # ... while whole-slab frames are served
+    x2 = torch.randn(256, 64, generator=g)
+    y2, part2 = ops.gemm_colstats(G(x2), G(w))
+    assert ops.ColStats(part2, 256, 32, frames=2).fusable()
+    st2 = ops.group_stats_from_colpart(part2, 256, 32, frames=2).cpu()
+    ref = y2.cpu().reshape(2, 128, 32, 4)
+    close(st2[:, :, 0], ref.mean((1, 3)), 1e-4)
 
 
 def test_loftr_layer_fused_tail_bf16x3(ops, mg, monkeypatch):
