@@ -19,22 +19,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, shared with the null and capture streams).  Measured on
-# MI355X (frames/s at 1 / 2 / 3 / 4 frames in flight): 4 queues 264 / 371 / 326 / 371; 5-8 queues 96-148 / 371 / 444 / 305-367.
-# Three frames in flight need their own queues; a single stream is slower when the command processor polls more queues.
-# Must be set before the HIP runtime initialises, hence the early look at --inflight.
-def _inflight_from_argv(default=3):
-    for i, a in enumerate(sys.argv):
-        if a == "--inflight" and i + 1 < len(sys.argv):
-            return int(sys.argv[i + 1])
-        if a.startswith("--inflight="):
-            return int(a.split("=", 1)[1])
-    return default
-
-
-if _inflight_from_argv() >= 3:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -79,10 +63,16 @@ def record_kernel_calls(model, dev, points=20480, batch=1):
     return kt
 
 
+_model_ref = []
+
+
 def make_streams(dev, n, cu_split=None):
     """n HIP streams; cu_split = "even" | "halves": experiment - each stream gets a disjoint CU mask (hipExtStreamCreateWithCUMask)."""
     if not cu_split or n != 2:
-        return [torch.cuda.Stream(device=dev) for _ in range(n)]
+        # the model hands out the streams the process already owns first (capture + default stream): every extra live stream makes
+        # two frame streams share one of HIP's 4 hardware queues (CoFiI2P.frame_streams)
+        return _model_ref[0].frame_streams(n, dev) if (_model_ref and os.environ.get("COFI_BENCH_STREAMS", "") != "new") else \
+            [torch.cuda.Stream(device=dev) for _ in range(n)]
     import ctypes
 
     hip = ctypes.CDLL("libamdhip64.so")
@@ -264,7 +254,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the hipGraph")
-    ap.add_argument("--inflight", type=int, default=3, help="frames in flight per GPU (each on its own HIP stream + hipGraph slot)")
+    ap.add_argument("--inflight", type=int, default=4, help="frame streams per GPU (HIP streams; each carries --slots-per-stream hipGraph slots)")
+    ap.add_argument("--slots-per-stream", type=int, default=2, help="submissions queued per frame stream: 2 = the next frame is already enqueued behind the running one (no host bubble)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for single-GPU tests of the N > 1 path)")
     ap.add_argument("--share-device", action="store_true", help="test aid: all ranks use cuda:0")
     ap.add_argument("--cu-split", default=None, choices=[None, "even", "halves"], help="experiment: the two frame streams get disjoint CU masks")
@@ -296,6 +287,7 @@ def main():
 
     cofi_ops.GEMM_MODE = args.gemm
     model = CoFiI2P(Opt()).to(dev)
+    _model_ref.append(model)
     if not args.eager:
         model.enable_graphs()
     n_distinct = 4
@@ -317,7 +309,7 @@ def main():
         for b in range(2):
             grp = [frames[(b * Bsz + i) % len(frames)] for i in range(Bsz)]
             batches.append(CoFiI2P.stack_frames([g[0] for g in grp], [g[1] for g in grp]))
-        streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+        streams = make_streams(dev, S)
         pending = [None] * S
 
         def runb(nsteps):
@@ -356,24 +348,26 @@ def main():
         # are still executing; a slot's result (incl. the host read of the match count) is collected just before
         # the slot is reused.  Every step is still ONE frame through the complete forward.
         streams = make_streams(dev, S, args.cu_split)
-        pending = [None] * S
+        NSLOT = S * max(1, args.slots_per_stream)   # submission i: stream i % S, hipGraph slot i % NSLOT
+        pending = [None] * NSLOT
 
         def run(nsteps, base):
             nm = 0
             for i in range(nsteps):
-                sl = i % S
+                sl = i % NSLOT
                 if pending[sl] is not None:
                     nm = model.finish(pending[sl])[4].shape[0]
                 pyr, img, _ = frames[(base + i) % len(frames)]
-                with torch.cuda.stream(streams[sl]):
+                with torch.cuda.stream(streams[i % S]):
                     pending[sl] = model.forward_async(sl, pyr, img)
-            for sl in range(S):
+            for k in range(NSLOT):   # collect in submission order
+                sl = (nsteps + k) % NSLOT
                 if pending[sl] is not None:
                     nm = model.finish(pending[sl])[4].shape[0]
                     pending[sl] = None
             return nm
 
-        nmatch = run(max(args.warmup, 2 * S), 0)
+        nmatch = run(max(args.warmup, 2 * NSLOT), 0)   # every slot captured and replayed at least once, whatever --warmup says
         barrier()
         t0 = time.perf_counter()
         run(args.steps, 0)
@@ -457,7 +451,7 @@ def main():
         for bsz in (4, 16):
             grp = [frames[i % len(frames)] for i in range(bsz)]
             pyr_b, img_b = CoFiI2P.stack_frames([g[0] for g in grp], [g[1] for g in grp])
-            st = [torch.cuda.Stream(device=dev) for _ in range(S)]
+            st = make_streams(dev, S)
             pend = [None] * S
             nst = max(2 * S, args.steps // bsz)
             for phase in range(2):  # 0 = warm-up (captures the graphs), 1 = timed
@@ -483,7 +477,7 @@ def main():
         model.compute_unused_image_maps = False
         model.enable_graphs(False)
         model.enable_graphs(True)
-        st = [torch.cuda.Stream(device=dev) for _ in range(S)]
+        st = make_streams(dev, S)
         pend = [None] * S
         for phase in range(2):
             torch.cuda.synchronize()
@@ -534,7 +528,7 @@ def main():
         if S > 1 and not args.eager:
             # ... and the whole chain on this GPU: every frame's pyramid is built on its frame stream right before its forward
             model.enable_graphs(True)
-            st = [torch.cuda.Stream(device=dev) for _ in range(S)]
+            st = make_streams(dev, S)
             pend = [None] * S
             feats0, img0 = frames[0][0]["feats"], frames[0][1]
             for phase in range(2):

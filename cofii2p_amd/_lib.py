@@ -19,7 +19,7 @@ _P, _I, _F, _Z = c_void_p, c_int, c_float, c_size_t
 class NormDesc(ctypes.Structure):
     """cofi_norm_desc_t (include/cofi_hip.h): a pending GroupNorm / InstanceNorm described by its statistics partials."""
     _fields_ = [("partials", c_void_p), ("nslab", c_int), ("width", c_int), ("channels", c_int), ("groups", c_int),
-                ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("slope", c_float)]
+                ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("slope", c_float), ("scale_shift", c_void_p)]
 
 
 _N = ctypes.POINTER(NormDesc)
@@ -52,6 +52,7 @@ SIGNATURES = {
     "cofi_group_stats_workspace": (_Z, [_I, _I, _I, _I]),
     "cofi_group_stats": (_I, [_P, _I, _I, _I, _I, _F, _P, _P, _Z, _I, _P]),
     "cofi_group_norm_apply": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _F, _P, _I, _P, _I, _P]),
+    "cofi_norm_finalize": (_I, [_N, _I, _I, _P, _P]),
     "cofi_group_norm_apply_partials": (_I, [_P, _I, _I, _I, _N, _P, _I, _N, _P, _I, _P, _I, _P]),
     "cofi_layer_norm": (_I, [_P, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _I, _P]),
     "cofi_loftr_tail_bf16x3": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P]),

@@ -2,37 +2,42 @@
 // Reference: model/transformer/linear_attention.py:56-79 (FullAttention) + the token-axis query
 // normalisation of model/transformer/transformer.py:53, folded in as a per-channel scale.
 //
-// WORK PARTITION.  A unit = one 32-query block x one 32-key block of one (frame, head): 16 + 16 MFMAs.  A PAIR = all P =
-// ceil(S/32) units of one (frame, head, query block).  One KITTI cross-attention call is 160 pairs x 40 units: handing whole
-// pairs to workgroups fills 160 of 256 CUs (and splitting keys inside a workgroup cannot help: a pair's 40 units then sit on
-// ONE CU).  Instead the T units of a launch are numbered pair-major and dealt out in equal contiguous ranges of U units to
-// ~one workgroup per CU (25 units each for that call); the dispatcher's round-robin over the 8 XCDs is undone so that an XCD
-// works through ONE contiguous eighth of the numbering = the query blocks of (mostly) one head: its L2 pulls only that head's
-// K / V.  A workgroup's range covers at most 3 pairs ("segments"); inside it the 8 waves take the units round-robin, each
-// running an online softmax in registers per segment, and the waves' states are merged through LDS at the end.  A pair that
-// is spread over several workgroups leaves one PARTIAL (running max m, row sum l, un-normalised O) per workgroup in a slot
-// table; the slots of a pair are combined by the consumer of the attention output (the fused layer tail, transformer_tail.hip)
-// or by attention_merge_kernel - a kernel boundary, not an in-launch hand-off, orders the two.  Everything is a fixed-order
-// reduction: bit-reproducible.
+// WORK PARTITION.  A unit = one 32-query block x one 32-key block of one (frame, head): 16 + 16 MFMAs on 8 KB of K / V.  A
+// compute unit can pull ~11-16 bytes per clock from L2, its four matrix pipes consume a unit per 512 clocks: a wave that streams
+// its own K / V blocks from L2 is bound by that fill rate (measured: 17.5 us for one KITTI cross-attention call whose MFMAs
+// take 8.5 us on the busiest SIMD).  So a workgroup = 8 waves = TWO query blocks (64 queries of one frame and head) x FOUR
+// key-block phases: every step it stages four K and four V tiles in LDS once (coalesced 16-byte loads, register-staged one step
+// ahead and written after the step's MFMAs were issued) and each tile feeds both query blocks - half the L2 traffic per flop.
+// One KITTI call has only 80 (frame, head, 64-query block) combinations for 256 CUs, so the P = ceil(S/32) key blocks are cut
+// into KS contiguous ranges (attn_layout: KS = 3 there, 240 workgroups of 13-14 key blocks = 7 units per SIMD), each handled by
+// its own workgroup; the dispatcher's round-robin over the 8 XCDs is undone so that an XCD works through neighbouring query
+// blocks of (mostly) ONE head and its L2 pulls only that head's K / V.  The KS partial results of a query block (running max
+// m, row sum l, un-normalised O) go to a slot table (attention_parts.h) and are combined by the consumer of the attention
+// output - the fused layer tail (transformer_tail.hip) - or by attention_merge_kernel: a kernel boundary, not an in-launch
+// hand-off, orders producer and consumer.  Everything is a fixed-order reduction: bit-reproducible.
 //
 // Per unit and wave:
-//   S^T[key, q] = K_blk . Q^T    16 MFMA, A = K straight from L2 (float4 per lane), B = Q registers
+//   S^T[key, q] = K_blk . Q^T    16 MFMA, A = K tile rows from LDS (ds_read_b128, row stride 36 dwords: conflict free), B = Q regs
 //   online softmax, per lane = per query column (q = lane&31), 16 keys per lane, halves joined by
 //   one __shfl_xor(.., 32)
-//   O^T[d, q] += V_blk^T . P^T   16 MFMA, A = V[key, d = lane&31] (block fetched as 16-B loads, transposed through a
-//                                wave-private LDS tile), B = P
+//   O^T[d, q] += V_blk^T . P^T   16 MFMA, A = V[key, d = lane&31] from the LDS tile, B = P
 // The MFMA D layout of S^T (lane (q,h) holds keys (r&3)+8(r>>2)+4h) is exactly the B-operand layout
 // the second chain needs once the contraction index is allowed to run in that (permuted) key order,
 // so P never moves between lanes and O^T keeps "one query per lane": the softmax rescale and the
-// final 1/l are plain per-lane multiplies.
+// final 1/l are plain per-lane multiplies.  The wave issues the QK^T chain of step t before the softmax / PV of step t-1 (whose
+// V operand it keeps in registers), so the softmax VALU work runs under matrix-core time.
 #include "attention_parts.h"
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int D = 32;      // head dimension
-constexpr int NW = 8;      // waves per workgroup
-constexpr int NSEG = COFI_ATTN_MAX_SEGMENTS;
+constexpr int D = 32;                    // head dimension
+constexpr int QG = COFI_ATTN_QG;         // query blocks per workgroup
+constexpr int KPH = COFI_ATTN_KPH;       // key-block phases per workgroup
+constexpr int NW = QG * KPH;             // waves
+constexpr int TLD = D + 4;               // LDS tile row stride (floats)
+constexpr int TILE = 32 * TLD;           // floats per staged tile
 
 struct AttnArgs {
     const float *Q, *K, *V, *qs;
@@ -59,168 +64,130 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nblk) {
 // b128 stores of 8 consecutive query lanes hit 8 different chunk slots (conflict free without padding: 4 KB per state)
 __device__ __forceinline__ int so_off(int q, int chunk) { return q * 32 + ((chunk ^ (q & 7)) << 2); }
 
+// ABL: timing ablations (tools only, COFI_ATTN_ABLATE): 1 no softmax, 2 no PV chain, 4 no QK^T chain, 8 no re-staging after the
+// prologue, 16 no per-step barrier.  0 = the product kernel.
+template <int ABL>
 __global__ __launch_bounds__(64 * NW) void attention_flat_kernel(AttnArgs a) {
-    // LDS carve (floats)
-    constexpr int SO = NSEG * NW * 1024, SM = NSEG * NW * 32, SV = NW * 32 * (D + 4), SQ = NSEG * 32, SP = 2 * NW * NSEG * 32;
-    __shared__ __attribute__((aligned(16))) float lds[SO + 2 * SM + SV + SQ + SP];
-    float *s_o = lds, *s_m = s_o + SO, *s_l = s_m + SM, *s_v = s_l + SM, *s_qs = s_v + SV, *s_part = s_qs + SQ;
+    // LDS carve (floats): two staging buffers of KPH K tiles + KPH V tiles | the waves' final states | Q scale | fold scratch
+    constexpr int BUF = 2 * KPH * TILE, SO = NW * 1024, SM = NW * 32, SP = 2 * NW * 32;
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF + SO + 2 * SM + 32 + SP];
+    float *s_buf = lds, *s_o = s_buf + 2 * BUF, *s_m = s_o + SO, *s_l = s_m + SM, *s_qs = s_l + SM, *s_part = s_qs + 32;
 
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
+    const int ph = wave >> 1, qb_w = wave & 1;   // waves w and w + 4 (phases p and p + 2) usually share a SIMD
     const AttnLayout &lay = a.lay;
     const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    const int u0 = lb * lay.U, u1 = min(lay.T, u0 + lay.U);
-    const int nu = u1 - u0;                      // >= 1
-    const int pair0 = u0 / lay.P;
-    const int nseg = (u1 - 1) / lay.P - pair0 + 1;   // <= NSEG (host: U <= 2P + 1)
+    const int sp = lb / lay.KS, ks = lb - sp * lay.KS;
+    const int fh = sp / lay.QSB, qsb = sp - fh * lay.QSB;
+    const int f = fh / a.H, h = fh - f * a.H;
+    // key range ks of KS: base blocks each, the first `rem` ranges one more
+    const int base = lay.P / lay.KS, rem = lay.P - base * lay.KS;
+    const int kb0 = ks * base + min(ks, rem), nblk = base + (ks < rem ? 1 : 0);
+    const int nsteps = (nblk + KPH - 1) / KPH;
+    const float *Kf = a.K + (size_t)f * a.S * a.ldk + h * D, *Vf = a.V + (size_t)f * a.S * a.ldv + h * D;
 
-    // pair -> (frame, head, first query row)
-    auto pair_fhq = [&](int pair, int &f, int &h, int &q0) {
-        const int fh = pair / lay.QB;
-        q0 = (pair - fh * lay.QB) * 32;
-        f = fh / a.H;
-        h = fh - f * a.H;
-    };
-    // unit j of this wave -> segment, key block, K / V base of its (frame, head)
-    struct Unit { int seg, kb; const float *k, *v; };
-    auto unit = [&](int j) {
-        const int u = u0 + wave + NW * j;
-        const int pair = u / lay.P;
-        int f, h, q0;
-        pair_fhq(pair, f, h, q0);
-        Unit r;
-        r.seg = pair - pair0;
-        r.kb = u - pair * lay.P;
-        r.k = a.K + (size_t)f * a.S * a.ldk + h * D;
-        r.v = a.V + (size_t)f * a.S * a.ldv + h * D;
-        return r;
-    };
-    const int nj = wave < nu ? (nu - wave + NW - 1) / NW : 0;
-
-    auto load_k = [&](const Unit &un, f32x4(&kf)[4]) {
-        const int key = min(un.kb * 32 + li, a.S - 1);
-        const float *kp = un.k + (size_t)key * a.ldk + 4 * lh;
+    // ---- staging: thread t moves float4 number t + 512 i (i < 4) of a step's image: [K tiles | V tiles] x KPH x 32 rows x 8 chunks
+    f32x4 stg[4];
+    auto stage_load = [&](int step) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) kf[c] = *reinterpret_cast<const f32x4 *>(kp + 8 * c);
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 64 * NW * i;
+            const int isv = e >> 10, blk = (e >> 8) & 3, r = (e >> 3) & 31, c4 = e & 7;
+            const int kb = min(kb0 + step * KPH + blk, kb0 + nblk - 1);        // blocks past the range: re-read the last one (unused)
+            const int row = min(kb * 32 + r, a.S - 1);                          // rows past S: masked in the softmax
+            const float *src = isv ? Vf + (size_t)row * a.ldv : Kf + (size_t)row * a.ldk;
+            stg[i] = *reinterpret_cast<const f32x4 *>(src + 4 * c4);
+        }
     };
-    auto load_v = [&](const Unit &un, f32x4(&vr)[4]) {   // raw rows: lane l holds float4 #(l & 7) of key rows (l >> 3) + 8j
+    auto stage_store = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int kr = min(un.kb * 32 + (lane >> 3) + 8 * j, a.S - 1);
-            vr[j] = *reinterpret_cast<const f32x4 *>(un.v + (size_t)kr * a.ldv + 4 * (lane & 7));
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 64 * NW * i;
+            const int tile = e >> 8, r = (e >> 3) & 31, c4 = e & 7;             // tile = isv * KPH + blk
+            *reinterpret_cast<f32x4 *>(s_buf + buf * BUF + tile * TILE + r * TLD + 4 * c4) = stg[i];
         }
     };
 
     // ---- prologue: everything that goes to memory is issued before the first wait
-    // raw Q fragments of the (up to 3) segments: lane (q = li, h) holds Q[q][8c+4h+e]
-    f32x4 qraw[NSEG][4];
-#pragma unroll
-    for (int s = 0; s < NSEG; ++s) {
-        int f, h, q0;
-        pair_fhq(pair0 + min(s, nseg - 1), f, h, q0);
-        const int q = min(q0 + li, a.L - 1);
+    stage_load(0);
+    f32x4 qraw[4];   // raw Q fragment: lane (q = li, h) holds Q[q][8c+4h+e]
+    const int qblk = qsb * QG + qb_w;            // this wave's query block; past the last one: idle wave (clamped loads, no slot)
+    {
+        const int q = min(qblk * 32 + li, a.L - 1);
         const float *qp = a.Q + ((size_t)f * a.L + q) * a.ldq + h * D + 4 * lh;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) qraw[s][c] = *reinterpret_cast<const f32x4 *>(qp + 8 * c);
+        for (int c = 0; c < 4; ++c) qraw[c] = *reinterpret_cast<const f32x4 *>(qp + 8 * c);
     }
-    f32x4 kC[4], kN[4], kN2[4], vR[4];
-    Unit uC{}, uN{};
-    if (nj > 0) {
-        uC = unit(0);
-        uN = unit(min(1, nj - 1));
-        load_k(uC, kC);
-        load_v(uC, vR);
-        load_k(uN, kN);
-    }
-    // token-axis norm of the segments' 32 Q columns (transformer.py:53): from the projection's column partials - thread
+    // token-axis norm of this head's 32 Q columns (transformer.py:53) from the projection's column partials: thread
     // (phase, column) sums the squares of slabs phase, phase + 2 NW, ...; column threads fold the phases in a fixed order
     {
-        const int col = threadIdx.x & 31, ph = threadIdx.x >> 5;   // 2 NW phases
+        const int col = tid & 31, php = tid >> 5;   // 2 NW phases
         if (a.q_colpart) {
-            for (int s = 0; s < nseg; ++s) {
-                int f, h, q0;
-                pair_fhq(pair0 + s, f, h, q0);
-                const float *cp = a.q_colpart + ((size_t)f * a.q_nslab * a.q_ncols + h * D + col) * 2 + 1;
-                float acc = 0.f;
-                for (int b = ph; b < a.q_nslab; b += 2 * NW) acc += cp[(size_t)b * a.q_ncols * 2];
-                s_part[(ph * NSEG + s) * 32 + col] = acc;
-            }
+            const float *cp = a.q_colpart + ((size_t)f * a.q_nslab * a.q_ncols + h * D + col) * 2 + 1;
+            float acc = 0.f;
+            for (int b = php; b < a.q_nslab; b += 2 * NW) acc += cp[(size_t)b * a.q_ncols * 2];
+            s_part[php * 32 + col] = acc;
         }
-        // neutral state in every (segment, wave) slot: a wave without a unit in a segment contributes nothing to its merge
-        if (lh == 0) {
-#pragma unroll
-            for (int s = 0; s < NSEG; ++s) {
-                s_m[(s * NW + wave) * 32 + li] = -1e30f;
-                s_l[(s * NW + wave) * 32 + li] = 0.f;
-            }
-        }
+        stage_store(0);
+        if (nsteps > 1) stage_load(1);
         __syncthreads();
-        if (threadIdx.x < 32 * NSEG) {
-            const int s = threadIdx.x >> 5;
+        if (tid < 32) {
             float v = 1.0f;
-            if (s < nseg) {
-                int f, h, q0;
-                pair_fhq(pair0 + s, f, h, q0);
-                if (a.q_colpart) {
-                    float t = 0.f;
+            if (a.q_colpart) {
+                float t = 0.f;
 #pragma unroll
-                    for (int p = 0; p < 2 * NW; ++p) t += s_part[(p * NSEG + s) * 32 + col];
-                    v = 1.0f / fmaxf(sqrtf(t), a.q_eps);
-                } else if (a.qs) {
-                    v = a.qs[((size_t)f * a.H + h) * D + col];
-                }
+                for (int p = 0; p < 2 * NW; ++p) t += s_part[p * 32 + tid];
+                v = 1.0f / fmaxf(sqrtf(t), a.q_eps);
+            } else if (a.qs) {
+                v = a.qs[((size_t)f * a.H + h) * D + tid];
             }
-            s_qs[threadIdx.x] = v;
+            s_qs[tid] = v;
         }
         __syncthreads();
     }
-    // scaled Q fragments: q * colscale * softmax scale * log2(e)
-    float qf[NSEG][16];
+    float qf[16];   // q * colscale * softmax scale * log2(e)
 #pragma unroll
-    for (int s = 0; s < NSEG; ++s)
+    for (int c = 0; c < 4; ++c) {
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(&s_qs[4 * lh + 8 * c]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const f32x4 sc = *reinterpret_cast<const f32x4 *>(&s_qs[s * 32 + 4 * lh + 8 * c]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) qf[s][4 * c + e] = (qraw[s][c][e] * sc[e]) * a.scale_log2e;
-        }
+        for (int e = 0; e < 4; ++e) qf[4 * c + e] = (qraw[c][e] * sc[e]) * a.scale_log2e;
+    }
 
     f32x16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
 
-    float *sv = s_v + wave * 32 * (D + 4);
-    auto transpose_v = [&](const f32x4(&vr)[4], float(&vf)[16]) {   // -> lane (d = li, h): V[keyrow(r, h)][d]
-#pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4 *>(&sv[((lane >> 3) + 8 * j) * (D + 4) + 4 * (lane & 7)]) = vr[j];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) vf[r] = sv[((r & 3) + 8 * (r >> 2) + 4 * lh) * (D + 4) + li];
-    };
-    auto qk1 = [&](const f32x4(&kf)[4], const float(&q)[16]) {  // S^T = K . Q^T, 16 chained MFMAs
+    auto qk = [&](const float *kt) {  // S^T = K . Q^T, 16 chained MFMAs; lane (key = li, h) reads K[key][4h + 8c ..]
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        if constexpr (ABL & 4) {
+            s[0] = kt[li * TLD + lh];
+            return s;
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+            const f32x4 kf = *reinterpret_cast<const f32x4 *>(kt + li * TLD + 4 * lh + 8 * c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c][e], q[4 * c + e], s, 0, 0, 0);
+            for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[4 * c + e], s, 0, 0, 0);
         }
         return s;
     };
-    auto qk = [&](const f32x4(&kf)[4], int seg) {   // seg is wave-uniform: a scalar branch, no register indexing
-        if (seg == 0) return qk1(kf, qf[0]);
-        if (seg == 1) return qk1(kf, qf[1]);
-        return qk1(kf, qf[2]);
-    };
-    auto softmax = [&](int kb, f32x16 &s) {  // online softmax (base 2); returns P in s, rescales o
-        const int k0 = kb * 32;
-        if (k0 + 32 > a.S) {
+    auto read_v = [&](const float *vt, float(&vf)[16]) {   // lane (d = li, h): V[keyrow(r, h)][d]
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (k0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= a.S) s[r] = -INFINITY;
-        }
+        for (int r = 0; r < 16; ++r) vf[r] = vt[((r & 3) + 8 * (r >> 2) + 4 * lh) * TLD + li];
+    };
+    auto mask_tail = [&](int kb, f32x16 &s) {   // keys past S (last block of a pair only) never win the max and weigh 0
+        const int k0 = kb * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (k0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= a.S) s[r] = -INFINITY;
+    };
+    auto softmax = [&](f32x16 &s) {  // online softmax (base 2); returns P in s, rescales o
+        if constexpr (ABL & 1) return;
         float bmax = -1e30f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) bmax = fmaxf(bmax, s[r]);
@@ -239,78 +206,106 @@ __global__ __launch_bounds__(64 * NW) void attention_flat_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) o[r] *= alpha;
     };
     auto pv = [&](const f32x16 &p, const float(&vf)[16]) {  // O^T += V^T . P^T in D-layout key order
+        if constexpr (ABL & 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] += vf[r] + p[r];
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], p[r], o, 0, 0, 0);
     };
-    auto flush = [&](int seg) {   // this wave's state of segment `seg` -> its LDS slot; fresh state for the next segment
-        l_run += __shfl_xor(l_run, 32, 64);   // join the two halves' row sums (same m in both halves by construction)
-        const int slot = seg * NW + wave;
-        if (lh == 0) {
-            s_m[slot * 32 + li] = m_run;
-            s_l[slot * 32 + li] = l_run;
-        }
-        float *so = s_o + slot * 1024;
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq)   // lane (q, h) holds O[q][8 rq + 4 h .. +3] in regs 4rq .. 4rq+3: chunk 2 rq + h
-            *reinterpret_cast<float4 *>(&so[so_off(li, 2 * rq + lh)]) = make_float4(o[4 * rq], o[4 * rq + 1], o[4 * rq + 2], o[4 * rq + 3]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = 0.f;
-        m_run = -1e30f;
-        l_run = 0.f;
-    };
 
-    // Software pipeline over this wave's units: the next unit's QK^T MFMA chain is issued before the current unit's softmax
-    // (VALU / transcendental work runs under matrix-core time), V of the next unit and K of the unit after it are in flight.
-    if (nj > 0) {
-        float vC[16];
-        f32x16 sC = qk(kC, uC.seg);
-        transpose_v(vR, vC);
-        for (int j = 0; j + 1 < nj; ++j) {
-            const Unit uN2 = unit(min(j + 2, nj - 1));
-            load_k(uN2, kN2);
-            load_v(uN, vR);                     // raw rows of the next unit fly under this unit's MFMA chains ...
-            f32x16 sN = qk(kN, uN.seg);
-            softmax(uC.kb, sC);
+    // ---- main loop: one unit per wave and step.  Step t: the QK^T chain of this step's tile and the softmax of step t-1 are
+    // ONE basic block in which the scheduler is told to put the softmax's VALU / transcendental instructions into the shadows
+    // of the QK^T MFMAs (64 cycles each: the wave would otherwise sit through 16 of them before its first exp); the PV chain of
+    // step t-1 follows (its V operand waits in registers), then the next step's tiles go from registers to the other buffer
+    // and the loads of the step after that are issued.  One barrier per step: buffer (t+1)&1 was last read in step t-1.
+    // Steps without a tile for this wave (the tail of the range) and the first step take the plain paths below.
+    const bool tail_keys = (a.S & 31) != 0;   // the last key block of every pair is partial
+    f32x16 sC;
+    float vC[16];
+    int kbC = -1;   // key block of the pending unit (wave-uniform), -1: none
+    for (int t = 0; t < nsteps; ++t) {
+        const float *bt = s_buf + (t & 1) * BUF;
+        const int kb = kb0 + t * KPH + ph;
+        const bool have = t * KPH + ph < nblk;   // wave-uniform
+        if (have && kbC >= 0) {
+            if (tail_keys && kbC == lay.P - 1) mask_tail(kbC, sC);
+            f32x16 sN = qk(bt + ph * TILE);
+            softmax(sC);
+            // 16 x { 1 MFMA, then VALU work of the softmax }: exp / max / sub / mul go under the matrix pipe's 64-cycle instructions
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+            }
+            float vN[16];
+            read_v(bt + (KPH + ph) * TILE, vN);
             pv(sC, vC);
-            if (uN.seg != uC.seg) flush(uC.seg);
-            transpose_v(vR, vC);                // ... and go through LDS once the PV chain has read the current ones
             sC = sN;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) kN[c] = kN2[c];
-            uC = uN;
-            uN = uN2;
-        }
-        softmax(uC.kb, sC);
-        pv(sC, vC);
-        flush(uC.seg);
-    }
-    __syncthreads();
-
-    // ---- merge the waves' states of every segment (fixed order: deterministic) -> the pair's slot of this workgroup
-    for (int e = threadIdx.x; e < nseg * 256; e += 64 * NW) {   // per segment: 32 queries x 8 float4 chunks
-        const int s = e >> 8, q = (e >> 3) & 31, ch = e & 7;
-        float mm = -1e30f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) mm = fmaxf(mm, s_m[(s * NW + w) * 32 + q]);
-        float l = 0.f;
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const float lw = s_l[(s * NW + w) * 32 + q];
-            if (lw > 0.f) {   // waves without a unit in this segment left the neutral state (and never wrote their O image)
-                const float sc = fast_exp2(s_m[(s * NW + w) * 32 + q] - mm);
-                l += lw * sc;
-                const float4 t = *reinterpret_cast<const float4 *>(&s_o[(s * NW + w) * 1024 + so_off(q, ch)]);
-                r.x += t.x * sc; r.y += t.y * sc; r.z += t.z * sc; r.w += t.w * sc;
+            for (int r = 0; r < 16; ++r) vC[r] = vN[r];
+            kbC = kb;
+        } else {
+            if (kbC >= 0) {
+                if (tail_keys && kbC == lay.P - 1) mask_tail(kbC, sC);
+                softmax(sC);
+                pv(sC, vC);
+                kbC = -1;
+            }
+            if (have) {
+                sC = qk(bt + ph * TILE);
+                read_v(bt + (KPH + ph) * TILE, vC);
+                kbC = kb;
             }
         }
-        const int pair = pair0 + s;
-        float *slot = a.parts + ((size_t)pair * lay.maxp + (lb - attn_first_wg(lay, pair))) * COFI_ATTN_SLOT_FLOATS;
-        if (ch == 0) {
-            slot[q] = mm;
-            slot[32 + q] = l;
+        if (t + 1 < nsteps && !(ABL & 8)) {
+            stage_store((t + 1) & 1);
+            if (t + 2 < nsteps) stage_load(t + 2);
         }
-        *reinterpret_cast<float4 *>(slot + 64 + q * 32 + 4 * ch) = r;
+        if constexpr (!(ABL & 16)) __syncthreads();
+    }
+    if (kbC >= 0) {
+        if (tail_keys && kbC == lay.P - 1) mask_tail(kbC, sC);
+        softmax(sC);
+        pv(sC, vC);
+    }
+
+    // ---- this wave's state -> LDS; the KPH phase waves of a query block are merged in a fixed order -> the block's slot
+    l_run += __shfl_xor(l_run, 32, 64);   // join the two halves' row sums (same m in both halves by construction)
+    if (lh == 0) {
+        s_m[wave * 32 + li] = m_run;      // a wave without a unit leaves (-1e30, 0): contributes nothing
+        s_l[wave * 32 + li] = l_run;
+    }
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq)   // lane (q, h) holds O[q][8 rq + 4 h .. +3] in regs 4rq .. 4rq+3: chunk 2 rq + h
+        *reinterpret_cast<float4 *>(&s_o[wave * 1024 + so_off(li, 2 * rq + lh)]) = make_float4(o[4 * rq], o[4 * rq + 1], o[4 * rq + 2], o[4 * rq + 3]);
+    __syncthreads();
+    {   // 512 threads = QG query blocks x 32 queries x 8 float4 chunks
+        const int qb = tid >> 8, q = (tid >> 3) & 31, ch = tid & 7;
+        const int blk = qsb * QG + qb;
+        if (blk < lay.QB) {
+            float mm = -1e30f;
+#pragma unroll
+            for (int p = 0; p < KPH; ++p) mm = fmaxf(mm, s_m[(p * QG + qb) * 32 + q]);
+            float l = 0.f;
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int p = 0; p < KPH; ++p) {
+                const int w = p * QG + qb;
+                const float sc = fast_exp2(s_m[w * 32 + q] - mm);
+                l += s_l[w * 32 + q] * sc;
+                const float4 t = *reinterpret_cast<const float4 *>(&s_o[w * 1024 + so_off(q, ch)]);
+                r.x += t.x * sc; r.y += t.y * sc; r.z += t.z * sc; r.w += t.w * sc;
+            }
+            const int pair = fh * lay.QB + blk;
+            float *slot = a.parts + ((size_t)pair * lay.KS + ks) * COFI_ATTN_SLOT_FLOATS;
+            if (ch == 0) {
+                slot[q] = mm;
+                slot[32 + q] = l;
+            }
+            *reinterpret_cast<float4 *>(slot + 64 + q * 32 + 4 * ch) = r;
+        }
     }
 }
 
@@ -337,7 +332,19 @@ int attention_check(const float *Q, int ldq, const float *K, int ldk, const floa
 
 int launch_parts(AttnArgs a, int frames, hipStream_t stream) {
     a.lay = attn_layout(a.L, a.S, a.H, frames);
-    hipLaunchKernelGGL(attention_flat_kernel, dim3(a.lay.nwg), dim3(64 * NW), 0, stream, a);
+    static const int abl = [] { const char *e = getenv("COFI_ATTN_ABLATE"); return e ? atoi(e) : 0; }();   // timing experiments only
+    const dim3 grid(a.lay.nwg), block(64 * NW);
+    switch (abl) {
+        case 1: hipLaunchKernelGGL(attention_flat_kernel<1>, grid, block, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL(attention_flat_kernel<2>, grid, block, 0, stream, a); break;
+        case 3: hipLaunchKernelGGL(attention_flat_kernel<3>, grid, block, 0, stream, a); break;
+        case 4: hipLaunchKernelGGL(attention_flat_kernel<4>, grid, block, 0, stream, a); break;
+        case 7: hipLaunchKernelGGL(attention_flat_kernel<7>, grid, block, 0, stream, a); break;
+        case 8: hipLaunchKernelGGL(attention_flat_kernel<8>, grid, block, 0, stream, a); break;
+        case 24: hipLaunchKernelGGL(attention_flat_kernel<24>, grid, block, 0, stream, a); break;
+        case 31: hipLaunchKernelGGL(attention_flat_kernel<31>, grid, block, 0, stream, a); break;
+        default: hipLaunchKernelGGL(attention_flat_kernel<0>, grid, block, 0, stream, a);
+    }
     return cofi_launch_status();
 }
 

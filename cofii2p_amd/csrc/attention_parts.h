@@ -1,25 +1,28 @@
 // Layout of the attention partials (attention.hip) shared by the producer, the stand-alone merge kernel and the consumers
 // that merge on the fly (transformer_tail.hip).
 //
-// The T = pairs * P units of a launch (pair = (frame, head, 32-query block), P = ceil(S / 32) key blocks) are numbered
-// pair-major and cut into `nwg` contiguous ranges of U units, one per workgroup.  Workgroup w leaves, for every pair its range
-// touches, ONE slot {m[32], l[32], O[32][32]} (running max, row sum, un-normalised output, all relative to m) at
-//     parts[(pair * maxp + (w - first_wg(pair))) * COFI_ATTN_SLOT_FLOATS],      first_wg(pair) = pair * P / U,
-// so a reader only needs (P, U, QB, maxp) - recomputed here from (L, S, H, frames) and the device's CU count - to find and
-// combine the slots of a query row:  O = sum_s O_s 2^(m_s - m) / sum_s l_s 2^(m_s - m),  m = max_s m_s  (fixed order).
+// A PAIR = (frame, head, 32-query block).  The P = ceil(S / 32) key blocks of every pair are cut into KS contiguous ranges
+// (as even as possible); each range is handled by another workgroup, which leaves ONE slot {m[32], l[32], O[32][32]} (running
+// max, row sum, un-normalised output relative to m) at
+//     parts[(pair * KS + ks) * COFI_ATTN_SLOT_FLOATS].
+// A reader combines the KS slots of a query row in a fixed order:
+//     O = sum_s O_s 2^(m_s - m) / sum_s l_s 2^(m_s - m),   m = max_s m_s.
+// KS comes from (L, S, H, frames) and the device's CU count (attn_layout): enough ranges to give every CU a workgroup, as few
+// as possible beyond that.
 #pragma once
 #include "common.h"
 
 #define COFI_ATTN_SLOT_FLOATS 1088
-#define COFI_ATTN_MAX_SEGMENTS 3   /* pairs one workgroup's range may touch: U <= 2 P + 1 */
+#define COFI_ATTN_MAX_KS 4
+#define COFI_ATTN_QG 2      /* query blocks sharing one workgroup's K / V tiles */
+#define COFI_ATTN_KPH 4     /* key blocks a workgroup stages and processes per step (one per wave group) */
 
 struct AttnLayout {
     int P;      // key blocks per pair
     int QB;     // query blocks per (frame, head)
-    int U;      // units per workgroup
-    int T;      // units of the launch
-    int maxp;   // slots reserved per pair
-    int nwg;    // workgroups
+    int QSB;    // 64-query super blocks per (frame, head)
+    int KS;     // key ranges = slots per pair
+    int nwg;    // workgroups = frames * H * QSB * KS
     size_t bytes;
 };
 
@@ -37,37 +40,52 @@ static inline AttnLayout attn_layout(int L, int S, int H, int frames) {
     AttnLayout a;
     a.P = cofi_cdiv(S, 32);
     a.QB = cofi_cdiv(L, 32);
-    const long pairs = (long)frames * H * a.QB;
-    a.T = (int)(pairs * a.P);
-    int U = cofi_cdiv(a.T, attn_num_cus());   // one range per CU ...
-    if (U > 2 * a.P + 1) U = 2 * a.P + 1;     // ... of at most COFI_ATTN_MAX_SEGMENTS pairs
-    if (U < 1) U = 1;
-    a.U = U;
-    a.nwg = cofi_cdiv(a.T, U);
-    a.maxp = (a.P + U - 2) / U + 1;
-    a.bytes = (size_t)pairs * a.maxp * COFI_ATTN_SLOT_FLOATS * sizeof(float);
+    a.QSB = cofi_cdiv(a.QB, COFI_ATTN_QG);
+    const long sp = (long)frames * H * a.QSB;   // workgroups per key range
+    // Cost of a split in "steps" (one 32 x 32 unit per wave): waves of workgroups the chip runs one after the other, each
+    // ceil(blocks / KPH) steps long plus a fixed prologue + merge cost of about 1.5 steps.
+    const int ncu = attn_num_cus();
+    int best = 1;
+    double best_cost = 1e30;
+    for (int ks = 1; ks <= COFI_ATTN_MAX_KS && ks <= a.P; ++ks) {
+        const double rounds = (double)cofi_cdiv(sp * ks, ncu);
+        const double cost = rounds * (cofi_cdiv(cofi_cdiv(a.P, ks), COFI_ATTN_KPH) + 1.5);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = ks; }
+    }
+    a.KS = best;
+    a.nwg = (int)(sp * a.KS);
+    a.bytes = (size_t)frames * H * a.QB * a.KS * COFI_ATTN_SLOT_FLOATS * sizeof(float);
     return a;
 }
 
-__host__ __device__ __forceinline__ int attn_first_wg(const AttnLayout &lay, int pair) { return (int)(((long)pair * lay.P) / lay.U); }
-
-// merged, normalised output of query row l (frame f, head h), 16-byte chunk `ch` (d = 4 ch .. 4 ch + 3)
+// merged, normalised output of query row l (frame f, head h), 16-byte chunk `ch` (d = 4 ch .. 4 ch + 3).  Every load is
+// issued before the first use: one round trip whatever KS is.
 __device__ __forceinline__ float4 attn_merged_chunk(const float *parts, const AttnLayout &lay, int f, int H, int h, int l, int ch) {
     const int q = l & 31;
     const int pair = (f * H + h) * lay.QB + (l >> 5);
-    const int w0 = attn_first_wg(lay, pair), w1 = (int)((((long)pair + 1) * lay.P - 1) / lay.U);
-    const float *slot = parts + (size_t)pair * lay.maxp * COFI_ATTN_SLOT_FLOATS;
+    const float *slot = parts + (size_t)pair * lay.KS * COFI_ATTN_SLOT_FLOATS;
+    float m[COFI_ATTN_MAX_KS], ls[COFI_ATTN_MAX_KS];
+    float4 o[COFI_ATTN_MAX_KS];
+#pragma unroll
+    for (int s = 0; s < COFI_ATTN_MAX_KS; ++s) {
+        const float *sl = slot + (size_t)(s < lay.KS ? s : 0) * COFI_ATTN_SLOT_FLOATS;
+        m[s] = sl[q];
+        ls[s] = sl[32 + q];
+        o[s] = *reinterpret_cast<const float4 *>(sl + 64 + q * 32 + 4 * ch);
+    }
     float mm = -1e30f;
-    for (int s = 0; s <= w1 - w0; ++s) mm = fmaxf(mm, slot[(size_t)s * COFI_ATTN_SLOT_FLOATS + q]);
+#pragma unroll
+    for (int s = 0; s < COFI_ATTN_MAX_KS; ++s)
+        if (s < lay.KS) mm = fmaxf(mm, m[s]);
     float lsum = 0.f;
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s <= w1 - w0; ++s) {
-        const float *sl = slot + (size_t)s * COFI_ATTN_SLOT_FLOATS;
-        const float sc = __builtin_amdgcn_exp2f(sl[q] - mm);
-        lsum += sl[32 + q] * sc;
-        const float4 t = *reinterpret_cast<const float4 *>(sl + 64 + q * 32 + 4 * ch);
-        r.x += t.x * sc; r.y += t.y * sc; r.z += t.z * sc; r.w += t.w * sc;
-    }
+#pragma unroll
+    for (int s = 0; s < COFI_ATTN_MAX_KS; ++s)
+        if (s < lay.KS) {
+            const float sc = __builtin_amdgcn_exp2f(m[s] - mm);
+            lsum += ls[s] * sc;
+            r.x += o[s].x * sc; r.y += o[s].y * sc; r.z += o[s].z * sc; r.w += o[s].w * sc;
+        }
     const float inv = 1.0f / lsum;
     r.x *= inv; r.y *= inv; r.z *= inv; r.w *= inv;
     return r;

@@ -473,7 +473,11 @@ __global__ void split_planes_kernel(const float *W, int ldw, int N, int K, unsig
 //        the workgroup folds the producer's statistics partials itself while its first tile is in flight, keeps the per-channel
 //        scale / shift in LDS and normalises every A element on its way into the bf16 planes - the stand-alone normalisation
 //        kernel, its statistics kernel and one round trip of the activation through HBM disappear.
-template <int BM, int BN, int TM, int TN, int BK3, int KW = 1, bool WSPLIT = false, int WPE = 1, bool ANORM = false>
+// PF2:   TWO K-tiles in flight in registers (loads of tile t+2 are issued before tile t is multiplied).  With one tile in flight a
+//        workgroup that has no neighbour on its CU spends a full memory round trip per K-tile (measured ~1.6 us per 32 KB tile on the
+//        320-workgroup M = 20480 launches, whose MFMAs take 0.2 us and whose bytes arrive in 0.5 us): the grids of a single frame
+//        give 1 - 2.5 workgroups per CU, too few for other workgroups to hide it.
+template <int BM, int BN, int TM, int TN, int BK3, int KW = 1, bool WSPLIT = false, int WPE = 1, bool ANORM = false, bool PF2 = false>
 __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
     static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 waves");
     constexpr int NT = 256 * KW;
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
     constexpr int LDS_BYTES = BUF > EPI ? BUF : EPI;
     static_assert((NT / (BN / 4)) * BN * 2 * 4 <= LDS_BYTES, "column-statistics scratch must fit");
     constexpr int AN_MAXC = 512;                                 // channels of a normalised A operand (scale + shift table behind the buffers)
-    static_assert(!ANORM || (NT * 16 + AN_MAXC * 8 <= LDS_BYTES), "statistics fold scratch must fit in the operand buffer");
+    static_assert(!ANORM || (NT * 32 + AN_MAXC * 8 <= LDS_BYTES), "statistics fold scratch must fit in the operand buffer");
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES + (ANORM ? AN_MAXC * 8 : 0)];
     float *nsc = reinterpret_cast<float *>(lds_raw + LDS_BYTES), *nsh = nsc + AN_MAXC;
 
@@ -506,9 +510,15 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
     const int kend = min(g.K, kbeg + g.kchunk);
     const int ntiles = (kend - kbeg + BK3 - 1) / BK3;
     const int lrow = tid / LPR, lk = (tid % LPR) * 4;            // LPR lanes cover one row slice; RPP rows per pass
-    f32x4 ra[A_LD4];                                             // native vectors: plain 16-B loads, no struct copies
-    f32x4 rw[WSPLIT ? 1 : W_LD4];                                // fp32 W: W_LD4 chunks of 4
-    f32x4 rwh[WSPLIT ? W_CH : 1], rwl[WSPLIT ? W_CH : 1];       // pre-split W: 16-B chunks (8 bf16) of the hi / lo plane, as opaque bits
+    struct Stage {                                               // one K-tile on its way from global memory to LDS
+        f32x4 ra[A_LD4];                                         // native vectors: plain 16-B loads, no struct copies
+        f32x4 rw[WSPLIT ? 1 : W_LD4];                            // fp32 W: W_LD4 chunks of 4
+        f32x4 rwh[WSPLIT ? W_CH : 1], rwl[WSPLIT ? W_CH : 1];   // pre-split W: 16-B chunks (8 bf16) of the hi / lo plane, as opaque bits
+        unsigned amask;                                          // validity of the A values (see gload)
+        bool afull;                                              // uniform: the A registers hold a full dense tile (no zeroing needed)
+        int achan;                                               // ANORM: first of the 4 channels the staged float4s of this thread belong to
+    };
+    Stage st0, st1;                                              // st1 only with PF2 (always indexed statically: registers, never scratch)
     const bool conv = g.cv_ks != 0;
 
     // Addressing: a workgroup-uniform base (scalar registers, advanced by one K-tile per iteration) plus a per-thread 32-bit
@@ -547,39 +557,36 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
     }
     // Validity of the A values is kept as a bit mask and applied when the registers are consumed (sstore), so nothing touches
     // a loaded value - and no s_waitcnt is needed - until after the MFMAs.  Full dense tiles carry no mask at all.
-    unsigned amask = 0;
-    bool afull = false;   // uniform: the A registers hold a full dense tile (no zeroing needed)
-    int achan = 0;        // ANORM: first of the 4 channels the staged float4s of this thread belong to
-    auto gload = [&](int t) {
+    auto gload = [&](int t, Stage &st) {
         const bool full = kbeg + (t + 1) * BK3 <= kend;   // uniform
         const int k = kbeg + t * BK3 + lk;
         const bool kin = k < kend;
         if (!conv) {
-            if constexpr (ANORM) achan = kin ? k : 0;
-            afull = full;
+            if constexpr (ANORM) st.achan = kin ? k : 0;
+            st.afull = full;
             const char *at = abase + (size_t)t * (BK3 * 4);
             if (full) {
 #pragma unroll
-                for (int j = 0; j < A_LD4; ++j) ra[j] = *reinterpret_cast<const f32x4 *>(at + aoff[j]);
+                for (int j = 0; j < A_LD4; ++j) st.ra[j] = *reinterpret_cast<const f32x4 *>(at + aoff[j]);
             } else {
-                amask = kin ? ~0u : 0u;   // lanes past the K range re-read the first values of their row (always in range)
+                st.amask = kin ? ~0u : 0u;   // lanes past the K range re-read the first values of their row (always in range)
 #pragma unroll
-                for (int j = 0; j < A_LD4; ++j) ra[j] = *reinterpret_cast<const f32x4 *>(kin ? at + aoff[j] : abase + (aoff[j] - 4u * lk));
+                for (int j = 0; j < A_LD4; ++j) st.ra[j] = *reinterpret_cast<const f32x4 *>(kin ? at + aoff[j] : abase + (aoff[j] - 4u * lk));
             }
         } else {
-            afull = false;
+            st.afull = false;
             const int kc = kin ? k : 0;
             const int tap = kc / g.cv_Cin, c = kc - tap * g.cv_Cin;
             const int dy = tap / g.cv_ks, dx = tap - dy * g.cv_ks;
-            if constexpr (ANORM) achan = c;
-            amask = 0;
+            if constexpr (ANORM) st.achan = c;
+            st.amask = 0;
 #pragma unroll
             for (int j = 0; j < A_LD4; ++j) {
                 const int yi = yo[j] * g.cv_stride - g.cv_pad + dy, xi = xo[j] * g.cv_stride - g.cv_pad + dx;
                 const bool ok = kin && (unsigned)yi < (unsigned)g.cv_H && (unsigned)xi < (unsigned)g.cv_W;
                 const int yc = min(max(yi, 0), g.cv_H - 1), xc = min(max(xi, 0), g.cv_W - 1);
-                ra[j] = *reinterpret_cast<const f32x4 *>(g.A + ((size_t)fb[j] + (size_t)yc * g.cv_W + xc) * g.lda + c);
-                amask |= ok ? (1u << j) : 0u;
+                st.ra[j] = *reinterpret_cast<const f32x4 *>(g.A + ((size_t)fb[j] + (size_t)yc * g.cv_W + xc) * g.lda + c);
+                st.amask |= ok ? (1u << j) : 0u;
             }
         }
         // W: lanes past the K range re-read the start of their row (finite values x zeroed A = 0)
@@ -588,8 +595,8 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
             if (full) {
 #pragma unroll
                 for (int j = 0; j < W_CH; ++j) {
-                    rwh[j] = *reinterpret_cast<const f32x4 *>(wt + woff[j]);
-                    rwl[j] = *reinterpret_cast<const f32x4 *>(wt + wlo + woff[j]);
+                    st.rwh[j] = *reinterpret_cast<const f32x4 *>(wt + woff[j]);
+                    st.rwl[j] = *reinterpret_cast<const f32x4 *>(wt + wlo + woff[j]);
                 }
             } else {  // chunks that start past the K range re-read the first chunk of their row (plane rows are padded to 8 values)
 #pragma unroll
@@ -597,40 +604,40 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
                     const int c8 = 8 * ((tid + NT * j) % CPR);
                     const bool cin = kbeg + t * BK3 + c8 < kend;
                     const char *q = cin ? wt + woff[j] : wbase + (woff[j] - 2u * c8);
-                    rwh[j] = *reinterpret_cast<const f32x4 *>(q);
-                    rwl[j] = *reinterpret_cast<const f32x4 *>(q + wlo);
+                    st.rwh[j] = *reinterpret_cast<const f32x4 *>(q);
+                    st.rwl[j] = *reinterpret_cast<const f32x4 *>(q + wlo);
                 }
             }
         } else {
             const char *wt = wbase + (size_t)t * (BK3 * 4);
             if (full) {
 #pragma unroll
-                for (int j = 0; j < W_LD4; ++j) rw[j] = *reinterpret_cast<const f32x4 *>(wt + woff[j]);
+                for (int j = 0; j < W_LD4; ++j) st.rw[j] = *reinterpret_cast<const f32x4 *>(wt + woff[j]);
             } else {
 #pragma unroll
-                for (int j = 0; j < W_LD4; ++j) rw[j] = *reinterpret_cast<const f32x4 *>(kin ? wt + woff[j] : wbase + (woff[j] - 4u * lk));
+                for (int j = 0; j < W_LD4; ++j) st.rw[j] = *reinterpret_cast<const f32x4 *>(kin ? wt + woff[j] : wbase + (woff[j] - 4u * lk));
             }
         }
     };
-    auto sstore = [&]() {
+    auto sstore = [&](Stage &st) {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         if constexpr (ANORM) {
             // the pending normalisation of the producer: y * sc + sh, LeakyReLU as max(v, v * slope) (0 <= slope <= 1) - the
             // same operations in the same order as the stand-alone apply kernel.  Zero padding / K tails are masked afterwards.
-            const f32x4 sc = *reinterpret_cast<const f32x4 *>(nsc + achan), sh = *reinterpret_cast<const f32x4 *>(nsh + achan);
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(nsc + st.achan), sh = *reinterpret_cast<const f32x4 *>(nsh + st.achan);
 #pragma unroll
             for (int j = 0; j < A_LD4; ++j) {
-                f32x4 v = ra[j] * sc + sh;
+                f32x4 v = st.ra[j] * sc + sh;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * g.an.slope;
-                ra[j] = v;
+                st.ra[j] = v;
             }
         }
-        if (afull) {
+        if (st.afull) {
 #pragma unroll
             for (int j = 0; j < A_LD4; ++j) {
                 uint2 hi, lo;
-                split4(ra[j], hi, lo);
+                split4(st.ra[j], hi, lo);
                 unsigned char *p = lds_raw + (lrow + RPP * j) * BROW3 + lk * 2;
                 *reinterpret_cast<uint2 *>(p) = hi;
                 *reinterpret_cast<uint2 *>(p + PLANE_A) = lo;
@@ -639,7 +646,7 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
 #pragma unroll
             for (int j = 0; j < A_LD4; ++j) {
                 uint2 hi, lo;
-                split4(((amask >> j) & 1u) ? ra[j] : zero, hi, lo);
+                split4(((st.amask >> j) & 1u) ? st.ra[j] : zero, hi, lo);
                 unsigned char *p = lds_raw + (lrow + RPP * j) * BROW3 + lk * 2;
                 *reinterpret_cast<uint2 *>(p) = hi;
                 *reinterpret_cast<uint2 *>(p + PLANE_A) = lo;
@@ -650,14 +657,14 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
             for (int j = 0; j < W_CH; ++j) {
                 const int c = tid + NT * j;
                 unsigned char *p = lds_raw + 2 * PLANE_A + (c / CPR) * BROW3 + (c % CPR) * 16;
-                *reinterpret_cast<f32x4 *>(p) = rwh[j];
-                *reinterpret_cast<f32x4 *>(p + PLANE_W) = rwl[j];
+                *reinterpret_cast<f32x4 *>(p) = st.rwh[j];
+                *reinterpret_cast<f32x4 *>(p + PLANE_W) = st.rwl[j];
             }
         } else {
 #pragma unroll
             for (int j = 0; j < W_LD4; ++j) {
                 uint2 hi, lo;
-                split4(rw[j], hi, lo);
+                split4(st.rw[j], hi, lo);
                 unsigned char *p = lds_raw + 2 * PLANE_A + (lrow + RPP * j) * BROW3 + lk * 2;
                 *reinterpret_cast<uint2 *>(p) = hi;
                 *reinterpret_cast<uint2 *>(p + PLANE_W) = lo;
@@ -706,26 +713,58 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
     // tile t+1 -> barrier.  (Measured on MI355X: deeper register prefetch (2-3 tiles in flight, exact vmcnt) and a second LDS
     // buffer do NOT shorten the ~1 us a lone workgroup spends per 64 KB tile - that is the CU's L2 fill rate; only spreading
     // the tiles over more CUs does, which is what split-K is tuned for.)
-    if (ntiles > 0) gload(0);
+    if (ntiles > 0) gload(0, st0);
+    if constexpr (PF2) {
+        if (ntiles > 1) gload(1, st1);
+    }
     if constexpr (ANORM) {
-        // statistics of this tile's frame -> scale / shift table (fold scratch lives in the still unused operand buffer)
+        // statistics of this tile's frame -> scale / shift table in LDS: copied from the finalized vectors (cofi_norm_finalize) or,
+        // without them, folded here from the producer's partials (fold scratch lives in the still unused operand buffer)
         const int f = g.an_rows > 0 ? m0 / g.an_rows : 0;
-        double *dred = reinterpret_cast<double *>(lds_raw);
-        float *sstat = reinterpret_cast<float *>(lds_raw + NT * 16);
-        fold_stat_table<NT>(g.an.part + (size_t)f * g.an.nslab * g.an.tcols * 2, g.an.nslab, g.an.tcols, g.an.groups, g.an.count, g.an.eps,
-                            dred, sstat);
-        norm_scale_shift<NT>(g.an, sstat, nsc, nsh);
+        if (g.an.scsh) {
+            const float *src = g.an.scsh + (size_t)f * 2 * g.an.C;
+            for (int c = tid * 4; c < g.an.C; c += NT * 4) {
+                *reinterpret_cast<f32x4 *>(nsc + c) = *reinterpret_cast<const f32x4 *>(src + c);
+                *reinterpret_cast<f32x4 *>(nsh + c) = *reinterpret_cast<const f32x4 *>(src + g.an.C + c);
+            }
+        } else {
+            double *dred = reinterpret_cast<double *>(lds_raw);
+            float *sstat = reinterpret_cast<float *>(lds_raw + NT * 32);
+            fold_stat_table<NT, 6>(g.an.part + (size_t)f * g.an.nslab * g.an.tcols * 2, g.an.nslab, g.an.tcols, g.an.groups, g.an.count, g.an.eps,
+                                   dred, sstat);
+            norm_scale_shift<NT>(g.an, sstat, nsc, nsh);
+        }
         __syncthreads();
     }
-    if (ntiles > 0) sstore();
+    if (ntiles > 0) sstore(st0);
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) gload(t + 1);
-        compute();
-        __syncthreads();              // every wave is done reading tile t
-        if (t + 1 < ntiles) {
-            sstore();
-            __syncthreads();          // tile t+1 visible
+    if constexpr (PF2) {
+        // tile t is in LDS, tile t+1 in flight in one register stage; the other stage (consumed by the last sstore) takes tile t+2
+        for (int t = 0; t < ntiles; t += 2) {
+            if (t + 2 < ntiles) gload(t + 2, st0);
+            compute();
+            __syncthreads();              // every wave is done reading tile t
+            if (t + 1 < ntiles) {
+                sstore(st1);
+                __syncthreads();          // tile t+1 visible
+                if (t + 3 < ntiles) gload(t + 3, st1);
+                compute();
+                __syncthreads();
+                if (t + 2 < ntiles) {
+                    sstore(st0);
+                    __syncthreads();
+                }
+            }
+        }
+    } else {
+        for (int t = 0; t < ntiles; ++t) {
+            if (t + 1 < ntiles) gload(t + 1, st0);
+            compute();
+            __syncthreads();              // every wave is done reading tile t
+            if (t + 1 < ntiles) {
+                sstore(st0);
+                __syncthreads();          // tile t+1 visible
+            }
         }
     }
 
@@ -942,14 +981,24 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
     g.xcd_rcp_gy = grid.y > 1 ? (unsigned)((0x100000000ULL + grid.y - 1) / grid.y) : 0u;   // 0: gy = 1
     if (g.bf16x3) {
         const int kw = (p.bm == 64 && p.bn == 64) ? latency_kw(p, g.M, g.N) : 1;
-#define COFI_LAUNCH_BF16X3_W(BM_, BN_, TM_, TN_, BK_, KW_, WPE_)                                                                            \
-    do {                                                                                                                                  \
-        if (g.an.part)                                                                                                                    \
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, true, WPE_, true>), grid, dim3(256 * KW_), 0, s, g);     \
-        else if (g.wsplit)                                                                                                                \
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, true, WPE_, false>), grid, dim3(256 * KW_), 0, s, g);    \
-        else                                                                                                                              \
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, false, WPE_, false>), grid, dim3(256 * KW_), 0, s, g);   \
+        static const bool pf2 = [] { const char *e = getenv("COFI_GEMM_PF2"); return e && atoi(e) != 0; }();
+#define COFI_LAUNCH_BF16X3_P(BM_, BN_, TM_, TN_, BK_, KW_, WPE_, PF2_)                                                                            \
+    do {                                                                                                                                        \
+        if (g.an.part)                                                                                                                          \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, true, WPE_, true, PF2_>), grid, dim3(256 * KW_), 0, s, g);     \
+        else if (g.wsplit)                                                                                                                      \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, true, WPE_, false, PF2_>), grid, dim3(256 * KW_), 0, s, g);    \
+        else                                                                                                                                    \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, false, WPE_, false, false>), grid, dim3(256 * KW_), 0, s, g);  \
+    } while (0)
+/* COFI_GEMM_PF2=1 (A/B runs): the 4-wave 64-row configurations keep two K-tiles in flight.  Measured on MI355X with three frames in
+ * flight: 445 vs 457 frames/s - other streams' kernels already hide the load latency, the extra registers cost co-residency. */
+#define COFI_LAUNCH_BF16X3_W(BM_, BN_, TM_, TN_, BK_, KW_, WPE_)                                     \
+    do {                                                                                            \
+        if ((KW_) == 1 && (BM_) == 64 && pf2)                                                       \
+            COFI_LAUNCH_BF16X3_P(BM_, BN_, TM_, TN_, BK_, KW_, WPE_, ((KW_) == 1 && (BM_) == 64));  \
+        else                                                                                        \
+            COFI_LAUNCH_BF16X3_P(BM_, BN_, TM_, TN_, BK_, KW_, WPE_, false);                        \
     } while (0)
 #define COFI_LAUNCH_BF16X3(BM_, BN_, TM_, TN_, BK_, KW_) COFI_LAUNCH_BF16X3_W(BM_, BN_, TM_, TN_, BK_, KW_, 1)
         // K-tile depth per tile shape (measured): the 128x128 tile is register-bound at 2 waves per SIMD either way; the 64x128 and
@@ -967,6 +1016,7 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
             COFI_LAUNCH_BF16X3(64, 64, 1, 1, 64, 1);
 #undef COFI_LAUNCH_BF16X3
 #undef COFI_LAUNCH_BF16X3_W
+#undef COFI_LAUNCH_BF16X3_P
     } else if (p.bm == 128 && p.bn == 128)
         hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, g);
     else if (p.bm == 64 && p.bn == 128)

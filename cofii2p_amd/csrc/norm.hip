@@ -156,6 +156,45 @@ struct GnApplyArgs {
     uint8_t *row_pos;   // optional: row_pos[m] = (sum_c y[m,c] > 0) (kpconv.py:113-114 for the next KPConv); needs C <= 256
 };
 
+// Row loop of the apply kernels for one float4 column chunk: a thread's rows are taken four at a time with every load issued
+// before the first use (x / res / y may alias as far as the compiler knows: written row by row it would serialise one memory
+// round trip per row).
+__device__ __forceinline__ void gn_apply_rows(const GnApplyArgs &a, int c, const float (&sc)[4], const float (&sh)[4], const float (&rsc)[4],
+                                              const float (&rsh)[4], int tr, int rpb, int tpr, int tc) {
+    constexpr int RU = 4;
+    const int stride = gridDim.x * rpb;
+    for (int m0 = blockIdx.x * rpb + tr; m0 < a.M; m0 += RU * stride) {
+        f32x4 xv[RU], rv[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int m = min(m0 + u * stride, a.M - 1);
+            xv[u] = *reinterpret_cast<const f32x4 *>(a.x + (size_t)m * a.ldx + c);
+            if (a.res) rv[u] = *reinterpret_cast<const f32x4 *>(a.res + (size_t)m * a.ldr + c);
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int m = m0 + u * stride;
+            if (m < a.M) {   // uniform over the tpr lanes of a row
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = xv[u][i] * sc[i] + sh[i];
+                if (a.res) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += rv[u][i] * rsc[i] + rsh[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = v[i] >= 0.f ? v[i] : v[i] * a.slope;
+                *reinterpret_cast<float4 *>(a.y + (size_t)m * a.ldy + c) = make_float4(v[0], v[1], v[2], v[3]);
+                if (a.row_pos) {   // host guarantees tpr <= 64 and one column pass: the tpr lanes of a row are adjacent lanes of one wave
+                    float rs = (v[0] + v[1]) + (v[2] + v[3]);
+                    for (int o = 1; o < tpr; o <<= 1) rs += __shfl_xor(rs, o, 64);
+                    if (tc == 0) a.row_pos[m] = rs > 0.0f ? 1 : 0;
+                }
+            }
+        }
+    }
+}
+
 // Thread = one float4 column chunk (its 4 channels' scale/shift are folded once: y = x*sc + sh), looping over a
 // strided set of rows: the inner loop is load - 4 fma - select - store with whole rows covered by adjacent lanes.
 __global__ __launch_bounds__(256) void group_norm_apply_kernel(GnApplyArgs a) {
@@ -191,25 +230,7 @@ __global__ __launch_bounds__(256) void group_norm_apply_kernel(GnApplyArgs a) {
                 rsh[i] = rb - rm * rr * rg;
             }
         }
-        for (int m = blockIdx.x * rpb + tr; m < a.M; m += gridDim.x * rpb) {
-            const float4 xv = *reinterpret_cast<const float4 *>(a.x + (size_t)m * a.ldx + c);
-            float v[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = v[i] * sc[i] + sh[i];
-            if (a.res) {
-                const float4 rv = *reinterpret_cast<const float4 *>(a.res + (size_t)m * a.ldr + c);
-                v[0] += rv.x * rsc[0] + rsh[0]; v[1] += rv.y * rsc[1] + rsh[1];
-                v[2] += rv.z * rsc[2] + rsh[2]; v[3] += rv.w * rsc[3] + rsh[3];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = v[i] >= 0.f ? v[i] : v[i] * a.slope;
-            *reinterpret_cast<float4 *>(a.y + (size_t)m * a.ldy + c) = make_float4(v[0], v[1], v[2], v[3]);
-            if (a.row_pos) {   // host guarantees tpr <= 64 and one column pass: the tpr lanes of a row are adjacent lanes of one wave
-                float rs = (v[0] + v[1]) + (v[2] + v[3]);
-                for (int o = 1; o < tpr; o <<= 1) rs += __shfl_xor(rs, o, 64);
-                if (tc == 0) a.row_pos[m] = rs > 0.0f ? 1 : 0;
-            }
-        }
+        gn_apply_rows(a, c, sc, sh, rsc, rsh, tr, rpb, tpr, tc);
     }
 }
 
@@ -221,9 +242,29 @@ struct GnFusedArgs {
     NormSrc n, rn;   // statistics source of x / of the shortcut (rn.part == nullptr: none); gamma / beta live in `a`
 };
 
+// Statistics partials -> per-channel scale | shift, once per (frame, 64 table columns): a handful of workgroups, so that the
+// hundreds of workgroups of the consuming GEMM / apply launch do not each repeat the fold.
+__global__ __launch_bounds__(256) void norm_finalize_kernel(NormSrc n, float *scsh) {
+    __shared__ double dred[4 * 256];
+    __shared__ float sstat[2 * 64];
+    const int f = blockIdx.y;
+    const int tc0 = blockIdx.x * 64, ntc = min(64, n.tcols - tc0);   // table columns of this workgroup (tcols: power of two)
+    const int epg = n.tcols / n.groups, g0 = tc0 / epg, ng = ntc / epg;
+    fold_stat_table<256>(n.part + ((size_t)f * n.nslab * n.tcols + tc0) * 2, n.nslab, ntc, ng, n.count, n.eps, dred, sstat, n.tcols);
+    const int cpg = n.C / n.groups;
+    float *sc = scsh + (size_t)f * 2 * n.C, *sh = sc + n.C;
+    for (int i = threadIdx.x; i < ng * cpg; i += 256) {
+        const int gl = i / cpg, c = (g0 + gl) * cpg + (i - gl * cpg);
+        const float mean = sstat[2 * gl], rstd = sstat[2 * gl + 1];
+        const float ga = n.gamma ? n.gamma[c] : 1.f, be = n.gamma ? n.beta[c] : 0.f;
+        sc[c] = rstd * ga;
+        sh[c] = be - mean * rstd * ga;
+    }
+}
+
 __global__ __launch_bounds__(256) void group_norm_apply_fused_kernel(GnFusedArgs fa) {
     GnApplyArgs a = fa.a;
-    __shared__ double dred[512];
+    __shared__ double dred[4 * 256];
     __shared__ float sstat[2 * 1024], rstat[2 * 1024];
     const int c4n = a.C >> 2;
     const int tpr = c4n < 256 ? c4n : 256;
@@ -238,45 +279,39 @@ __global__ __launch_bounds__(256) void group_norm_apply_fused_kernel(GnFusedArgs
         if (fa.rn.part) fa.rn.part += f * fa.rn.nslab * fa.rn.tcols * 2;
         if (a.row_pos) a.row_pos += f * a.M;
     }
-    fold_stat_table<256>(fa.n.part, fa.n.nslab, fa.n.tcols, fa.n.groups, fa.n.count, fa.n.eps, dred, sstat);
-    if (fa.rn.part) fold_stat_table<256>(fa.rn.part, fa.rn.nslab, fa.rn.tcols, fa.rn.groups, fa.rn.count, fa.rn.eps, dred, rstat);
+    const float *nsc = fa.n.scsh ? fa.n.scsh + (size_t)blockIdx.y * 2 * a.C : nullptr;       // finalized scale | shift of this frame
+    const float *rsc_g = fa.rn.scsh ? fa.rn.scsh + (size_t)blockIdx.y * 2 * a.C : nullptr;
+    if (!nsc) fold_stat_table<256>(fa.n.part, fa.n.nslab, fa.n.tcols, fa.n.groups, fa.n.count, fa.n.eps, dred, sstat);
+    if (fa.rn.part && !rsc_g) fold_stat_table<256>(fa.rn.part, fa.rn.nslab, fa.rn.tcols, fa.rn.groups, fa.rn.count, fa.rn.eps, dred, rstat);
     for (int cb = tc; cb < c4n; cb += tpr) {
         const int c = cb * 4;
         float sc[4], sh[4], rsc[4], rsh[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int ch = c + i, g = ch / a.cpg;
-            const float mean = sstat[2 * g], rstd = sstat[2 * g + 1];
-            const float ga = a.gamma ? a.gamma[ch] : 1.f, be = a.gamma ? a.beta[ch] : 0.f;
-            sc[i] = rstd * ga;
-            sh[i] = be - mean * rstd * ga;
+            if (nsc) {
+                sc[i] = nsc[ch];
+                sh[i] = nsc[a.C + ch];
+            } else {
+                const float mean = sstat[2 * g], rstd = sstat[2 * g + 1];
+                const float ga = a.gamma ? a.gamma[ch] : 1.f, be = a.gamma ? a.beta[ch] : 0.f;
+                sc[i] = rstd * ga;
+                sh[i] = be - mean * rstd * ga;
+            }
             rsc[i] = 1.f; rsh[i] = 0.f;
             if (a.res && fa.rn.part) {
-                const float rm = rstat[2 * g], rr = rstat[2 * g + 1];
-                const float rg = a.res_gamma ? a.res_gamma[ch] : 1.f, rb = a.res_gamma ? a.res_beta[ch] : 0.f;
-                rsc[i] = rr * rg;
-                rsh[i] = rb - rm * rr * rg;
+                if (rsc_g) {
+                    rsc[i] = rsc_g[ch];
+                    rsh[i] = rsc_g[a.C + ch];
+                } else {
+                    const float rm = rstat[2 * g], rr = rstat[2 * g + 1];
+                    const float rg = a.res_gamma ? a.res_gamma[ch] : 1.f, rb = a.res_gamma ? a.res_beta[ch] : 0.f;
+                    rsc[i] = rr * rg;
+                    rsh[i] = rb - rm * rr * rg;
+                }
             }
         }
-        for (int m = blockIdx.x * rpb + tr; m < a.M; m += gridDim.x * rpb) {
-            const float4 xv = *reinterpret_cast<const float4 *>(a.x + (size_t)m * a.ldx + c);
-            float v[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = v[i] * sc[i] + sh[i];
-            if (a.res) {
-                const float4 rv = *reinterpret_cast<const float4 *>(a.res + (size_t)m * a.ldr + c);
-                v[0] += rv.x * rsc[0] + rsh[0]; v[1] += rv.y * rsc[1] + rsh[1];
-                v[2] += rv.z * rsc[2] + rsh[2]; v[3] += rv.w * rsc[3] + rsh[3];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = v[i] >= 0.f ? v[i] : v[i] * a.slope;
-            *reinterpret_cast<float4 *>(a.y + (size_t)m * a.ldy + c) = make_float4(v[0], v[1], v[2], v[3]);
-            if (a.row_pos) {   // host guarantees tpr <= 64 and one column pass: the tpr lanes of a row are adjacent lanes of one wave
-                float rs = (v[0] + v[1]) + (v[2] + v[3]);
-                for (int o = 1; o < tpr; o <<= 1) rs += __shfl_xor(rs, o, 64);
-                if (tc == 0) a.row_pos[m] = rs > 0.0f ? 1 : 0;
-            }
-        }
+        gn_apply_rows(a, c, sc, sh, rsc, rsh, tr, rpb, tpr, tc);
     }
 }
 
@@ -491,6 +526,16 @@ extern "C" int cofi_group_norm_apply(const float *x, int ldx, int M, int C, int 
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(group_norm_apply_kernel, dim3(nb, frames), dim3(256), 0, cofi_s(stream), a);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_norm_finalize(const cofi_norm_desc_t *norm, int rows, int frames, float *scale_shift, cofi_stream_t stream) {
+    if (!norm || !scale_shift || rows <= 0 || frames <= 0 || (rows % frames) || ((uintptr_t)scale_shift & 15)) return COFI_EINVAL;
+    NormSrc n;
+    if (int rc = make_norm_src(norm, rows / frames, frames, 1 << 20, &n)) return rc;
+    const int epg = n.tcols / n.groups;
+    if (epg > 64) return COFI_EUNSUPPORTED;   // a group's table columns stay inside one workgroup's 64
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(cofi_cdiv(n.tcols, 64), frames), dim3(256), 0, cofi_s(stream), n, scale_shift);
     return cofi_launch_status();
 }
 

@@ -20,52 +20,78 @@ struct NormSrc {
     int cshift;                 // log2(C / groups)
     float eps, slope;
     double count;               // rows per frame * C / groups
+    const float *scsh;          // optional: FINALIZED per-channel scale | shift, (frames, 2, C) (cofi_norm_finalize): consumers
+                                // then read 2 C floats instead of folding the table
 };
 
 // sstat[2g] = mean, sstat[2g+1] = rstd for g < groups.  NT = threads of the workgroup (all must call),
-// dred = 2 * NT doubles of LDS scratch.  Ends on a barrier (sstat visible to every thread).
-template <int NT>
+// dred = 4 * NT doubles of LDS scratch.  Ends on a barrier (sstat visible to every thread).
+//
+// The fold is bound by L2 round trips, not by arithmetic: a thread reads 16 bytes (two table columns of one slab) per load and
+// issues up to 16 independent loads before the first wait, so a 320-slab x 32-group table (80 KB, the largest GroupNorm table of
+// a KITTI frame) takes 256 threads two batches = two round trips.  tcols is even (host-checked: a power of two >= 2).
+template <int NT, int UNR = 16>   // UNR = loads in flight per thread (16 bytes each): registers vs round trips
 __device__ __forceinline__ void fold_stat_table(const float *part, int nslab, int tcols, int groups, double count, float eps,
-                                                double *dred, float *sstat) {
+                                                double *dred, float *sstat, int tstride = 0) {
+    // tstride: columns per table row when `part` points at a column sub-range of a wider table (0: tcols)
+    if (tstride == 0) tstride = tcols;
     const int epg = tcols / groups;   // table columns per group
     const int tid = threadIdx.x;
-    for (int c0 = 0; c0 < tcols; c0 += NT) {
-        const int cw = min(tcols - c0, NT);   // power-of-two tcols: cw divides NT or equals it
+    const int hc = tcols >> 1;        // column pairs (float4 chunks) per slab
+    for (int c0 = 0; c0 < hc; c0 += NT) {
+        const int cw = min(hc - c0, NT);      // power-of-two tcols: cw divides NT or equals it
         const int PH = NT / cw;               // slab phases
-        const int c = c0 + tid % cw, ph = tid / cw;
-        double s = 0.0, q = 0.0;
-        for (int b0 = ph; b0 < nslab; b0 += 8 * PH) {   // 8 independent loads per round: the fold is bound by L2 round trips
-            float2 t[8];
+        const int cp = c0 + tid % cw, ph = tid / cw;
+        double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+        for (int b0 = ph; b0 < nslab; b0 += UNR * PH) {
+            f32x4 t[UNR];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < UNR; ++u) {
                 const int b = b0 + u * PH;
-                t[u] = *reinterpret_cast<const float2 *>(part + ((size_t)(b < nslab ? b : ph) * tcols + c) * 2);
+                t[u] = *reinterpret_cast<const f32x4 *>(part + ((size_t)(b < nslab ? b : ph) * tstride + 2 * cp) * 2);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < UNR; ++u)
                 if (b0 + u * PH < nslab) {
-                    s += (double)t[u].x;
-                    q += (double)t[u].y;
+                    s0 += (double)t[u][0]; q0 += (double)t[u][1];
+                    s1 += (double)t[u][2]; q1 += (double)t[u][3];
                 }
         }
         __syncthreads();   // dred reuse between passes / by the caller
-        dred[2 * tid] = s;
-        dred[2 * tid + 1] = q;
+        dred[4 * tid] = s0; dred[4 * tid + 1] = q0; dred[4 * tid + 2] = s1; dred[4 * tid + 3] = q1;
         __syncthreads();
-        const int g0 = c0 / epg, ng = cw / epg;   // groups fully inside this pass (epg <= cw: host-checked)
-        for (int g = tid; g < ng; g += NT) {
-            double ts = 0.0, tq = 0.0;
-            for (int p = 0; p < PH; ++p)
-                for (int i = 0; i < epg; ++i) {
-                    const int t = p * cw + g * epg + i;
-                    ts += dred[2 * t];
-                    tq += dred[2 * t + 1];
+        // table columns 2 c0 .. 2 (c0 + cw) of every phase are in dred: entry (phase p, column pair i) = dred[4 (p cw + i)]
+        const int col0 = 2 * c0, ncol = 2 * cw;
+        if (epg >= 2) {   // a group = epg / 2 adjacent column pairs, all inside this pass
+            const int g0 = col0 / epg, ng = ncol / epg, ppg = epg >> 1;
+            for (int g = tid; g < ng; g += NT) {
+                double ts = 0.0, tq = 0.0;
+                for (int p = 0; p < PH; ++p)
+                    for (int i = 0; i < ppg; ++i) {
+                        const double *e = dred + 4 * (p * cw + g * ppg + i);
+                        ts += e[0] + e[2];
+                        tq += e[1] + e[3];
+                    }
+                const double mean = ts / count;
+                double var = tq / count - mean * mean;
+                if (var < 0.0) var = 0.0;
+                sstat[2 * (g0 + g)] = (float)mean;
+                sstat[2 * (g0 + g) + 1] = (float)(1.0 / sqrt(var + (double)eps));
+            }
+        } else {          // one table column per group (InstanceNorm, or GroupNorm with a group-wide table)
+            for (int c = tid; c < ncol; c += NT) {
+                double ts = 0.0, tq = 0.0;
+                for (int p = 0; p < PH; ++p) {
+                    const double *e = dred + 4 * (p * cw + (c >> 1)) + 2 * (c & 1);
+                    ts += e[0];
+                    tq += e[1];
                 }
-            const double mean = ts / count;
-            double var = tq / count - mean * mean;
-            if (var < 0.0) var = 0.0;
-            sstat[2 * (g0 + g)] = (float)mean;
-            sstat[2 * (g0 + g) + 1] = (float)(1.0 / sqrt(var + (double)eps));
+                const double mean = ts / count;
+                double var = tq / count - mean * mean;
+                if (var < 0.0) var = 0.0;
+                sstat[2 * (col0 + c)] = (float)mean;
+                sstat[2 * (col0 + c) + 1] = (float)(1.0 / sqrt(var + (double)eps));
+            }
         }
     }
     __syncthreads();
@@ -92,7 +118,7 @@ static inline int make_norm_src(const cofi_norm_desc_t *d, int rows_per_frame, i
     const int C = d->channels, w = d->width, G = d->groups;
     if ((C % w) || (C % G) || (d->nslab % frames)) return COFI_EINVAL;
     const int tcols = C / w, cpg = C / G;
-    if ((cpg % w) || (tcols & (tcols - 1)) || (G & (G - 1)) || C > max_channels) return COFI_EUNSUPPORTED;
+    if ((cpg % w) || (tcols & (tcols - 1)) || tcols < 2 || (G & (G - 1)) || C > max_channels) return COFI_EUNSUPPORTED;
     // slabs are 64 rows and must not straddle frames (stack mode)
     if (frames > 1 && (rows_per_frame % 64)) return COFI_EINVAL;
     if (d->nslab / frames != (rows_per_frame + 63) / 64) return COFI_EINVAL;
@@ -102,5 +128,7 @@ static inline int make_norm_src(const cofi_norm_desc_t *d, int rows_per_frame, i
     out->nslab = d->nslab / frames; out->tcols = tcols; out->groups = G; out->C = C; out->cshift = cs;
     out->eps = d->eps; out->slope = d->slope;
     out->count = (double)rows_per_frame * cpg;
+    out->scsh = d->scale_shift;
+    if (out->scsh && ((uintptr_t)out->scsh & 15)) return COFI_EINVAL;
     return 0;
 }

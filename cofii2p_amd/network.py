@@ -325,6 +325,19 @@ class CoFiI2P(nn.Module):
             out["order"] = [torch.cat([p["order"][i] for p in pyramids], 0).contiguous() for i in range(len(pyramids[0]["order"]))]
         return out, torch.cat([im.reshape(1, *im.shape[-3:]) for im in imgs], 0).contiguous()
 
+    def frame_streams(self, n: int, device=None):
+        """The HIP streams to keep n frames in flight on (one `forward_async` slot - or two, alternating - per stream).
+        HIP multiplexes all streams of a process onto GPU_MAX_HW_QUEUES (default 4) hardware queues, and the command processor serves
+        them best one queue per frame stream: measured on MI355X, four frame streams on the four default queues run 495 frames/s,
+        while every EXTRA live stream (a dedicated capture stream, torch's default stream next to four others) makes two of them share
+        a queue (319 frames/s).  So the streams handed out here are the ones the process already owns - the graph-capture stream and
+        the device's default stream - before any new one is created; more than 4 lose again (5: 341, 6: 379 frames/s)."""
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        if getattr(self, "_capture_stream", None) is None or self._capture_stream.device != dev:
+            self._capture_stream = torch.cuda.Stream(device=dev)
+        pool = [self._capture_stream, torch.cuda.default_stream(dev)]
+        return (pool + [torch.cuda.Stream(device=dev) for _ in range(max(0, n - len(pool)))])[:n]
+
     @torch.no_grad()
     def forward_async(self, slot: int, pc_data_dict, img, mode: str = "test"):
         """Enqueue one test-mode forward on the CURRENT stream through the hipGraph of slot `slot` and return
@@ -343,7 +356,10 @@ class CoFiI2P(nn.Module):
         outs = self._graph_forward(P, points, tabs[0], tabs[1], tabs[2], pc_data_dict["feats"].contiguous(), img.contiguous(), mode, None,
                                    None, slot=slot, branch_mask=self.async_branch_mask,
                                    order=None if os.environ.get("COFI_NO_ORDER") else pc_data_dict.get("order"))
-        host = torch.empty((len(outs), 2), dtype=torch.int32, pin_memory=True)
+        hosts = self.__dict__.setdefault("_count_host", {})   # one pinned landing buffer per slot (a slot is finished before it is reused)
+        host = hosts.get((slot, len(outs)))
+        if host is None:
+            host = hosts[(slot, len(outs))] = torch.empty((len(outs), 2), dtype=torch.int32, pin_memory=True)
         for f, o in enumerate(outs):
             host[f].copy_(o["count"], non_blocking=True)
         done = torch.cuda.Event()

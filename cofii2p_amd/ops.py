@@ -177,6 +177,12 @@ def set_workspace_slot(slot: int):
     Workspace.slot = int(slot)
 
 
+# Who turns statistics partials into per-channel scale / shift: "kernel" = one small cofi_norm_finalize launch per
+# normalisation, consumers read the finished vectors; "inline" = every consumer workgroup folds the table itself (no extra
+# launch; the default - measured equal within noise, 443 vs 446 frames/s, and it keeps ~80 launches out of a frame).  COFI_NORM_FOLD selects.
+NORM_FOLD = os.environ.get("COFI_NORM_FOLD", "inline")
+
+
 # ------------------------------------------------------------------------------------------ dense
 class ColStats:
     """Statistics partials a GEMM / convolution epilogue left behind for its (M, C) output: part (nslab, C // width, 2)
@@ -195,7 +201,7 @@ class ColStats:
         C, tc, G = self.C, self.part.shape[1], self.groups
         cpg = C // G
         rows = self.M // self.frames
-        return ((tc & (tc - 1)) == 0 and (G & (G - 1)) == 0 and cpg % self.width == 0 and G <= 1024
+        return ((tc & (tc - 1)) == 0 and tc >= 2 and (G & (G - 1)) == 0 and cpg % self.width == 0 and G <= 1024
                 and (self.frames == 1 or rows % 64 == 0) and self.part.shape[0] == self.frames * ((rows + 63) // 64))
 
     def finalize(self) -> torch.Tensor:
@@ -210,7 +216,22 @@ class ColStats:
         d.gamma = None if gamma is None else gamma.data_ptr()
         d.beta = None if beta is None else beta.data_ptr()
         d.eps, d.slope = self.eps, slope
+        d.scale_shift = None
+        if NORM_FOLD == "kernel":
+            d.scale_shift = self.scale_shift(d, gamma, beta).data_ptr()
         return d
+
+    def scale_shift(self, d, gamma, beta) -> torch.Tensor:
+        """(frames, 2, C) finalized scale | shift for this affine pair, computed once (cofi_norm_finalize) and kept with the statistics."""
+        key = (None if gamma is None else gamma.data_ptr(), None if beta is None else beta.data_ptr())
+        cache = self.__dict__.setdefault("_scsh", {})
+        t = cache.get(key)
+        if t is None:
+            lib = _lib.load()
+            t = torch.empty((self.frames, 2, self.C), dtype=torch.float32, device=self.part.device)
+            _lib.check(lib.cofi_norm_finalize(ctypes.byref(d), self.M, self.frames, _p(t), _stream()), "cofi_norm_finalize")
+            cache[key] = t
+        return t
 
 
 class Normed:

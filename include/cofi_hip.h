@@ -61,6 +61,8 @@ typedef struct cofi_norm_desc {
     const float *gamma, *beta; /* (channels) or both NULL */
     float eps;
     float slope;  /* LeakyReLU slope in [0, 1]: 1 = identity, 0 = ReLU, 0.1 = the reference's LeakyReLU */
+    const float *scale_shift; /* optional (frames, 2, channels): the statistics already FINALIZED by cofi_norm_finalize into per-channel
+                               * scale[c] = rstd_g gamma[c] | shift[c] = beta[c] - mean_g rstd_g gamma[c]; consumers then skip their own fold */
 } cofi_norm_desc_t;
 
 /* activation codes of the GEMM epilogue */
@@ -210,6 +212,9 @@ int cofi_group_norm_apply(const float *x, int ldx, int M, int C, int groups, con
 /* cofi_group_norm_apply with the statistics folded in-kernel from the producer's partials (cofi_norm_desc_t; `res_norm` = the
  * shortcut's own GroupNorm, same group count): no separate statistics launch.  row_pos (optional, M bytes):
  * row_pos[m] = (sum_c y[m,c] > 0), the per-row flag cofi_kpconv_aggregate takes (kpconv.py:113-114); needs C <= 256. */
+/* Finalize a pending normalisation once, in a few workgroups: scale_shift (frames, 2, channels) as described at cofi_norm_desc_t.
+ * Same fixed-order fp64 fold as the consumers' own: results do not depend on who folds. */
+int cofi_norm_finalize(const cofi_norm_desc_t *norm, int rows, int frames, float *scale_shift, cofi_stream_t stream);
 int cofi_group_norm_apply_partials(const float *x, int ldx, int M, int C, const cofi_norm_desc_t *norm, const float *res, int ldr,
                                    const cofi_norm_desc_t *res_norm, float *y, int ldy, uint8_t *row_pos, int frames,
                                    cofi_stream_t stream);
