@@ -202,17 +202,125 @@ class KernelTimer:
         return out
 
 
+def kernel_rooflines(model, dev, args, Bsz, frame=None, batch=None):
+    """roofline / roofline_attention / kernel_ms_per_frame of one submission (a frame, or a stack-mode batch of Bsz frames): every
+    C-ABI call of the submission is recorded, then each entry point's launches are replayed back-to-back in a hipGraph and timed
+    with HIP events on the launch stream (KernelTimer)."""
+    out = {}
+    kt = KernelTimer()
+    if Bsz == 1:
+        kt.record(model, frame)
+    else:
+        pyr_b, img_b = batch
+        P_b = model._pack(dev)
+        kt.record_fn(lambda: model._run_device(P_b, pyr_b["points"], pyr_b["neighbors"], pyr_b["subsampling"], pyr_b["upsampling"],
+                                               pyr_b["feats"], img_b, "test", None, None))
+    # cross-attention launches (frames == Bsz: one stream attends to the other) apart from the joint self-attention ones (2 Bsz)
+    att = kt.calls.get("attention", [])
+    cross = [c for c in att if c[2].get("frames", 1) == Bsz]
+    if cross and len(cross) != len(att):
+        kt.calls["attention_cross"] = cross
+    per = kt.measure()
+    del kt
+    for v in per.values():  # per FRAME figures (launch counts stay per submission)
+        for kk in ("seconds_per_frame", "flops_per_frame", "bytes_per_frame"):
+            v[kk] /= Bsz
+        v["launches_per_frame"] = v["launches_per_frame"] / Bsz
+    across = per.pop("attention_cross", None)
+    # the GEMM / implicit-GEMM convolution entry points launch the same MFMA kernel (different loaders / epilogues): one roofline row
+    gsum = {"seconds_per_frame": 0.0, "flops_per_frame": 0.0, "bytes_per_frame": 0.0, "launches_per_frame": 0}
+    for n in ("gemm", "gemm_colstats", "gemm_layernorm", "conv2d_nhwc"):
+        if n in per:
+            for k in gsum:
+                gsum[k] += per[n][k]
+            del per[n]
+    per["gemm"] = gsum
+    dom = max(per, key=lambda n: per[n]["seconds_per_frame"])
+    d = per[dom]
+    if d["flops_per_frame"] > 0:
+        ach = d["flops_per_frame"] / d["seconds_per_frame"] / 1e12
+        # the bf16-split GEMM issues 3 bf16 MFMA flops per algorithmic flop: its MFMA roof for ALGORITHMIC flops is 2500/3
+        peak = BF16_MFMA_PEAK_TF / 3.0 if (dom == "gemm" and args.gemm == "bf16x3") else FP32_MFMA_PEAK_TF
+        pmc = pmc_traffic(dom) if (Bsz == 1 and args.gemm == "bf16x3" and args.points == 20480 and Opt.img_H == 160) else None
+        out["roofline"] = {"kernel": "cofi_" + dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                           # HBM bytes per launch from the committed rocprofv3 PMC passes of the default command (stamped with
+                           # the commit they were collected on); None for any other configuration
+                           "traffic": None if pmc is None else pmc.get("traffic_bytes_per_launch"),
+                           "traffic_collected_on": None if pmc is None else pmc.get("collected_on"),
+                           "algorithmic_bytes_per_launch": d["bytes_per_frame"] / d["launches_per_frame"],
+                           "launches_per_frame": d["launches_per_frame"], "avg_launch_us": 1e6 * d["seconds_per_frame"] / d["launches_per_frame"]}
+    else:
+        ach = d["bytes_per_frame"] / d["seconds_per_frame"] / 1e9
+        out["roofline"] = {"kernel": "cofi_" + dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None}
+
+    def att_row(a, what):
+        ach = a["flops_per_frame"] / a["seconds_per_frame"] / 1e12
+        return {"kernel": "cofi_attention_parts", "launches": what, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": ach / FP32_MFMA_PEAK_TF, "launches_per_frame": a["launches_per_frame"],
+                "avg_launch_us": 1e6 * a["seconds_per_frame"] * Bsz / (a["launches_per_frame"] * Bsz)}
+
+    if per.get("attention"):
+        out["roofline_attention"] = att_row(per["attention"], "all (cross + joint self)")
+    if across:
+        out["roofline_cross_attention"] = att_row(across, "cross-attention only")
+    out["kernel_ms_per_frame"] = {n: round(1e3 * v["seconds_per_frame"], 4) for n, v in sorted(per.items(), key=lambda kv: -kv[1]["seconds_per_frame"])}
+    out["launches_per_frame"] = {n: v["launches_per_frame"] for n, v in per.items()}
+    return out
+
+
 def pmc_traffic(kernel_family):
     """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic.json, produced by tools/pmc_to_json.py from separate FETCH_SIZE / WRITE_SIZE runs of this
-    same command; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  None if absent."""
+    same command; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  -> the family's record with the commit the
+    passes were collected on, or None if absent."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
     try:
-        return json.load(open(path)).get(kernel_family, {}).get("traffic_bytes_per_launch")
+        doc = json.load(open(path))
+        rec = doc.get(kernel_family)
+        if rec is None:
+            return None
+        rec = dict(rec)
+        rec["collected_on"] = doc.get("collected_on", "round 1 (before the commit stamp existed)")
+        return rec
     except Exception:
         return None
+
+
+def stress_summary(dev, args):
+    """BASELINE configs[4] (large-attention / HBM-bound stress): 896 x 1600 image (22 400 image tokens; 900 is not divisible by 32, which
+    the reference's up-sampler needs - SURVEY.md section 7), 40 960 points, one frame, reference-surface forward + fine matching."""
+    from cofii2p_amd.network import CoFiI2P
+
+    saved = (Opt.img_H, Opt.img_W)
+    Opt.img_H, Opt.img_W = 896, 1600
+    try:
+        big = CoFiI2P(Opt()).to(dev)
+        big.enable_graphs(True)
+        fr = make_inputs(dev, [0], 40960)[0]
+        for _ in range(2):
+            one_step(big, fr)
+        torch.cuda.synchronize()
+        n = 5
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out, _ = one_step(big, fr)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        res = {"workload": "896x1600 image (22400 image tokens), 40960 points (2560 point tokens), batch 1, forward(mode='test') + fine matching, "
+                           "one frame at a time", "ms_per_frame": 1e3 * dt, "frames_per_s": 1.0 / dt, "matches": int(out[4].shape[0]),
+               "peak_mem_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
+        if not args.no_kernel_timing:
+            big.enable_graphs(False)
+            saved_pts, args.points = args.points, 40960
+            res.update(kernel_rooflines(big, dev, args, 1, frame=fr))
+            args.points = saved_pts
+        del big
+        return res
+    finally:
+        Opt.img_H, Opt.img_W = saved
 
 
 def cpu_baseline(frame, n_frames=2):
@@ -261,14 +369,32 @@ def main():
     ap.add_argument("--cu-split", default=None, choices=[None, "even", "halves"], help="experiment: the two frame streams get disjoint CU masks")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the extra stack-mode batch-4/16 measurements")
     ap.add_argument("--batch", type=int, default=1, help="frames per submission in stack mode (BASELINE configs[2] uses 16); a step is then one batch")
+    ap.add_argument("--stress", action="store_true", help="bench BASELINE configs[4] instead: 896x1600 image, 40960 points (implies --points 40960)")
     ap.add_argument("--gemm", default=os.environ.get("COFI_GEMM", "bf16x3"), choices=["f32", "bf16x3"],
                     help="arithmetic of the dense contractions: exact fp32 MFMA, or 3-term bf16 split with fp32 accumulation")
     args = ap.parse_args()
+    if args.stress:
+        Opt.img_H, Opt.img_W, args.points = 896, 1600, 40960
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: become N ranks (one process per GPU) under torch.distributed.run
+        import socket
+        import subprocess
+
+        have = torch.cuda.device_count()
+        if have < args.gpus and not args.share_device:
+            raise SystemExit("--gpus %d but this node exposes %d GPU(s)" % (args.gpus, have))
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
     if world > 1:
@@ -276,6 +402,8 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("--gpus %d but the process group has %d ranks" % (args.gpus, dist.get_world_size()))
     if args.share_device:  # test aid: every rank on cuda:0 (with --dist-backend gloo; RCCL refuses two ranks on one GPU)
         local = 0
     torch.cuda.set_device(local)
@@ -373,16 +501,26 @@ def main():
         run(args.steps, 0)
         barrier()
         dt = time.perf_counter() - t0
+    gathered = None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # the one exchange of a frame-parallel evaluation: per-frame results of every rank -> all ranks, global
+        # frame order, over the process group the ranks were timed in (RCCL over xGMI with the default backend)
+        from cofii2p_amd.parallel import gather_frame_results
+
+        vals = torch.tensor([[float(nmatch), float(rank)] for _ in my_ids], dtype=torch.float32, device=dev if args.dist_backend == "nccl" else "cpu")
+        gathered = gather_frame_results(my_ids, vals.reshape(len(my_ids), 2), n_distinct * world)
+        assert sorted(set(int(r) for r in gathered[:, 1].tolist())) == list(range(world))
     result = {
         "metric": "I2P frames/sec (160x512 img, 20480 pts)", "value": world * args.steps * Bsz / dt, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic", "launch": "eager" if args.eager else "hipGraph replay",
+        "data": "synthetic", "launch": "eager" if args.eager else "hipGraph replay", "gemm_mode": args.gemm,
+        "ranks": world if dist is None else dist.get_world_size(), "dist_backend": None if dist is None else args.dist_backend,
+        "gathered_frame_results": None if gathered is None else int(gathered.shape[0]),
         "arithmetic": "fp32 storage and accumulation everywhere; dense contractions " + (
             "on the exact fp32 MFMA" if args.gemm == "f32" else
             "as a 3-term bf16 split (hi*hi + hi*lo + lo*hi) on the bf16 matrix cores: 4e-6 max abs deviation from the reference's "
@@ -391,59 +529,35 @@ def main():
         # frame (4 self + 4 cross layers over both token streams: 4 * 512 * (1280 + 1280)^2) / the fp32 MFMA peak of the GPUs used (attention runs on v_mfma_f32_16x16x4_f32)
         "attention_roofline_frac": (world * args.steps * Bsz / dt) * 4 * 512 * ((Opt.img_H // 8) * (Opt.img_W // 8) + args.points // 16) ** 2
                                    / (world * FP32_MFMA_PEAK_TF * 1e12),
-        "config": {"workload": "KITTI-shape synthetic frame (160x512 image, %d points, KNN-128 pyramid resident in HBM), batch %d, "
+        "config": {"workload": "%s synthetic frame (%dx%d image, %d points, KNN-128 pyramid resident in HBM), batch %d, "
                                "CoFiI2P.forward(mode='test') + fine matching, one %s per step per GPU"
-                               % (args.points, Bsz, "frame" if Bsz == 1 else "stack-mode batch of %d frames" % Bsz),
-                   "matches_per_frame": int(nmatch), "parallelism": "frame-parallel x%d" % world, "frames_in_flight_per_gpu": S},
+                               % ("KITTI-shape" if not args.stress else "stress (BASELINE configs[4])", Opt.img_H, Opt.img_W, args.points, Bsz,
+                                  "frame" if Bsz == 1 else "stack-mode batch of %d frames" % Bsz),
+                   "matches_per_frame": int(nmatch), "parallelism": "frame-parallel x%d" % world, "frame_streams_per_gpu": S,
+                   "hipgraph_slots_per_stream": max(1, args.slots_per_stream) if (S > 1 and Bsz == 1) else 1},
     }
 
+    if rank == 0 and world == 1 and Bsz == 1 and not args.eager and not args.no_batch_sweep:
+        # the reference-surface call pattern (evaluation/eval_all.py:94-96): model(...) per frame, one host synchronisation per
+        # frame, nothing in flight behind it - what a caller gets without forward_async / finish
+        n_sync = max(20, min(100, args.steps))
+        for i in range(4):
+            one_step(model, frames[i % len(frames)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_sync):
+            one_step(model, frames[i % len(frames)])
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t0
+        result["forward_sync"] = {"frames_per_s": n_sync / dts, "ms_per_frame": 1e3 * dts / n_sync, "frames": n_sync,
+                                  "note": "model(pc_data_dict, img, ..., 'test') per frame as eval_all.py:94-96 calls it (hipGraph replay, one host "
+                                          "sync per frame, no frames in flight); `value` is the pipelined forward_async / finish rate"}
     if rank == 0 and not args.no_kernel_timing:
         model.enable_graphs(False)
-        kt = KernelTimer()
         if Bsz == 1:
-            kt.record(model, frames[0])
+            result.update(kernel_rooflines(model, dev, args, 1, frame=frames[0]))
         else:
-            pyr_b, img_b = batches[0]
-            P_b = model._pack(dev)
-            kt.record_fn(lambda: model._run_device(P_b, pyr_b["points"], pyr_b["neighbors"], pyr_b["subsampling"], pyr_b["upsampling"],
-                                                   pyr_b["feats"], img_b, "test", None, None))
-        per = kt.measure()
-        del kt
-        for v in per.values():  # per FRAME figures (launch counts stay per submission)
-            for kk in ("seconds_per_frame", "flops_per_frame", "bytes_per_frame"):
-                v[kk] /= Bsz
-            v["launches_per_frame"] = v["launches_per_frame"] / Bsz
-        # the GEMM / implicit-GEMM convolution entry points launch the same MFMA kernel (different loaders / epilogues): one roofline row
-        gsum = {"seconds_per_frame": 0.0, "flops_per_frame": 0.0, "bytes_per_frame": 0.0, "launches_per_frame": 0}
-        for n in ("gemm", "gemm_colstats", "gemm_layernorm", "conv2d_nhwc"):
-            if n in per:
-                for k in gsum:
-                    gsum[k] += per[n][k]
-                del per[n]
-        per["gemm"] = gsum
-        dom = max(per, key=lambda n: per[n]["seconds_per_frame"])
-        d = per[dom]
-        if d["flops_per_frame"] > 0:
-            ach = d["flops_per_frame"] / d["seconds_per_frame"] / 1e12
-            # the bf16-split GEMM issues 3 bf16 MFMA flops per algorithmic flop: its MFMA roof for ALGORITHMIC flops is 2500/3
-            peak = BF16_MFMA_PEAK_TF / 3.0 if (dom == "gemm" and args.gemm == "bf16x3") else FP32_MFMA_PEAK_TF
-            result["roofline"] = {"kernel": "cofi_" + dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                                  "frac": ach / peak,
-                                  # the committed PMC passes were collected on the default (batch 1, bf16x3) command only
-                                  "traffic": pmc_traffic(dom) if (args.batch == 1 and args.gemm == "bf16x3" and args.points == 20480) else None,
-                                  "algorithmic_bytes_per_launch": d["bytes_per_frame"] / d["launches_per_frame"],
-                                  "launches_per_frame": d["launches_per_frame"], "avg_launch_us": 1e6 * d["seconds_per_frame"] / d["launches_per_frame"]}
-        else:
-            ach = d["bytes_per_frame"] / d["seconds_per_frame"] / 1e9
-            result["roofline"] = {"kernel": "cofi_" + dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": ach / HBM_PEAK_GBS, "traffic": None}
-        a = per.get("attention")
-        if a:
-            ach = a["flops_per_frame"] / a["seconds_per_frame"] / 1e12
-            result["roofline_attention"] = {"kernel": "cofi_attention_fwd", "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF,
-                                            "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TF,
-                                            "avg_launch_us": 1e6 * a["seconds_per_frame"] / a["launches_per_frame"]}
-        result["kernel_ms_per_frame"] = {n: round(1e3 * v["seconds_per_frame"], 4) for n, v in sorted(per.items(), key=lambda kv: -kv[1]["seconds_per_frame"])}
+            result.update(kernel_rooflines(model, dev, args, Bsz, batch=batches[0]))
     if rank == 0 and world == 1 and Bsz == 1 and not args.eager and not args.no_batch_sweep:
         # additional information (BASELINE configs[2]): the same frames in stack-mode batches through the same kernels
         model.enable_graphs(True)
@@ -470,6 +584,10 @@ def main():
                 torch.cuda.synchronize()
                 dtb = time.perf_counter() - t0
             sweep["batch_%d" % bsz] = {"frames_per_s": nst * bsz / dtb, "ms_per_frame": 1e3 * dtb / (nst * bsz), "submissions_in_flight": S}
+            if bsz == 16 and not args.no_kernel_timing:   # BASELINE configs[2]: the same roofline rows for the stacked batch
+                model.enable_graphs(False)
+                sweep["batch_16"].update(kernel_rooflines(model, dev, args, bsz, batch=(pyr_b, img_b)))
+                model.enable_graphs(True)
             del pyr_b, img_b
         result["stack_mode_batches"] = sweep
         # additional information, NOT the headline: the reference computes ResNet layer3, layer4 and the average pool and never reads
@@ -551,6 +669,8 @@ def main():
                 dte = time.perf_counter() - t0
             result["with_pyramid_build"] = {"frames_per_s": nfr / dte, "ms_per_frame": 1e3 * dte / nfr,
                                             "note": "pyramid construction (KNN) + forward + fine matching per frame on the same GPU; not the headline"}
+    if rank == 0 and world == 1 and Bsz == 1 and not args.eager and not args.no_batch_sweep and not args.stress:
+        result["stress_config"] = stress_summary(dev, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(frames[0])
     if rank == 0:

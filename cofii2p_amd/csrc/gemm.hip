@@ -896,9 +896,13 @@ Plan make_plan(int M, int N, int K, bool fused_ln) {
         if (fused_ln && p.ksplit == 1 && p.bn < N) { p.bm = 64; p.bn = 128; }
         return p;
     }
+    // COFI_GEMM_KS_SCALE (A/B runs): scales the split-K factor of the tuned plans (0 = never split)
+    static const float ks_scale = [] { const char *e = getenv("COFI_GEMM_KS_SCALE"); return e ? (float)atof(e) : 1.0f; }();
     for (const TunedPlan &t : kTunedPlans)
         if (t.M == M && t.N == N && t.K == K) {
-            p = finish_plan(K, t.bm, t.bn, t.ks);
+            int ks = t.ks;
+            if (ks_scale != 1.0f && ks > 1) ks = (int)(ks * ks_scale + 0.5f) < 1 ? 1 : (int)(ks * ks_scale + 0.5f);
+            p = finish_plan(K, t.bm, t.bn, ks);
             if (fused_ln && p.ksplit == 1 && p.bn < N) { p.bm = 64; p.bn = 128; }
             return p;
         }

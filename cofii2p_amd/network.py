@@ -378,11 +378,13 @@ class CoFiI2P(nn.Module):
         """-> the reference's 8-tuple for a single-frame submission, or a list of B 8-tuples for a stack-mode one
         (`handle["fine_xy"]` then holds the per-frame fine matches)."""
         handle["done"].synchronize()
-        res, fine = [], []
+        res, fine, per_frame = [], [], []
         for f, o in enumerate(handle["out"]):
             res.append(self._slice_result(o, int(handle["count_host"][f, 0]), int(handle["count_host"][f, 1])))
             fine.append(self.last_match["fine_xy"])
+            per_frame.append(self.last_match)
         handle["fine_xy"] = fine
+        self.last_match_frames = per_frame   # stack mode: one last_match record per frame
         return res[0] if len(res) == 1 else res
 
     def forward(self, pc_data_dict, img, fine_center_kpt_coors, fine_xy, fine_pc_inline_index, mode, taps=None):

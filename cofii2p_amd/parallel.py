@@ -17,25 +17,35 @@ def shard_frames(frame_ids: Sequence[int], rank: int, world: int) -> List[int]:
 def gather_frame_results(frame_ids: Sequence[int], values: torch.Tensor, total_frames: int) -> torch.Tensor:
     """values (n_local, D) per-frame results of this rank (e.g. RRE/RTE, match counts), frame_ids the
     global ids they belong to.  Returns (total_frames, D) on every rank, rows in global frame order.
-    Ragged shards are padded to the largest shard; one all_gather per call."""
+    Ragged shards are padded to the largest shard; the ids travel in their own int64 tensor (a float payload would round ids
+    above 2^24, or above 2048 in half precision): two all_gathers per call."""
     import torch.distributed as dist
 
+    ids = torch.as_tensor(list(frame_ids), dtype=torch.int64, device=values.device)
+    if ids.numel() != values.shape[0]:
+        raise ValueError("%d frame ids for %d result rows" % (ids.numel(), values.shape[0]))
+    if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= total_frames):
+        raise ValueError("frame id outside [0, %d)" % total_frames)
     if not (dist.is_available() and dist.is_initialized()):
         out = torch.zeros((total_frames, values.shape[1]), dtype=values.dtype, device=values.device)
-        out[torch.as_tensor(list(frame_ids), dtype=torch.long, device=values.device)] = values
+        out[ids] = values
         return out
     world = dist.get_world_size()
     n_max = (total_frames + world - 1) // world
     D = values.shape[1]
-    pad = torch.full((n_max, D + 1), -1.0, dtype=values.dtype, device=values.device)
-    n = len(frame_ids)
-    if n:
-        pad[:n, 0] = torch.as_tensor(list(frame_ids), dtype=values.dtype, device=values.device)
-        pad[:n, 1:] = values
-    bucket = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bucket, pad)
+    n = ids.numel()
+    if n > n_max:
+        raise ValueError("a rank holds %d frames, more than ceil(%d / %d)" % (n, total_frames, world))
+    pad_ids = torch.full((n_max,), -1, dtype=torch.int64, device=values.device)
+    pad_val = torch.zeros((n_max, D), dtype=values.dtype, device=values.device)
+    pad_ids[:n] = ids
+    pad_val[:n] = values
+    b_ids = [torch.empty_like(pad_ids) for _ in range(world)]
+    b_val = [torch.empty_like(pad_val) for _ in range(world)]
+    dist.all_gather(b_ids, pad_ids)
+    dist.all_gather(b_val, pad_val)
     out = torch.zeros((total_frames, D), dtype=values.dtype, device=values.device)
-    for b in bucket:
-        ok = b[:, 0] >= 0
-        out[b[ok, 0].long()] = b[ok, 1:]
+    for i_, v_ in zip(b_ids, b_val):
+        ok = i_ >= 0
+        out[i_[ok]] = v_[ok]
     return out

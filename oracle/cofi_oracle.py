@@ -261,10 +261,15 @@ def pos_sine(xyz: Tensor, d_model: int = 128, temperature: float = 10000.0) -> T
     return F.pad(emb, (0, d_model - f * n_dim))
 
 
-def full_attention(q: Tensor, k: Tensor, v: Tensor) -> Tensor:
-    """linear_attention.py:56-79.  (L,H,D),(S,H,D),(S,H,D) -> (L,H,D)."""
-    scores = torch.einsum("lhd,shd->hls", q, k) / math.sqrt(q.shape[-1])
-    return torch.einsum("hls,shd->lhd", scores.softmax(-1), v)
+def full_attention(q: Tensor, k: Tensor, v: Tensor, chunk: int = 2048) -> Tensor:
+    """linear_attention.py:56-79.  (L,H,D),(S,H,D),(S,H,D) -> (L,H,D).  The softmax runs over the whole key axis per query row,
+    so evaluating the query rows in chunks changes no value: the stress frame's (4, 22400, 22400) score tensor (8 GB in the
+    reference) then never has to exist on the host."""
+    out = []
+    for l0 in range(0, q.shape[0], chunk):
+        scores = torch.einsum("lhd,shd->hls", q[l0:l0 + chunk], k) / math.sqrt(q.shape[-1])
+        out.append(torch.einsum("hls,shd->lhd", scores.softmax(-1), v))
+    return out[0] if len(out) == 1 else torch.cat(out, 0)
 
 
 def loftr_layer(sd, p: str, x: Tensor, src: Tensor, nhead: int = 4) -> Tensor:

@@ -53,3 +53,44 @@ def check_input_hashes(gold, fr, data):
         if i < 4:
             assert sha(data["subsampling"][i].numpy()) == str(gold["sha_subsampling%d" % i]), i
             assert sha(data["upsampling"][i].numpy()) == str(gold["sha_upsampling%d" % i]), i
+
+
+TIE = 1e-5   # two candidates closer than this in similarity may legitimately swap between implementations
+
+
+def assert_coarse_mismatches_are_ties(img_desc, pc_desc, sel, got_xy, ref_xy, tie=TIE):
+    """Coarse matches (network.py:175-180: per selected super-point the pixel of maximal similarity).  Wherever the pixel this
+    implementation picked differs from the reference's, the two pixels' similarities (recomputed here in fp64 from the returned
+    descriptors) must be a near-tie - an indexing bug would show a real margin.  got_xy / ref_xy: (2, n) centre coordinates
+    (pixel * 4).  Returns the fraction of identical picks."""
+    import numpy as np
+
+    I = img_desc.detach().cpu().double().reshape(img_desc.shape[1], -1)    # (C, H8*W8)
+    Pd = pc_desc.detach().cpu().double()                                    # (C, N4)
+    W8 = img_desc.shape[3]
+    got, ref = np.asarray(got_xy), np.asarray(ref_xy)
+    same = (got == ref).all(0)
+    for j in np.nonzero(~same)[0]:
+        srow = Pd[:, int(sel[j])] @ I
+        pg = int(got[1, j] // 4) * W8 + int(got[0, j] // 4)
+        pr = int(ref[1, j] // 4) * W8 + int(ref[0, j] // 4)
+        margin = abs(float(srow[pg] - srow[pr]))
+        assert margin < tie, "coarse match %d: pixel %d vs reference %d differ by %.3g in similarity" % (j, pg, pr, margin)
+        assert float(srow.max() - srow[pg]) < tie, "coarse match %d is not (near) the best pixel" % j
+    return float(same.mean())
+
+
+def assert_fine_mismatches_are_ties(patches, fine_pc, best, ref_best, tie=TIE):
+    """Fine matches (eval_all.py:99-102: arg-max of the cosine similarity of the 16 patch pixels): every disagreement with the
+    reference / oracle pick must be a near-tie of the two similarities."""
+    import numpy as np
+    import torch
+
+    p = patches.detach().cpu().double().reshape(patches.shape[0], patches.shape[1], 16)
+    f = fine_pc.detach().cpu().double()
+    cs = torch.nn.functional.cosine_similarity(p, f[:, :, None], dim=1)   # (n, 16)
+    b, rb = np.asarray(best.cpu() if torch.is_tensor(best) else best), np.asarray(ref_best.cpu() if torch.is_tensor(ref_best) else ref_best)
+    for j in np.nonzero(b != rb)[0]:
+        margin = abs(float(cs[j, int(b[j])] - cs[j, int(rb[j])]))
+        assert margin < tie, "fine match %d: pixel %d vs %d differ by %.3g in similarity" % (j, b[j], rb[j], margin)
+    return float((b == rb).mean())

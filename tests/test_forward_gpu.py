@@ -8,7 +8,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import cofi_oracle as O  # noqa: E402
-from common import check_input_hashes, frame_inputs, load_golden, synth_sd  # noqa: E402
+from common import (assert_coarse_mismatches_are_ties, assert_fine_mismatches_are_ties, check_input_hashes, frame_inputs, load_golden,  # noqa: E402
+                    synth_sd)
 
 DEV = "cuda:0"
 TOL = 1e-3
@@ -85,7 +86,8 @@ def test_kitti_frame_vs_reference(model):
     assert got_xy.shape == ref_xy.shape, (got_xy.shape, ref_xy.shape)
     assert np.array_equal(res[7].cpu().numpy(), gold["test_coarse_pts"])
     same = (got_xy == ref_xy).all(0)
-    assert same.mean() > 0.98, same.mean()  # an argmin may flip only on a near-tie of two pixels
+    # an argmin may flip only on a near-tie of two pixels: every mismatch is checked for its margin
+    assert assert_coarse_mismatches_are_ties(res[0], res[1], model.last_match["sel"].cpu().numpy(), got_xy, ref_xy) > 0.9
     assert maxdiff(res[5], gold["test_fine_pc"]) <= TOL
     assert float(np.abs(res[4].cpu().numpy()[same] - gold["test_patches"][same]).max()) <= TOL
     # fine matching in the caller (eval_all.py:99-105) through the HIP kernel vs the oracle
@@ -93,8 +95,7 @@ def test_kitti_frame_vs_reference(model):
 
     fxy, best = fine_matching(res[4], res[5], res[6])
     oxy, obest = O.fine_match(res[4].cpu(), res[5].cpu(), res[6].cpu())
-    agree = (best.cpu() == obest).float().mean()
-    assert agree > 0.98
+    assert assert_fine_mismatches_are_ties(res[4], res[5], best, obest) > 0.9
     assert np.array_equal(fxy.cpu().numpy()[:, (best.cpu() == obest).numpy()], oxy.numpy()[:, (best.cpu() == obest).numpy()])
 
 
@@ -131,8 +132,7 @@ def test_product_refuses_cpu_tensors(model):
 
 def test_hipgraph_replay_equals_eager(model):
     """the captured graph replays the same kernels on the same data; also on a second frame that reuses the
-    captured graph.  (The MIOpen convolutions of the image branch are not run-to-run bit-reproducible, so
-    floats are compared at 2e-5; everything written by this repository's kernels is bit-stable.)"""
+    captured graph.  Every kernel is a fixed-order reduction (no vendor library, no float atomics): replay == eager bit for bit."""
     from cofii2p_amd.preprocess import build_pyramid
     from cofii2p_amd.synth import make_frame, subsample_indices
 
@@ -149,9 +149,9 @@ def test_hipgraph_replay_equals_eager(model):
         model.enable_graphs(True)
         graph = [t.clone() for t in model(pyr, img, None, None, None, "test")]
         gfx = model.last_match["fine_xy"].clone()
-        for a, b in zip(eager[:4], graph[:4]):
-            assert maxdiff(a, b.cpu()) < 2e-5
-        assert eager[6].shape == graph[6].shape and (eager[6] == graph[6]).float().mean() > 0.98
+        for a, b in zip(eager[:6], graph[:6]):
+            assert torch.equal(a, b)
+        assert eager[6].shape == graph[6].shape and torch.equal(eager[6], graph[6])   # same kernels, same data: bit-reproducible
         assert efx.shape == gfx.shape
         outs[fid] = graph
     assert len(model._graphs) == 1  # one capture served both frames
@@ -233,7 +233,10 @@ def test_stack_mode_batch_equals_single_frames(model):
             assert maxdiff(a, b.cpu()) < 2e-5, maxdiff(a, b.cpu())
         assert seq[k][6].shape == got[k][6].shape
         assert torch.equal(seq[k][7], got[k][7])
-        assert (seq[k][6] == got[k][6]).float().mean() > 0.98
+        # a stacked GEMM may run another tile / split-K plan than the single-frame one: floats agree to rounding, picks up to near-ties
+        sel = model.last_match_frames[k]["sel"].cpu().numpy() if hasattr(model, "last_match_frames") else None
+        assert assert_coarse_mismatches_are_ties(got[k][0], got[k][1], sel if sel is not None else None, got[k][6].cpu().numpy(),
+                                                 seq[k][6].cpu().numpy()) > 0.9
 
 
 @pytest.mark.parametrize("fid,gemm", [(41, "bf16x3"), (42, "f32")])
@@ -262,3 +265,157 @@ def test_other_kitti_frames_vs_oracle(model, monkeypatch, fid, gemm):
     assert abs(res[6].shape[1] - ref[6].shape[1]) <= 3
     if res[7].shape == ref[7].shape:
         assert torch.equal(res[7].cpu(), ref[7])
+
+
+def _oracle_frame(pyr, fr):
+    data = {k: [t.cpu().long() if t.dtype == torch.int32 else t.cpu() for t in pyr[k]] for k in ("points", "neighbors", "subsampling", "upsampling")}
+    data["feats"] = torch.from_numpy(fr.feats)
+    with torch.no_grad():
+        return O.forward(synth_sd(), data, torch.from_numpy(fr.img)[None], None, None, "test")
+
+
+def test_batch16_kitti_bf16x3_vs_oracle(model, monkeypatch):
+    """BASELINE configs[2]: 16 KITTI-shaped frames (20 480 points each) stacked through ONE set of launches in the library's default
+    arithmetic (3-term bf16 split, normalising loaders, fused layer tail, partial-slot attention) - three of the sixteen frames
+    against the CPU oracle: descriptors / scores within 1e-3, the matched super-point set exact (up to a score within 1e-5 of
+    the 0.9 threshold), coarse pixels equal up to near-ties."""
+    from cofii2p_amd import ops
+    from cofii2p_amd.network import CoFiI2P
+    from cofii2p_amd.preprocess import build_pyramid
+    from cofii2p_amd.synth import make_frame, subsample_indices
+
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x3")
+    B = 16
+    frs, pyrs, imgs = [], [], []
+    for b in range(B):
+        fr = make_frame(100 + b, 20480)
+        sub = [torch.from_numpy(s_).to(DEV) for s_ in subsample_indices(20480, 5, seed=100 + b)]
+        pyr = build_pyramid(torch.from_numpy(fr.points).to(DEV), sub)
+        pyr["feats"] = torch.from_numpy(fr.feats).to(DEV)
+        frs.append(fr); pyrs.append(pyr); imgs.append(torch.from_numpy(fr.img)[None].to(DEV))
+    model.enable_graphs(True)
+    stacked, img = CoFiI2P.stack_frames(pyrs, imgs)
+    got = model.finish(model.forward_async(9, stacked, img))
+    sels = [m["sel"].cpu().numpy() for m in model.last_match_frames]
+    model.enable_graphs(False)
+    assert len(got) == B
+    for b in (0, 7, 15):
+        ref = _oracle_frame(pyrs[b], frs[b])
+        for i, n in enumerate(("img_desc", "pc_desc", "img_score", "pc_score")):
+            assert maxdiff(got[b][i], ref[i]) <= TOL, (b, n, maxdiff(got[b][i], ref[i]))
+        score = ref[3].reshape(-1).numpy()
+        near_thr = np.abs(score - np.float32(0.9)) < 1e-5
+        if not near_thr.any():
+            assert got[b][7].shape == ref[7].shape and torch.equal(got[b][7].cpu(), ref[7]), b   # same super-points, same order
+            assert assert_coarse_mismatches_are_ties(got[b][0], got[b][1], sels[b], got[b][6].cpu().numpy(), ref[6].numpy()) > 0.9
+
+
+def test_stress_frame_vs_oracle(model, monkeypatch):
+    """BASELINE configs[4]: 896 x 1600 image (22 400 image tokens: 900 is not divisible by 32), 40 960 points,
+    the whole forward + matching in the default arithmetic against the CPU oracle (attention evaluated in query chunks there:
+    the reference itself would materialise an 8 GB score tensor per call)."""
+    from cofii2p_amd import ops
+    from cofii2p_amd.network import CoFiI2P
+    from cofii2p_amd.preprocess import build_pyramid
+    from cofii2p_amd.synth import make_frame, subsample_indices
+
+    class OptS:
+        img_H, img_W, img_fine_resolution_scale, norm = 896, 1600, 32, "gn"
+
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x3")
+    big = CoFiI2P(OptS()).to(DEV)
+    fr = make_frame(55, 40960, img_hw=(896, 1600))
+    sub = [torch.from_numpy(s_).to(DEV) for s_ in subsample_indices(40960, 5, seed=55)]
+    pyr = build_pyramid(torch.from_numpy(fr.points).to(DEV), sub)
+    pyr["feats"] = torch.from_numpy(fr.feats).to(DEV)
+    res = big(pyr, torch.from_numpy(fr.img)[None].to(DEV), None, None, None, "test")
+    assert res[0].shape == (1, 128, 112, 200) and res[1].shape == (128, 2560)
+    ref = _oracle_frame(pyr, fr)
+    for i, n in enumerate(("img_desc", "pc_desc", "img_score", "pc_score")):
+        assert maxdiff(res[i], ref[i]) <= TOL, (n, maxdiff(res[i], ref[i]))
+    score = ref[3].reshape(-1).numpy()
+    if not (np.abs(score - np.float32(0.9)) < 1e-5).any():
+        assert res[7].shape == ref[7].shape and torch.equal(res[7].cpu(), ref[7])
+        assert assert_coarse_mismatches_are_ties(res[0], res[1], big.last_match["sel"].cpu().numpy(), res[6].cpu().numpy(), ref[6].numpy()) > 0.9
+    del big
+
+
+def test_eval_all_shaped_caller(model, tmp_path, monkeypatch):
+    """The loop body of evaluation/eval_all.py:63-131 with the reference's own statements, the model imported through the
+    reference's import path (`from model.network import CoFiI2P`): CPU int64 pc_data_dict moved tensor by tensor with .cuda(),
+    forward('test') under torch.no_grad(), the caller-side fine matching written with torch ops, pose (cofi_pnp_ransac in place of
+    cv2.solvePnPRansac, absent here), get_P_diff, the per-frame result file.  The HIP fine matching must agree with the caller's
+    torch expression, the result file must round-trip through the offline metrics."""
+    from model.network import CoFiI2P as ShimCoFiI2P   # the shim package at the repository root
+
+    from cofii2p_amd import metrics, ops
+    from cofii2p_amd.network import CoFiI2P, fine_matching
+    from cofii2p_amd.pose import get_P_diff, pose_matrix, solve_pnp_ransac
+
+    assert ShimCoFiI2P is CoFiI2P
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x3")   # what a caller gets by default
+    gold = load_golden("frame_kitti.npz")
+    fr, data = frame_inputs(int(gold["frame_id"]), int(gold["num_points"]), int(gold["pyr_seed"]))
+    batched = {k: [t[None] for t in data[k]] for k in ("points", "neighbors", "subsampling", "upsampling")}   # DataLoader adds a batch axis of 1
+    batched["feats"] = data["feats"][None]
+    data = {"img": torch.from_numpy(fr.img)[None], "pc_data_dict": batched,
+            "K": torch.tensor([[[300.0, 0, 256.0], [0, 300.0, 80.0], [0, 0, 1.0]]]), "P": torch.eye(4)[None]}   # DataLoader batch of 1
+    net = ShimCoFiI2P(Opt())
+    net.load_state_dict({k: v.clone() for k, v in synth_sd().items()})   # eval_all.py:49 (strict)
+    net = net.cuda()
+    with torch.no_grad():
+        net.eval()
+        img = data["img"].cuda()
+        pc_data_dict = data["pc_data_dict"]
+        for key in ("points", "neighbors", "subsampling", "upsampling"):
+            for j in range(len(pc_data_dict[key])):
+                pc_data_dict[key][j] = torch.squeeze(pc_data_dict[key][j]).cuda()
+        pc_data_dict["feats"] = torch.squeeze(pc_data_dict["feats"]).cuda()
+        assert pc_data_dict["neighbors"][0].dtype == torch.int64
+        K = torch.squeeze(data["K"].cuda())
+        P = torch.squeeze(data["P"]).cpu().numpy()
+        (img_features, pc_features, coarse_img_score, coarse_pc_score, fine_img_feature_patch, fine_pc_inline_feature, fine_center_xy,
+         coarse_pc_points) = net(pc_data_dict, img, None, None, None, "test")
+        # eval_all.py:98-105, verbatim semantics
+        fpf = fine_pc_inline_feature.unsqueeze(-1)
+        dist = torch.cosine_similarity(fine_img_feature_patch.unsqueeze(-1), fpf.unsqueeze(-2))
+        dist = torch.squeeze(dist)
+        predict_index = torch.argmax(dist, dim=1)
+        fine_xy = fine_center_xy - 2
+        fine_xy[0] = fine_xy[0] + predict_index // 4
+        fine_xy[1] = fine_xy[1] + predict_index % 4
+    hxy, hidx = fine_matching(fine_img_feature_patch, fine_pc_inline_feature, fine_center_xy)
+    assert assert_fine_mismatches_are_ties(fine_img_feature_patch, fine_pc_inline_feature, hidx, predict_index) > 0.9
+    agree = (hidx == predict_index).cpu().numpy()
+    assert np.array_equal(hxy.cpu().numpy()[:, agree], fine_xy.cpu().numpy()[:, agree])
+    res, R, t, inl = solve_pnp_ransac(coarse_pc_points.contiguous(), fine_xy.t().contiguous(), K, iterations=2000)
+    assert int(res[0]) in (0, 1)
+    T_pred = pose_matrix(R, t)
+    t_diff, angles_diff = get_P_diff(T_pred, P) if int(res[0]) else (float("nan"), float("nan"))
+    path = metrics.save_frame_result(str(tmp_path), 0, metrics.frame_result(P, T_pred, K, pc_data_dict["points"][1], pc_data_dict["points"][-1],
+                                                                             coarse_pc_score, fine_xy, coarse_pc_points))
+    back = metrics.load_frame_result(path)
+    assert set(back) == set(metrics.FRAME_KEYS) and back["fine_xy"].shape == fine_xy.shape
+    assert fine_xy.shape[1] == coarse_pc_points.shape[0] >= 4
+    # the forward refuses to pretend it can train (train.py:224-226 + loss.backward() at :285 would get no gradient)
+    with pytest.raises(NotImplementedError):
+        net(pc_data_dict, img, torch.zeros(2, 4, device=DEV), None, torch.zeros(4, dtype=torch.int64, device=DEV), "train")
+
+
+def test_bench_two_ranks_share_device(tmp_path):
+    """`python bench.py --gpus 2` started WITHOUT torchrun spawns its two ranks itself, runs them as one process group (gloo here:
+    RCCL refuses two ranks on one GPU), gathers the per-frame results and reports n_gpus = 2"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--dist-backend", "gloo", "--steps", "6",
+                          "--warmup", "2", "--points", "4096", "--no-cpu-baseline", "--no-kernel-timing", "--no-batch-sweep"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["gathered_frame_results"] == 8 and d["value"] > 0

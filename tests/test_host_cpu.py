@@ -113,3 +113,35 @@ def test_integration_md_ctypes_example_matches_the_abi():
     for name, body in found:
         n = len([x for x in body.replace("\n", " ").split(",") if x.strip()])
         assert n == len(_lib.SIGNATURES[name][1]), name
+
+
+def test_model_import_path_shim_and_training_guard():
+    """`from model.network import CoFiI2P` (the reference's import path) resolves to this implementation; mode='train' with
+    autograd enabled raises instead of returning tensors without a graph"""
+    import model.network as shim
+    from model.kpconv.preprocess_data import precompute_point_cloud_cuda, precompute_point_cloud_stack_mode
+
+    from cofii2p_amd import network, preprocess
+
+    assert shim.CoFiI2P is network.CoFiI2P and shim.point2node is network.point2node and shim.CoFiI2P_wrapper is network.CoFiI2P_wrapper
+    assert precompute_point_cloud_stack_mode is preprocess.precompute_point_cloud_stack_mode is precompute_point_cloud_cuda
+
+    class Opt:
+        img_H, img_W, img_fine_resolution_scale, norm = 160, 512, 32, "gn"
+
+    m = network.CoFiI2P(Opt())
+    with pytest.raises(NotImplementedError):
+        m({"feats": torch.zeros(4, 4)}, torch.zeros(1, 3, 160, 512), None, None, None, "train")
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "--gpus 2 but this node exposes 0 GPU(s)" in (out.stderr + out.stdout)
+    env["WORLD_SIZE"], env["RANK"], env["LOCAL_RANK"] = "4", "0", "0"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "--gpus 1 but WORLD_SIZE=4" in (out.stderr + out.stdout)

@@ -703,6 +703,23 @@ def test_attention_stress_size_sampled_rows(ops):
     assert torch.isfinite(out).all()
 
 
+@pytest.mark.parametrize("name", ["self", "down", "up", "tiny"])
+def test_knn_against_reference_knn(ops, name):
+    """both HIP searches against the rows the reference's own knn() returned (tests/golden/knn_ref.npz): distances bit for bit,
+    indices up to the ties torch.topk leaves unspecified - and bit-equal to the tie-defined C oracle"""
+    from test_oracle_golden import _knn_case, check_knn_against_reference
+
+    gold = load_golden("knn_ref.npz")
+    support, query, k = _knn_case(gold, name)
+    ic, dc = knn_c.knn(support, query, k, True)
+    sup = G(support)
+    for grid in (None, ops.KnnGrid(sup)):
+        idx, dist = ops.knn(sup, G(query), k, return_dist=True, grid=grid)
+        i, d = idx.cpu().numpy().astype(np.int64), dist.cpu().numpy()
+        assert np.array_equal(i, ic) and np.array_equal(d, dc)
+        check_knn_against_reference(i, d, gold["idx_" + name], gold["dist_" + name], support, query)
+
+
 def test_knn_stress_size_properties(ops):
     """40 960 points, k = 128 (BASELINE configs[4]): sorted ascending, self first, and a sample of rows bit-equal to the oracle"""
     from cofii2p_amd.synth import make_frame

@@ -108,6 +108,39 @@ def test_knn_c_against_torch_formula():
             assert np.array_equal(np.sort(ties), cand[: len(ties)])
 
 
+def _knn_case(gold, name):
+    support = {"self": gold["pts"], "down": gold["pts"], "up": gold["sub"], "tiny": gold["pts"][:100]}[name]
+    query = {"self": gold["pts"], "down": gold["sub"], "up": gold["pts"], "tiny": gold["pts"]}[name][: int(gold["nq_" + name])]
+    return np.ascontiguousarray(support), np.ascontiguousarray(query), int(gold["k_" + name])
+
+
+def check_knn_against_reference(idx, dist, ref_idx, ref_dist, support, query):
+    """idx / dist from this repository (lowest index wins ties) vs the rows the REFERENCE's knn() returned: the sorted distance
+    vectors are bit-identical; strictly inside the k-th distance the index sets are equal; at the k-th distance (a tie that topk
+    cuts arbitrarily) ours are the lowest candidate indices."""
+    assert np.array_equal(dist, ref_dist)
+    d_all = O.expansion_sqdist(torch.from_numpy(query), torch.from_numpy(support)).numpy()
+    for r in range(query.shape[0]):
+        kth = dist[r, -1]
+        assert set(idx[r][dist[r] < kth]) == set(ref_idx[r][ref_dist[r] < kth])
+        ties = idx[r][dist[r] == kth]
+        cand = np.nonzero(d_all[r] == kth)[0]
+        assert np.array_equal(np.sort(ties), cand[: len(ties)])
+
+
+@pytest.mark.parametrize("name", ["self", "down", "up", "tiny"])
+def test_knn_c_against_reference_knn(name):
+    """oracle/knn_oracle.c against rows recorded from the reference's own model/kpconv/preprocess_data.py::knn (golden knn_ref.npz,
+    tests/tools/make_golden.py::gen_knn): clouds with duplicates and lattice ties."""
+    gold = load_golden("knn_ref.npz")
+    support, query, k = _knn_case(gold, name)
+    ic, dc = knn_c.knn(support, query, k, True)
+    check_knn_against_reference(ic, dc, gold["idx_" + name], gold["dist_" + name], support, query)
+    # the oracle's own restatement of the distance formula reproduces the reference's values at the reference's indices
+    d_all = O.expansion_sqdist(torch.from_numpy(query), torch.from_numpy(support)).numpy()
+    assert np.array_equal(np.take_along_axis(d_all, gold["idx_" + name], 1), gold["dist_" + name])
+
+
 def test_knn_shadow_padding():
     pts = np.random.RandomState(1).randn(10, 3).astype(np.float32)
     idx = knn_c.knn(pts, pts[:4], 16)

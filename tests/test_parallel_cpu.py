@@ -57,3 +57,17 @@ def test_gather_two_ranks_ragged():
 def test_gather_without_process_group():
     out = gather_frame_results([2, 0], torch.tensor([[1.0], [3.0]]), 3)
     assert out.flatten().tolist() == [3.0, 0.0, 1.0]
+
+
+def test_gather_keeps_large_frame_ids_exact():
+    """ids travel as int64, not inside the (possibly half-precision) payload: 2^24 + 1 and a bf16 payload stay exact"""
+    total = (1 << 24) + 8
+    ids = [total - 1, (1 << 24) + 1, 5]
+    vals = torch.tensor([[1.0], [2.0], [3.0]], dtype=torch.bfloat16)
+    out = gather_frame_results(ids, vals, total)
+    assert out.dtype == torch.bfloat16 and float(out[total - 1]) == 1.0 and float(out[(1 << 24) + 1]) == 2.0 and float(out[5]) == 3.0
+    assert float(out[1 << 24]) == 0.0
+    import pytest
+
+    with pytest.raises(ValueError):
+        gather_frame_results([total], torch.zeros(1, 1), total)

@@ -1,6 +1,6 @@
 """Generate tests/golden/*.npz by RUNNING THE REFERENCE (development container only).
 
-    python tests/tools/make_golden.py [--only micro|tiny|kitti]
+    python tests/tools/make_golden.py [--only micro|tiny|kitti|knn]
 
 Imports /root/reference through tests/tools/ref_shims.py, fills it with the name-keyed
 synthetic weights of cofii2p_amd.spec.synth_state_dict and records the reference's outputs on
@@ -207,12 +207,44 @@ def run_frame(model, name, frame_id, num_points, pyr_seed, modes):
     print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if not k.startswith("sha")})
 
 
+def gen_knn():
+    """The reference's OWN neighbour search: model/kpconv/preprocess_data.py `square_distance` (:109-128) + `knn` (:131-143), the
+    functions `precompute_point_cloud_cuda` (:145-203) builds every table of the pyramid with.  Recorded per (support, query)
+    pair: the reference's index rows and the distances it ranked them by (its own square_distance values at those indices).
+    The clouds hold duplicates (sub-sampling with replacement, :58) and lattice ties."""
+    import importlib
+
+    ref_shims.import_reference()
+    pre = importlib.import_module("model.kpconv.preprocess_data")
+    fr = make_frame(3, 2048)
+    pts = torch.from_numpy(fr.points)
+    rs = np.random.RandomState(0)
+    sub = pts[torch.from_numpy(rs.choice(2048, 1024))]          # with replacement: duplicates
+    tiny = pts[:100]                                            # fewer support points than k is not a reference case: k = 64 here
+    out = {"pts": pts.numpy(), "sub": sub.numpy()}
+    cases = {"self": (pts, pts[:192], 128), "down": (pts, sub[:192], 128), "up": (sub, pts[:192], 128), "tiny": (tiny, pts[:64], 64)}
+    with torch.no_grad():
+        for name, (support, query, k) in cases.items():
+            idx = pre.knn(support, query, k)                                          # (Q, k) int64, reference order
+            d_all = pre.square_distance(query.unsqueeze(0), support.unsqueeze(0))[0]   # (Q, S)
+            out["idx_" + name] = idx.numpy()
+            out["dist_" + name] = torch.gather(d_all, 1, idx).numpy()
+            out["k_" + name] = k
+            out["nq_" + name] = query.shape[0]
+    np.savez_compressed(os.path.join(GOLD, "knn_ref.npz"), **out)
+    print("knn_ref.npz:", {k_: (v.shape if hasattr(v, "shape") else v) for k_, v in out.items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     torch.manual_seed(0)
+    if args.only == "knn":
+        return gen_knn()
     net, model, sd = build_reference_model()
+    if args.only is None:
+        gen_knn()
     if args.only in (None, "micro"):
         gen_micro(net, model)
     if args.only in (None, "tiny"):
