@@ -590,32 +590,6 @@ def main():
                 model.enable_graphs(True)
             del pyr_b, img_b
         result["stack_mode_batches"] = sweep
-        # additional information, NOT the headline: the reference computes ResNet layer3, layer4 and the average pool and never reads
-        # them (model/network.py:87-89 only names them); `value` above includes them.  Without that dead branch:
-        model.compute_unused_image_maps = False
-        model.enable_graphs(False)
-        model.enable_graphs(True)
-        st = make_streams(dev, S)
-        pend = [None] * S
-        for phase in range(2):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(args.steps):
-                sl = i % S
-                if pend[sl] is not None:
-                    model.finish(pend[sl])
-                pyr, img, _ = frames[i % len(frames)]
-                with torch.cuda.stream(st[sl]):
-                    pend[sl] = model.forward_async(20 + sl, pyr, img)
-            for sl in range(S):
-                if pend[sl] is not None:
-                    model.finish(pend[sl])
-                    pend[sl] = None
-            torch.cuda.synchronize()
-            dtb = time.perf_counter() - t0
-        model.compute_unused_image_maps = True
-        result["without_unread_resnet_maps"] = {"frames_per_s": args.steps / dtb, "ms_per_frame": 1e3 * dtb / args.steps,
-                                                "note": "batch 1; layer3/layer4/avg-pool of the image encoder skipped (outputs identical: nothing reads them)"}
     if rank == 0 and world == 1 and Bsz == 1 and not args.no_batch_sweep:
         # additional information, outside `value` (the reference's DataLoader builds the pyramid, preprocess_data.py:36-107): the 13
         # KNN-128 searches of one frame's pyramid on this GPU, cell-grid search vs the brute-force kernel (identical tables)
@@ -647,21 +621,22 @@ def main():
             # ... and the whole chain on this GPU: every frame's pyramid is built on its frame stream right before its forward
             model.enable_graphs(True)
             st = make_streams(dev, S)
-            pend = [None] * S
+            NSL = S * max(1, args.slots_per_stream)
+            pend = [None] * NSL
             feats0, img0 = frames[0][0]["feats"], frames[0][1]
-            for phase in range(2):
-                nfr = max(args.steps // 2, 2 * S)
+            for phase in range(2):   # 0 = warm-up (captures the graphs of these slots), 1 = timed
+                nfr = max(args.steps, 3 * NSL)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for i in range(nfr):
-                    sl = i % S
+                    sl = i % NSL
                     if pend[sl] is not None:
                         model.finish(pend[sl])
-                    with torch.cuda.stream(st[sl]):
+                    with torch.cuda.stream(st[i % S]):
                         pyr = build_pyramid(p0, sub)
                         pyr["feats"] = feats0
                         pend[sl] = model.forward_async(30 + sl, pyr, img0)
-                for sl in range(S):
+                for sl in range(NSL):
                     if pend[sl] is not None:
                         model.finish(pend[sl])
                         pend[sl] = None

@@ -68,7 +68,7 @@ SIGNATURES = {
     "cofi_transpose": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "cofi_col_mean": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "cofi_conv2d_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _Z, _I, _P]),
-    "cofi_conv2d_nhwc_fused": (_I, [_P, _I, _N, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P, _Z, _I, _P]),
+    "cofi_conv2d_nhwc_fused": (_I, [_P, _I, _N, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _Z, _I, _P]),
     "cofi_im2col_stem": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "cofi_maxpool3x3s2_nhwc": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "cofi_upsample2x_cat_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P]),

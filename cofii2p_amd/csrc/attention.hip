@@ -68,10 +68,13 @@ __device__ __forceinline__ int so_off(int q, int chunk) { return q * 32 + ((chun
 // prologue, 16 no per-step barrier.  0 = the product kernel.
 template <int ABL>
 __global__ __launch_bounds__(64 * NW) void attention_flat_kernel(AttnArgs a) {
-    // LDS carve (floats): two staging buffers of KPH K tiles + KPH V tiles | the waves' final states | Q scale | fold scratch
+    // LDS carve (floats): two staging buffers of KPH K tiles + KPH V tiles | running max / row sum of the waves | Q scale | fold
+    // scratch.  The waves' final O states (s_o) re-use the staging buffers: they are written after the loop's last barrier.  78 KB
+    // in all, so workgroups of other kernels (the other frame streams' GEMMs) still fit on the CU next to this one.
     constexpr int BUF = 2 * KPH * TILE, SO = NW * 1024, SM = NW * 32, SP = 2 * NW * 32;
-    __shared__ __attribute__((aligned(16))) float lds[2 * BUF + SO + 2 * SM + 32 + SP];
-    float *s_buf = lds, *s_o = s_buf + 2 * BUF, *s_m = s_o + SO, *s_l = s_m + SM, *s_qs = s_l + SM, *s_part = s_qs + 32;
+    static_assert(SO <= 2 * BUF, "the final states must fit in the staging buffers");
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF + 2 * SM + 32 + SP];
+    float *s_buf = lds, *s_o = lds, *s_m = s_buf + 2 * BUF, *s_l = s_m + SM, *s_qs = s_l + SM, *s_part = s_qs + 32;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -49,6 +49,7 @@ struct GemmArgs {
     int cv_Pout;  // output pixels per frame (stack mode: GEMM row m is frame m / cv_Pout, pixel m % cv_Pout)
     int xcd;      // 0: hardware tile order; 1 + log2(gridDim.x): XCD-contiguous tile order (gemm_block_id)
     unsigned xcd_rcp_gy;
+    int act_col0;     // the activation applies to output columns >= act_col0 only (two layers sharing one A operand: [skip | conv1])
     int stat_shift;   // colpart holds one entry per 2^stat_shift adjacent columns: (nslab, N >> stat_shift, 2)
     // pending normalisation of the A operand (stat_fold.h): the loader applies  a -> leaky(a * sc[c] + sh[c])  to every element
     // it stages, c = column of a dense A / input channel of a convolution; an.part == nullptr: none.  an_rows = GEMM rows per
@@ -225,7 +226,7 @@ __device__ __forceinline__ void rowwise_epilogue(const GemmArgs &g, const float 
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[p][e] = apply_act(v[p][e] + rs[p][e], g.act);  // residual before the activation
+            for (int e = 0; e < 4; ++e) v[p][e] = apply_act(v[p][e] + rs[p][e], col + e >= g.act_col0 ? g.act : COFI_ACT_NONE);  // residual before the activation
         }
         if (rin) {
             if (g.colpart) {
@@ -1089,8 +1090,8 @@ int gemm_entry(const float *A, int lda, const cofi_norm_desc_t *a_norm, const fl
 }
 
 int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, int W, int Cin, const float *Wt, int Cout, int ks, int stride,
-               int pad, const float *bias, const float *res, int ldr, int act, float *y, int ldy, float *colpart, int stat_width, void *ws,
-               size_t ws_bytes, int frames, cofi_stream_t stream) {
+               int pad, const float *bias, const float *res, int ldr, int act, int act_col0, float *y, int ldy, float *colpart, int stat_width,
+               void *ws, size_t ws_bytes, int frames, cofi_stream_t stream) {
     if (!x || !Wt || !y || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ks != 1 && ks != 3) || stride <= 0 || pad < 0) return COFI_EINVAL;
     if ((Cin & 3) || (ldx & 3) || ldx < Cin || ldy < Cout || (res && ldr < Cout) || ((uintptr_t)x & 15) || ((uintptr_t)Wt & 15)) return COFI_EINVAL;
     const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
@@ -1099,7 +1100,7 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
     const int bf16x3 = (act & COFI_GEMM_BF16X3) ? 1 : 0;
     const int wsplit = (act & COFI_GEMM_W_SPLIT) ? 1 : 0;
     act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_W_SPLIT);
-    if (act < 0 || act > 2 || (wsplit && !bf16x3)) return COFI_EINVAL;
+    if (act < 0 || act > 2 || (wsplit && !bf16x3) || act_col0 < 0 || act_col0 > Cout) return COFI_EINVAL;
     const int sshift = colpart ? stat_shift_of(stat_width, Cout) : 0;
     if (sshift < 0) return COFI_EINVAL;
     const int ldw = wsplit ? (K + 7) / 8 * 8 : K;   // pre-split planes: rows padded to 8 values
@@ -1111,6 +1112,7 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
     g.bf16x3 = bf16x3; g.wsplit = wsplit; g.w_lo_off = (long)Cout * ldw;
     g.cv_ks = ks; g.cv_H = H; g.cv_W = W; g.cv_Cin = Cin; g.cv_Wo = Wo; g.cv_stride = stride; g.cv_pad = pad; g.cv_Pout = Ho * Wo;
     g.stat_shift = sshift;
+    g.act_col0 = act_col0;
     if (int rc = set_a_norm(g, x_norm, Cin, H * W, frames, p)) return rc;   // statistics of the INPUT map: H * W rows per frame
     return launch(g, p, cofi_s(stream));
 }
@@ -1167,14 +1169,14 @@ extern "C" int cofi_gemm_f32_layernorm(const float *A, int lda, const float *W, 
 extern "C" int cofi_conv2d_nhwc(const float *x, int ldx, int H, int W, int Cin, const float *Wt, int Cout, int ks, int stride, int pad,
                                 const float *bias, const float *res, int ldr, int act, float *y, int ldy, float *colpart, void *ws,
                                 size_t ws_bytes, int frames, cofi_stream_t stream) {
-    return conv_entry(x, ldx, nullptr, H, W, Cin, Wt, Cout, ks, stride, pad, bias, res, ldr, act, y, ldy, colpart, 1, ws, ws_bytes, frames, stream);
+    return conv_entry(x, ldx, nullptr, H, W, Cin, Wt, Cout, ks, stride, pad, bias, res, ldr, act, 0, y, ldy, colpart, 1, ws, ws_bytes, frames, stream);
 }
 
 extern "C" int cofi_conv2d_nhwc_fused(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, int W, int Cin, const float *Wt, int Cout,
-                                      int ks, int stride, int pad, const float *bias, const float *res, int ldr, int act, float *y, int ldy,
-                                      float *colpart, int stat_width, void *ws, size_t ws_bytes, int frames, cofi_stream_t stream) {
-    return conv_entry(x, ldx, x_norm, H, W, Cin, Wt, Cout, ks, stride, pad, bias, res, ldr, act, y, ldy, colpart, stat_width, ws, ws_bytes,
-                      frames, stream);
+                                      int ks, int stride, int pad, const float *bias, const float *res, int ldr, int act, int act_col0, float *y,
+                                      int ldy, float *colpart, int stat_width, void *ws, size_t ws_bytes, int frames, cofi_stream_t stream) {
+    return conv_entry(x, ldx, x_norm, H, W, Cin, Wt, Cout, ks, stride, pad, bias, res, ldr, act, act_col0, y, ldy, colpart, stat_width, ws,
+                      ws_bytes, frames, stream);
 }
 
 extern "C" int cofi_split_bf16_planes(const float *W, int ldw, int N, int K, void *planes, int ldp, cofi_stream_t stream) {

@@ -38,6 +38,10 @@ def pack_image(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
                 scale = sd[p + bn + ".weight"] * torch.rsqrt(sd[p + bn + ".running_var"] + eps)
                 out[p + conv + ".w.nhwc"] = _nhwc_weight(w * scale[:, None, None, None])
                 out[p + conv + ".b"] = (sd[p + bn + ".bias"] - sd[p + bn + ".running_mean"] * scale).contiguous()
+            # conv_skip and conv1 read the same input (imagenet.py:399-402): their filters run as ONE implicit GEMM [skip | conv1]
+            out[p + "skip_conv1.w.nhwc"] = torch.cat([out[p + "conv_skip.0.w.nhwc"], out[p + "conv1.w.nhwc"]], 0).contiguous()
+            out[p + "skip_conv1.b"] = torch.cat([out[p + "conv_skip.0.b"], out[p + "conv1.b"]], 0).contiguous()
+            del out[p + "conv_skip.0.w.nhwc"], out[p + "conv1.w.nhwc"]
     return out
 
 
@@ -116,11 +120,12 @@ def resnet34_nhwc(P, img: torch.Tensor, full: bool = True, tail_branch=None):
 
 
 def _residual_conv_nhwc(P, p: str, x, H, W, frames: int = 1):
-    """imagenet.py:397-411: three implicit-GEMM convolutions; folded-BN bias, ReLU and the skip add live in the
-    epilogues."""
-    skip, _, _ = ops.conv2d_nhwc(x, H, W, P[p + "conv_skip.0.w.nhwc"], 3, 1, 1, bias=P[p + "conv_skip.0.b"], frames=frames)
-    y, _, _ = ops.conv2d_nhwc(x, H, W, P[p + "conv1.w.nhwc"], 3, 1, 1, bias=P[p + "conv1.b"], act=ops.ACT_RELU, frames=frames)
-    out, _, _ = ops.conv2d_nhwc(y, H, W, P[p + "conv2.w.nhwc"], 3, 1, 1, bias=P[p + "conv2.b"], res=skip, act=ops.ACT_RELU, frames=frames)
+    """imagenet.py:397-411: the skip convolution and conv1 share their input and run as ONE implicit GEMM (filters stacked
+    [skip | conv1], ReLU on the conv1 half only), conv2 reads that half as a strided view; folded-BN bias, ReLU and the skip add
+    live in the epilogues."""
+    C = P[p + "conv2.b"].shape[0]
+    z, _, _ = ops.conv2d_nhwc(x, H, W, P[p + "skip_conv1.w.nhwc"], 3, 1, 1, bias=P[p + "skip_conv1.b"], act=ops.ACT_RELU, act_col0=C, frames=frames)
+    out, _, _ = ops.conv2d_nhwc(z[:, C:], H, W, P[p + "conv2.w.nhwc"], 3, 1, 1, bias=P[p + "conv2.b"], res=z[:, :C], act=ops.ACT_RELU, frames=frames)
     return out
 
 

@@ -550,9 +550,10 @@ def pos_sine(coords, out, accumulate: bool, d_model: int = 128):
 
 # ------------------------------------------------------------------------------------------ image branch, NHWC
 def conv2d_nhwc(x, H: int, W: int, w, ks: int, stride: int = 1, pad: int = 1, bias=None, res=None, act: int = ACT_NONE,
-                colstats: bool = False, out=None, frames: int = 1, stat_width: int = 1):
+                colstats: bool = False, out=None, frames: int = 1, stat_width: int = 1, act_col0: int = 0):
     """Implicit-GEMM convolution on an NHWC map x (H*W, Cin) [row-major view, any leading dimension; or a Normed: the pending
     InstanceNorm + ReLU of the previous convolution is applied by the operand loader]; w (Cout, ks*ks*Cin).
+    act applies to output columns >= act_col0 (stacked filters of two convolutions of the same input).
     -> y (Ho*Wo, Cout) [, colpart]."""
     lib = _lib.load()
     Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
@@ -577,7 +578,7 @@ def conv2d_nhwc(x, H: int, W: int, w, ks: int, stride: int = 1, pad: int = 1, bi
     ws = _WS_GEMM.get(lib.cofi_gemm_f32_workspace(M, Cout, K), x.device)
     wp, _wld, wflag = _wargs(w)   # convolution weights are dense (Cout, K) / planes (2, Cout, roundup8(K))
     rc = lib.cofi_conv2d_nhwc_fused(_p(x), _ld(x), None if nd is None else ctypes.byref(nd), H, W, Cin, wp, Cout, ks, stride, pad, _p(bias),
-                                    _p(res), 0 if res is None else _ld(res), act | _gemm_flag() | wflag, _p(out), _ld(out), _p(part), stat_width,
+                                    _p(res), 0 if res is None else _ld(res), act | _gemm_flag() | wflag, act_col0, _p(out), _ld(out), _p(part), stat_width,
                                     _p(ws), 0 if ws is None else ws.numel(), frames, _stream())
     _lib.check(rc, "cofi_conv2d_nhwc_fused")
     return (out, part, Ho, Wo) if colstats else (out, Ho, Wo)

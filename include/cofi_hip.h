@@ -310,10 +310,12 @@ int cofi_conv2d_nhwc(const float *x, int ldx, int H, int W, int Cin, const float
                      int frames, cofi_stream_t stream);
 /* cofi_conv2d_nhwc with a pending normalisation of the INPUT map (x_norm, channels == Cin <= 512: the InstanceNorm + ReLU between
  * the two convolutions of a BasicBlock, imagenet.py:58-66; zero padding is applied after the normalisation, as nn.Conv2d pads the
- * normalised map) and a statistics table of width `stat_width`; see cofi_gemm_f32_fused. */
+ * normalised map) and a statistics table of width `stat_width`; see cofi_gemm_f32_fused.  `act` applies to the output columns
+ * >= act_col0 only: two convolutions of ONE input - the skip branch and the first convolution of a ResidualConv, imagenet.py:397-403 -
+ * run as one launch with the filters stacked [skip | conv1], act_col0 = the skip branch's channel count. */
 int cofi_conv2d_nhwc_fused(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, int W, int Cin, const float *Wt, int Cout, int ks,
-                           int stride, int pad, const float *bias, const float *res, int ldr, int act, float *y, int ldy, float *colpart,
-                           int stat_width, void *ws, size_t ws_bytes, int frames, cofi_stream_t stream);
+                           int stride, int pad, const float *bias, const float *res, int ldr, int act, int act_col0, float *y, int ldy,
+                           float *colpart, int stat_width, void *ws, size_t ws_bytes, int frames, cofi_stream_t stream);
 int cofi_im2col_stem(const float *img_chw, int H, int W, int Kpad, float *out, int frames, cofi_stream_t stream);
 int cofi_maxpool3x3s2_nhwc(const float *x, int H, int W, int C, float *y, int frames, cofi_stream_t stream);
 int cofi_upsample2x_cat_nhwc(const float *low, int ldl, int C1, int h, int w, const float *skip, int lds, int C2, float *out, int ldo,
