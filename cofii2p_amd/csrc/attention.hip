@@ -66,8 +66,10 @@ __device__ __forceinline__ int so_off(int q, int chunk) { return q * 32 + ((chun
 
 // ABL: timing ablations (tools only, COFI_ATTN_ABLATE): 1 no softmax, 2 no PV chain, 4 no QK^T chain, 8 no re-staging after the
 // prologue, 16 no per-step barrier.  0 = the product kernel.
-template <int ABL>
-__global__ __launch_bounds__(64 * NW) void attention_flat_kernel(AttnArgs a) {
+// LIGHT: two workgroups per CU (<= 128 VGPRs): a wave runs QK^T, softmax and PV of a unit back to back - with four waves per SIMD
+// the other waves' MFMAs cover its softmax - and one workgroup's prologue / merge runs under the other's MFMA phase.
+template <int ABL, bool LIGHT>
+__global__ __launch_bounds__(64 * NW, LIGHT ? 4 : 2) void attention_flat_kernel(AttnArgs a) {
     // LDS carve (floats): two staging buffers of KPH K tiles + KPH V tiles | running max / row sum of the waves | Q scale | fold
     // scratch.  The waves' final O states (s_o) re-use the staging buffers: they are written after the loop's last barrier.  78 KB
     // in all, so workgroups of other kernels (the other frame streams' GEMMs) still fit on the CU next to this one.
@@ -225,6 +227,25 @@ __global__ __launch_bounds__(64 * NW) void attention_flat_kernel(AttnArgs a) {
     // and the loads of the step after that are issued.  One barrier per step: buffer (t+1)&1 was last read in step t-1.
     // Steps without a tile for this wave (the tail of the range) and the first step take the plain paths below.
     const bool tail_keys = (a.S & 31) != 0;   // the last key block of every pair is partial
+    if constexpr (LIGHT) {
+        for (int t = 0; t < nsteps; ++t) {
+            const float *bt = s_buf + (t & 1) * BUF;
+            const int kb = kb0 + t * KPH + ph;
+            if (t * KPH + ph < nblk) {   // wave-uniform
+                f32x16 sC = qk(bt + ph * TILE);
+                float vC[16];
+                read_v(bt + (KPH + ph) * TILE, vC);
+                if (tail_keys && kb == lay.P - 1) mask_tail(kb, sC);
+                softmax(sC);
+                pv(sC, vC);
+            }
+            if (t + 1 < nsteps && !(ABL & 8)) {
+                stage_store((t + 1) & 1);
+                if (t + 2 < nsteps) stage_load(t + 2);
+            }
+            if constexpr (!(ABL & 16)) __syncthreads();
+        }
+    } else {
     f32x16 sC;
     float vC[16];
     int kbC = -1;   // key block of the pending unit (wave-uniform), -1: none
@@ -272,6 +293,7 @@ __global__ __launch_bounds__(64 * NW) void attention_flat_kernel(AttnArgs a) {
         if (tail_keys && kbC == lay.P - 1) mask_tail(kbC, sC);
         softmax(sC);
         pv(sC, vC);
+    }
     }
 
     // ---- this wave's state -> LDS; the KPH phase waves of a query block are merged in a fixed order -> the block's slot
@@ -337,16 +359,21 @@ int launch_parts(AttnArgs a, int frames, hipStream_t stream) {
     a.lay = attn_layout(a.L, a.S, a.H, frames);
     static const int abl = [] { const char *e = getenv("COFI_ATTN_ABLATE"); return e ? atoi(e) : 0; }();   // timing experiments only
     const dim3 grid(a.lay.nwg), block(64 * NW);
+    if (a.lay.light) {
+        switch (abl) {
+            case 7: hipLaunchKernelGGL((attention_flat_kernel<7, true>), grid, block, 0, stream, a); break;
+            case 31: hipLaunchKernelGGL((attention_flat_kernel<31, true>), grid, block, 0, stream, a); break;
+            default: hipLaunchKernelGGL((attention_flat_kernel<0, true>), grid, block, 0, stream, a);
+        }
+        return cofi_launch_status();
+    }
     switch (abl) {
-        case 1: hipLaunchKernelGGL(attention_flat_kernel<1>, grid, block, 0, stream, a); break;
-        case 2: hipLaunchKernelGGL(attention_flat_kernel<2>, grid, block, 0, stream, a); break;
-        case 3: hipLaunchKernelGGL(attention_flat_kernel<3>, grid, block, 0, stream, a); break;
-        case 4: hipLaunchKernelGGL(attention_flat_kernel<4>, grid, block, 0, stream, a); break;
-        case 7: hipLaunchKernelGGL(attention_flat_kernel<7>, grid, block, 0, stream, a); break;
-        case 8: hipLaunchKernelGGL(attention_flat_kernel<8>, grid, block, 0, stream, a); break;
-        case 24: hipLaunchKernelGGL(attention_flat_kernel<24>, grid, block, 0, stream, a); break;
-        case 31: hipLaunchKernelGGL(attention_flat_kernel<31>, grid, block, 0, stream, a); break;
-        default: hipLaunchKernelGGL(attention_flat_kernel<0>, grid, block, 0, stream, a);
+        case 1: hipLaunchKernelGGL((attention_flat_kernel<1, false>), grid, block, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((attention_flat_kernel<2, false>), grid, block, 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((attention_flat_kernel<4, false>), grid, block, 0, stream, a); break;
+        case 7: hipLaunchKernelGGL((attention_flat_kernel<7, false>), grid, block, 0, stream, a); break;
+        case 31: hipLaunchKernelGGL((attention_flat_kernel<31, false>), grid, block, 0, stream, a); break;
+        default: hipLaunchKernelGGL((attention_flat_kernel<0, false>), grid, block, 0, stream, a);
     }
     return cofi_launch_status();
 }

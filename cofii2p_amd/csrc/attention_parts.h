@@ -11,9 +11,10 @@
 // as possible beyond that.
 #pragma once
 #include "common.h"
+#include <stdlib.h>
 
 #define COFI_ATTN_SLOT_FLOATS 1088
-#define COFI_ATTN_MAX_KS 4
+#define COFI_ATTN_MAX_KS 8
 #define COFI_ATTN_QG 2      /* query blocks sharing one workgroup's K / V tiles */
 #define COFI_ATTN_KPH 4     /* key blocks a workgroup stages and processes per step (one per wave group) */
 
@@ -23,6 +24,7 @@ struct AttnLayout {
     int QSB;    // 64-query super blocks per (frame, head)
     int KS;     // key ranges = slots per pair
     int nwg;    // workgroups = frames * H * QSB * KS
+    int light;  // kernel variant: 1 = two workgroups per CU
     size_t bytes;
 };
 
@@ -36,6 +38,17 @@ static inline int attn_num_cus() {
     return n;
 }
 
+// Two variants of the attention kernel: the "heavy" one (one workgroup per CU, the wave software-pipelines QK^T of the next unit
+// over the softmax of the current one) and the "light" one (<= 128 VGPRs, two workgroups per CU: one workgroup's prologue - first
+// K / V tiles, Q-norm fold - and merge run under the other's MFMA phase).  Measured on MI355X (us per launch, heavy / light): one
+// KITTI cross-attention call (80 query super blocks) 14.9 / 16.3, the joint self-attention call (160) 28.3 / 24.6, 16 stacked
+// frames 158.9 / 150.0 - light wins once there are enough super blocks to give every CU two workgroups without splitting the keys
+// further.  COFI_ATTN_WG_PER_CU = 1 / 2 forces a variant (A/B runs).  Read once: producer and consumers always agree.
+static inline int attn_forced_wg_per_cu() {
+    static const int n = [] { const char *e = getenv("COFI_ATTN_WG_PER_CU"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2) ? v : 0; }();
+    return n;
+}
+
 static inline AttnLayout attn_layout(int L, int S, int H, int frames) {
     AttnLayout a;
     a.P = cofi_cdiv(S, 32);
@@ -44,7 +57,9 @@ static inline AttnLayout attn_layout(int L, int S, int H, int frames) {
     const long sp = (long)frames * H * a.QSB;   // workgroups per key range
     // Cost of a split in "steps" (one 32 x 32 unit per wave): waves of workgroups the chip runs one after the other, each
     // ceil(blocks / KPH) steps long plus a fixed prologue + merge cost of about 1.5 steps.
-    const int ncu = attn_num_cus();
+    const int forced = attn_forced_wg_per_cu();
+    a.light = forced ? forced == 2 : sp * 2 >= attn_num_cus();
+    const int ncu = attn_num_cus() * (a.light ? 2 : 1);
     int best = 1;
     double best_cost = 1e30;
     for (int ks = 1; ks <= COFI_ATTN_MAX_KS && ks <= a.P; ++ks) {
@@ -68,10 +83,12 @@ __device__ __forceinline__ float4 attn_merged_chunk(const float *parts, const At
     float4 o[COFI_ATTN_MAX_KS];
 #pragma unroll
     for (int s = 0; s < COFI_ATTN_MAX_KS; ++s) {
-        const float *sl = slot + (size_t)(s < lay.KS ? s : 0) * COFI_ATTN_SLOT_FLOATS;
-        m[s] = sl[q];
-        ls[s] = sl[32 + q];
-        o[s] = *reinterpret_cast<const float4 *>(sl + 64 + q * 32 + 4 * ch);
+        if (s < lay.KS) {   // uniform
+            const float *sl = slot + (size_t)s * COFI_ATTN_SLOT_FLOATS;
+            m[s] = sl[q];
+            ls[s] = sl[32 + q];
+            o[s] = *reinterpret_cast<const float4 *>(sl + 64 + q * 32 + 4 * ch);
+        }
     }
     float mm = -1e30f;
 #pragma unroll
