@@ -81,6 +81,11 @@ SIGNATURES = {
     "cofi_pnp_ransac_workspace": (_Z, [_I]),
     "cofi_pnp_ransac": (_I, [_P, _P, _P, _I, _F, _F, _F, _F, _I, _F, ctypes.c_uint, _I, _P, _Z, _P, _P, _P, _P]),
     "cofi_fine_match": (_I, [_P, _P, _I, _I, _P, _I, _F, _P, _I, _P, _P, _P]),
+    "cofi_pack_transform_scan": (_I, [_P, _I, _P, _P, _P]),
+    "cofi_voxel_downsample_workspace": (_Z, [_I]),
+    "cofi_voxel_downsample": (_I, [_P, _I, ctypes.c_double, _P, _I, _P, _P, _Z, _P]),
+    "cofi_gather_transform": (_I, [_P, _P, _I, _P, _P, _P, _P]),
+    "cofi_resize_crop_image": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
 }
 
 

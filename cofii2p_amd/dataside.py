@@ -1,0 +1,250 @@
+"""The data side of one KITTI frame on the device: what kitti_pc_img_dataset.__getitem__
+(data/kitti.py:259-393) does between the disk read and the model call, with the heavy parts as HIP kernels
+(csrc/dataside.hip, csrc/knn_grid.hip):
+
+    raw scan (7, N)  --calibration transform-->  0.1 m voxel grid  --resample to num_pc-->  random SE(3)  -->  KNN pyramid
+    raw image (H, W, 3) uint8  --x0.5 bilinear resize, crop, / 255, CHW-->  model image
+    coarsest-stage points  --project with K/8 and K/2-->  coarse / fine labels                     (host numpy, 1280 points)
+
+The reference seeds the GLOBAL numpy and `random` generators per frame index and draws from them in a fixed order
+(kitti.py:261-264, then :170/:175, :220-229, preprocess_data.py:58 four times, :313-314 in train mode, :345/:349/:358);
+`FrameSampler` makes the same draws in the same order from private generators, so a frame prepared here gets the reference's
+choice indices, SE(3) and label permutations.  The draws are host-side by nature (Mersenne Twister streams); they are handed
+to the kernels as plain index arrays / a 4x4 matrix.  One host sync per frame: the voxel count (the resampling draw depends on it).
+"""
+import random
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .preprocess import build_pyramid
+
+NUM_STAGES = 5
+VOXEL_SIZE = 0.1   # kitti.py:283
+
+
+def frame_seed(index: int) -> int:
+    """kitti.py:261-262"""
+    (seed,) = np.random.SeedSequence([index]).generate_state(1)
+    return int(seed)
+
+
+class FrameSampler:
+    """The random draws of one __getitem__(index) call, in the reference's order."""
+
+    def __init__(self, index: int, seed: Optional[int] = None):
+        self.seed = frame_seed(index) if seed is None else int(seed)
+        self.rs = np.random.RandomState(self.seed)   # the global numpy state after np.random.seed(seed)
+        self.rnd = random.Random(self.seed)          # the global `random` state after random.seed(seed)
+
+    def downsample_choice(self, n: int, num_pc: int) -> np.ndarray:
+        """kitti.py:168-176"""
+        if n >= num_pc:
+            return self.rs.choice(n, num_pc, replace=False)
+        fix = np.arange(n)
+        while n + fix.shape[0] < num_pc:
+            fix = np.concatenate((fix, np.arange(n)), axis=0)
+        return np.concatenate((fix, self.rs.choice(n, num_pc - fix.shape[0], replace=False)), axis=0)
+
+    def random_transform(self, opt) -> np.ndarray:
+        """kitti.py:216-235 (+ :203-214): t, then the angles; R = Rz Ry Rx; 4x4 float32."""
+        u = self.rnd.uniform
+        t = [u(-opt.P_tx_amplitude, opt.P_tx_amplitude), u(-opt.P_ty_amplitude, opt.P_ty_amplitude), u(-opt.P_tz_amplitude, opt.P_tz_amplitude)]
+        a = [u(-opt.P_Rx_amplitude, opt.P_Rx_amplitude), u(-opt.P_Ry_amplitude, opt.P_Ry_amplitude), u(-opt.P_Rz_amplitude, opt.P_Rz_amplitude)]
+        Rx = np.array([[1, 0, 0], [0, np.cos(a[0]), -np.sin(a[0])], [0, np.sin(a[0]), np.cos(a[0])]])
+        Ry = np.array([[np.cos(a[1]), 0, np.sin(a[1])], [0, 1, 0], [-np.sin(a[1]), 0, np.cos(a[1])]])
+        Rz = np.array([[np.cos(a[2]), -np.sin(a[2]), 0], [np.sin(a[2]), np.cos(a[2]), 0], [0, 0, 1]])
+        P = np.identity(4, dtype=np.float32)
+        P[0:3, 0:3] = np.dot(Rz, np.dot(Ry, Rx))
+        P[0:3, 3] = t
+        return P
+
+    def subsample_indices(self, n: int, num_stages: int = NUM_STAGES):
+        """preprocess_data.py:55-59: half of the previous stage, WITH replacement."""
+        out = []
+        for _ in range(num_stages - 1):
+            out.append(self.rs.choice(np.arange(n), size=n // 2))
+            n //= 2
+        return out
+
+    def crop_offsets(self, small_hw, opt, mode: str):
+        """kitti.py:312-317: random crop in train mode, centred otherwise."""
+        h, w = small_hw
+        if mode == "train":
+            dx = self.rnd.randint(0, w - opt.img_W)
+            dy = self.rnd.randint(0, h - opt.img_H)
+        else:
+            dx = int((w - opt.img_W) / 2)
+            dy = int((h - opt.img_H) / 2)
+        return dy, dx
+
+    def permutation(self, n: int) -> np.ndarray:
+        return self.rs.permutation(n)
+
+
+def calib_matrices(lines: Dict[str, str]) -> Dict[str, np.ndarray]:
+    """KittiCalibHelper.read_calib_files for one sequence (kitti.py:24-63): {'Tr', 'P0'.., 'P0_K'..}; lines = {key: twelve numbers}."""
+    out = {}
+    for key, text in lines.items():
+        mat = np.array(text.split(), dtype=np.float64).reshape(3, 4).astype(np.float32)
+        P = np.identity(4, dtype=np.float32)
+        if key == "Tr":
+            P[0:3, :] = mat
+        else:
+            K = mat[0:3, 0:3]
+            out[key + "_K"] = K
+            tz = mat[2, 3]
+            P[0:3, 3] = np.asarray([(mat[0, 3] - K[0, 2] * tz) / K[0, 0], (mat[1, 3] - K[1, 2] * tz) / K[1, 1], tz], dtype=np.float32)
+        out[key] = P
+    return out
+
+
+def intrinsics_and_crop(K: np.ndarray, img_hw, opt, sampler: Optional[FrameSampler], mode: str = "val"):
+    """kitti.py:306-328: size of the x0.5 image, crop offsets, K of the cropped image at 1/2 (-> 'K') and 1/8 (-> 'K_4') of it.
+    Returns (K_2, K_4, (dy, dx), (resized_h, resized_w)) in K's own dtype (the reference keeps the dtype of the stored matrix)."""
+    rh, rw = int(round(img_hw[0] * 0.5)), int(round(img_hw[1] * 0.5))
+
+    def scaled(M, s):   # camera_matrix_scaling, kitti.py:188-191
+        Ms = s * M
+        Ms[2, 2] = 1
+        return Ms
+
+    Ks = scaled(K, 0.5)
+    dy, dx = (sampler or FrameSampler(0)).crop_offsets((rh, rw), opt, mode) if mode == "train" else (int((rh - opt.img_H) / 2), int((rw - opt.img_W) / 2))
+    Kc = np.copy(Ks)    # camera_matrix_cropping, kitti.py:182-186
+    Kc[0, 2] -= dx
+    Kc[1, 2] -= dy
+    return scaled(Kc, 0.5), scaled(Kc, 0.125), (dy, dx), (rh, rw)
+
+
+def project_labels(coarse_points: np.ndarray, P: np.ndarray, K_2: np.ndarray, K_4: np.ndarray, opt, sampler: FrameSampler) -> Dict:
+    """kitti.py:334-372 on the coarsest-stage points (n, 3): projection to the 1/8 image, in-picture mask, `num_kpt` random in / out
+    points, occupied-pixel mask, then the fine (1/2 image) pixel of every kept point.  Plain numpy on 1280 points, written the way
+    the reference writes it (same operations, same dtypes): nothing here is worth a kernel launch."""
+    cp = np.ascontiguousarray(coarse_points, dtype=np.float32).T          # (3, n)
+    s8 = 0.125
+    Rinv = np.linalg.inv(P[0:3, 0:3])
+    proj = np.dot(K_4, np.dot(Rinv, cp) - np.dot(Rinv, P[0:3, 3:]))
+    proj[0:2, :] = proj[0:2, :] / proj[2:, :]
+    xy = np.floor(proj[0:2, :] + 0.5)
+    inpic = (xy[0] >= 1) & (xy[0] <= (opt.img_W * s8 - 3)) & (xy[1] >= 1) & (xy[1] <= (opt.img_H * s8 - 3)) & (proj[2] > 0)
+    pc_kpt_idx = np.where(inpic)[0]
+    pc_kpt_idx = pc_kpt_idx[sampler.permutation(len(pc_kpt_idx))[0:opt.num_kpt]]
+    pc_outline_idx = np.where(~inpic)[0]
+    pc_outline_idx = pc_outline_idx[sampler.permutation(len(pc_outline_idx))[0:opt.num_kpt]]
+    H8, W8 = int(opt.img_H * s8), int(opt.img_W * s8)
+    mask = np.zeros((H8, W8), dtype=np.float32)
+    mask[xy[1, inpic].astype(np.int64), xy[0, inpic].astype(np.int64)] = 1.0
+    coarse_xy = xy[:, pc_kpt_idx]
+    img_outline = np.where(mask.reshape(-1) == 0)[0]
+    img_outline = img_outline[sampler.permutation(len(img_outline))[0:opt.num_kpt]]
+    pp = np.dot(K_2, np.dot(Rinv, cp[:, pc_kpt_idx]) - np.dot(Rinv, P[0:3, 3:]))
+    pp[0:2, :] = pp[0:2, :] / pp[2:, :]
+    fine_xy = np.floor(pp[0:2, :])
+    ok = (fine_xy[0] >= 0) & (fine_xy[0] <= (opt.img_W * 0.5 - 1)) & (fine_xy[1] >= 0) & (fine_xy[1] <= (opt.img_H * 0.5 - 1)) & (pp[2] > 0)
+    if not np.all(ok):
+        raise AssertionError("a coarse in-picture point projects outside the 1/2 image (kitti.py:366)")
+    return {
+        "coarse_img_mask": mask,
+        "pc_kpt_idx": pc_kpt_idx,
+        "pc_outline_idx": pc_outline_idx,
+        "fine_xy_coors": fine_xy.astype(np.int32),
+        "coarse_img_kpt_idx": (xy[1, pc_kpt_idx] * opt.img_W * s8 + xy[0, pc_kpt_idx]).astype(np.int64),
+        "fine_img_kpt_index": (fine_xy[1, :] * opt.img_W * 0.5 + fine_xy[0, :]).astype(np.int64),
+        "fine_center_kpt_coors": (coarse_xy * 4).astype(np.int32),
+        "coarse_img_outline_index": img_outline.astype(np.int64),
+    }
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class FramePreparer:
+    """Device-side __getitem__: `prepare(data, img, K, P_Tr, index)` returns the reference's sample dict (kitti.py:375-393) with
+    the tensors on the device (`img` (3,H,W), `pc_data_dict` with int64 tables and `feats`, the label tensors, K / K_4 / P).
+    Buffers are cached per input size; one preparer per stream."""
+
+    def __init__(self, opt, device="cuda", mode: str = "val"):
+        if mode not in ("val", "train"):
+            raise ValueError("mode must be 'val' or 'train'")
+        if mode == "train":
+            # kitti.py:329-330 augments the image with torchvision ColorJitter in train mode: not built (training is out of scope)
+            raise NotImplementedError("train-mode image augmentation (ColorJitter, kitti.py:193-201) is not implemented")
+        self.opt, self.device, self.mode = opt, torch.device(device), mode
+        self._ws = ops.Workspace()
+        self._rows = self._vox = None
+        self.last = {}
+
+    def voxel_downsample(self, data: torch.Tensor, P_Tr: torch.Tensor):
+        """(7, N) raw scan + 4x4 calibration transform (device) -> ((cap, 8) voxel rows, count).  Syncs on the count."""
+        lib = _lib.load()
+        if data.dim() != 2 or data.shape[0] != 7 or data.dtype != torch.float32 or not data.is_contiguous():
+            raise _lib.CofiError("dataside: the raw scan must be a contiguous (7, N) float32 tensor")
+        N = data.shape[1]
+        if self._rows is None or self._rows.shape[0] < N:
+            self._rows = torch.empty((N, 8), dtype=torch.float32, device=self.device)
+            self._vox = torch.empty((N, 8), dtype=torch.float32, device=self.device)
+        rows, vox = self._rows[:N], self._vox[:N]
+        cnt = torch.empty(2, dtype=torch.int32, device=self.device)
+        _lib.check(lib.cofi_pack_transform_scan(_p(data), N, _p(P_Tr), _p(rows), _stream()), "cofi_pack_transform_scan")
+        nbytes = lib.cofi_voxel_downsample_workspace(N)
+        ws = self._ws.get(nbytes, self.device)
+        _lib.check(lib.cofi_voxel_downsample(_p(rows), N, VOXEL_SIZE, _p(vox), N, _p(cnt), _p(ws), ws.numel(), _stream()), "cofi_voxel_downsample")
+        c = cnt.cpu()
+        if int(c[1]):
+            raise _lib.CofiError("dataside: the scan spans more than 8192 voxels along an axis")
+        return vox, int(c[0])
+
+    def resample_transform(self, vox: torch.Tensor, choice: np.ndarray, P: np.ndarray):
+        """rows `choice` of the voxel table, x' = R x + t, n' = R n -> points (n, 3), feats (n, 4) (kitti.py:284-288, 293)."""
+        lib = _lib.load()
+        n = int(choice.shape[0])
+        ch = torch.from_numpy(np.ascontiguousarray(choice, dtype=np.int32)).to(self.device, non_blocking=True)
+        Pd = torch.from_numpy(np.ascontiguousarray(P, dtype=np.float32)).to(self.device, non_blocking=True)
+        points = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        feats = torch.empty((n, 4), dtype=torch.float32, device=self.device)
+        _lib.check(lib.cofi_gather_transform(_p(vox), _p(ch), n, _p(Pd), _p(points), _p(feats), _stream()), "cofi_gather_transform")
+        return points, feats
+
+    def image(self, img_u8: torch.Tensor, resized_hw, crop_yx):
+        """(H, W, 3) uint8 device tensor -> (3, img_H, img_W) float32 (kitti.py:306-322, 375)."""
+        lib = _lib.load()
+        if img_u8.dim() != 3 or img_u8.shape[2] != 3 or img_u8.dtype != torch.uint8 or not img_u8.is_contiguous():
+            raise _lib.CofiError("dataside: the image must be a contiguous (H, W, 3) uint8 tensor")
+        out = torch.empty((3, self.opt.img_H, self.opt.img_W), dtype=torch.float32, device=self.device)
+        _lib.check(lib.cofi_resize_crop_image(_p(img_u8), img_u8.shape[0], img_u8.shape[1], resized_hw[0], resized_hw[1], crop_yx[0], crop_yx[1],
+                                              self.opt.img_H, self.opt.img_W, _p(out), _stream()), "cofi_resize_crop_image")
+        return out
+
+    def prepare(self, data, img, K: np.ndarray, P_Tr: np.ndarray, index: int) -> Dict:
+        opt, dev = self.opt, self.device
+        s = FrameSampler(index)
+        data = (torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)) if isinstance(data, np.ndarray) else data).to(dev, non_blocking=True)
+        img = (torch.from_numpy(np.ascontiguousarray(img)) if isinstance(img, np.ndarray) else img).to(dev, non_blocking=True)
+        Ptr = torch.from_numpy(np.ascontiguousarray(P_Tr, dtype=np.float32)).to(dev, non_blocking=True)
+        vox, nvox = self.voxel_downsample(data, Ptr)
+        choice = s.downsample_choice(nvox, opt.num_pc)
+        P = s.random_transform(opt)
+        points, feats = self.resample_transform(vox, choice, P)
+        sub = s.subsample_indices(opt.num_pc, NUM_STAGES)
+        pyr = build_pyramid(points, [torch.from_numpy(i).to(dev, non_blocking=True) for i in sub], int64=True)
+        pyr["feats"] = feats
+        K_2, K_4, crop, rhw = intrinsics_and_crop(K, img.shape[:2], opt, s, self.mode)
+        image = self.image(img, rhw, crop)
+        lab = project_labels(pyr["points"][-1].cpu().numpy(), P, K_2, K_4, opt, s)
+        kpt = torch.from_numpy(lab["pc_kpt_idx"]).to(dev)
+        inline = ops.nearest_node(pyr["points"][1], pyr["points"][-1][kpt].contiguous()).to(torch.int64)   # point2node, kitti.py:374
+        self.last = {"voxels": nvox, "choice": choice, "P_random": P, "subsample": sub, "crop": crop}
+        out = {"img": image, "pc_data_dict": pyr, "fine_pc_inline_index": inline,
+               "K": torch.from_numpy(K_2.astype(np.float32)).to(dev), "K_4": torch.from_numpy(K_4.astype(np.float32)).to(dev),
+               "P": torch.from_numpy(np.linalg.inv(P).astype(np.float32)).to(dev), "index": index}
+        for k, v in lab.items():
+            out[k] = torch.from_numpy(v).to(dev)
+        return out

@@ -82,3 +82,51 @@ def subsample_indices(n: int, num_stages: int, seed: int):
         out.append(g.choice(np.arange(n), size=n // 2))
         n //= 2
     return out
+
+
+# KITTI odometry calibration of sequence 09 / 10 as data/kitti.py:24-63 reads it from calib.txt ("P2: ..." 3x4 projection row,
+# "Tr: ..." velodyne -> camera 0), rounded values of the public calibration files
+KITTI_CALIB_LINES = {
+    "P0": "7.070912000000e+02 0.000000000000e+00 6.018873000000e+02 0.000000000000e+00 0.000000000000e+00 7.070912000000e+02 1.831104000000e+02 0.000000000000e+00 0.000000000000e+00 0.000000000000e+00 1.000000000000e+00 0.000000000000e+00",
+    "P2": "7.070912000000e+02 0.000000000000e+00 6.018873000000e+02 4.688783000000e+01 0.000000000000e+00 7.070912000000e+02 1.831104000000e+02 1.178601000000e-01 0.000000000000e+00 0.000000000000e+00 1.000000000000e+00 6.203223000000e-03",
+    "P3": "7.070912000000e+02 0.000000000000e+00 6.018873000000e+02 -3.334597000000e+02 0.000000000000e+00 7.070912000000e+02 1.831104000000e+02 1.930130000000e+00 0.000000000000e+00 0.000000000000e+00 1.000000000000e+00 3.318498000000e-03",
+    "Tr": "-1.857739385241e-03 -9.999659513510e-01 -8.039975204516e-03 -4.784029760483e-03 -6.481465826011e-03 8.051860151134e-03 -9.999466081774e-01 -7.337429464231e-02 9.999773098287e-01 -1.805528627661e-03 -6.496203536139e-03 -3.339968064433e-01",
+}
+
+
+def make_raw_scan(frame_id: int = 0, num_points: int = 120000, img_hw=(376, 1241)):
+    """A raw frame as it lies on disk for data/kitti.py:262-279: `data` (7, N) float32 = [xyz | intensity | normal] in the velodyne
+    frame (x forward, y left, z up), `img` (H, W, 3) uint8, `K` (3, 3) float64.  Ground plane + facades sampled along rotating
+    beams, denser near the sensor like a real scan, so the 0.1 m voxel grid merges several points per voxel close in and keeps
+    single points far out."""
+    g = np.random.default_rng(977 + int(frame_id))
+    H, W = img_hw
+    img = g.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    n_ground = int(0.6 * num_points)
+    # ground: range ~ 3..70 m with 1/r density, full azimuth
+    r = np.exp(g.uniform(np.log(3.0), np.log(70.0), n_ground))
+    az = g.uniform(-np.pi, np.pi, n_ground)
+    ground = np.stack([r * np.cos(az), r * np.sin(az), -1.73 + g.normal(0.0, 0.02, n_ground)], 1)
+    g_n = np.tile(np.array([0.0, 0.0, 1.0]), (n_ground, 1))
+    pts, nrm = [ground], [g_n]
+    n_fac = num_points - n_ground
+    per = n_fac // 10
+    for f in range(10):
+        cnt = per if f < 9 else n_fac - 9 * per
+        d = g.uniform(5.0, 45.0) * (1 if f % 4 < 2 else -1)
+        u = g.uniform(-50.0, 50.0, cnt) * g.uniform(0.2, 1.0, cnt)
+        h = g.uniform(-1.73, 4.0, cnt)
+        if f % 2 == 0:
+            pts.append(np.stack([np.full(cnt, d) + g.normal(0, 0.02, cnt), u, h], 1))
+            nrm.append(np.tile(np.array([-np.sign(d), 0.0, 0.0]), (cnt, 1)))
+        else:
+            pts.append(np.stack([u, np.full(cnt, d) + g.normal(0, 0.02, cnt), h], 1))
+            nrm.append(np.tile(np.array([0.0, -np.sign(d), 0.0]), (cnt, 1)))
+    pts = np.concatenate(pts, 0)
+    nrm = np.concatenate(nrm, 0) + g.normal(0.0, 0.05, (num_points, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    inten = g.random((num_points, 1)) * 0.99
+    order = g.permutation(num_points)
+    data = np.concatenate([pts, inten, nrm], 1)[order].T.astype(np.float32)
+    K = np.array([[707.0912, 0.0, 601.8873], [0.0, 707.0912, 183.1104], [0.0, 0.0, 1.0]])
+    return np.ascontiguousarray(data), img, K

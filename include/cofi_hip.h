@@ -364,6 +364,32 @@ int cofi_pnp_ransac(const float *obj, const float *img, const int32_t *count_dev
                     int iterations, float reproj_err, unsigned seed, int refine_iters, void *ws, size_t ws_bytes, float *pose,
                     int32_t *result, uint8_t *inlier_mask, cofi_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Row f2: the data side of one frame on the device, replacing the numpy / open3d / cv2 part of
+ *   kitti_pc_img_dataset.__getitem__                                        (data/kitti.py:259-393)
+ * between the disk read and the model call.  The random draws (choice indices, SE(3), permutations) are made on the host in the
+ * reference's call order (cofii2p_amd/dataside.py: FrameSampler) and handed in as plain arrays; the coarse / fine label
+ * projection works on 1280 points and stays host-side numpy.
+ *   cofi_pack_transform_scan  data7n (7, N) channel-major [xyz | intensity | normal] (the on-disk layout) -> rows8 (N, 8) =
+ *       [T p | intensity | R n | 0], T = 4x4 row-major in device memory (P_cam * Tr, kitti.py:273-277)
+ *   cofi_voxel_downsample     open3d voxel_down_sample(voxel) of points + colours(intensity / max) + normals (kitti.py:145-166):
+ *       voxel index = floor((p - (min_bound - voxel / 2)) / voxel), double-precision means per voxel, out_rows8 (cap, 8) in ascending
+ *       (ix, iy, iz) order (open3d's order is that of an unordered_map: parity with it is unpinned), count_dev[0] = voxels,
+ *       count_dev[1] = 1 if an index overflowed 13 bits.  Stable radix sort + segmented means: bit-reproducible.
+ *   cofi_gather_transform     rows choice[i] (kitti.py:168-180), x' = R x + t, n' = R n (kitti.py:284-288), feats = [intensity | n']
+ *       (kitti.py:293): points (n, 3), feats (n, 4)
+ *   cofi_resize_crop_image    cv2.resize(INTER_LINEAR) of the uint8 HWC image to (dst_h, dst_w) in OpenCV's 11-bit fixed point, crop
+ *       [crop_y, crop_y + H) x [crop_x, crop_x + W), / 255, HWC -> CHW (kitti.py:306-322, 375).  cv2 is absent from this image:
+ *       parity with it is unpinned. */
+int cofi_pack_transform_scan(const float *data7n, int N, const float *P44_dev, float *rows8, cofi_stream_t stream);
+size_t cofi_voxel_downsample_workspace(int N);
+int cofi_voxel_downsample(const float *rows8, int N, double voxel, float *out_rows8, int cap, int32_t *count_dev, void *ws, size_t ws_bytes,
+                          cofi_stream_t stream);
+int cofi_gather_transform(const float *vox_rows, const int32_t *choice, int n, const float *P44_dev, float *points, float *feats,
+                          cofi_stream_t stream);
+int cofi_resize_crop_image(const uint8_t *src_hwc, int src_h, int src_w, int dst_h, int dst_w, int crop_y, int crop_x, int H, int W,
+                           float *out_chw, cofi_stream_t stream);
+
 /* Batched device-to-device copy in one launch: descs_dev = n records {const void *src; void *dst; uint64 bytes} in device
  * memory (e.g. the per-frame inputs -> the static buffers of a captured forward graph); blocks_per_copy workgroups per record. */
 int cofi_multi_copy(const void *descs_dev, int n, int blocks_per_copy, cofi_stream_t stream);
