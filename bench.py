@@ -644,6 +644,55 @@ def main():
                 dte = time.perf_counter() - t0
             result["with_pyramid_build"] = {"frames_per_s": nfr / dte, "ms_per_frame": 1e3 * dte / nfr,
                                             "note": "pyramid construction (KNN) + forward + fine matching per frame on the same GPU; not the headline"}
+    if rank == 0 and world == 1 and Bsz == 1 and not args.no_batch_sweep and not args.eager:
+        # row f2: the whole data side of a frame on this GPU (data/kitti.py:259-393: calibration transform, 0.1 m voxel grid, resample to
+        # num_pc, random SE(3), KNN pyramid, image resize / crop, labels) from a raw 120 000-point scan + 376 x 1241 image already in
+        # HBM, alone and in front of the forward
+        from cofii2p_amd import dataside, synth as _synth
+
+        raw, rimg, rK = _synth.make_raw_scan(0)
+        cal = dataside.calib_matrices(_synth.KITTI_CALIB_LINES)
+        P_Tr = np.dot(cal["P2"], cal["Tr"])
+        raw_d, img_d = torch.from_numpy(raw).to(dev), torch.from_numpy(rimg).to(dev)
+        opt_ds = Opt()
+        for k_, v_ in dict(num_pc=args.points, num_kpt=64, P_tx_amplitude=10, P_ty_amplitude=0, P_tz_amplitude=10, P_Rx_amplitude=0.0, P_Ry_amplitude=2.0 * np.pi, P_Rz_amplitude=0.0).items():
+            setattr(opt_ds, k_, v_)
+        st = make_streams(dev, max(S, 1))
+        preps = [dataside.FramePreparer(opt_ds, dev) for _ in st]
+        for i in range(3):
+            preps[0].prepare(raw_d, img_d, rK, P_Tr, i)
+        torch.cuda.synchronize()
+        nl = 20
+        t0 = time.perf_counter()
+        for i in range(nl):
+            preps[0].prepare(raw_d, img_d, rK, P_Tr, i)
+        torch.cuda.synchronize()
+        loader_ms = 1e3 * (time.perf_counter() - t0) / nl
+        model.enable_graphs(True)
+        NSL = len(st) * max(1, args.slots_per_stream)
+        pend = [None] * NSL
+        for phase in range(2):
+            nfr = max(args.steps, 3 * NSL)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(nfr):
+                sl = i % NSL
+                if pend[sl] is not None:
+                    model.finish(pend[sl])
+                with torch.cuda.stream(st[i % len(st)]):
+                    smp = preps[i % len(st)].prepare(raw_d, img_d, rK, P_Tr, i)
+                    pend[sl] = model.forward_async(60 + sl, smp["pc_data_dict"], smp["img"][None])
+            for sl in range(NSL):
+                if pend[sl] is not None:
+                    model.finish(pend[sl])
+                    pend[sl] = None
+            torch.cuda.synchronize()
+            dtl = time.perf_counter() - t0
+        result["with_dataside"] = {"loader_ms_per_frame": loader_ms, "loader_frames_per_s": 1e3 / loader_ms, "frames_per_s": nfr / dtl,
+                                   "ms_per_frame": 1e3 * dtl / nfr, "voxels": preps[0].last["voxels"], "raw_points": int(raw.shape[1]),
+                                   "note": "kitti.py:259-393 on the device (voxel grid + resample + SE(3) + KNN pyramid + image + labels) in front of the "
+                                           "forward + fine matching; raw scan and image resident in HBM; two host syncs per frame (voxel count, coarse "
+                                           "points for the labels); not the headline"}
     if rank == 0 and world == 1 and Bsz == 1 and not args.eager and not args.no_batch_sweep and not args.stress:
         result["stress_config"] = stress_summary(dev, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

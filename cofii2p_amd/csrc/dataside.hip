@@ -7,18 +7,26 @@
 // host-side numpy, exactly as the reference writes it (cofii2p_amd/dataside.py).
 //
 // Voxel grid: every point gets the key of its voxel (open3d: index = floor((p - (min_bound - voxel/2)) / voxel) per axis), the
-// (key, point index) pairs go through a STABLE least-significant-digit radix sort (4-bit digits; one workgroup, every thread owns a
-// contiguous chunk, so equal keys keep their original order), and one thread per voxel averages its run in that order with fp64
-// accumulators (open3d accumulates in double): bit-reproducible, no float atomics, no hash table.  Output order = ascending key
-// (open3d's is the iteration order of an unordered_map: unspecified, parity with it is unpinned).
-// These are HBM / latency-bound integer and streaming kernels on ~120 000 points: no MFMA anywhere.
+// (key, point index) pairs go through a STABLE least-significant-digit radix sort (8-bit digits, 5 passes over the 39-bit key), and
+// one thread per voxel averages its run in sorted = original order with fp64 accumulators (open3d accumulates in double):
+// bit-reproducible, no float atomics, no hash table.  Output order = ascending key (open3d's is the iteration order of an
+// unordered_map: unspecified, parity with it is unpinned).
+// A sort pass = three launches.  The input is cut into SORT_TILES contiguous tiles, ONE WAVE per tile:
+//   histogram  digit counts per tile -> table [digit][tile]
+//   scan       one wave per digit: exclusive scan over the tiles + the digit's total
+//   scatter    every workgroup scans the 256 digit totals itself, a wave then walks its tile 64 keys at a time IN ORDER: lanes holding
+//              the same digit find each other with 8 ballots, take consecutive slots after the digit's running offset (an LDS counter
+//              private to the wave) - stable by construction, no atomics.
+// These are latency / HBM-bound integer and streaming kernels on ~120 000 points: no MFMA anywhere.
 #include "common.h"
 
 namespace {
 
-constexpr int SORT_T = 1024;      // threads of the sorting workgroup
 constexpr int KEY_BITS = 13;      // voxel index bits per axis (8192 voxels of 0.1 m = 819 m)
-constexpr int KEY_TOTAL = 3 * KEY_BITS;
+constexpr int SORT_PASSES = 5;    // 8-bit digits over 3 * KEY_BITS = 39 bits
+constexpr int SORT_TILES = 512;   // one wave each; 4 waves per workgroup
+constexpr int SORT_WPB = 4;
+constexpr int RED_T = 1024;       // threads of the reduction / head-scan workgroups
 
 struct VoxHeader {
     double minb[3];  // min_bound - voxel / 2 (open3d keeps it in double)
@@ -27,14 +35,15 @@ struct VoxHeader {
     int overflow;    // a voxel index did not fit KEY_BITS
 };
 
-// bounding box minimum + intensity maximum: one workgroup, fixed-order fold
-__global__ __launch_bounds__(1024) void vox_bounds_kernel(const float *pts, int ldp, const float *inten, int ldi, int N, double voxel, VoxHeader *hdr) {
-    __shared__ float red[4][16];
+// bounding box minimum + intensity maximum of one RED_T-row chunk -> part[block] = {min x, min y, min z, max intensity}
+__global__ __launch_bounds__(RED_T) void vox_bounds_kernel(const float *pts, int ldp, const float *inten, int ldi, int N, float *part) {
+    __shared__ float red[4][RED_T / 64];
+    const int i = blockIdx.x * RED_T + threadIdx.x;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx = -INFINITY;
-    for (int i = threadIdx.x; i < N; i += 1024) {
+    if (i < N) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) mn[a] = fminf(mn[a], pts[(size_t)i * ldp + a]);
-        mx = fmaxf(mx, inten[(size_t)i * ldi]);
+        for (int a = 0; a < 3; ++a) mn[a] = pts[(size_t)i * ldp + a];
+        mx = inten[(size_t)i * ldi];
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -45,27 +54,47 @@ __global__ __launch_bounds__(1024) void vox_bounds_kernel(const float *pts, int 
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[0][w] = mn[0]; red[1][w] = mn[1]; red[2][w] = mn[2]; red[3][w] = mx; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < 16; ++k) {
-            for (int a = 0; a < 3; ++a) red[a][0] = fminf(red[a][0], red[a][k]);
-            red[3][0] = fmaxf(red[3][0], red[3][k]);
-        }
-        // open3d: voxel_min_bound = min_bound - voxel_size * 0.5 (computed in double from the float coordinates)
-        for (int a = 0; a < 3; ++a) hdr->minb[a] = (double)red[a][0] - voxel * 0.5;
-        hdr->imax = red[3][0];
-        hdr->nvox = 0;
-        hdr->overflow = 0;
+    if (threadIdx.x < 4) {
+        float v = red[threadIdx.x][0];
+        for (int k = 1; k < RED_T / 64; ++k) v = threadIdx.x < 3 ? fminf(v, red[threadIdx.x][k]) : fmaxf(v, red[threadIdx.x][k]);
+        part[4 * blockIdx.x + threadIdx.x] = v;
     }
 }
 
-__global__ void vox_keys_kernel(const float *pts, int ldp, int N, double voxel, VoxHeader *hdr, unsigned long long *keys, int *idx) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// every workgroup folds the chunk partials itself (min / max: order-free), then keys its 256 points; block 0 publishes the header
+__global__ __launch_bounds__(256) void vox_keys_kernel(const float *pts, int ldp, int N, double voxel, const float *part, int nchunk, VoxHeader *hdr,
+                                                      unsigned long long *keys, int *idx) {
+    __shared__ float red[4][4];
+    __shared__ double s_minb[3];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx = -INFINITY;
+    for (int c = threadIdx.x; c < nchunk; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(part + 4 * c);
+        mn[0] = fminf(mn[0], v[0]); mn[1] = fminf(mn[1], v[1]); mn[2] = fminf(mn[2], v[2]); mx = fmaxf(mx, v[3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = mn[0]; red[1][w] = mn[1]; red[2][w] = mn[2]; red[3][w] = mx; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        const float m = fminf(fminf(red[a][0], red[a][1]), fminf(red[a][2], red[a][3]));
+        s_minb[a] = (double)m - voxel * 0.5;   // open3d: voxel_min_bound = min_bound - voxel_size * 0.5, in double
+        if (blockIdx.x == 0) hdr->minb[a] = s_minb[a];
+    }
+    if (threadIdx.x == 3 && blockIdx.x == 0) hdr->imax = fmaxf(fmaxf(red[3][0], red[3][1]), fmaxf(red[3][2], red[3][3]));
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     unsigned long long key = 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         // open3d: floor((point - voxel_min_bound) / voxel_size) in double
-        const double r = ((double)pts[(size_t)i * ldp + a] - hdr->minb[a]) / voxel;
+        const double r = ((double)pts[(size_t)i * ldp + a] - s_minb[a]) / voxel;
         long long v = (long long)floor(r);
         if (v < 0 || v >= (1 << KEY_BITS)) { hdr->overflow = 1; v = v < 0 ? 0 : (1 << KEY_BITS) - 1; }
         key = (key << KEY_BITS) | (unsigned long long)v;
@@ -74,86 +103,134 @@ __global__ void vox_keys_kernel(const float *pts, int ldp, int N, double voxel, 
     idx[i] = i;
 }
 
-// One pass of the stable LSD radix sort (4-bit digit at `shift`): thread t owns elements [t*chunk, (t+1)*chunk); per-thread digit
-// counts -> LDS table [digit][thread] -> exclusive scan in that (digit-major) order = every thread's first output slot per digit.
-__global__ __launch_bounds__(SORT_T) void vox_sort_pass_kernel(const unsigned long long *kin, const int *vin, unsigned long long *kout, int *vout,
-                                                              int N, int shift) {
-    __shared__ int tab[16 * SORT_T];
-    __shared__ int wsum[SORT_T / 64];
-    const int t = threadIdx.x;
-    const int chunk = (N + SORT_T - 1) / SORT_T;
-    const int b = min(N, t * chunk), e = min(N, b + chunk);
-    int cnt[16];
+// ---- one radix pass ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * SORT_WPB) void sort_hist_kernel(const unsigned long long *kin, int N, int shift, int tile, int *hist) {
+    __shared__ int cnt[SORT_WPB][256];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * SORT_WPB + wv;
+    for (int d = lane; d < 256; d += 64) cnt[wv][d] = 0;
+    const int b = min(N, t * tile), e = min(N, b + tile);
+    for (int i = b + lane; i < e; i += 64) atomicAdd(&cnt[wv][(int)((kin[i] >> shift) & 255)], 1);   // LDS integer add: order-free
+    for (int d = lane; d < 256; d += 64) hist[d * SORT_TILES + t] = cnt[wv][d];
+}
+
+// wave per digit: hist[d][*] -> exclusive offsets inside the digit, tot[d] = the digit's count
+__global__ __launch_bounds__(256) void sort_scan_kernel(int *hist, int *tot) {
+    const int d = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int carry = 0;
+    for (int t0 = 0; t0 < SORT_TILES; t0 += 64) {
+        const int v = hist[d * SORT_TILES + t0 + lane];
+        int incl = v;
 #pragma unroll
-    for (int d = 0; d < 16; ++d) cnt[d] = 0;
-    for (int i = b; i < e; ++i) {
-        const int d = (int)((kin[i] >> shift) & 15);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) cnt[q] += (q == d);
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += u;
+        }
+        hist[d * SORT_TILES + t0 + lane] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
     }
+    if (lane == 0) tot[d] = carry;
+}
+
+__global__ __launch_bounds__(64 * SORT_WPB) void sort_scatter_kernel(const unsigned long long *kin, const int *vin, unsigned long long *kout, int *vout,
+                                                                    int N, int shift, int tile, const int *hist, const int *tot) {
+    __shared__ int cnt[SORT_WPB][256];
+    __shared__ int dbase[256];
+    __shared__ int wsum[SORT_WPB];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * SORT_WPB + wv;
+    {   // exclusive scan of the 256 digit totals (threads = digits)
+        const int v = tot[threadIdx.x];
+        int incl = v;
 #pragma unroll
-    for (int d = 0; d < 16; ++d) tab[d * SORT_T + t] = cnt[d];
-    __syncthreads();
-    // exclusive scan of the 16 * SORT_T table: thread t scans entries [16 t, 16 t + 16), wave + workgroup offsets on top
-    int loc[16], s = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { loc[k] = s; s += tab[16 * t + k]; }
-    int incl = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if ((t & 63) >= o) incl += v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += u;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int off = 0;
+        for (int w = 0; w < wv; ++w) off += wsum[w];
+        dbase[threadIdx.x] = off + incl - v;
+        __syncthreads();
     }
-    if ((t & 63) == 63) wsum[t >> 6] = incl;
-    __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < (t >> 6); ++w) woff += wsum[w];
-    const int base = woff + incl - s;
-    __syncthreads();
+    for (int d = lane; d < 256; d += 64) cnt[wv][d] = dbase[d] + hist[d * SORT_TILES + t];
+    const int b = min(N, t * tile), e = min(N, b + tile);
+    for (int i0 = b; i0 < e; i0 += 64) {
+        const int i = i0 + lane;
+        const bool valid = i < e;
+        const unsigned long long key = valid ? kin[i] : 0ull;
+        const int val = valid ? vin[i] : 0;
+        const int d = (int)((key >> shift) & 255);
+        unsigned long long peers = __ballot(valid);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) tab[16 * t + k] = base + loc[k];
-    __syncthreads();
-    int pos[16];
-#pragma unroll
-    for (int d = 0; d < 16; ++d) pos[d] = tab[d * SORT_T + t];
-    for (int i = b; i < e; ++i) {
-        const unsigned long long k = kin[i];
-        const int d = (int)((k >> shift) & 15);
-        int p = 0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-            if (q == d) p = pos[q]++;
-        kout[p] = k;
-        vout[p] = vin[i];
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool on = (d >> bit) & 1;
+            const unsigned long long bm = __ballot(on);
+            peers &= on ? bm : ~bm;
+        }
+        const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+        const int base = cnt[wv][d];            // every lane of a digit reads the same running offset ...
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            kout[base + rank] = key;
+            vout[base + rank] = val;
+            if (rank == 0) cnt[wv][d] = base + __popcll(peers);   // ... and its first lane advances it (one wave: program order)
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
-// segment heads of the sorted keys -> voxel ids (exclusive scan by one workgroup), then one thread per voxel averages its run
-__global__ __launch_bounds__(SORT_T) void vox_heads_kernel(const unsigned long long *keys, int N, int *head_pos, VoxHeader *hdr, int32_t *count_dev) {
-    __shared__ int wsum[SORT_T / 64];
-    __shared__ int carry;
-    const int t = threadIdx.x;
-    if (t == 0) carry = 0;
+// ---- segment heads of the sorted keys -> voxel ids ------------------------------------------------------------------------------
+__global__ __launch_bounds__(RED_T) void vox_head_count_kernel(const unsigned long long *keys, int N, int *chunk_heads) {
+    __shared__ int red[RED_T / 64];
+    const int i = blockIdx.x * RED_T + threadIdx.x;
+    const int h = (i < N && (i == 0 || keys[i] != keys[i - 1])) ? 1 : 0;
+    const int c = __popcll(__ballot(h));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
     __syncthreads();
-    for (int i0 = 0; i0 < N; i0 += SORT_T) {
-        const int i = i0 + t;
-        const int h = (i < N && (i == 0 || keys[i] != keys[i - 1])) ? 1 : 0;
-        int incl = h;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o, 64);
-            if ((t & 63) >= o) incl += v;
-        }
-        if ((t & 63) == 63) wsum[t >> 6] = incl;
-        __syncthreads();
-        int woff = carry;
-        for (int w = 0; w < (t >> 6); ++w) woff += wsum[w];
-        if (h) head_pos[woff + incl - 1] = i;   // voxel id -> first sorted position
-        __syncthreads();
-        if (t == SORT_T - 1) carry = woff + incl;
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int k = 0; k < RED_T / 64; ++k) s += red[k];
+        chunk_heads[blockIdx.x] = s;
     }
-    if (t == 0) { hdr->nvox = carry; count_dev[0] = carry; count_dev[1] = hdr->overflow; }
+}
+
+__global__ __launch_bounds__(RED_T) void vox_head_write_kernel(const unsigned long long *keys, int N, const int *chunk_heads, int nchunk, int *head_pos,
+                                                              VoxHeader *hdr, int32_t *count_dev) {
+    __shared__ int red[RED_T / 64];
+    __shared__ int s_before;
+    // heads in the chunks before this one (and, for the last chunk, the total)
+    int part = 0;
+    for (int c = threadIdx.x; c < (int)blockIdx.x; c += RED_T) part += chunk_heads[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int k = 0; k < RED_T / 64; ++k) s += red[k];
+        s_before = s;
+    }
+    __syncthreads();
+    const int before = s_before;
+    __syncthreads();
+    const int i = blockIdx.x * RED_T + threadIdx.x;
+    const int h = (i < N && (i == 0 || keys[i] != keys[i - 1])) ? 1 : 0;
+    const unsigned long long bal = __ballot(h);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) red[w] = __popcll(bal);
+    __syncthreads();
+    int woff = before;
+    for (int k = 0; k < w; ++k) woff += red[k];
+    if (h) head_pos[woff + __popcll(bal & ((1ull << lane) - 1ull))] = i;   // voxel id -> first sorted position
+    if ((int)blockIdx.x == nchunk - 1 && threadIdx.x == 0) {
+        int total = before;
+        for (int k = 0; k < RED_T / 64; ++k) total += red[k];
+        hdr->nvox = total;
+        count_dev[0] = total;
+        count_dev[1] = hdr->overflow;
+    }
 }
 
 // out row v = [mean xyz | mean(intensity / imax) * imax | mean normal], 8 floats (last one 0)
@@ -260,10 +337,14 @@ __global__ void resize_crop_kernel(const uint8_t *src, int sh, int sw, int dh, i
 
 }  // namespace
 
+static inline size_t vox_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
 extern "C" size_t cofi_voxel_downsample_workspace(int N) {
     if (N <= 0) return 0;
-    // header | keys A, B (8 N each) | idx A, B (4 N each) | head positions (4 N)
-    return 256 + (size_t)N * (8 + 8 + 4 + 4 + 4) + 64;
+    // header | chunk partials (bounds: 4 floats, heads: 1 int per 1024 rows) | histogram table + digit totals | keys A, B | idx A, B | heads
+    const size_t nchunk = (size_t)cofi_cdiv(N, RED_T);
+    return 256 + vox_align(nchunk * 16) + vox_align(nchunk * 4) + vox_align((size_t)(256 * SORT_TILES + 256) * 4) + 2 * vox_align((size_t)N * 8) +
+           3 * vox_align((size_t)N * 4);
 }
 
 extern "C" int cofi_pack_transform_scan(const float *data7n, int N, const float *P44_dev, float *rows8, cofi_stream_t stream) {
@@ -279,22 +360,34 @@ extern "C" int cofi_voxel_downsample(const float *rows8, int N, double voxel, fl
     hipStream_t s = cofi_s(stream);
     const float *points = rows8, *intensity = rows8 + 3, *normals = rows8 + 4;
     const int ldp = 8, ldi = 8, ldn = 8;
+    const int nchunk = cofi_cdiv(N, RED_T);
     char *w = (char *)ws;
-    VoxHeader *hdr = (VoxHeader *)w;
-    unsigned long long *kA = (unsigned long long *)(w + 256), *kB = kA + N;
-    int *vA = (int *)(kB + N), *vB = vA + N, *heads = vB + N;
-    hipLaunchKernelGGL(vox_bounds_kernel, dim3(1), dim3(1024), 0, s, points, ldp, intensity, ldi, N, voxel, hdr);
-    hipLaunchKernelGGL(vox_keys_kernel, dim3(cofi_cdiv(N, 256)), dim3(256), 0, s, points, ldp, N, voxel, hdr, kA, vA);
-    for (int shift = 0; shift < KEY_TOTAL; shift += 4) {   // 10 passes: an even count, the result is back in buffer A
-        hipLaunchKernelGGL(vox_sort_pass_kernel, dim3(1), dim3(SORT_T), 0, s, kA, vA, kB, vB, N, shift);
+    VoxHeader *hdr = (VoxHeader *)w; w += 256;
+    float *bpart = (float *)w; w += vox_align((size_t)nchunk * 16);
+    int *hpart = (int *)w; w += vox_align((size_t)nchunk * 4);
+    int *hist = (int *)w, *tot = hist + 256 * SORT_TILES; w += vox_align((size_t)(256 * SORT_TILES + 256) * 4);
+    unsigned long long *kA = (unsigned long long *)w; w += vox_align((size_t)N * 8);
+    unsigned long long *kB = (unsigned long long *)w; w += vox_align((size_t)N * 8);
+    int *vA = (int *)w; w += vox_align((size_t)N * 4);
+    int *vB = (int *)w; w += vox_align((size_t)N * 4);
+    int *heads = (int *)w;
+    (void)hipMemsetAsync(hdr, 0, sizeof(VoxHeader), s);
+    hipLaunchKernelGGL(vox_bounds_kernel, dim3(nchunk), dim3(RED_T), 0, s, points, ldp, intensity, ldi, N, bpart);
+    hipLaunchKernelGGL(vox_keys_kernel, dim3(cofi_cdiv(N, 256)), dim3(256), 0, s, points, ldp, N, voxel, bpart, nchunk, hdr, kA, vA);
+    const int tile = cofi_cdiv(N, SORT_TILES);
+    for (int pass = 0; pass < SORT_PASSES; ++pass) {
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(SORT_TILES / SORT_WPB), dim3(64 * SORT_WPB), 0, s, kA, N, 8 * pass, tile, hist);
+        hipLaunchKernelGGL(sort_scan_kernel, dim3(64), dim3(256), 0, s, hist, tot);
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(SORT_TILES / SORT_WPB), dim3(64 * SORT_WPB), 0, s, kA, vA, kB, vB, N, 8 * pass, tile, hist, tot);
         unsigned long long *tk = kA; kA = kB; kB = tk;
         int *tv = vA; vA = vB; vB = tv;
     }
-    hipLaunchKernelGGL(vox_heads_kernel, dim3(1), dim3(SORT_T), 0, s, kA, N, heads, hdr, count_dev);
+    hipLaunchKernelGGL(vox_head_count_kernel, dim3(nchunk), dim3(RED_T), 0, s, kA, N, hpart);
+    hipLaunchKernelGGL(vox_head_write_kernel, dim3(nchunk), dim3(RED_T), 0, s, kA, N, hpart, nchunk, heads, hdr, count_dev);
     hipLaunchKernelGGL(vox_mean_kernel, dim3(cofi_cdiv(N, 256)), dim3(256), 0, s, points, ldp, intensity, ldi, normals, ldn, vA, heads, hdr, N, cap,
                        out_rows8);
     // count_dev[0] = voxels (may exceed cap: only the first cap rows were written), count_dev[1] = 1 if a voxel index overflowed the
-    // 13-bit key field (coordinates spread over more than 819 m at this voxel size)
+    // 13-bit key field (coordinates spread over more than 819 m at this voxel size) - written by the last head-scan workgroup
     return cofi_launch_status();
 }
 
