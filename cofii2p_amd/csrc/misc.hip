@@ -19,10 +19,16 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(const CopyDesc *descs) 
     const uint4 *s4 = reinterpret_cast<const uint4 *>(d.src);
     uint4 *d4 = reinterpret_cast<uint4 *>(d.dst);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) d4[i] = s4[i];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // four independent 16-byte loads in flight per lane: the 10 MB neighbour table of a frame is latency-bound otherwise
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 v0 = s4[i], v1 = s4[i + stride], v2 = s4[i + 2 * stride], v3 = s4[i + 3 * stride];
+        d4[i] = v0; d4[i + stride] = v1; d4[i + 2 * stride] = v2; d4[i + 3 * stride] = v3;
+    }
+    for (; i < n16; i += stride) d4[i] = s4[i];
     const unsigned char *sb = reinterpret_cast<const unsigned char *>(d.src);
     unsigned char *db = reinterpret_cast<unsigned char *>(d.dst);
-    for (size_t i = n16 * 16 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.bytes; i += stride) db[i] = sb[i];
+    for (size_t b = n16 * 16 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < d.bytes; b += stride) db[b] = sb[b];
 }
 }  // namespace
 

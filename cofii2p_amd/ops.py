@@ -705,6 +705,9 @@ def loftr_tail(msg, x, w, out, eps: float = 1e-5):
     return out
 
 
+MULTI_COPY_BLOCKS = int(os.environ.get("COFI_COPY_BLOCKS", "64"))   # workgroups per record (the largest record of a frame is ~10 MB)
+
+
 class MultiCopy:
     """One-launch copy of a list of (src -> dst) tensor pairs (cofi_multi_copy).  The descriptor table of an address set is
     built once (pinned host buffer -> device) and cached: a stream of frames that recycles its buffers pays one kernel launch."""
@@ -731,7 +734,7 @@ class MultiCopy:
             if len(self.tables) >= self.MAX_TABLES:
                 self.tables.pop(next(iter(self.tables)))
             self.tables[key] = table
-        _lib.check(lib.cofi_multi_copy(_p(table), len(pairs), 64, _stream()), "cofi_multi_copy")
+        _lib.check(lib.cofi_multi_copy(_p(table), len(pairs), MULTI_COPY_BLOCKS, _stream()), "cofi_multi_copy")
 
 
 # ------------------------------------------------------------------------------------------ KNN / indices

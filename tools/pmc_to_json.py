@@ -1,5 +1,6 @@
 #!/usr/bin/env python
 """profiles/<tag>_fetch_pmc.md + <tag>_write_pmc.md (tools/rocpd_pmc_summary.py tables) -> profiles/pmc_traffic.json.
+    python tools/pmc_to_json.py FETCH.md WRITE.md <submissions | auto> [commit stamp] [attention launches per submission]
 Kernel families: gemm = every gemm_*kernel + splitk epilogues (the launches behind cofi_gemm_f32* / cofi_conv2d_nhwc),
 attention, kpconv_aggregate, neighbor_maxpool, group_norm_apply.
 HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in KB and on gfx950 FETCH_SIZE counts
@@ -10,7 +11,7 @@ import sys
 
 FAMILIES = {"gemm": ("gemm_kernel", "gemm_bf16x3_kernel", "splitk_epilogue"), "attention": ("attention_flat_kernel", "attention_fwd_kernel"),
             "kpconv_aggregate": ("kpconv_aggregate_kernel",), "neighbor_maxpool": ("neighbor_maxpool_kernel",),
-            "group_norm_apply": ("group_norm_apply_kernel",)}
+            "group_norm_apply": ("group_norm_apply",), "loftr_tail": ("loftr_tail_kernel",)}
 
 
 def parse(path, counter):
@@ -23,8 +24,13 @@ def parse(path, counter):
 
 
 def main():
-    fetch, write, frames, launches_main = parse(sys.argv[1], "FETCH_SIZE"), parse(sys.argv[2], "WRITE_SIZE"), int(sys.argv[3]), None
-    res = {}
+    fetch, write = parse(sys.argv[1], "FETCH_SIZE"), parse(sys.argv[2], "WRITE_SIZE")
+    if sys.argv[3] == "auto":   # 12 attention launches per submission (4 self layers x 1 joint or 2, 4 cross x 2: transformer.py)
+        per = int(sys.argv[5]) if len(sys.argv) > 5 else 12
+        frames = sum(v[0] for k, v in fetch.items() if "attention_flat_kernel" in k) // per
+    else:
+        frames = int(sys.argv[3])
+    res = {"collected_on": sys.argv[4] if len(sys.argv) > 4 else "unknown"}
     for fam, pats in FAMILIES.items():
         f = sum(v[1] for k, v in fetch.items() if any(p in k for p in pats))
         w = sum(v[1] for k, v in write.items() if any(p in k for p in pats))
