@@ -19,7 +19,7 @@ _P, _I, _F, _Z = c_void_p, c_int, c_float, c_size_t
 class NormDesc(ctypes.Structure):
     """cofi_norm_desc_t (include/cofi_hip.h): a pending GroupNorm / InstanceNorm described by its statistics partials."""
     _fields_ = [("partials", c_void_p), ("nslab", c_int), ("width", c_int), ("channels", c_int), ("groups", c_int),
-                ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("slope", c_float), ("scale_shift", c_void_p)]
+                ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("slope", c_float), ("scale_shift", c_void_p), ("slab_rows", c_int)]
 
 
 _N = ctypes.POINTER(NormDesc)
@@ -81,6 +81,8 @@ SIGNATURES = {
     "cofi_pnp_ransac_workspace": (_Z, [_I]),
     "cofi_pnp_ransac": (_I, [_P, _P, _P, _I, _F, _F, _F, _F, _I, _F, ctypes.c_uint, _I, _P, _Z, _P, _P, _P, _P]),
     "cofi_fine_match": (_I, [_P, _P, _I, _I, _P, _I, _F, _P, _I, _P, _P, _P]),
+    "cofi_kpconv_fused_slab_rows": (_I, [_I, _I, _I]),
+    "cofi_kpconv_fused": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _F, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P, _P]),
     "cofi_pack_transform_scan": (_I, [_P, _I, _P, _P, _P]),
     "cofi_voxel_downsample_workspace": (_Z, [_I]),
     "cofi_voxel_downsample": (_I, [_P, _I, ctypes.c_double, _P, _I, _P, _P, _Z, _P]),

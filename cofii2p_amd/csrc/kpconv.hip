@@ -11,7 +11,9 @@
 //     bytes of one row, so the gather is served in coalesced 64-B segments from L2.
 // Nothing is staged through LDS and the (M,H,15) influence tensor / (M,H,C) gather of the reference
 // never exist in memory.  Channel passes of 16*NACC channels go over gridDim.y.
+#include "bf16_split.h"
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -46,7 +48,7 @@ struct KpArgs {
 // per (step, channel chunk).  Everything else a step needs - the neighbour's offset from the query, its validity, its
 // row id - is staged per 64 neighbours with coalesced/gather loads by lane = neighbour, parked in a wave-private LDS
 // record, and fetched back per step with one broadcast ds_read_b128 (4 distinct addresses per wave).
-constexpr int KP_PHASE = 128;  // neighbour records staged per wave and phase (H <= 128: one phase)
+constexpr int KP_PHASE_DEFAULT = 128;  // neighbour records staged per wave and phase (H <= 128: one phase)
 constexpr int KP_PAD = 32;     // shadow records behind the phase: the pipeline's look-ahead (<= 7 steps) reads them
 
 template <int VEC, int NCH>
@@ -54,16 +56,14 @@ struct KpFeat {
     float f[NCH][VEC];
 };
 
-template <int VEC, int NCH>
-__global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
-    __shared__ float4 rec_s[4][KP_PHASE + KP_PAD];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    // the query id is wave-uniform: keep it (and everything derived from it) in scalar registers
-    int m = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + wv);
-    if (m >= a.M) return;
-    if (a.order) m = (m / a.Mpf) * a.Mpf + a.order[m];
+// The aggregation of ONE query m by one wave (see the file header): acc[ch][v] = MFMA accumulators (rows = kernel points,
+// column j = channel c0 + ch*16*VEC + VEC*j + v), npos = neighbours whose feature row sums to > 0 (kpconv.py:113-114).
+// rec = the wave's private LDS record buffer (PHASE + KP_PAD entries); a is a private copy (frame shift).
+template <int VEC, int NCH, int PHASE>
+__device__ __forceinline__ void kp_aggregate_query(KpArgs a, const int m, const int c0, float4 *rec, f32x4 (&acc)[NCH][VEC], int &npos) {
+    constexpr int KP_PHASE = PHASE;
+    const int lane = threadIdx.x & 63;
     const int j = lane & 15, g = lane >> 4;
-    const int c0 = blockIdx.y * (16 * VEC * NCH);
     {   // stack mode: shift the support-side bases to this query's frame (indices are frame-local)
         const size_t fo = (size_t)(m / a.Mpf) * a.N;
         a.feats += fo * a.ldf;
@@ -74,12 +74,11 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
     // MFMA row 15 (lane j == 15) is a padding row that is never stored: it may hold any finite weight
     const int jk = j < 15 ? j : 0;
     const float kx = a.kp[3 * jk], ky = a.kp[3 * jk + 1], kz = a.kp[3 * jk + 2];
-    f32x4 acc[NCH][VEC];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[ch][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int npos = 0;
+    npos = 0;
     const int32_t *irow = a.idx + (size_t)m * a.H;
     // per-lane channel byte offsets, clamped so that every load is unconditional (branch-free inner loop).  A lane whose
     // channels are out of range multiplies whatever it loaded into MFMA columns that are never stored; a shadow neighbour
@@ -92,7 +91,6 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
     }
     const char *fbase = reinterpret_cast<const char *>(a.feats);
     const unsigned ldfb = 4u * a.ldf;
-    float4 *rec = rec_s[wv];
     if (lane < KP_PAD) rec[KP_PHASE + lane] = make_float4(1e18f, 0.f, 0.f, __int_as_float(0));  // look-ahead lands here
     const float inv_sigma = 1.0f / a.sigma;
 
@@ -176,6 +174,21 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+template <int VEC, int NCH>
+__global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
+    __shared__ float4 rec_s[4][KP_PHASE_DEFAULT + KP_PAD];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // the query id is wave-uniform: keep it (and everything derived from it) in scalar registers
+    int m = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + wv);
+    if (m >= a.M) return;
+    if (a.order) m = (m / a.Mpf) * a.Mpf + a.order[m];
+    const int j = lane & 15, g = lane >> 4;
+    const int c0 = blockIdx.y * (16 * VEC * NCH);
+    f32x4 acc[NCH][VEC];
+    int npos;
+    kp_aggregate_query<VEC, NCH, KP_PHASE_DEFAULT>(a, m, c0, rec_s[wv], acc, npos);
     // D layout 16x16: row (kernel point) = 4*g + r, col = j  ->  channels c .. c+VEC-1 contiguous
     float *orow = a.agg + (size_t)m * a.ld_agg;
 #pragma unroll
@@ -198,6 +211,176 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
         }
     }
     if (blockIdx.y == 0 && lane == 0) a.cnt[m] = (float)(npos > 1 ? npos : 1);
+}
+
+// ---- KPConv as ONE kernel for the narrow layers (mid = 32 / 64 channels: the stages with 20 480 ... 5 120 queries) ----------------
+// kpconv.py:91-116 end to end:  y[m] = (sum_k agg[m, k, :] W[k]) / max(#neighbours with positive feature sum, 1) + bias,
+// plus the GroupNorm statistics partials of y.  The (M, 15 mid) aggregate - 39 MB per layer at these stages, written and read back
+// by the two-kernel form - never leaves the CU:
+//   a workgroup (8 waves) owns `qt` queries (= one statistics slab: 64 / 32 / 16 rows, so that a layer is >= 256 workgroups) and
+//   works through them 16 at a time: every wave aggregates two queries exactly as kpconv_aggregate_kernel does and leaves their
+//   (15 x mid) results as bf16 hi / lo planes in an LDS tile (16 x 15 mid); then the 8 waves multiply the tile with W
+//   (pre-split bf16 planes streamed from L2, 3-term split on v_mfma_f32_16x16x32_bf16): wave = (16-column tile, K range), partial
+//   tiles summed through LDS in a fixed order; epilogue: / count, + bias, store, column sums for the statistics.
+// LDS 75 KB (mid 64, records staged 64 neighbours at a time) / 52 KB (mid 32): two workgroups per CU; the gather phase is
+// bound by the texture-address unit, not by occupancy (measured: 16 waves per CU run it as fast as 28).
+// MEASURED on MI355X (KITTI frame, us per launch, fused vs aggregate + GEMM): mid 32, 20 480 queries 58-91 vs ~65; mid 64, 10 240
+// queries 63-87 vs ~52; whole forward 490 vs 503 frames/s.  A workgroup alternates between a gather phase (texture unit busy,
+// matrix cores idle) and a GEMM phase (the opposite) with barriers in between, and 320-1280 such workgroups quantise badly on 256 CUs
+// x 2 slots, while the two-kernel form spreads 20 480 independent one-wave queries evenly and its GEMM runs at full occupancy.  Kept
+// as an opt-in (COFI_KPCONV_FUSED=1 in cofii2p_amd/kpfpn.py): it removes 2 x 39 MB of fabric traffic per layer, which matters once
+// the frame is bandwidth-bound; not the default.
+struct KpFusedArgs {
+    KpArgs a;                       // agg / cnt / ld_agg unused
+    const uint16_t *w_hi, *w_lo;    // bf16 planes of W, (mid rows, ldw), K index = kernel point * mid + channel
+    int ldw;
+    const float *bias;
+    float *y;
+    int ldy;
+    float *colpart;                 // (M / qt, mid >> stat_shift, 2) or nullptr
+    int stat_shift;
+    int qt;                         // queries per workgroup = rows per statistics slab: 16, 32 or 64
+};
+
+template <int MID, int PHASE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void kpconv_fused_kernel(KpFusedArgs fa) {   // two workgroups per CU
+
+    constexpr int VEC = MID / 16, K = 15 * MID, KLD = K + 8, NT = MID / 16, KQ = 8 / NT, KSTEPS = K / 32;
+    constexpr int REC = PHASE + KP_PAD;
+    constexpr int RG = 512 / MID;   // epilogue: thread = (column, row group); row groups
+    constexpr int RPT = 16 / RG;    // rows per thread and 16-query step
+    constexpr int PF = 4;           // k-steps of W fragments in flight per wave
+    static_assert(REC * 16 >= 256 * 4, "the partial tiles alias the record buffers");
+    __shared__ float4 rec_s[8][REC];
+    __shared__ __attribute__((aligned(16))) uint16_t t_hi[16 * KLD];
+    __shared__ __attribute__((aligned(16))) uint16_t t_lo[16 * KLD];
+    __shared__ float cnt_s[16];
+    __shared__ int m_s[16];
+    float *part_s = reinterpret_cast<float *>(&rec_s[0][0]);   // [8][256]; live only inside the GEMM phase / the final fold
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int en = tid % MID, erg = tid / MID;
+    const float bias_n = fa.bias ? fa.bias[en] : 0.f;
+    float cs = 0.f, cq = 0.f;
+    // GEMM-phase role of this wave
+    const int nt = wv % NT, kq = wv / NT;
+    const int ks0 = kq * KSTEPS / KQ, ks1 = (kq + 1) * KSTEPS / KQ;
+    const uint16_t *wh = fa.w_hi + (size_t)(nt * 16 + j) * fa.ldw + g * 8;
+    const uint16_t *wl = fa.w_lo + (size_t)(nt * 16 + j) * fa.ldw + g * 8;
+    const uint16_t *ah = t_hi + j * KLD + g * 8, *al = t_lo + j * KLD + g * 8;
+
+    for (int st = 0; st < fa.qt; st += 16) {
+        // ---- aggregation: two queries per wave
+#pragma unroll 1
+        for (int u = 0; u < 2; ++u) {
+            const int ql = 2 * wv + u;
+            const int pos = b * fa.qt + st + ql;
+            int m = pos;
+            if (fa.a.order) m = (pos / fa.a.Mpf) * fa.a.Mpf + fa.a.order[pos];
+            m = __builtin_amdgcn_readfirstlane(m);
+            f32x4 acc[1][VEC];
+            int npos;
+            kp_aggregate_query<VEC, 1, PHASE>(fa.a, m, 0, rec_s[wv], acc, npos);
+            // D layout 16x16: row (kernel point) = 4 g + r, column j -> channels VEC j .. VEC j + VEC - 1 of tile row ql
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 4 * g + r;
+                if (k < 15) {
+                    const int off = ql * KLD + k * MID + VEC * j;
+                    if constexpr (VEC == 4) {
+                        uint2 hi, lo;
+                        cofi_split2(acc[0][0][r], acc[0][1][r], hi.x, lo.x);
+                        cofi_split2(acc[0][2][r], acc[0][3][r], hi.y, lo.y);
+                        *reinterpret_cast<uint2 *>(t_hi + off) = hi;
+                        *reinterpret_cast<uint2 *>(t_lo + off) = lo;
+                    } else {
+                        unsigned hi, lo;
+                        cofi_split2(acc[0][0][r], acc[0][1][r], hi, lo);
+                        *reinterpret_cast<unsigned *>(t_hi + off) = hi;
+                        *reinterpret_cast<unsigned *>(t_lo + off) = lo;
+                    }
+                }
+            }
+            if (lane == 0) {
+                cnt_s[ql] = (float)(npos > 1 ? npos : 1);
+                m_s[ql] = m;
+            }
+        }
+        // ---- tile (16 x K) . W^T (K x MID): this wave's 16 columns over its K range; the first W fragments are requested before
+        //      the barrier (they do not depend on the tile)
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        CofiFrag bh[PF], bl[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int ks = ks0 + i < ks1 ? ks0 + i : ks1 - 1;
+            bh[i].u = *reinterpret_cast<const uint4 *>(wh + ks * 32);
+            bl[i].u = *reinterpret_cast<const uint4 *>(wl + ks * 32);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int k0 = ks0; k0 < ks1; k0 += PF) {
+            if (k0 != ks0) {
+#pragma unroll
+                for (int i = 0; i < PF; ++i) {
+                    const int ks = k0 + i < ks1 ? k0 + i : ks1 - 1;
+                    bh[i].u = *reinterpret_cast<const uint4 *>(wh + ks * 32);
+                    bl[i].u = *reinterpret_cast<const uint4 *>(wl + ks * 32);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                if (k0 + i < ks1) {   // wave-uniform
+                    CofiFrag fh, fl;
+                    fh.u = *reinterpret_cast<const uint4 *>(ah + (k0 + i) * 32);
+                    fl.u = *reinterpret_cast<const uint4 *>(al + (k0 + i) * 32);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl.v, bh[i].v, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh.v, bl[i].v, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh.v, bh[i].v, c, 0, 0, 0);
+                }
+            }
+        }
+        // D layout: column j, rows 4 g + r -> part_s[wave][row][column]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part_s[wv * 256 + (4 * g + r) * 16 + j] = c[r];
+        __syncthreads();
+        // ---- fold the K ranges (fixed order), / count, + bias, store, column sums
+#pragma unroll
+        for (int rr = 0; rr < RPT; ++rr) {
+            const int q = erg * RPT + rr;
+            float x = 0.f;
+#pragma unroll
+            for (int z = 0; z < KQ; ++z) x += part_s[(z * NT + (en >> 4)) * 256 + q * 16 + (en & 15)];
+            x = x / cnt_s[q] + bias_n;
+            fa.y[(size_t)m_s[q] * fa.ldy + en] = x;
+            cs += x;
+            cq += x * x;
+        }
+        __syncthreads();   // tile, records (= partial tiles), cnt_s / m_s are rewritten by the next step
+    }
+    if (fa.colpart) {
+        part_s[(erg * MID + en) * 2] = cs;
+        part_s[(erg * MID + en) * 2 + 1] = cq;
+        __syncthreads();
+        if (tid < MID) {
+            float s = 0.f, q = 0.f;
+            for (int p = 0; p < RG; ++p) {
+                s += part_s[(p * MID + tid) * 2];
+                q += part_s[(p * MID + tid) * 2 + 1];
+            }
+            // one table entry per 2^stat_shift adjacent columns (fp64 butterfly, fixed order), as the GEMM epilogue writes it
+            double ds = s, dq = q;
+            for (int o = 1; o < (1 << fa.stat_shift); o <<= 1) {
+                ds += __shfl_xor(ds, o, 64);
+                dq += __shfl_xor(dq, o, 64);
+            }
+            if ((tid & ((1 << fa.stat_shift) - 1)) == 0) {
+                float *o = fa.colpart + ((size_t)b * (MID >> fa.stat_shift) + (tid >> fa.stat_shift)) * 2;
+                o[0] = (float)ds;
+                o[1] = (float)dq;
+            }
+        }
+    }
 }
 
 // row_pos[n] = (sum_c feats[n,c] > 0); one wave per row (kpconv.py:113-114 applied per source row)
@@ -309,6 +492,44 @@ extern "C" int cofi_kpconv_aggregate(const float *feats, int ldf, int N, int C, 
     } else {
         hipLaunchKernelGGL((kpconv_aggregate_kernel<1, 1>), dim3(mb, cofi_cdiv(C, 16)), dim3(256), 0, s, a);
     }
+    return cofi_launch_status();
+}
+
+// rows per statistics slab (= queries per workgroup) the fused kernel uses for M queries per frame: the largest of 64 / 32 / 16 that
+// divides M and still gives >= 256 workgroups; 0 = shape not supported (use cofi_kpconv_aggregate + cofi_gemm_f32_fused)
+extern "C" int cofi_kpconv_fused_slab_rows(int C, int M, int frames) {
+    if ((C != 32 && C != 64) || M <= 0 || frames <= 0 || (M % 16)) return 0;
+    static const int forced = [] { const char *e = getenv("COFI_KPF_QT"); return e ? atoi(e) : 0; }();
+    if ((forced == 16 || forced == 32 || forced == 64) && M % forced == 0) return forced;   // A/B runs
+    for (int q = 64; q >= 32; q >>= 1)
+        if (M % q == 0 && (long)M * frames / q >= 256) return q;
+    return 16;
+}
+
+extern "C" int cofi_kpconv_fused(const float *feats, int ldf, int N, int C, const float *q_pts, const float *s_pts, const int32_t *idx, int M, int H,
+                                 const float *kernel_points, float sigma, const uint8_t *row_pos, const void *w_planes, int ldw, const float *bias,
+                                 float *y, int ldy, float *colpart, int stat_width, int frames, const int32_t *order, cofi_stream_t stream) {
+    if (!feats || !q_pts || !s_pts || !idx || !kernel_points || !row_pos || !w_planes || !y) return COFI_EINVAL;
+    if (N <= 0 || M <= 0 || H <= 0 || (H & 3) || ldf < C || ldy < C || !(sigma > 0.f) || frames <= 0) return COFI_EINVAL;
+    if (ldw < 15 * C || (ldw & 7) || ((uintptr_t)w_planes & 15)) return COFI_EINVAL;
+    const int qt = cofi_kpconv_fused_slab_rows(C, M, frames);
+    if (qt == 0 || (ldf & (C / 16 - 1))) return COFI_EUNSUPPORTED;
+    if ((size_t)N * ldf * 4 >= ((size_t)1 << 32) || N >= (1 << 24) || (size_t)ldf * 4 >= (1u << 24)) return COFI_EUNSUPPORTED;  // 24x24-bit row offsets
+    int shift = 0;
+    if (colpart) {
+        if (stat_width <= 0 || (stat_width & (stat_width - 1)) || stat_width > 16 || (C % stat_width)) return COFI_EINVAL;
+        while ((1 << shift) < stat_width) ++shift;
+    }
+    KpFusedArgs fa{};
+    fa.a = KpArgs{feats, q_pts, s_pts, kernel_points, idx, row_pos, nullptr, nullptr, ldf, N, C, M * frames, H, 0, sigma, M, order};
+    fa.w_hi = (const uint16_t *)w_planes;
+    fa.w_lo = fa.w_hi + (size_t)C * ldw;
+    fa.ldw = ldw; fa.bias = bias; fa.y = y; fa.ldy = ldy; fa.colpart = colpart; fa.stat_shift = shift; fa.qt = qt;
+    const int nwg = (int)((long)M * frames / qt);
+    if (C == 64)
+        hipLaunchKernelGGL((kpconv_fused_kernel<64, 64>), dim3(nwg), dim3(512), 0, cofi_s(stream), fa);
+    else
+        hipLaunchKernelGGL((kpconv_fused_kernel<32, 128>), dim3(nwg), dim3(512), 0, cofi_s(stream), fa);
     return cofi_launch_status();
 }
 

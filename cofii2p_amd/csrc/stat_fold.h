@@ -119,9 +119,10 @@ static inline int make_norm_src(const cofi_norm_desc_t *d, int rows_per_frame, i
     if ((C % w) || (C % G) || (d->nslab % frames)) return COFI_EINVAL;
     const int tcols = C / w, cpg = C / G;
     if ((cpg % w) || (tcols & (tcols - 1)) || tcols < 2 || (G & (G - 1)) || C > max_channels) return COFI_EUNSUPPORTED;
-    // slabs are 64 rows and must not straddle frames (stack mode)
-    if (frames > 1 && (rows_per_frame % 64)) return COFI_EINVAL;
-    if (d->nslab / frames != (rows_per_frame + 63) / 64) return COFI_EINVAL;
+    // slabs (64 rows unless the producer says otherwise) must not straddle frames (stack mode)
+    const int sr = d->slab_rows > 0 ? d->slab_rows : 64;
+    if (frames > 1 && (rows_per_frame % sr)) return COFI_EINVAL;
+    if (d->nslab / frames != (rows_per_frame + sr - 1) / sr) return COFI_EINVAL;
     int cs = 0;
     while ((1 << cs) < cpg) ++cs;
     out->part = d->partials; out->gamma = d->gamma; out->beta = d->beta;

@@ -1,5 +1,6 @@
 """KPConv-FPN point encoder assembled from the HIP kernels
 (reference: model/kpconv/kp_backbone.py:79-128, modules.py:115-240, kpconv.py:79-122)."""
+import os
 from typing import Dict, List
 
 import torch
@@ -8,6 +9,10 @@ from . import ops
 from .spec import DECODERS, ENCODER, GN_GROUPS, KPBlock
 
 LRELU = 0.1
+# Opt-in (COFI_KPCONV_FUSED=1): narrow KPConv layers as ONE kernel (cofi_kpconv_fused).  Correct and 470 MB / frame lighter on the
+# fabric, but measured SLOWER on MI355X (490 vs 503 frames/s): 320-1280 eight-wave workgroups that alternate between a gather phase
+# and a GEMM phase quantise badly on 256 CUs, while the two-kernel form spreads 20 480 one-wave queries evenly.
+FUSED_KPCONV = os.environ.get("COFI_KPCONV_FUSED", "0") == "1"
 
 
 def pack_encoder(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -40,11 +45,17 @@ def _stats(y, part, frames: int, width: int = 1):
 
 
 def _kpconv(P, p: str, feats, q_pts, s_pts, idx, sigma: float, frames: int = 1, order=None):
-    """-> (KPConv output, its GroupNorm statistics).  The statistics come out of the GEMM epilogue (partials per
-    slab and group) instead of another pass over the activation."""
-    agg, cnt = ops.kpconv_aggregate(feats, q_pts, s_pts, idx, P[p + "KPConv.kernel_points"], sigma, frames=frames, order=order)
+    """-> (KPConv output, its GroupNorm statistics).  The statistics come out of the producing kernel's epilogue (partials per
+    slab and group) instead of another pass over the activation.  Aggregate + GEMM; with COFI_KPCONV_FUSED=1 the narrow layers
+    (32 / 64 channels in = out) run as ONE kernel and the (M, 15 C) aggregate never reaches memory (slower, see FUSED_KPCONV)."""
     w = P[p + "KPConv.weights"]
     sw = _gn_width(w.shape[0])
+    C = feats.shape[1]
+    if FUSED_KPCONV and isinstance(w, ops.SplitW) and w.shape[0] == C and ops.kpconv_fused_slab_rows(C, idx.shape[0] // frames, frames):
+        y, part, sr = ops.kpconv_fused(feats, q_pts, s_pts, idx, P[p + "KPConv.kernel_points"], sigma, w, P[p + "KPConv.bias"], stat_width=sw,
+                                       frames=frames, order=order)
+        return y, ops.ColStats(part, y.shape[0], GN_GROUPS, frames, width=sw, slab_rows=sr)
+    agg, cnt = ops.kpconv_aggregate(feats, q_pts, s_pts, idx, P[p + "KPConv.kernel_points"], sigma, frames=frames, order=order)
     y, part = ops.gemm_colstats(agg, w, bias=P[p + "KPConv.bias"], rowdiv=cnt, stat_width=sw)
     return y, _stats(y, part, frames, sw)
 

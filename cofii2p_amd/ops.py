@@ -190,8 +190,9 @@ class ColStats:
     Consumers fold them in-kernel; `finalize()` (separate launch, width 1 only) is the fallback for layouts the in-kernel
     fold does not take."""
 
-    def __init__(self, part: torch.Tensor, M: int, groups: int, frames: int = 1, eps: float = 1e-5, width: int = 1):
+    def __init__(self, part: torch.Tensor, M: int, groups: int, frames: int = 1, eps: float = 1e-5, width: int = 1, slab_rows: int = 64):
         self.part, self.M, self.groups, self.frames, self.eps, self.width = part, M, groups, frames, eps, width
+        self.slab_rows = slab_rows   # rows per slab of the producer (64: GEMM / convolution epilogues; kpconv_fused: 64 / 32 / 16)
 
     @property
     def C(self) -> int:
@@ -202,11 +203,12 @@ class ColStats:
         cpg = C // G
         rows = self.M // self.frames
         return ((tc & (tc - 1)) == 0 and tc >= 2 and (G & (G - 1)) == 0 and cpg % self.width == 0 and G <= 1024
-                and (self.frames == 1 or rows % 64 == 0) and self.part.shape[0] == self.frames * ((rows + 63) // 64))
+                and (self.frames == 1 or rows % self.slab_rows == 0)
+                and self.part.shape[0] == self.frames * ((rows + self.slab_rows - 1) // self.slab_rows))
 
     def finalize(self) -> torch.Tensor:
-        if self.width != 1:
-            raise _lib.CofiError("ColStats.finalize needs per-column partials (width 1)")
+        if self.width != 1 or self.slab_rows != 64:
+            raise _lib.CofiError("ColStats.finalize needs per-column partials (width 1) in 64-row slabs")
         return group_stats_from_colpart(self.part, self.M, self.groups, self.eps, self.frames)
 
     def desc(self, gamma=None, beta=None, slope: float = 1.0) -> "_lib.NormDesc":
@@ -216,6 +218,7 @@ class ColStats:
         d.gamma = None if gamma is None else gamma.data_ptr()
         d.beta = None if beta is None else beta.data_ptr()
         d.eps, d.slope = self.eps, slope
+        d.slab_rows = self.slab_rows
         d.scale_shift = None
         if NORM_FOLD == "kernel":
             d.scale_shift = self.scale_shift(d, gamma, beta).data_ptr()
@@ -393,6 +396,42 @@ def kpconv_aggregate(feats, q_pts, s_pts, idx, kernel_points, sigma: float, row_
                                    _p(kernel_points), float(sigma), _p(row_pos), _p(agg), 15 * C, _p(cnt), frames, _p(order), _stream())
     _lib.check(rc, "cofi_kpconv_aggregate")
     return agg, cnt
+
+
+def kpconv_fused_slab_rows(C: int, M: int, frames: int = 1) -> int:
+    """Rows per statistics slab of `kpconv_fused` for M queries per frame; 0 = shape not served by the fused kernel."""
+    if GEMM_MODE != "bf16x3":
+        return 0
+    return int(_lib.load().cofi_kpconv_fused_slab_rows(C, M, frames))
+
+
+def kpconv_fused(feats, q_pts, s_pts, idx, kernel_points, sigma: float, w: "SplitW", bias, stat_width: int = 1, row_pos=None, frames: int = 1,
+                 order=None):
+    """The whole KPConv operator (kpconv.py:91-116) of a narrow layer (C = 32 / 64 in = out channels) in one launch: -> (y (M, C),
+    statistics partials (M / slab_rows, C / stat_width, 2), slab_rows).  `w`: the (C, 15 C) packed weight as pre-split planes."""
+    lib = _lib.load()
+    _mat(feats, "feats"), _mat(idx, "idx", torch.int32)
+    if not (q_pts.is_contiguous() and s_pts.is_contiguous() and kernel_points.is_contiguous() and idx.is_contiguous()):
+        raise _lib.CofiError("kpconv_fused: points / idx / kernel_points must be contiguous")
+    N, C = feats.shape
+    M, H = idx.shape
+    if s_pts.shape != (N, 3) or q_pts.shape != (M, 3) or kernel_points.shape != (15, 3) or N % frames or M % frames:
+        raise _lib.CofiError("kpconv_fused: shape mismatch")
+    if not isinstance(w, SplitW) or tuple(w.shape) != (C, 15 * C):
+        raise _lib.CofiError("kpconv_fused: the weight must be the pre-split (C, 15 C) packing")
+    sr = kpconv_fused_slab_rows(C, M // frames, frames)
+    if sr == 0:
+        raise _lib.CofiError("kpconv_fused: shape not supported (C in {32, 64}, M % 16 == 0, bf16x3 arithmetic)")
+    if row_pos is None:
+        row_pos = getattr(feats, "cofi_row_pos", None)   # left there by the group_norm_apply that produced feats
+    if row_pos is None:
+        row_pos = row_sum_positive(feats)
+    y = torch.empty((M, C), dtype=torch.float32, device=feats.device)
+    part = torch.empty((M // sr, C // stat_width, 2), dtype=torch.float32, device=feats.device)
+    rc = lib.cofi_kpconv_fused(_p(feats), _ld(feats), N // frames, C, _p(q_pts), _p(s_pts), _p(idx), M // frames, H, _p(kernel_points), float(sigma),
+                               _p(row_pos), _p(w.planes), w.ldp, _p(bias), _p(y), _ld(y), _p(part), stat_width, frames, _p(order), _stream())
+    _lib.check(rc, "cofi_kpconv_fused")
+    return y, part, sr
 
 
 def neighbor_maxpool(x, idx, out=None, frames: int = 1, order=None):

@@ -46,7 +46,7 @@ typedef void *cofi_stream_t;
 /* A PENDING normalisation: an activation y (rows, channels) whose GroupNorm / InstanceNorm (+ affine + LeakyReLU) has not been
  * applied yet, described by the statistics partials its producer left behind.  Producers (cofi_gemm_f32_colstats / _fused,
  * cofi_conv2d_nhwc / _fused) write, per 64-row slab and per `width` adjacent output columns, {sum, sum of squares}:
- *   partials (nslab, channels / width, 2) fp32, nslab = frames * ceil(rows_per_frame / 64).
+ *   partials (nslab, channels / width, 2) fp32, nslab = frames * ceil(rows_per_frame / 64)  (other slab heights: `slab_rows`).
  * Consumers (cofi_gemm_f32_fused, cofi_conv2d_nhwc_fused, cofi_group_norm_apply_partials) fold the table themselves
  * (fixed order, fp64) and evaluate   leaky( (y - mean_g) * rstd_g * gamma[c] + beta[c], slope ),  g = c / (channels / groups),
  * i.e. nn.GroupNorm(groups, channels) over ALL rows of the frame (model/kpconv/modules.py:45-48) or, with groups == channels and
@@ -63,6 +63,8 @@ typedef struct cofi_norm_desc {
     float slope;  /* LeakyReLU slope in [0, 1]: 1 = identity, 0 = ReLU, 0.1 = the reference's LeakyReLU */
     const float *scale_shift; /* optional (frames, 2, channels): the statistics already FINALIZED by cofi_norm_finalize into per-channel
                                * scale[c] = rstd_g gamma[c] | shift[c] = beta[c] - mean_g rstd_g gamma[c]; consumers then skip their own fold */
+    int slab_rows; /* rows per slab of the producer: 0 = 64 (GEMM / convolution epilogues); cofi_kpconv_fused writes 64-, 32- or 16-row slabs
+                    * (cofi_kpconv_fused_slab_rows).  nslab = frames * ceil(rows_per_frame / slab_rows); consumers only sum over the slabs */
 } cofi_norm_desc_t;
 
 /* activation codes of the GEMM epilogue */
@@ -134,6 +136,18 @@ int cofi_kpconv_aggregate(const float *feats, int ldf, int N, int C, const float
                           processing order of the queries, e.g. Morton-sorted: results do not depend on it */,
                           cofi_stream_t stream);
 
+/* KPConv as ONE kernel for the narrow layers (C = 32 or 64 = in = out channels, the stages with the most queries):
+ *   y[m] = (sum_k agg[m, k, :] W[k]) / max(#neighbours whose feature row sums to > 0, 1) + bias       (kpconv.py:91-116)
+ * with agg as cofi_kpconv_aggregate computes it - but the (M, 15 C) aggregate (39 MB per layer at these stages) stays in LDS as bf16
+ * hi / lo planes and is multiplied there with the pre-split weight planes (3-term bf16 split on the bf16 matrix cores, fp32
+ * accumulation; w_planes = hi plane (C rows x ldw bf16, K index = kernel point * C + channel, i.e. the (Cout, 15 Cin) packing the
+ * GEMM path uses) followed by the lo plane, cofi_split_bf16_planes).  colpart != NULL: GroupNorm statistics partials of y per
+ * slab of cofi_kpconv_fused_slab_rows(C, M, frames) rows and `stat_width` adjacent columns.  M % 16 == 0, H % 4 == 0;
+ * COFI_EUNSUPPORTED for other shapes (use cofi_kpconv_aggregate + cofi_gemm_f32_fused). */
+int cofi_kpconv_fused_slab_rows(int C, int M, int frames);
+int cofi_kpconv_fused(const float *feats, int ldf, int N, int C, const float *q_pts, const float *s_pts, const int32_t *idx, int M, int H,
+                      const float *kernel_points, float sigma, const uint8_t *row_pos, const void *w_planes, int ldw, const float *bias,
+                      float *y, int ldy, float *colpart, int stat_width, int frames, const int32_t *order, cofi_stream_t stream);
 /* K3 / K4  neighbour max-pool and nearest up-sample.
  * Replace model/kpconv/functional.py:53-66 (`maxpool`) and :5-21 (`nearest_upsample`): a zero
  * pad row stands behind index N. */

@@ -208,6 +208,32 @@ def test_kitti_frame_bf16x3_gemms_within_tolerance(model, monkeypatch):
     assert abs(res[6].shape[1] - gold["test_center_xy"].shape[1]) <= 3  # a score may cross the 0.9 threshold
 
 
+def test_kitti_frame_fused_kpconv_optin(model, monkeypatch):
+    """COFI_KPCONV_FUSED=1 (narrow KPConv layers as one kernel, cofi_kpconv_fused): same golden comparison, one frame and a stacked
+    pair; the layers really take the fused path."""
+    from cofii2p_amd import kpfpn, ops
+    from cofii2p_amd.network import CoFiI2P
+
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x3")
+    monkeypatch.setattr(kpfpn, "FUSED_KPCONV", True)
+    calls = []
+    real = ops.kpconv_fused
+    monkeypatch.setattr(ops, "kpconv_fused", lambda *a, **k: (calls.append(a[0].shape), real(*a, **k))[1])
+    model.enable_graphs(False)
+    gold = load_golden("frame_kitti.npz")
+    fr, data = frame_inputs(int(gold["frame_id"]), int(gold["num_points"]), int(gold["pyr_seed"]))
+    dd, img = to_dev(data), torch.from_numpy(fr.img)[None].to(DEV)
+    res = model(dd, img, None, None, None, "test")
+    assert len(calls) == 5, calls   # encoder1_2, 2_1 (32 channels), 2_2, 2_3, 3_1 (64 channels)
+    for n, t in zip(("img_desc", "pc_desc", "img_score", "pc_score"), res[:4]):
+        assert maxdiff(t, gold["test_" + n]) <= TOL, n
+    ref = [t.clone() for t in res[:4]]
+    stacked, imgs = CoFiI2P.stack_frames([dd, dd], [img, img])
+    for out in model.finish(model.forward_async(6, stacked, imgs)):
+        for a, b in zip(ref, out[:4]):
+            assert maxdiff(a.cpu(), b.cpu()) < 2e-5
+
+
 def test_stack_mode_batch_equals_single_frames(model):
     """B = 3 frames stacked through ONE set of launches (per-frame GroupNorm / InstanceNorm / Q-norm statistics,
     frame-local neighbour tables, batched attention) == the same frames run one at a time"""

@@ -128,6 +128,68 @@ def test_kpconv_random(ops, N, M, H, C, Co):
     close(out, ref, 1e-4)
 
 
+@pytest.mark.parametrize("N,M,H,C,frames,use_order", [(900, 320, 128, 64, 1, False), (1200, 512, 128, 32, 1, True), (5000, 16384, 128, 32, 1, True),
+                                                      (4000, 8192, 64, 64, 1, True), (600, 256, 128, 64, 2, True), (300, 16, 128, 32, 1, False)])
+def test_kpconv_fused_vs_oracle_and_two_kernel_path(ops, monkeypatch, N, M, H, C, frames, use_order):
+    """cofi_kpconv_fused (aggregate + bf16x3 GEMM + statistics partials in one kernel, kpconv.py:91-116) against the oracle, against
+    the aggregate + GEMM path it replaces, its partials against sums of its own output, and its partials as consumed by a
+    normalising GEMM loader (slabs of 64 / 32 / 16 rows)."""
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x3")
+    g = np.random.default_rng(N + C + M)
+    ys, refs = [], []
+    s_all, q_all, i_all, f_all = [], [], [], []
+    kp = torch.from_numpy((g.uniform(-0.3, 0.3, (15, 3))).astype(np.float32))
+    w = torch.from_numpy((g.standard_normal((15, C, C)) * 0.1).astype(np.float32))
+    b = torch.from_numpy(g.standard_normal(C).astype(np.float32))
+    for f in range(frames):
+        s_pts = torch.from_numpy(g.uniform(-1, 1, (N, 3)).astype(np.float32))
+        q_pts = s_pts[g.integers(0, N, M)] + 0.01
+        idx = torch.from_numpy(knn_c.knn(s_pts.numpy(), q_pts.numpy(), H).astype(np.int64))
+        idx[::11, -5:] = N          # shadow neighbours
+        idx[5, :] = N               # a query without any neighbour: bias only
+        feats = torch.from_numpy(g.standard_normal((N, C)).astype(np.float32))
+        feats[::9] = 0
+        refs.append(O.kpconv(feats, q_pts, s_pts, idx, kp, w, b, 0.35))
+        s_all.append(s_pts), q_all.append(q_pts), i_all.append(idx), f_all.append(feats)
+    S, Q, I, F = (torch.cat(t) for t in (s_all, q_all, i_all, f_all))
+    ref = torch.cat(refs)
+    wp = ops.presplit(G(w.permute(2, 0, 1).reshape(C, -1).contiguous()))
+    order = None
+    if use_order:   # any permutation of the queries of a frame is a valid processing order
+        order = G(np.concatenate([g.permutation(M) for _ in range(frames)]).astype(np.int32))
+    width = 2 if C == 64 else 1
+    y, part, sr = ops.kpconv_fused(G(F), G(Q), G(S), G(I, torch.int32), G(kp), 0.35, wp, G(b), stat_width=width, frames=frames, order=order)
+    assert sr == ops.kpconv_fused_slab_rows(C, M, frames) and sr in (16, 32, 64) and part.shape == (M * frames // sr, C // width, 2)
+    close(y, ref, 1e-4)
+    assert torch.allclose(y[5].cpu(), b)
+    agg, cnt = ops.kpconv_aggregate(G(F), G(Q), G(S), G(I, torch.int32), G(kp), 0.35, frames=frames)
+    two = ops.gemm(agg, wp, bias=G(b), rowdiv=cnt)
+    assert float((y - two).abs().max()) < 2e-5 * max(1.0, float(two.abs().max()))
+    # partials: per frame, the sum over its slabs = column (group) sums of y
+    yd = y.double().reshape(frames, M, C // width, width)
+    pd = part.double().reshape(frames, -1, C // width, 2).sum(1)
+    assert torch.allclose(pd[..., 0], yd.sum((1, 3)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(pd[..., 1], (yd * yd).sum((1, 3)), rtol=1e-5, atol=1e-3)
+    # ... and a normalising GEMM loader folds them like any other table
+    if M % 128 == 0 or frames == 1:
+        st = ops.ColStats(part, M * frames, 32, frames, width=width, slab_rows=sr)
+        gam, bet = G(g.standard_normal(C).astype(np.float32)), G(g.standard_normal(C).astype(np.float32))
+        w2 = ops.presplit(G((g.standard_normal((48, C)) * 0.2).astype(np.float32)))
+        fused = ops.gemm(ops.Normed(y, st, gam, bet, 0.1), w2, frames=frames)
+        yn = torch.cat([O.group_norm_rows(y[f * M:(f + 1) * M].cpu(), gam.cpu(), bet.cpu()) for f in range(frames)])
+        want = torch.nn.functional.leaky_relu(yn, 0.1) @ w2.w.cpu().T
+        close(fused, want, 2e-4 if M >= 256 else 1e-3)   # 16 rows: the statistics amplify the bf16x3 rounding of y
+
+
+def test_kpconv_fused_rejects_unsupported_shapes(ops, monkeypatch):
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x3")
+    assert ops.kpconv_fused_slab_rows(128, 1024) == 0 and ops.kpconv_fused_slab_rows(64, 1000) == 0
+    assert ops.kpconv_fused_slab_rows(64, 20480) == 64 and ops.kpconv_fused_slab_rows(64, 10240) == 32 and ops.kpconv_fused_slab_rows(32, 5120) == 16
+    assert ops.kpconv_fused_slab_rows(64, 20480, 16) == 64 and ops.kpconv_fused_slab_rows(64, 2560, 16) == 64
+    monkeypatch.setattr(ops, "GEMM_MODE", "f32")
+    assert ops.kpconv_fused_slab_rows(64, 20480) == 0
+
+
 def test_pool_gather(ops, mg):
     idx = G(mg["kp_idx"], torch.int32)
     x = G(mg["pool_x"])
