@@ -367,6 +367,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for single-GPU tests of the N > 1 path)")
     ap.add_argument("--share-device", action="store_true", help="test aid: all ranks use cuda:0")
     ap.add_argument("--cu-split", default=None, choices=[None, "even", "halves"], help="experiment: the two frame streams get disjoint CU masks")
+    ap.add_argument("--copy-inputs", action="store_true", help="stage every frame's inputs into per-slot static buffers (one 27 MB copy launch per frame) "
+                    "instead of letting the hipGraph read the resident input tensors in place (forward_async(inputs_stable=True))")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the extra stack-mode batch-4/16 measurements")
     ap.add_argument("--batch", type=int, default=1, help="frames per submission in stack mode (BASELINE configs[2] uses 16); a step is then one batch")
     ap.add_argument("--stress", action="store_true", help="bench BASELINE configs[4] instead: 896x1600 image, 40960 points (implies --points 40960)")
@@ -448,7 +450,7 @@ def main():
                     nm = model.finish(pending[sl])[0][4].shape[0]
                 pyr, img = batches[i % len(batches)]
                 with torch.cuda.stream(streams[sl]):
-                    pending[sl] = model.forward_async(sl, pyr, img)
+                    pending[sl] = model.forward_async(sl, pyr, img, inputs_stable=not args.copy_inputs)
             for sl in range(S):
                 if pending[sl] is not None:
                     nm = model.finish(pending[sl])[0][4].shape[0]
@@ -487,7 +489,7 @@ def main():
                     nm = model.finish(pending[sl])[4].shape[0]
                 pyr, img, _ = frames[(base + i) % len(frames)]
                 with torch.cuda.stream(streams[i % S]):
-                    pending[sl] = model.forward_async(sl, pyr, img)
+                    pending[sl] = model.forward_async(sl, pyr, img, inputs_stable=not args.copy_inputs)
             for k in range(NSLOT):   # collect in submission order
                 sl = (nsteps + k) % NSLOT
                 if pending[sl] is not None:
@@ -518,7 +520,8 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic", "launch": "eager" if args.eager else "hipGraph replay", "gemm_mode": args.gemm,
+        "data": "synthetic", "launch": "eager" if args.eager else "hipGraph replay",
+        "input_staging": "copied into per-slot static buffers" if (args.copy_inputs or args.eager) else "read in place (inputs resident in HBM, forward_async(inputs_stable=True))", "gemm_mode": args.gemm,
         "ranks": world if dist is None else dist.get_world_size(), "dist_backend": None if dist is None else args.dist_backend,
         "gathered_frame_results": None if gathered is None else int(gathered.shape[0]),
         "arithmetic": "fp32 storage and accumulation everywhere; dense contractions " + (

@@ -53,6 +53,8 @@ class CoFiI2P(nn.Module):
     """See module docstring.  ``opt`` needs ``img_H, img_W, img_fine_resolution_scale, norm``
     (data/options.py:17-19,51); only ``norm == 'gn'`` (the shipped configuration) is implemented."""
 
+    MAX_STABLE_GRAPHS = 64   # distinct (slot, input set) graphs kept for forward_async(inputs_stable=True)
+
     def __init__(self, opt, init: str = "synthetic"):
         super().__init__()
         self.opt = opt
@@ -260,25 +262,37 @@ class CoFiI2P(nn.Module):
         return self
 
     def _graph_forward(self, P, points, neighbors, subsampling, upsampling, feats, img, mode, kpt, inl, slot: int = 0,
-                       branch_mask: int = 7, order=None):
+                       branch_mask: int = 7, order=None, inputs_stable: bool = False):
         def sig(t):
-            return None if t is None else (tuple(t.shape), str(t.dtype))
+            if t is None:
+                return None
+            if inputs_stable:   # the graph reads the caller's tensors in place: their addresses are part of its identity
+                if not t.is_contiguous():
+                    raise _lib.CofiError("inputs_stable=True needs contiguous input tensors")
+                return (tuple(t.shape), str(t.dtype), t.data_ptr())
+            return (tuple(t.shape), str(t.dtype))
 
         order = [] if order is None else list(order)
         tensors = list(points) + list(neighbors) + list(subsampling) + list(upsampling) + order + [feats, img, kpt, inl]
         # everything a captured launch sequence depends on besides the tensor signature: arithmetic, optional branches
-        key = (mode, str(img.device), slot, branch_mask, ops.GEMM_MODE, self.compute_unused_image_maps, transformer.JOINT_SELF) \
-            + tuple(sig(t) for t in tensors)
+        key = ("stable" if inputs_stable else "copy", mode, str(img.device), slot, branch_mask, ops.GEMM_MODE, self.compute_unused_image_maps,
+               transformer.JOINT_SELF, kpfpn.FUSED_KPCONV) + tuple(sig(t) for t in tensors)
         saved_mask, saved_slot = ops.BRANCH_MASK, ops.Workspace.slot
         ops.set_workspace_slot(slot)
         ops.BRANCH_MASK = branch_mask  # which intra-frame forks the capture records
         try:
             ent = self._graphs.get(key)
             if ent is None:
-                static = [None if t is None else torch.empty_like(t) for t in tensors]
-                for s_, t in zip(static, tensors):
-                    if t is not None:
-                        s_.copy_(t)
+                if inputs_stable:
+                    if sum(1 for k_ in self._graphs if k_[0] == "stable") >= self.MAX_STABLE_GRAPHS:
+                        raise _lib.CofiError("inputs_stable=True: more than %d distinct input sets; recycle the input buffers or pass "
+                                             "inputs_stable=False" % self.MAX_STABLE_GRAPHS)
+                    static = list(tensors)   # the entry keeps the tensors alive for as long as the graph exists
+                else:
+                    static = [None if t is None else torch.empty_like(t) for t in tensors]
+                    for s_, t in zip(static, tensors):
+                        if t is not None:
+                            s_.copy_(t)
                 n = [len(points), len(neighbors), len(subsampling), len(upsampling), len(order)]
                 o = [0, n[0], n[0] + n[1], n[0] + n[1] + n[2], n[0] + n[1] + n[2] + n[3], sum(n)]
                 args = (static[o[0]:o[1]], static[o[1]:o[2]], static[o[2]:o[3]], static[o[3]:o[4]], static[o[5]], static[o[5] + 1], mode,
@@ -300,11 +314,12 @@ class CoFiI2P(nn.Module):
                 ent = (graph, static, outs)
                 self._graphs[key] = ent
             graph, static, outs = ent
-            # per-frame inputs -> the static buffers the graph reads: one batched copy launch (20+ tensors)
-            mc = self._multicopy.get(key)
-            if mc is None:
-                mc = self._multicopy[key] = ops.MultiCopy(img.device)
-            mc.run([None if t is None else t.contiguous() for t in tensors], static)
+            if not inputs_stable:
+                # per-frame inputs -> the static buffers the graph reads: one batched copy launch (20+ tensors)
+                mc = self._multicopy.get(key)
+                if mc is None:
+                    mc = self._multicopy[key] = ops.MultiCopy(img.device)
+                mc.run([None if t is None else t.contiguous() for t in tensors], static)
             graph.replay()
         finally:   # an exception during warm-up / capture must not leave later eager forwards in this slot's scratch namespace
             ops.set_workspace_slot(saved_slot)
@@ -339,23 +354,36 @@ class CoFiI2P(nn.Module):
         return (pool + [torch.cuda.Stream(device=dev) for _ in range(max(0, n - len(pool)))])[:n]
 
     @torch.no_grad()
-    def forward_async(self, slot: int, pc_data_dict, img, mode: str = "test"):
+    def forward_async(self, slot: int, pc_data_dict, img, mode: str = "test", inputs_stable: bool = False):
         """Enqueue one test-mode forward on the CURRENT stream through the hipGraph of slot `slot` and return
         immediately (no host sync).  `img` (1,3,H,W) = one frame, or (B,3,H,W) with a stack-mode `pc_data_dict`
         (see stack_frames) = B frames through the same launches.  Slots own their static buffers and scratch, so
         several submissions can be in flight on different streams; `finish(handle)` synchronises on that
-        submission only.  A slot must be finished before it is reused."""
+        submission only.  A slot must be finished before it is reused.
+
+        inputs_stable=False: the inputs are copied into the slot's static buffers first (one batched launch, 27 MB for a KITTI frame),
+        so any tensors may be passed.  inputs_stable=True: the caller promises that these very tensors (contiguous, device-resident,
+        int32 tables) stay allocated and unmodified until `finish()`; the graph then reads them IN PLACE - no staging copy - and is
+        cached per (slot, input addresses): the natural mode for a loader that recycles a ring of input buffers
+        (at most MAX_STABLE_GRAPHS distinct sets)."""
         if mode != "test":
             raise ValueError("forward_async serves the test-mode pipeline")
         _lib.load()
         P = self._pack(img.device)
+        if inputs_stable:
+            for k in ("points", "neighbors", "subsampling", "upsampling"):
+                for t in pc_data_dict[k]:
+                    if not t.is_contiguous() or (k != "points" and t.dtype != torch.int32):
+                        raise _lib.CofiError("inputs_stable=True reads the inputs in place: contiguous tensors and int32 tables only (%s)" % k)
+            if not (pc_data_dict["feats"].is_contiguous() and img.is_contiguous()):
+                raise _lib.CofiError("inputs_stable=True reads the inputs in place: contiguous feats / img only")
         points = [p.contiguous() for p in pc_data_dict["points"]]
         tabs = [[self._as_idx32(t) for t in pc_data_dict[k]] for k in ("neighbors", "subsampling", "upsampling")]
         # submissions in flight fill the GPU by themselves: the per-submission graph is a linear chain (intra-frame
         # fork/join only adds join latency then — measured 254 vs 331 frames/s at two frames in flight; DESIGN.md §3)
         outs = self._graph_forward(P, points, tabs[0], tabs[1], tabs[2], pc_data_dict["feats"].contiguous(), img.contiguous(), mode, None,
                                    None, slot=slot, branch_mask=self.async_branch_mask,
-                                   order=None if os.environ.get("COFI_NO_ORDER") else pc_data_dict.get("order"))
+                                   order=None if os.environ.get("COFI_NO_ORDER") else pc_data_dict.get("order"), inputs_stable=inputs_stable)
         hosts = self.__dict__.setdefault("_count_host", {})   # one pinned landing buffer per slot (a slot is finished before it is reused)
         host = hosts.get((slot, len(outs)))
         if host is None:

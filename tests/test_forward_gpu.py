@@ -159,6 +159,53 @@ def test_hipgraph_replay_equals_eager(model):
     model.enable_graphs(False)
 
 
+def test_forward_async_reads_stable_inputs_in_place(model):
+    """forward_async(inputs_stable=True): no staging copy - the graph reads the caller's tensors, one graph per (slot, input set);
+    same bits as the staged path; new CONTENT in the same buffers is picked up by the replay; a new buffer set is a new graph."""
+    from cofii2p_amd.preprocess import build_pyramid
+    from cofii2p_amd.synth import make_frame, subsample_indices
+
+    def inputs(fid):
+        fr = make_frame(fid, 4096)
+        sub = [torch.from_numpy(s).to(DEV) for s in subsample_indices(4096, 5, seed=fid)]
+        pyr = build_pyramid(torch.from_numpy(fr.points).to(DEV), sub)
+        pyr["feats"] = torch.from_numpy(fr.feats).to(DEV)
+        return pyr, torch.from_numpy(fr.img)[None].to(DEV)
+
+    pa, ia = inputs(41)
+    pb, ib = inputs(42)
+    staged_a = [t.clone() for t in model.finish(model.forward_async(20, pa, ia))[:6]]
+    staged_b = [t.clone() for t in model.finish(model.forward_async(20, pb, ib))[:6]]
+    n0 = len(model._graphs)
+    place_a = [t.clone() for t in model.finish(model.forward_async(21, pa, ia, inputs_stable=True))[:6]]
+    assert len(model._graphs) == n0 + 1
+    for x, y in zip(staged_a, place_a):
+        assert torch.equal(x, y)
+    # same buffers, new content (what a loader recycling its buffers does): the replay reads it
+    for k in ("points", "neighbors", "subsampling", "upsampling"):
+        for dst, src in zip(pa[k], pb[k]):
+            dst.copy_(src)
+    pa["feats"].copy_(pb["feats"])
+    ia.copy_(ib)
+    again = [t.clone() for t in model.finish(model.forward_async(21, pa, ia, inputs_stable=True))[:6]]
+    assert len(model._graphs) == n0 + 1
+    for x, y in zip(staged_b, again):
+        assert torch.equal(x, y)
+    # another buffer set on the same slot: its own graph
+    model.finish(model.forward_async(21, pb, ib, inputs_stable=True))
+    assert len(model._graphs) == n0 + 2
+    from cofii2p_amd._lib import CofiError
+
+    bad = dict(pb)
+    bad["feats"] = torch.zeros((pb["feats"].shape[0], 8), device=DEV)[:, :4]   # a strided view: would be copied, i.e. not stable
+    with pytest.raises(CofiError):
+        model.forward_async(21, bad, ib, inputs_stable=True)
+    bad = dict(pb)
+    bad["neighbors"] = [t.long() for t in pb["neighbors"]]                       # int64 tables are converted, i.e. not read in place
+    with pytest.raises(CofiError):
+        model.forward_async(21, bad, ib, inputs_stable=True)
+
+
 def test_frames_in_flight_match_sequential(model):
     """three frames pipelined over two slots/streams give the same results as one-at-a-time forwards"""
     from cofii2p_amd.preprocess import build_pyramid
