@@ -37,6 +37,8 @@ SIGNATURES = {
     "cofi_idx64_to_idx32": (_I, [_P, _P, _Z, _P]),
     "cofi_idx32_to_idx64": (_I, [_P, _P, _Z, _P]),
     "cofi_row_sum_positive": (_I, [_P, _I, _I, _I, _P, _P]),
+    "cofi_kp_pack_c4": (_I, [_P, _I, _I, _P, _I, _P, _P]),
+    "cofi_kpconv_aggregate_c4": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _F, _P, _I, _P, _I, _P, _P]),
     "cofi_kpconv_aggregate": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _F, _P, _P, _I, _P, _I, _P, _P]),
     "cofi_neighbor_maxpool": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P]),
     "cofi_gather_rows": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P]),

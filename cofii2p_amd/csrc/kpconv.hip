@@ -213,6 +213,87 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
     if (blockIdx.y == 0 && lane == 0) a.cnt[m] = (float)(npos > 1 ? npos : 1);
 }
 
+// C <= 4 (the first layer of the encoder: [intensity | normal]).  What a neighbour costs in the staging is the number of distinct
+// cache lines its data lies in (measured: without the separate position gathers the general kernel's 40 us for this layer drop to
+// 29), so this layer reads ONE 32-byte record per neighbour, packed once per frame by kp_pack_c4_kernel: [f0 f1 f2 f3 | x y z | pos],
+// pos = (f0 + .. + f3 > 0) (kpconv.py:113-114).  Lane = neighbour gathers the record, parks offset and features in LDS, and the MFMA
+// chain (same operands, same order as the general kernel: identical bits) runs from LDS alone.
+__global__ void kp_pack_c4_kernel(const float *feats, int ldf, int C, const float *pts, int N, float4 *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float *f = feats + (size_t)i * ldf, *p = pts + (size_t)i * 3;
+    const float4 fv = make_float4(f[0], C > 1 ? f[1] : 0.f, C > 2 ? f[2] : 0.f, C > 3 ? f[3] : 0.f);
+    const float sum = (fv.x + fv.z) + (fv.y + fv.w);   // the butterfly order of row_sum_positive_kernel (wave_sum) for C <= 4
+    out[2 * (size_t)i] = fv;
+    out[2 * (size_t)i + 1] = make_float4(p[0], p[1], p[2], sum > 0.0f ? 1.0f : 0.0f);
+}
+
+__global__ __launch_bounds__(256) void kpconv_aggregate_c4_kernel(KpArgs a) {   // a.feats = packed records (N, 8)
+    constexpr int PH = 128;
+    __shared__ float4 rec_s[4][PH];
+    __shared__ float4 fea_s[4][PH];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int m = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + wv);
+    if (m >= a.M) return;
+    if (a.order) m = (m / a.Mpf) * a.Mpf + a.order[m];
+    const int j = lane & 15, g = lane >> 4;
+    const float4 *recs = reinterpret_cast<const float4 *>(a.feats) + 2 * (size_t)(m / a.Mpf) * a.N;   // stack mode: this query's frame
+    const float qx = a.q_pts[3 * m], qy = a.q_pts[3 * m + 1], qz = a.q_pts[3 * m + 2];
+    const int jk = j < 15 ? j : 0;
+    const float kx = a.kp[3 * jk], ky = a.kp[3 * jk + 1], kz = a.kp[3 * jk + 2];
+    const float inv_sigma = 1.0f / a.sigma;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int npos = 0;
+    const int32_t *irow = a.idx + (size_t)m * a.H;
+    float4 *rec = rec_s[wv], *fea = fea_s[wv];
+    const float fmask = j < a.C ? 1.0f : 0.0f;           // MFMA columns past C multiply zeros
+    const float *fsel = reinterpret_cast<const float *>(fea) + (j & 3);
+    for (int h0 = 0; h0 < a.H; h0 += PH) {
+        const int nh = a.H - h0 < PH ? a.H - h0 : PH;    // multiple of 4
+        int idr[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int hl = r * 64 + lane;
+            idr[r] = hl < nh ? irow[h0 + hl] : a.N;
+        }
+        float4 fr[2], pp[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int idc = (unsigned)idr[r] < (unsigned)a.N ? idr[r] : 0;
+            fr[r] = recs[2 * (size_t)idc];
+            pp[r] = recs[2 * (size_t)idc + 1];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const bool valid = (unsigned)idr[r] < (unsigned)a.N;
+            npos += __popcll(__ballot(valid && pp[r].w != 0.f));
+            rec[r * 64 + lane] = make_float4(valid ? pp[r].x - qx : 1e18f, pp[r].y - qy, pp[r].z - qz, 0.f);   // shadow: influence exactly 0
+            fea[r * 64 + lane] = valid ? fr[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int steps = nh >> 2;
+#pragma unroll 4
+        for (int t = 0; t < steps; ++t) {
+            const float4 rc = rec[4 * t + g];
+            const float f = fsel[(4 * t + g) * 4] * fmask;
+            const float dx = rc.x - kx, dy = rc.y - ky, dz = rc.z - kz;
+            const float sq = (dx * dx + dy * dy) + dz * dz;
+            const float w = fmaxf(1.0f - __builtin_amdgcn_sqrtf(sq) * inv_sigma, 0.0f);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w, f, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (j < a.C) {
+        float *orow = a.agg + (size_t)m * a.ld_agg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * g + r;
+            if (k < 15) orow[(size_t)k * a.C + j] = acc[r];
+        }
+    }
+    if (lane == 0) a.cnt[m] = (float)(npos > 1 ? npos : 1);
+}
+
 // ---- KPConv as ONE kernel for the narrow layers (mid = 32 / 64 channels: the stages with 20 480 ... 5 120 queries) ----------------
 // kpconv.py:91-116 end to end:  y[m] = (sum_k agg[m, k, :] W[k]) / max(#neighbours with positive feature sum, 1) + bias,
 // plus the GroupNorm statistics partials of y.  The (M, 15 mid) aggregate - 39 MB per layer at these stages, written and read back
@@ -492,6 +573,24 @@ extern "C" int cofi_kpconv_aggregate(const float *feats, int ldf, int N, int C, 
     } else {
         hipLaunchKernelGGL((kpconv_aggregate_kernel<1, 1>), dim3(mb, cofi_cdiv(C, 16)), dim3(256), 0, s, a);
     }
+    return cofi_launch_status();
+}
+
+// First-layer form (C <= 4): pack [features | position | positive-sum flag] into 32-byte records once, then aggregate from them.
+extern "C" int cofi_kp_pack_c4(const float *feats, int ldf, int C, const float *points, int N, float *records, cofi_stream_t stream) {
+    if (!feats || !points || !records || N <= 0 || C <= 0 || C > 4 || ldf < C || ((uintptr_t)records & 15)) return COFI_EINVAL;
+    hipLaunchKernelGGL(kp_pack_c4_kernel, dim3(cofi_cdiv(N, 256)), dim3(256), 0, cofi_s(stream), feats, ldf, C, points, N, (float4 *)records);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_kpconv_aggregate_c4(const float *records, int N, int C, const float *q_pts, const int32_t *idx, int M, int H,
+                                        const float *kernel_points, float sigma, float *agg, int ld_agg, float *cnt, int frames,
+                                        const int32_t *order, cofi_stream_t stream) {
+    if (!records || !q_pts || !idx || !kernel_points || !agg || !cnt || ((uintptr_t)records & 15)) return COFI_EINVAL;
+    if (N <= 0 || C <= 0 || C > 4 || M < 0 || H <= 0 || (H & 3) || ld_agg < 15 * C || !(sigma > 0.f) || frames <= 0) return COFI_EINVAL;
+    if (M == 0) return 0;
+    KpArgs a{records, q_pts, nullptr, kernel_points, idx, nullptr, agg, cnt, 8, N, C, M * frames, H, ld_agg, sigma, M, order};
+    hipLaunchKernelGGL(kpconv_aggregate_c4_kernel, dim3(cofi_cdiv((long)M * frames, 4)), dim3(256), 0, cofi_s(stream), a);
     return cofi_launch_status();
 }
 

@@ -388,10 +388,18 @@ def kpconv_aggregate(feats, q_pts, s_pts, idx, kernel_points, sigma: float, row_
         raise _lib.CofiError("kpconv_aggregate: shape mismatch")
     if row_pos is None:
         row_pos = getattr(feats, "cofi_row_pos", None)   # left there by the group_norm_apply that produced feats
-    if row_pos is None:
-        row_pos = row_sum_positive(feats)
     agg = torch.empty((M, 15 * C), dtype=torch.float32, device=feats.device)
     cnt = torch.empty((M,), dtype=torch.float32, device=feats.device)
+    if C <= 4 and row_pos is None and M > 0:
+        # first layer: [features | position | positive-sum flag] packed into 32-byte records, one gather per neighbour
+        recs = torch.empty((N, 8), dtype=torch.float32, device=feats.device)
+        _lib.check(lib.cofi_kp_pack_c4(_p(feats), _ld(feats), C, _p(s_pts), N, _p(recs), _stream()), "cofi_kp_pack_c4")
+        rc = lib.cofi_kpconv_aggregate_c4(_p(recs), N // frames, C, _p(q_pts), _p(idx), M // frames, H, _p(kernel_points), float(sigma), _p(agg),
+                                          15 * C, _p(cnt), frames, _p(order), _stream())
+        _lib.check(rc, "cofi_kpconv_aggregate_c4")
+        return agg, cnt
+    if row_pos is None:
+        row_pos = row_sum_positive(feats)
     rc = lib.cofi_kpconv_aggregate(_p(feats), _ld(feats), N // frames, C, _p(q_pts), _p(s_pts), _p(idx), M // frames, H,
                                    _p(kernel_points), float(sigma), _p(row_pos), _p(agg), 15 * C, _p(cnt), frames, _p(order), _stream())
     _lib.check(rc, "cofi_kpconv_aggregate")

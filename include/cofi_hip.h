@@ -130,6 +130,14 @@ int cofi_idx32_to_idx64(const int32_t *src, int64_t *dst, size_t n, cofi_stream_
  * agg is (M, 15*C) with leading dimension ld_agg; part 2 is cofi_gemm_f32 with `rowdiv = cnt`.
  */
 int cofi_row_sum_positive(const float *feats, int ld, int N, int C, uint8_t *row_pos, cofi_stream_t stream);
+/* First layer (C <= 4 feature channels, e.g. [intensity | normal]): the cost of a neighbour in the staging is the number of cache lines
+ * its data lies in, so features, position and the positive-sum flag of every support point are packed ONCE into 32-byte records
+ * (N, 8) = [f0 f1 f2 f3 | x y z | flag] (cofi_kp_pack_c4, replaces cofi_row_sum_positive for this layer) and cofi_kpconv_aggregate_c4
+ * gathers one record per neighbour.  Same operands and order as cofi_kpconv_aggregate: identical results. */
+int cofi_kp_pack_c4(const float *feats, int ldf, int C, const float *points /* (N,3) */, int N, float *records, cofi_stream_t stream);
+int cofi_kpconv_aggregate_c4(const float *records, int N, int C, const float *q_pts, const int32_t *idx, int M, int H,
+                             const float *kernel_points, float sigma, float *agg, int ld_agg, float *cnt, int frames,
+                             const int32_t *order, cofi_stream_t stream);
 int cofi_kpconv_aggregate(const float *feats, int ldf, int N, int C, const float *q_pts, const float *s_pts, const int32_t *idx,
                           int M, int H, const float *kernel_points /* (15,3) */, float sigma, const uint8_t *row_pos,
                           float *agg, int ld_agg, float *cnt, int frames, const int32_t *order /* optional (frames*M) frame-local
