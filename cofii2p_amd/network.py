@@ -49,6 +49,9 @@ def score_thresholds(n: int = 64) -> np.ndarray:
     return np.asarray(out, dtype=np.float64).astype(np.float32)
 
 
+ALTERNATE_ORDER = os.environ.get("COFI_ALTERNATE_ORDER", "1") != "0"   # A/B switch: odd forward_async slots run the point encoder first (515-518 vs 510 f/s)
+
+
 class CoFiI2P(nn.Module):
     """See module docstring.  ``opt`` needs ``img_H, img_W, img_fine_resolution_scale, norm``
     (data/options.py:17-19,51); only ``norm == 'gn'`` (the shipped configuration) is implemented."""
@@ -163,7 +166,7 @@ class CoFiI2P(nn.Module):
 
     # ------------------------------------------------------------------ device-side forward (no host sync)
     def _run_device(self, P, points, neighbors, subsampling, upsampling, feats, img, mode, fine_center_kpt_coors,
-                    fine_pc_inline_index, taps=None, order=None):
+                    fine_pc_inline_index, taps=None, order=None, pc_first: bool = False):
         """Everything of network.py:74-161 that runs on the device.  Test-mode outputs are sized at
         capacity (N4 rows) with the match count left in device memory: capturable in a hipGraph.
 
@@ -182,18 +185,33 @@ class CoFiI2P(nn.Module):
         ts = transformer.TokenStreams(B * T_img, B * N4, D_MODEL, dev)
         # ---- image branch (network.py:77,90,104-106,110) on a side stream, concurrent with the point encoder
         br_dead = ops.Branch(dev, 3)  # ResNet layer3/layer4/avg-pool: computed (reference parity), read by nothing downstream
-        with ops.Branch(dev, 0) as br_img:
-            grid = self._pixel_grid(H8, W8, B, dev)   # (y, x) of every token of the 1/8 map: a constant, built once
-            img_set, dims = image.resnet34_nhwc(P, img, full=self.compute_unused_image_maps, tail_branch=br_dead)
-            s2, s4, s8 = img_set[0], img_set[1], img_set[2]  # (B*H*W, C) pixel-major
-            s8n = ops.l2norm_rows(s8)  # the normalised s8 map also feeds the up-sampler (network.py:90,129)
-            ops.l2norm_rows(s8, out=ts.img[0][:, :D_MODEL])
-            ops.pos_sine(grid, ts.img[0], accumulate=True)
-        # ---- point branch (network.py:76,83-84,107,111)
-        pc_set = kpfpn.run_fpn(P, points, neighbors, subsampling, upsampling, feats, taps=taps, frames=B, order=order)
-        fine_pc = ops.l2norm_rows(pc_set[0])  # (B*N1,64)
-        ops.l2norm_rows(self._pc_feature_mlp(P, pc_set[-1]), out=ts.pc[0][:, :D_MODEL])
-        ops.pos_sine(points[-1], ts.pc[0], accumulate=True)
+
+        def image_branch():
+            with ops.Branch(dev, 0) as br:
+                grid = self._pixel_grid(H8, W8, B, dev)   # (y, x) of every token of the 1/8 map: a constant, built once
+                img_set, dims = image.resnet34_nhwc(P, img, full=self.compute_unused_image_maps, tail_branch=br_dead)
+                s2_, s4_, s8_ = img_set[0], img_set[1], img_set[2]  # (B*H*W, C) pixel-major
+                s8n_ = ops.l2norm_rows(s8_)  # the normalised s8 map also feeds the up-sampler (network.py:90,129)
+                ops.l2norm_rows(s8_, out=ts.img[0][:, :D_MODEL])
+                ops.pos_sine(grid, ts.img[0], accumulate=True)
+            return br, s2_, s4_, s8n_
+
+        def point_branch():   # network.py:76,83-84,107,111
+            pc_set_ = kpfpn.run_fpn(P, points, neighbors, subsampling, upsampling, feats, taps=taps, frames=B, order=order)
+            fine_pc_ = ops.l2norm_rows(pc_set_[0])  # (B*N1,64)
+            ops.l2norm_rows(self._pc_feature_mlp(P, pc_set_[-1]), out=ts.pc[0][:, :D_MODEL])
+            ops.pos_sine(points[-1], ts.pc[0], accumulate=True)
+            return pc_set_, fine_pc_
+
+        # The two encoders are independent.  In a LINEAR capture (forward_async) their order is free: odd slots run the point encoder
+        # first, so that frames in flight on different streams do not march through the same kernels in lock step (complementary
+        # kernels - full-grid gathers next to small-grid convolutions - overlap better than two copies of the same one).
+        if pc_first:
+            pc_set, fine_pc = point_branch()
+            br_img, s2, s4, s8n = image_branch()
+        else:
+            br_img, s2, s4, s8n = image_branch()
+            pc_set, fine_pc = point_branch()
         br_img.join(s2, s4, s8n, ts.img[0])
         if taps is not None:
             taps["tok_img"], taps["tok_pc"] = ts.img_tokens().clone(), ts.pc_tokens().clone()
@@ -296,7 +314,8 @@ class CoFiI2P(nn.Module):
                 n = [len(points), len(neighbors), len(subsampling), len(upsampling), len(order)]
                 o = [0, n[0], n[0] + n[1], n[0] + n[1] + n[2], n[0] + n[1] + n[2] + n[3], sum(n)]
                 args = (static[o[0]:o[1]], static[o[1]:o[2]], static[o[2]:o[3]], static[o[3]:o[4]], static[o[5]], static[o[5] + 1], mode,
-                        static[o[5] + 2], static[o[5] + 3], None, (static[o[4]:o[5]] or None))
+                        static[o[5] + 2], static[o[5] + 3], None, (static[o[4]:o[5]] or None),
+                        ALTERNATE_ORDER and branch_mask == 0 and bool(slot & 1))
                 # warm-up AND capture run on one persistent stream, so every per-stream workspace is grown (in the
                 # ordinary allocator pool) before the capture starts and nothing is allocated for it inside
                 if getattr(self, "_capture_stream", None) is None or self._capture_stream.device != img.device:
