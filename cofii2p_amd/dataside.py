@@ -223,7 +223,10 @@ class FramePreparer:
                                               self.opt.img_H, self.opt.img_W, _p(out), _stream()), "cofi_resize_crop_image")
         return out
 
-    def prepare(self, data, img, K: np.ndarray, P_Tr: np.ndarray, index: int) -> Dict:
+    def prepare(self, data, img, K: np.ndarray, P_Tr: np.ndarray, index: int, defer_labels: bool = False) -> Dict:
+        """defer_labels=True: the model inputs come back at once (ONE host sync: the voxel count); the label tensors, which need the
+        coarsest-stage points on the host, are produced by calling out["finish_labels"]() later - e.g. after the forward of this
+        frame has been submitted, when the points have long arrived - and are then added to the same dict."""
         opt, dev = self.opt, self.device
         s = FrameSampler(index)
         data = (torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)) if isinstance(data, np.ndarray) else data).to(dev, non_blocking=True)
@@ -238,13 +241,26 @@ class FramePreparer:
         pyr["feats"] = feats
         K_2, K_4, crop, rhw = intrinsics_and_crop(K, img.shape[:2], opt, s, self.mode)
         image = self.image(img, rhw, crop)
-        lab = project_labels(pyr["points"][-1].cpu().numpy(), P, K_2, K_4, opt, s)
-        kpt = torch.from_numpy(lab["pc_kpt_idx"]).to(dev)
-        inline = ops.nearest_node(pyr["points"][1], pyr["points"][-1][kpt].contiguous()).to(torch.int64)   # point2node, kitti.py:374
         self.last = {"voxels": nvox, "choice": choice, "P_random": P, "subsample": sub, "crop": crop}
-        out = {"img": image, "pc_data_dict": pyr, "fine_pc_inline_index": inline,
-               "K": torch.from_numpy(K_2.astype(np.float32)).to(dev), "K_4": torch.from_numpy(K_4.astype(np.float32)).to(dev),
-               "P": torch.from_numpy(np.linalg.inv(P).astype(np.float32)).to(dev), "index": index}
-        for k, v in lab.items():
-            out[k] = torch.from_numpy(v).to(dev)
-        return out
+        out = {"img": image, "pc_data_dict": pyr,
+               "K": torch.from_numpy(K_2.astype(np.float32)).to(dev, non_blocking=True), "K_4": torch.from_numpy(K_4.astype(np.float32)).to(dev, non_blocking=True),
+               "P": torch.from_numpy(np.linalg.inv(P).astype(np.float32)).to(dev, non_blocking=True), "index": index}
+        coarse_host = torch.empty(pyr["points"][-1].shape, dtype=torch.float32, pin_memory=True)
+        coarse_host.copy_(pyr["points"][-1], non_blocking=True)
+        ready = torch.cuda.Event()
+        ready.record()
+
+        def finish_labels():
+            ready.synchronize()
+            lab = project_labels(coarse_host.numpy(), P, K_2, K_4, opt, s)
+            kpt = torch.from_numpy(lab["pc_kpt_idx"]).to(dev)
+            out["fine_pc_inline_index"] = ops.nearest_node(pyr["points"][1], pyr["points"][-1][kpt].contiguous()).to(torch.int64)   # point2node, kitti.py:374
+            for k, v in lab.items():
+                out[k] = torch.from_numpy(v).to(dev)
+            out.pop("finish_labels", None)
+            return out
+
+        if defer_labels:
+            out["finish_labels"] = finish_labels
+            return out
+        return finish_labels()
