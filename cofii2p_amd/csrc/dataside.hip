@@ -335,6 +335,78 @@ __global__ void resize_crop_kernel(const uint8_t *src, int sh, int sw, int dh, i
     out[e] = (float)min(max(v, 0), 255) / 255.f;
 }
 
+
+// ---- grid sub-sampling of a point set (model/kpconv/ops/grid_subsample.py -> geotransformer.ext.grid_subsampling, the KPConv
+// barycentre sub-sampler): origin = floor(min * (1 / dl)) * dl, cell = floor((p - origin) / dl) per axis, output = barycentre of every
+// occupied cell, all in float32 with sums in input order - the arithmetic of the published C++ (KPConv-PyTorch
+// cpp_wrappers/cpp_subsampling/grid_subsampling/grid_subsampling.cpp).  Output order here: ascending (iz, iy, ix) = ascending
+// map index of that code; the C++ emits its unordered_map's iteration order (unspecified).  Same sort / head-scan kernels as above.
+__global__ __launch_bounds__(256) void grid_keys_kernel(const float *pts, int N, float dl, const float *part, int nchunk, VoxHeader *hdr,
+                                                       unsigned long long *keys, int *idx) {
+    __shared__ float red[3][4];
+    __shared__ float s_org[3];
+    float mn[3] = {INFINITY, INFINITY, INFINITY};
+    for (int c = threadIdx.x; c < nchunk; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(part + 4 * c);
+        mn[0] = fminf(mn[0], v[0]); mn[1] = fminf(mn[1], v[1]); mn[2] = fminf(mn[2], v[2]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64));
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = mn[0]; red[1][w] = mn[1]; red[2][w] = mn[2]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        const float m = fminf(fminf(red[a][0], red[a][1]), fminf(red[a][2], red[a][3]));
+        s_org[a] = floorf(m * (1.0f / dl)) * dl;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    unsigned long long key = 0;
+#pragma unroll
+    for (int a = 2; a >= 0; --a) {   // z is the slowest axis of the map index
+        long long v = (long long)floorf((pts[(size_t)i * 3 + a] - s_org[a]) / dl);
+        if (v < 0 || v >= (1 << KEY_BITS)) { hdr->overflow = 1; v = v < 0 ? 0 : (1 << KEY_BITS) - 1; }
+        key = (key << KEY_BITS) | (unsigned long long)v;
+    }
+    keys[i] = key;
+    idx[i] = i;
+}
+
+__global__ void grid_mean_kernel(const float *pts, const int *sorted_idx, const int *head_pos, const VoxHeader *hdr, int N, int cap, float *out) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nv = hdr->nvox;
+    if (v >= nv || v >= cap) return;
+    const int b = head_pos[v], e = v + 1 < nv ? head_pos[v + 1] : N;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int s = b; s < e; ++s) {
+        const float *p = pts + (size_t)sorted_idx[s] * 3;
+        sx += p[0]; sy += p[1]; sz += p[2];
+    }
+    const float inv = (float)(1.0 / (double)(e - b));
+    out[(size_t)v * 3] = sx * inv;
+    out[(size_t)v * 3 + 1] = sy * inv;
+    out[(size_t)v * 3 + 2] = sz * inv;
+}
+
+// out[m][j] = idx[m][j] + offset if dist[m][j] < r2 (and the slot is a real neighbour) else fill; max_count[0] = max over rows of the
+// number of neighbours kept (integer atomicMax: order-free).  model/kpconv/ops/radius_search.py on top of the sorted k-nearest rows.
+__global__ void radius_mask_kernel(const int32_t *idx, const float *dist, int M, int k, int S, float r2, long long offset, long long fill,
+                                   long long *out, int32_t *max_count) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= M) return;
+    int cnt = 0;
+    for (int j = lane; j < k; j += 64) {
+        const int id = idx[(size_t)m * k + j];
+        const bool keep = (unsigned)id < (unsigned)S && dist[(size_t)m * k + j] < r2;
+        out[(size_t)m * k + j] = keep ? (long long)id + offset : fill;
+        cnt += __popcll(__ballot(keep));
+    }
+    if (lane == 0) atomicMax(max_count, cnt);
+}
 }  // namespace
 
 static inline size_t vox_align(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -388,6 +460,48 @@ extern "C" int cofi_voxel_downsample(const float *rows8, int N, double voxel, fl
                        out_rows8);
     // count_dev[0] = voxels (may exceed cap: only the first cap rows were written), count_dev[1] = 1 if a voxel index overflowed the
     // 13-bit key field (coordinates spread over more than 819 m at this voxel size) - written by the last head-scan workgroup
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_grid_subsample(const float *points, int N, float voxel, float *out_points, int cap, int32_t *count_dev, void *ws, size_t ws_bytes,
+                                   cofi_stream_t stream) {
+    if (!points || !out_points || !count_dev || N <= 0 || !(voxel > 0.f) || cap <= 0) return COFI_EINVAL;
+    if (!ws || ws_bytes < cofi_voxel_downsample_workspace(N) || ((uintptr_t)ws & 15)) return COFI_EWORKSPACE;
+    hipStream_t s = cofi_s(stream);
+    const int nchunk = cofi_cdiv(N, RED_T);
+    char *w = (char *)ws;
+    VoxHeader *hdr = (VoxHeader *)w; w += 256;
+    float *bpart = (float *)w; w += vox_align((size_t)nchunk * 16);
+    int *hpart = (int *)w; w += vox_align((size_t)nchunk * 4);
+    int *hist = (int *)w, *tot = hist + 256 * SORT_TILES; w += vox_align((size_t)(256 * SORT_TILES + 256) * 4);
+    unsigned long long *kA = (unsigned long long *)w; w += vox_align((size_t)N * 8);
+    unsigned long long *kB = (unsigned long long *)w; w += vox_align((size_t)N * 8);
+    int *vA = (int *)w; w += vox_align((size_t)N * 4);
+    int *vB = (int *)w; w += vox_align((size_t)N * 4);
+    int *heads = (int *)w;
+    (void)hipMemsetAsync(hdr, 0, sizeof(VoxHeader), s);
+    hipLaunchKernelGGL(vox_bounds_kernel, dim3(nchunk), dim3(RED_T), 0, s, points, 3, points, 3, N, bpart);
+    hipLaunchKernelGGL(grid_keys_kernel, dim3(cofi_cdiv(N, 256)), dim3(256), 0, s, points, N, voxel, bpart, nchunk, hdr, kA, vA);
+    const int tile = cofi_cdiv(N, SORT_TILES);
+    for (int pass = 0; pass < SORT_PASSES; ++pass) {
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(SORT_TILES / SORT_WPB), dim3(64 * SORT_WPB), 0, s, kA, N, 8 * pass, tile, hist);
+        hipLaunchKernelGGL(sort_scan_kernel, dim3(64), dim3(256), 0, s, hist, tot);
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(SORT_TILES / SORT_WPB), dim3(64 * SORT_WPB), 0, s, kA, vA, kB, vB, N, 8 * pass, tile, hist, tot);
+        unsigned long long *tk = kA; kA = kB; kB = tk;
+        int *tv = vA; vA = vB; vB = tv;
+    }
+    hipLaunchKernelGGL(vox_head_count_kernel, dim3(nchunk), dim3(RED_T), 0, s, kA, N, hpart);
+    hipLaunchKernelGGL(vox_head_write_kernel, dim3(nchunk), dim3(RED_T), 0, s, kA, N, hpart, nchunk, heads, hdr, count_dev);
+    hipLaunchKernelGGL(grid_mean_kernel, dim3(cofi_cdiv(N, 256)), dim3(256), 0, s, points, vA, heads, hdr, N, cap, out_points);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_radius_mask(const int32_t *idx, const float *dist, int M, int k, int S, float radius, long long offset, long long fill,
+                                long long *out, int32_t *max_count_dev, cofi_stream_t stream) {
+    if (!idx || !dist || !out || !max_count_dev || M < 0 || k <= 0 || S <= 0 || !(radius > 0.f)) return COFI_EINVAL;
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(radius_mask_kernel, dim3(cofi_cdiv(M, 4)), dim3(256), 0, cofi_s(stream), idx, dist, M, k, S, radius * radius, offset, fill, out,
+                       max_count_dev);
     return cofi_launch_status();
 }
 

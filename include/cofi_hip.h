@@ -407,6 +407,18 @@ int cofi_pack_transform_scan(const float *data7n, int N, const float *P44_dev, f
 size_t cofi_voxel_downsample_workspace(int N);
 int cofi_voxel_downsample(const float *rows8, int N, double voxel, float *out_rows8, int cap, int32_t *count_dev, void *ws, size_t ws_bytes,
                           cofi_stream_t stream);
+/* The two neighbourhood operators north_star names, model/kpconv/ops/grid_subsample.py and radius_search.py.  In the reference both
+ * call an extension that is not vendored (geotransformer.ext) and nothing on the forward path uses them; built here on the kernels
+ * above, parity with the extension unpinned (restated from the published KPConv / GeoTransformer C++):
+ *   cofi_grid_subsample  barycentre of every occupied cell of a `voxel` grid with origin floor(min / voxel) * voxel, float32 arithmetic in
+ *       input order, output (count, 3) in ascending (iz, iy, ix) order; ONE batch element per call; ws = cofi_voxel_downsample_workspace(N)
+ *   cofi_radius_mask     sorted k-nearest rows (cofi_knn_topk*: idx (M,k) into S support rows, squared distances) -> int64 rows in which
+ *       slots at squared distance >= radius^2 (or past the support) hold `fill`, the others idx + offset; max_count_dev[0] (zeroed by the
+ *       caller) = the largest number of neighbours kept in a row (the extension's output width) */
+int cofi_grid_subsample(const float *points, int N, float voxel, float *out_points, int cap, int32_t *count_dev, void *ws, size_t ws_bytes,
+                        cofi_stream_t stream);
+int cofi_radius_mask(const int32_t *idx, const float *dist, int M, int k, int S, float radius, long long offset, long long fill, long long *out,
+                     int32_t *max_count_dev, cofi_stream_t stream);
 int cofi_gather_transform(const float *vox_rows, const int32_t *choice, int n, const float *P44_dev, float *points, float *feats,
                           cofi_stream_t stream);
 int cofi_resize_crop_image(const uint8_t *src_hwc, int src_h, int src_w, int dst_h, int dst_w, int crop_y, int crop_x, int H, int W,

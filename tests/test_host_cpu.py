@@ -145,3 +145,34 @@ def test_bench_refuses_more_ranks_than_gpus():
     env["WORLD_SIZE"], env["RANK"], env["LOCAL_RANK"] = "4", "0", "0"
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "--gpus 1 but WORLD_SIZE=4" in (out.stderr + out.stdout)
+
+
+def test_neighbourhood_operator_shims_and_oracle_properties():
+    """model/kpconv/ops/{grid_subsample,radius_search}.py import paths resolve to cofii2p_amd.neighbors; the numpy oracle the GPU tests
+    compare against has the properties of the published algorithm (one barycentre per occupied cell, mass preserved; neighbours
+    inside the radius, nearest first, shadow index behind them)."""
+    import neighbors_oracle as NO
+    from cofii2p_amd import neighbors
+    from model.kpconv.ops import grid_subsample, radius_search
+    from model.kpconv.ops.grid_subsample import grid_subsample as gs2
+    from model.kpconv.ops.radius_search import radius_search as rs2
+
+    assert grid_subsample is neighbors.grid_subsample is gs2 and radius_search is neighbors.radius_search is rs2
+    g = np.random.default_rng(3)
+    p = g.uniform(-4, 4, (4000, 3)).astype(np.float32)
+    sp, sl = NO.grid_subsample(p, [2500, 1500], 0.7)
+    assert sp.shape[0] == sl.sum() and (sl < np.array([2500, 1500])).all()
+    for seg, bary in ((p[:2500], sp[:sl[0]]), (p[2500:], sp[sl[0]:])):
+        origin = np.floor(seg.min(0) * (np.float32(1) / np.float32(0.7))) * np.float32(0.7)
+        cells = np.floor((seg - origin) / np.float32(0.7)).astype(np.int64)
+        uniq, cnt = np.unique(cells[:, [2, 1, 0]], axis=0, return_counts=True)
+        assert len(uniq) == len(bary)
+        np.testing.assert_allclose((bary.astype(np.float64) * cnt[:, None]).sum(0) / len(seg), seg.astype(np.float64).mean(0), atol=1e-4)
+    rows = NO.radius_search(p[:200], p, [120, 80], [2500, 1500], 0.9, 48)
+    assert rows.shape[0] == 200 and rows.shape[1] <= 48 and rows.dtype == np.int64
+    assert ((rows[:120] < 2500) | (rows[:120] == 4000)).all() and ((rows[120:] >= 2500)).all()
+    assert (rows[:120, 0] == np.arange(120)).all()   # a query that is a support point finds itself first
+    for r in (0, 57, 150):
+        ids = rows[r][rows[r] != 4000]
+        d = ((p[ids].astype(np.float64) - p[r].astype(np.float64)) ** 2).sum(1)
+        assert (d < 0.81 + 1e-5).all() and (np.diff(d) >= -1e-6).all()
