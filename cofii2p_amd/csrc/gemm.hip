@@ -903,7 +903,11 @@ Plan make_plan(int M, int N, int K, bool fused_ln) {
         if (t.M == M && t.N == N && t.K == K) {
             int ks = t.ks;
             if (ks_scale != 1.0f && ks > 1) ks = (int)(ks * ks_scale + 0.5f) < 1 ? 1 : (int)(ks * ks_scale + 0.5f);
-            p = finish_plan(K, t.bm, t.bn, ks);
+            // COFI_GEMM_MAX_TILE = "<bm>x<bn>" (A/B runs): caps the tuned tile (e.g. 64x64: smallest register / LDS footprint)
+            static const struct Cap { int bm, bn; } cap = [] { Cap c{128, 128}; if (const char *e = getenv("COFI_GEMM_MAX_TILE")) sscanf(e, "%dx%d", &c.bm, &c.bn); return c; }();
+            int bm = t.bm < cap.bm ? t.bm : cap.bm, bn = t.bn < cap.bn ? t.bn : cap.bn;
+            if (bm == 128 && bn == 64) bm = 64;
+            p = finish_plan(K, bm, bn, ks);
             if (fused_ln && p.ksplit == 1 && p.bn < N) { p.bm = 64; p.bn = 128; }
             return p;
         }
