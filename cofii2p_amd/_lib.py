@@ -57,6 +57,7 @@ SIGNATURES = {
     "cofi_norm_finalize": (_I, [_N, _I, _I, _P, _P]),
     "cofi_group_norm_apply_partials": (_I, [_P, _I, _I, _I, _N, _P, _I, _N, _P, _I, _P, _I, _P]),
     "cofi_layer_norm": (_I, [_P, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _I, _P]),
+    "cofi_layer_norm_act": (_I, [_P, _I, _I, _I, _P, _P, _F, _F, _P, _I, _I, _P, _I, _P]),
     "cofi_loftr_tail_bf16x3": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
     "cofi_loftr_tail_parts_bf16x3": (_I, [_P, _Z, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P]),
     "cofi_attention_workspace": (_Z, [_I, _I, _I, _I, _I]),

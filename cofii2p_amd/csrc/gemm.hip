@@ -126,6 +126,7 @@ struct ATileLoader {
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == COFI_ACT_RELU) return fmaxf(v, 0.0f);
     if (act == COFI_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    if (act == COFI_ACT_LEAKY01) return v >= 0.0f ? v : v * 0.1f;
     return v;
 }
 
@@ -1080,7 +1081,7 @@ int gemm_entry(const float *A, int lda, const cofi_norm_desc_t *a_norm, const fl
     const int bf16x3 = (act & COFI_GEMM_BF16X3) ? 1 : 0;
     const int wsplit = (act & COFI_GEMM_W_SPLIT) ? 1 : 0;
     act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_W_SPLIT);
-    if (act < 0 || act > 2 || (wsplit && (!bf16x3 || (ldw & 7))) || frames <= 0) return COFI_EINVAL;
+    if (act < 0 || act > 3 || (wsplit && (!bf16x3 || (ldw & 7))) || frames <= 0) return COFI_EINVAL;
     const int sshift = colpart ? stat_shift_of(stat_width, N) : 0;
     if (sshift < 0) return COFI_EINVAL;
     Plan p = make_plan(M, N, K, false);
@@ -1104,7 +1105,7 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
     const int bf16x3 = (act & COFI_GEMM_BF16X3) ? 1 : 0;
     const int wsplit = (act & COFI_GEMM_W_SPLIT) ? 1 : 0;
     act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_W_SPLIT);
-    if (act < 0 || act > 2 || (wsplit && !bf16x3) || act_col0 < 0 || act_col0 > Cout) return COFI_EINVAL;
+    if (act < 0 || act > 3 || (wsplit && !bf16x3) || act_col0 < 0 || act_col0 > Cout) return COFI_EINVAL;
     const int sshift = colpart ? stat_shift_of(stat_width, Cout) : 0;
     if (sshift < 0) return COFI_EINVAL;
     const int ldw = wsplit ? (K + 7) / 8 * 8 : K;   // pre-split planes: rows padded to 8 values

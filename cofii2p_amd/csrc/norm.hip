@@ -318,8 +318,8 @@ __global__ __launch_bounds__(256) void group_norm_apply_fused_kernel(GnFusedArgs
 // ---------------------------------------------------------------------------- LayerNorm
 // one wave per row, C <= 2048 held in registers (8 float4 per lane)
 __global__ __launch_bounds__(256) void layer_norm_kernel(const float *x, int ldx, int M, int C, const float *gamma,
-                                                         const float *beta, float eps, int relu, const float *res, int ldr,
-                                                         float *y, int ldy) {
+                                                         const float *beta, float eps, float slope, const float *res, int ldr,
+                                                         int res_first, float *y, int ldy) {
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     const int lane = threadIdx.x & 63;
@@ -355,13 +355,14 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float *x, int ldx
             o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
             o.z = (v[i].z - mean) * rstd * gm.z + bt.z;
             o.w = (v[i].w - mean) * rstd * gm.w + bt.w;
-            if (relu) {
-                o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+            float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (res) rv = reinterpret_cast<const float4 *>(res + (size_t)m * ldr)[c4];
+            if (res_first) { o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w; }
+            if (slope != 1.0f) {   // slope 0: max(o, 0) exactly
+                o.x = o.x >= 0.f ? o.x : o.x * slope; o.y = o.y >= 0.f ? o.y : o.y * slope;
+                o.z = o.z >= 0.f ? o.z : o.z * slope; o.w = o.w >= 0.f ? o.w : o.w * slope;
             }
-            if (res) {
-                const float4 rv = reinterpret_cast<const float4 *>(res + (size_t)m * ldr)[c4];
-                o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
-            }
+            if (!res_first) { o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w; }
             reinterpret_cast<float4 *>(y + (size_t)m * ldy)[c4] = o;
         }
     }
@@ -566,8 +567,17 @@ extern "C" int cofi_layer_norm(const float *x, int ldx, int M, int C, const floa
                                const float *res, int ldr, float *y, int ldy, cofi_stream_t stream) {
     if (!x || !y || !gamma || !beta || M <= 0 || C <= 0 || C > 2048 || (C & 3) || (ldx & 3) || (ldy & 3) || (res && (ldr & 3)))
         return COFI_EINVAL;
-    hipLaunchKernelGGL(layer_norm_kernel, dim3(cofi_cdiv(M, 4)), dim3(256), 0, cofi_s(stream), x, ldx, M, C, gamma, beta, eps, relu,
-                       res, ldr, y, ldy);
+    hipLaunchKernelGGL(layer_norm_kernel, dim3(cofi_cdiv(M, 4)), dim3(256), 0, cofi_s(stream), x, ldx, M, C, gamma, beta, eps, relu ? 0.0f : 1.0f,
+                       res, ldr, 0, y, ldy);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_layer_norm_act(const float *x, int ldx, int M, int C, const float *gamma, const float *beta, float eps, float slope, const float *res,
+                                   int ldr, int res_first, float *y, int ldy, cofi_stream_t stream) {
+    if (!x || !y || !gamma || !beta || M <= 0 || C <= 0 || C > 2048 || (C & 3) || (ldx & 3) || (ldy & 3) || (res && (ldr & 3)) || !(slope >= 0.f && slope <= 1.f))
+        return COFI_EINVAL;
+    hipLaunchKernelGGL(layer_norm_kernel, dim3(cofi_cdiv(M, 4)), dim3(256), 0, cofi_s(stream), x, ldx, M, C, gamma, beta, eps, slope, res, ldr,
+                       res_first ? 1 : 0, y, ldy);
     return cofi_launch_status();
 }
 

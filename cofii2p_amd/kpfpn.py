@@ -15,17 +15,49 @@ LRELU = 0.1
 FUSED_KPCONV = os.environ.get("COFI_KPCONV_FUSED", "0") == "1"
 
 
+def norm_kind(sd) -> str:
+    """Which get_norm() variant (modules.py:51-60) the point encoder's state holds: the key layout differs per kind."""
+    if "pc_encoder.encoder1_1.norm.norm.weight" in sd:
+        return "gn"
+    return "bn" if "pc_encoder.encoder1_1.norm.running_mean" in sd else "ln"
+
+
 def pack_encoder(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """KPConv weights (15,Cin,Cout) -> (Cout, 15*Cin) so that part 2 of the operator
-    (kpconv.py:107-110: sum_k agg[:,k,:] @ W[k]) is ONE K-contiguous GEMM; the rest is used in place."""
+    (kpconv.py:107-110: sum_k agg[:,k,:] @ W[k]) is ONE K-contiguous GEMM; the rest is used in place.
+    'bn' configuration (inference = running statistics): every BatchNorm1d is an affine map per channel behind a Linear / KPConv and
+    is folded into that layer's weights and bias here: y * s + t with s = gamma / sqrt(var + eps), t = beta - mean * s."""
     out = {}
+    kind = norm_kind(sd)
+    fold = {}   # prefix of the layer a BatchNorm follows -> (s, t)
+    if kind == "bn":
+        for k in sd:
+            if k.startswith("pc_encoder.") and k.endswith("running_mean"):
+                np_ = k[:-len("running_mean")]                      # "...unary1.norm." / "...norm_conv." / "...encoder1_1.norm."
+                s_ = sd[np_ + "weight"].double() / torch.sqrt(sd[np_ + "running_var"].double() + 1e-5)
+                t_ = sd[np_ + "bias"].double() - sd[k].double() * s_
+                if np_.endswith("norm_conv."):
+                    layer = np_[:-len("norm_conv.")] + "KPConv."
+                elif (np_[:-len("norm.")] + "KPConv.weights") in sd:   # ConvBlock: X.KPConv + X.norm
+                    layer = np_[:-len("norm.")] + "KPConv."
+                else:
+                    layer = np_[:-len("norm.")] + "mlp."            # UnaryBlock: X.mlp + X.norm
+                fold[layer] = (s_, t_)
     for k, v in sd.items():
         if not k.startswith("pc_encoder."):
             continue
+        layer = k.rsplit(".", 1)[0] + "."
+        st = fold.get(layer)
         if k.endswith("KPConv.weights"):
-            out[k] = v.permute(2, 0, 1).reshape(v.shape[2], -1).contiguous()
+            w = v.permute(2, 0, 1).reshape(v.shape[2], -1)
+            out[k] = (w.double() * st[0][:, None]).float().contiguous() if st else w.contiguous()
+        elif st is not None and k.endswith("mlp.weight"):
+            out[k] = (v.double() * st[0][:, None]).float().contiguous()
+        elif st is not None and k.endswith(("mlp.bias", "KPConv.bias")):
+            out[k] = (v.double() * st[0] + st[1]).float().contiguous()
         else:
             out[k] = v.contiguous()
+    out["pc_encoder.__norm__"] = kind
     return out
 
 
@@ -104,6 +136,44 @@ def run_block(P, blk: KPBlock, feats, q_pts, s_pts, idx, out=None, concurrent: b
     return ops.group_norm_apply(y2, st2, g2, b2, slope=LRELU, res=sc, out=out, frames=frames)
 
 
+# ---- 'bn' / 'ln' configurations of get_norm() (modules.py:51-60).  Row-wise normalisations: nothing to accumulate across rows, so these
+# paths are plain kernel sequences - BatchNorm (running statistics) is already folded into the weights, the LeakyReLU and the residual
+# join ride in the GEMM epilogue; LayerNorm is the row kernel with LeakyReLU / residual fused.
+def _ln(P, np_: str, y, slope: float, res=None, out=None):
+    return ops.layer_norm_act(y, P[np_ + "weight"], P[np_ + "bias"], slope=slope, res=res, res_first=True, out=out)
+
+
+def _unary_plain(P, kind: str, p: str, x, slope: float, res=None, out=None):
+    """UnaryBlock (modules.py:63-94): Linear -> norm -> LeakyReLU(slope) with an optional residual joined before the activation."""
+    w, b = P[p + "mlp.weight"], P[p + "mlp.bias"]
+    if kind == "bn":
+        act = ops.ACT_LEAKY01 if slope != 1.0 else ops.ACT_NONE
+        if res is None:
+            return ops.gemm(x, w, bias=b, act=act, out=out)
+        return ops.conv2d_nhwc(x, x.shape[0], 1, w, 1, stride=1, pad=0, bias=b, res=res, act=act, out=out)[0]   # 1x1 "convolution" = GEMM + residual
+    return _ln(P, p + "norm.", ops.gemm(x, w, bias=b), slope, res=res, out=out)
+
+
+def _kpconv_plain(P, kind: str, p: str, np_: str, feats, q_pts, s_pts, idx, sigma, frames, order, out=None):
+    agg, cnt = ops.kpconv_aggregate(feats, q_pts, s_pts, idx, P[p + "KPConv.kernel_points"], sigma, frames=frames, order=order)
+    w, b = P[p + "KPConv.weights"], P[p + "KPConv.bias"]
+    if kind == "bn":
+        return ops.gemm(agg, w, bias=b, rowdiv=cnt, act=ops.ACT_LEAKY01, out=out)
+    return _ln(P, np_, ops.gemm(agg, w, bias=b, rowdiv=cnt), LRELU, out=out)
+
+
+def run_block_plain(P, kind: str, blk: KPBlock, feats, q_pts, s_pts, idx, out=None, frames: int = 1, order=None):
+    p = "pc_encoder.%s." % blk.name
+    if blk.kind == "conv":   # modules.py:155-159
+        return _kpconv_plain(P, kind, p, p + "norm.", feats, q_pts, s_pts, idx, blk.sigma, frames, order, out=out)
+    x = _unary_plain(P, kind, p + "unary1.", feats, LRELU) if blk.cin != blk.mid else feats   # modules.py:222-240
+    x = _kpconv_plain(P, kind, p, p + "norm_conv.", x, q_pts, s_pts, idx, blk.sigma, frames, order)
+    sc = ops.neighbor_maxpool(feats, idx, frames=frames, order=order) if blk.strided else feats
+    if blk.has_shortcut_unary:
+        sc = _unary_plain(P, kind, p + "unary_shortcut.", sc, 1.0)
+    return _unary_plain(P, kind, p + "unary2.", x, LRELU, res=sc, out=out)
+
+
 def run_fpn(P, points: List[torch.Tensor], neighbors, subsampling, upsampling, feats, taps=None, frames: int = 1, order=None):
     """`order` (optional): per stage, the frame-local processing order of the stage's points (spatially sorted)."""
     """Returns [latent_s2 (N1,64), latent_s3 (N2,512), latent_s4 (N3,1024), feats_s5 (N4,2048)].
@@ -121,6 +191,7 @@ def run_fpn(P, points: List[torch.Tensor], neighbors, subsampling, upsampling, f
         last_of_stage[blk.stage] = blk.name
     x = feats
     stage_out = {}
+    kind = P.get("pc_encoder.__norm__", "gn")
     for blk in ENCODER:
         st = blk.stage
         if blk.strided:
@@ -131,15 +202,19 @@ def run_fpn(P, points: List[torch.Tensor], neighbors, subsampling, upsampling, f
         if st in cat and last_of_stage[st] == blk.name:
             w = stage_width[st]
             out = cat[st][:, cat[st].shape[1] - w:]
-        x = run_block(P, blk, x, q, s, idx, out=out, frames=frames, order=None if order is None else order[st])
+        if kind == "gn":
+            x = run_block(P, blk, x, q, s, idx, out=out, frames=frames, order=None if order is None else order[st])
+        else:
+            x = run_block_plain(P, kind, blk, x, q, s, idx, out=out, frames=frames, order=None if order is None else order[st])
         stage_out[st] = x
         if taps is not None:
             taps[blk.name] = x
     s5 = stage_out[4]
     ops.gather_rows(s5, upsampling[3], out=cat[3][:, :2048], frames=frames)
-    l4 = _unary(P, "pc_encoder.decoder4.", cat[3], LRELU, frames=frames)
+    dec = (lambda name, x_: _unary(P, name, x_, LRELU, frames=frames)) if kind == "gn" else (lambda name, x_: _unary_plain(P, kind, name, x_, LRELU))
+    l4 = dec("pc_encoder.decoder4.", cat[3])
     ops.gather_rows(l4, upsampling[2], out=cat[2][:, :1024], frames=frames)
-    l3 = _unary(P, "pc_encoder.decoder3.", cat[2], LRELU, frames=frames)
+    l3 = dec("pc_encoder.decoder3.", cat[2])
     ops.gather_rows(l3, upsampling[1], out=cat[1][:, :512], frames=frames)
     l2 = ops.gemm(cat[1], P["pc_encoder.decoder2.mlp.weight"], bias=P["pc_encoder.decoder2.mlp.bias"])
     if taps is not None:

@@ -54,25 +54,27 @@ ALTERNATE_ORDER = os.environ.get("COFI_ALTERNATE_ORDER", "1") != "0"   # A/B swi
 
 class CoFiI2P(nn.Module):
     """See module docstring.  ``opt`` needs ``img_H, img_W, img_fine_resolution_scale, norm``
-    (data/options.py:17-19,51); only ``norm == 'gn'`` (the shipped configuration) is implemented."""
+    (data/options.py:17-19,51).  ``norm``: 'gn' (the shipped configuration, the fast path), 'bn' (inference: running statistics, folded
+    into the weights) or 'ln' - the three get_norm() variants of model/kpconv/modules.py:51-60."""
 
     MAX_STABLE_GRAPHS = 64   # distinct (slot, input set) graphs kept for forward_async(inputs_stable=True)
 
     def __init__(self, opt, init: str = "synthetic"):
         super().__init__()
         self.opt = opt
-        if getattr(opt, "norm", "gn") != "gn":
-            raise NotImplementedError("only opt.norm == 'gn' (data/options.py:51) is implemented")
+        self.pc_norm_kind = getattr(opt, "norm", "gn")   # get_norm() of the point encoder: 'gn' (shipped), 'bn' (running statistics), 'ln'
+        if self.pc_norm_kind not in ("gn", "bn", "ln"):
+            raise ValueError("only support batch normalization, layer normalization and group normalization now!")   # modules.py:60
         self.pe_H = int(opt.img_H / 8)
         self.pe_W = int(opt.img_W / 8)
         self.H_fine_res = int(round(opt.img_H / opt.img_fine_resolution_scale))
         self.W_fine_res = int(round(opt.img_W / opt.img_fine_resolution_scale))
-        for name, (shape, dtype) in state_dict_spec().items():
+        for name, (shape, dtype) in state_dict_spec(self.pc_norm_kind).items():
             _attach(self, name, shape, dtype)
         if init == "synthetic":
             from .spec import synth_state_dict
 
-            self.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict().items()}, strict=True)
+            self.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(norm=self.pc_norm_kind).items()}, strict=True)
         self._packed: Optional[Dict[str, torch.Tensor]] = None
         self._packed_key = None
         self.compute_unused_image_maps = True  # layer3/layer4/avg-pool of the ResNet (network.py:87-89)
@@ -444,6 +446,8 @@ class CoFiI2P(nn.Module):
         if torch.is_grad_enabled() and (mode == "train" or img.requires_grad or pc_data_dict["feats"].requires_grad):
             raise NotImplementedError("cofii2p_amd.CoFiI2P is forward-only (no autograd through the HIP kernels): call it under "
                                       "torch.no_grad() for inference / validation; training needs the reference's PyTorch model")
+        if self.training and self.pc_norm_kind == "bn":
+            raise NotImplementedError("opt.norm == 'bn' is served with running statistics (module.eval()); batch statistics need the reference's model")
         with torch.no_grad():
             return self._forward(pc_data_dict, img, fine_center_kpt_coors, fine_pc_inline_index, mode, taps)
 

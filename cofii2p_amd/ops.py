@@ -15,7 +15,7 @@ from . import _lib
 
 import os
 
-ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_LEAKY01 = 0, 1, 2, 3
 GEMM_BF16X3 = 0x100
 # arithmetic of the dense contractions: "bf16x3" (default) = 3-term bf16 split (hi*hi + hi*lo + lo*hi) on the bf16 matrix cores
 # with fp32 accumulation, ~2^-16 relative error per product; "f32" = exact fp32 MFMA (COFI_GEMM=f32)
@@ -533,6 +533,21 @@ def layer_norm(x, gamma, beta, relu: bool = False, res=None, out=None, eps: floa
     rc = lib.cofi_layer_norm(_p(x), _ld(x), M, C, _p(gamma), _p(beta), eps, int(relu), _p(res), 0 if res is None else _ld(res), _p(out),
                              _ld(out), _stream())
     _lib.check(rc, "cofi_layer_norm")
+    return out
+
+
+def layer_norm_act(x, gamma, beta, slope: float = 1.0, res=None, res_first: bool = True, out=None, eps: float = 1e-5):
+    """y = leaky(LN(x) * gamma + beta + (res if res_first), slope) + (res if not res_first)   (cofi_layer_norm_act)."""
+    lib = _lib.load()
+    _mat(x, "x")
+    M, C = x.shape
+    if out is None:
+        out = torch.empty((M, C), dtype=torch.float32, device=x.device)
+    if M == 0:
+        return out
+    rc = lib.cofi_layer_norm_act(_p(x), _ld(x), M, C, _p(gamma), _p(beta), eps, float(slope), _p(res), 0 if res is None else _ld(res),
+                                 int(res_first), _p(out), _ld(out), _stream())
+    _lib.check(rc, "cofi_layer_norm_act")
     return out
 
 

@@ -77,8 +77,11 @@ def _f32(shape):
     return (tuple(shape), "float32")
 
 
-def state_dict_spec() -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
-    """name -> (shape, dtype) in the reference's registration order."""
+def state_dict_spec(norm: str = "gn") -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
+    """name -> (shape, dtype) in the reference's registration order.  norm: the point encoder's normalisation, get_norm() of
+    model/kpconv/modules.py:51-60: 'gn' GroupNorm(32, C) (the shipped configuration), 'bn' BatchNorm1d(C), 'ln' LayerNorm(C)."""
+    if norm not in ("gn", "bn", "ln"):
+        raise ValueError("only support batch normalization, layer normalization and group normalization now!")   # modules.py:60
     s: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
 
     # --- image encoder: ResNet-34 with affine-less InstanceNorm (imagenet.py:119-217) ---
@@ -97,12 +100,23 @@ def state_dict_spec() -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
     s[bb + "fc.bias"] = _f32((1000,))
 
     # --- point encoder: KPConv-FPN (kp_backbone.py) ---
-    def unary(prefix, cin, cout, norm=True):
+    def pc_norm(prefix, c):   # prefix ends in "norm." / "norm_conv."
+        if norm == "gn":      # modules.py:32-49: wrapper module with the nn.GroupNorm as `.norm`
+            s[prefix + "norm.weight"] = _f32((c,))
+            s[prefix + "norm.bias"] = _f32((c,))
+        else:
+            s[prefix + "weight"] = _f32((c,))
+            s[prefix + "bias"] = _f32((c,))
+            if norm == "bn":
+                s[prefix + "running_mean"] = _f32((c,))
+                s[prefix + "running_var"] = _f32((c,))
+                s[prefix + "num_batches_tracked"] = ((), "int64")
+
+    def unary(prefix, cin, cout, has_norm=True):
         s[prefix + "mlp.weight"] = _f32((cout, cin))
         s[prefix + "mlp.bias"] = _f32((cout,))
-        if norm:
-            s[prefix + "norm.norm.weight"] = _f32((cout,))
-            s[prefix + "norm.norm.bias"] = _f32((cout,))
+        if has_norm:
+            pc_norm(prefix + "norm.", cout)
 
     for blk in ENCODER:
         p = "pc_encoder.%s." % blk.name
@@ -110,8 +124,7 @@ def state_dict_spec() -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
             s[p + "KPConv.weights"] = _f32((KP_K, blk.cin, blk.cout))
             s[p + "KPConv.bias"] = _f32((blk.cout,))
             s[p + "KPConv.kernel_points"] = _f32((KP_K, 3))
-            s[p + "norm.norm.weight"] = _f32((blk.cout,))
-            s[p + "norm.norm.bias"] = _f32((blk.cout,))
+            pc_norm(p + "norm.", blk.cout)
         else:
             mid = blk.mid
             if blk.cin != mid:
@@ -119,13 +132,12 @@ def state_dict_spec() -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
             s[p + "KPConv.weights"] = _f32((KP_K, mid, mid))
             s[p + "KPConv.bias"] = _f32((mid,))
             s[p + "KPConv.kernel_points"] = _f32((KP_K, 3))
-            s[p + "norm_conv.norm.weight"] = _f32((mid,))
-            s[p + "norm_conv.norm.bias"] = _f32((mid,))
+            pc_norm(p + "norm_conv.", mid)
             unary(p + "unary2.", mid, blk.cout)
             if blk.has_shortcut_unary:
                 unary(p + "unary_shortcut.", blk.cin, blk.cout)
-    for name, cin, cout, norm in DECODERS:
-        unary("pc_encoder.%s." % name, cin, cout, norm)
+    for name, cin, cout, has_norm in DECODERS:
+        unary("pc_encoder.%s." % name, cin, cout, has_norm)
 
     # --- heads (network.py:29-43) ---
     s["pc_feature_layer.0.weight"] = _f32((1024, 2048))
@@ -189,14 +201,14 @@ def kpconv_radius_of(name: str) -> Optional[float]:
     return None
 
 
-def synth_state_dict(salt: int = 0):
+def synth_state_dict(salt: int = 0, norm: str = "gn"):
     """Full synthetic state_dict (numpy arrays) from the name-keyed generator."""
     import numpy as np
 
     from .weights import kernel_point_table, synth_tensor
 
     out = OrderedDict()
-    for name, (shape, dtype) in state_dict_spec().items():
+    for name, (shape, dtype) in state_dict_spec(norm).items():
         if name.endswith("kernel_points"):
             out[name] = kernel_point_table(KP_K, kpconv_radius_of(name))
         else:

@@ -71,6 +71,7 @@ typedef struct cofi_norm_desc {
 #define COFI_ACT_NONE 0
 #define COFI_ACT_RELU 1
 #define COFI_ACT_SIGMOID 2
+#define COFI_ACT_LEAKY01 3 /* LeakyReLU(0.1), the point encoder's activation (model/kpconv/modules.py:85,142,222) */
 /* OR-ed into `act` (or into `relu` of cofi_gemm_f32_layernorm): form the fp32 products as a 3-term bf16 split
  * (hi*hi + hi*lo + lo*hi, fp32 accumulate) on the bf16 matrix cores instead of the exact fp32 MFMA:
  * ~2^-16 relative error per product, 5.3x the MFMA rate. */
@@ -243,6 +244,11 @@ int cofi_group_norm_apply_partials(const float *x, int ldx, int M, int C, const 
 
 /* Row LayerNorm: y = act(LN(x) * gamma + beta) (+ res).  Replaces nn.LayerNorm at
  * model/transformer/transformer.py:40-41,58,62 and model/network.py:29.  C <= 2048, C % 4 == 0. */
+/* cofi_layer_norm_act: the general form, y = leaky(LN(x) * gamma + beta + R1, slope) + R2 with R1 = res if res_first else 0 and
+ * R2 = res otherwise; slope 1 = no activation, 0 = ReLU, 0.1 = the point encoder's LeakyReLU (the 'ln' configuration of
+ * model/kpconv/modules.py:51-60: UnaryBlock / ConvBlock / the residual join of ResidualBlock). */
+int cofi_layer_norm_act(const float *x, int ldx, int M, int C, const float *gamma, const float *beta, float eps, float slope, const float *res,
+                        int ldr, int res_first, float *y, int ldy, cofi_stream_t stream);
 int cofi_layer_norm(const float *x, int ldx, int M, int C, const float *gamma, const float *beta, float eps, int relu,
                     const float *res, int ldr, float *y, int ldy, cofi_stream_t stream);
 

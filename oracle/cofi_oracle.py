@@ -125,11 +125,21 @@ def leaky(x: Tensor) -> Tensor:
     return F.leaky_relu(x, 0.1)
 
 
+def pc_norm(sd, p: str, x: Tensor) -> Tensor:
+    """get_norm() of modules.py:51-60 applied to (N, C) rows, picked by the keys the state_dict holds under prefix p ("...norm." /
+    "...norm_conv."): GroupNorm wrapper (p + "norm.weight"), BatchNorm1d in eval mode (running statistics), LayerNorm."""
+    if (p + "norm.weight") in sd:
+        return group_norm_rows(x, sd[p + "norm.weight"], sd[p + "norm.bias"])
+    if (p + "running_mean") in sd:
+        return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"], False, 0.1, 1e-5)
+    return F.layer_norm(x, (x.shape[1],), sd[p + "weight"], sd[p + "bias"], 1e-5)
+
+
 def unary_block(sd, p: str, x: Tensor, norm: bool = True, act: bool = True) -> Tensor:
     """modules.py:63-112 UnaryBlock / LastUnaryBlock."""
     y = x @ sd[p + "mlp.weight"].t() + sd[p + "mlp.bias"]
     if norm:
-        y = group_norm_rows(y, sd[p + "norm.norm.weight"], sd[p + "norm.norm.bias"])
+        y = pc_norm(sd, p + "norm.", y)
         if act:
             y = leaky(y)
     return y
@@ -148,14 +158,14 @@ def nearest_upsample(x: Tensor, idx: Tensor) -> Tensor:
 def conv_block(sd, p: str, feats, q_pts, s_pts, idx, sigma) -> Tensor:
     """modules.py:115-159."""
     y = kpconv(feats, q_pts, s_pts, idx, sd[p + "KPConv.kernel_points"], sd[p + "KPConv.weights"], sd[p + "KPConv.bias"], sigma)
-    return leaky(group_norm_rows(y, sd[p + "norm.norm.weight"], sd[p + "norm.norm.bias"]))
+    return leaky(pc_norm(sd, p + "norm.", y))
 
 
 def residual_block(sd, p: str, feats, q_pts, s_pts, idx, sigma, strided: bool) -> Tensor:
     """modules.py:162-240 (bottleneck: unary1 -> KPConv -> GN -> LReLU -> unary2 (+ shortcut) -> LReLU)."""
     x = unary_block(sd, p + "unary1.", feats) if (p + "unary1.mlp.weight") in sd else feats
     x = kpconv(x, q_pts, s_pts, idx, sd[p + "KPConv.kernel_points"], sd[p + "KPConv.weights"], sd[p + "KPConv.bias"], sigma)
-    x = leaky(group_norm_rows(x, sd[p + "norm_conv.norm.weight"], sd[p + "norm_conv.norm.bias"]))
+    x = leaky(pc_norm(sd, p + "norm_conv.", x))
     x = unary_block(sd, p + "unary2.", x, act=False)
     sc = neighbor_maxpool(feats, idx) if strided else feats
     if (p + "unary_shortcut.mlp.weight") in sd:

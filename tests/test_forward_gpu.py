@@ -255,6 +255,49 @@ def test_kitti_frame_bf16x3_gemms_within_tolerance(model, monkeypatch):
     assert abs(res[6].shape[1] - gold["test_center_xy"].shape[1]) <= 3  # a score may cross the 0.9 threshold
 
 
+@pytest.mark.parametrize("norm", ["bn", "ln"])
+def test_tiny_frame_other_point_encoder_norms(norm, monkeypatch):
+    """opt.norm = 'bn' / 'ln' (get_norm(), modules.py:51-60) against the reference built with that option: BatchNorm (running
+    statistics) folded into the weights with LeakyReLU / residual in the GEMM epilogue, LayerNorm as the fused row kernel.  Default
+    arithmetic (bf16x3), one frame eager + graph replay + a stacked pair."""
+    from cofii2p_amd import ops
+    from cofii2p_amd.network import CoFiI2P
+
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x3")
+
+    class O2(Opt):
+        pass
+
+    O2.norm = norm
+    m = CoFiI2P(O2()).to(DEV)
+    assert ("pc_encoder.encoder1_1.norm.running_mean" in m.state_dict()) == (norm == "bn")
+    gold = load_golden("frame_tiny_%s.npz" % norm)
+    fr, data = frame_inputs(int(gold["frame_id"]), int(gold["num_points"]), int(gold["pyr_seed"]))
+    dd, img = to_dev(data), torch.from_numpy(fr.img)[None].to(DEV)
+    taps = {}
+    res = m(dd, img, None, None, None, "test", taps=taps)
+    for k in gold.files:
+        if k.startswith("tap_encoder"):
+            v = taps[k[4:]]
+            d = maxdiff(v[:: max(1, v.shape[0] // 8)][:8], gold[k])
+            assert d <= 5e-4 * max(1.0, float(np.abs(gold[k]).max())), (k, d)
+    for n, t in zip(("img_desc", "pc_desc", "img_score", "pc_score"), res[:4]):
+        assert maxdiff(t, gold["test_" + n]) <= TOL, (n, maxdiff(t, gold["test_" + n]))
+    assert abs(res[6].shape[1] - gold["test_center_xy"].shape[1]) <= 2
+    ref = [t.clone() for t in res[:4]]
+    m.enable_graphs(True)
+    for a, b in zip(ref, m(dd, img, None, None, None, "test")[:4]):
+        assert torch.equal(a, b)
+    stacked, imgs = CoFiI2P.stack_frames([dd, dd], [img, img])
+    for out in m.finish(m.forward_async(3, stacked, imgs)):
+        for a, b in zip(ref, out[:4]):
+            assert maxdiff(a.cpu(), b.cpu()) < 1e-4   # other GEMM plans for the stacked shapes: another bf16x3 summation order
+    if norm == "bn":
+        m.train()
+        with pytest.raises(NotImplementedError):
+            m(dd, img, None, None, None, "test")
+
+
 def test_kitti_frame_fused_kpconv_optin(model, monkeypatch):
     """COFI_KPCONV_FUSED=1 (narrow KPConv layers as one kernel, cofi_kpconv_fused): same golden comparison, one frame and a stacked
     pair; the layers really take the fused path."""

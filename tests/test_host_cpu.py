@@ -57,6 +57,28 @@ def test_state_dict_layout_matches_reference_dump():
         m.load_state_dict({k: v for k, v in list(other.items())[:-1]}, strict=True)
 
 
+@pytest.mark.parametrize("norm,n_params", [("bn", 51588744), ("ln", 51588744)])
+def test_state_dict_layout_of_the_other_norm_configurations(norm, n_params):
+    """opt.norm = 'bn' / 'ln' (get_norm(), model/kpconv/modules.py:51-60): key order, shapes and dtypes of the reference's own
+    state_dict for that option (tests/golden/state_dict_spec_<norm>.json, dumped from the reference)."""
+    from cofii2p_amd.network import CoFiI2P
+
+    class Opt:
+        img_H, img_W, img_fine_resolution_scale = 160, 512, 32
+
+    Opt.norm = norm
+    m = CoFiI2P(Opt())
+    ref = json.load(open(os.path.join(GOLD, "state_dict_spec_%s.json" % norm)))
+    sd = m.state_dict()
+    assert [k for k, _, _ in ref] == list(sd.keys())
+    for k, shape, dtype in ref:
+        assert list(sd[k].shape) == shape and str(sd[k].dtype) == "torch." + dtype, k
+    assert sum(p.numel() for p in m.parameters()) == n_params
+    Opt.norm = "in"
+    with pytest.raises(ValueError):
+        CoFiI2P(Opt())
+
+
 def test_forward_has_no_cpu_path():
     from cofii2p_amd._lib import CofiError
     from cofii2p_amd.network import CoFiI2P

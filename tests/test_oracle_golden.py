@@ -168,6 +168,27 @@ def test_tiny_frame(mode):
             close(v[:: max(1, v.shape[0] // 8)][:8], gold[k], 1e-4)
 
 
+@pytest.mark.parametrize("norm", ["bn", "ln"])
+def test_tiny_frame_other_point_encoder_norms(norm):
+    """opt.norm = 'bn' (eval mode: running statistics) / 'ln': the other two get_norm() configurations (modules.py:51-60), recorded
+    from the reference built with that option; the synthetic state_dict of that layout loaded strictly into the reference."""
+    from cofii2p_amd.spec import synth_state_dict
+
+    gold = load_golden("frame_tiny_%s.npz" % norm)
+    fr, data = frame_inputs(int(gold["frame_id"]), int(gold["num_points"]), int(gold["pyr_seed"]))
+    check_input_hashes(gold, fr, data)
+    sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(norm=norm).items()}
+    taps = {}
+    with torch.no_grad():
+        res = O.forward(sd, data, T(fr.img)[None], None, None, "test", taps=taps)
+    for n, t in zip(("img_desc", "pc_desc", "img_score", "pc_score", "patches", "fine_pc", "center_xy", "coarse_pts"), res):
+        close(t, gold["test_" + n], 5e-5)
+    for k in gold.files:
+        if k.startswith("tap_encoder"):
+            v = taps[k[4:]]
+            close(v[:: max(1, v.shape[0] // 8)][:8], gold[k], 2e-4)
+
+
 def test_kitti_frame():
     gold = load_golden("frame_kitti.npz")
     fr, data = frame_inputs(int(gold["frame_id"]), int(gold["num_points"]), int(gold["pyr_seed"]))

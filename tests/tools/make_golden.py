@@ -45,11 +45,14 @@ def frame_inputs(frame_id, num_points, pyr_seed):
     return fr, data
 
 
-def build_reference_model():
+def build_reference_model(norm="gn"):
     net = ref_shims.import_reference()
-    sd = {k: torch.from_numpy(v) for k, v in synth_state_dict().items()}
-    model = net.CoFiI2P(ref_shims.reference_options())
-    model.load_state_dict(sd, strict=True)
+    sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(norm=norm).items()}
+    opt = ref_shims.reference_options()
+    opt.norm = norm   # get_norm(), model/kpconv/modules.py:51-60
+    model = net.CoFiI2P(opt)
+    model.load_state_dict(sd, strict=True)   # strict: the generated spec has the reference's keys and shapes for this norm
+    assert list(model.state_dict().keys()) == list(sd.keys())
     model.eval()
     return net, model, sd
 
@@ -251,6 +254,10 @@ def main():
         run_frame(model, "frame_tiny.npz", frame_id=1, num_points=2048, pyr_seed=11, modes=("val", "test"))
     if args.only in (None, "kitti"):
         run_frame(model, "frame_kitti.npz", frame_id=0, num_points=20480, pyr_seed=7, modes=("test",))
+    if args.only in (None, "norms"):   # the other two get_norm() configurations of the point encoder (eval mode: BatchNorm = running statistics)
+        for norm in ("bn", "ln"):
+            _, m2, _ = build_reference_model(norm)
+            run_frame(m2, "frame_tiny_%s.npz" % norm, frame_id=1, num_points=2048, pyr_seed=11, modes=("test",))
 
 
 if __name__ == "__main__":
