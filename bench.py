@@ -497,7 +497,10 @@ def main():
                     pending[sl] = None
             return nm
 
-        nmatch = run(max(args.warmup, 2 * NSLOT), 0)   # every slot captured and replayed at least once, whatever --warmup says
+        import math
+
+        # every (slot, input set) graph captured and replayed at least once, whatever --warmup says (in-place inputs: one graph per pair)
+        nmatch = run(max(args.warmup, 2 * NSLOT, math.lcm(NSLOT, len(frames))), 0)
         barrier()
         t0 = time.perf_counter()
         run(args.steps, 0)
