@@ -39,7 +39,7 @@ SIGNATURES = {
     "cofi_row_sum_positive": (_I, [_P, _I, _I, _I, _P, _P]),
     "cofi_kp_pack_c4": (_I, [_P, _I, _I, _P, _I, _P, _P]),
     "cofi_kpconv_aggregate_c4": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _F, _P, _I, _P, _I, _P, _P]),
-    "cofi_kpconv_aggregate": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _F, _P, _P, _I, _P, _I, _P, _P]),
+    "cofi_kpconv_aggregate": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _F, _P, _P, _I, _I, _P, _I, _P, _P]),
     "cofi_neighbor_maxpool": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P]),
     "cofi_gather_rows": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P]),
     "cofi_gemm_f32_workspace": (_Z, [_I, _I, _I]),

@@ -43,6 +43,8 @@ struct GemmArgs {
     int bf16x3;
     int wsplit;        // W is pre-split: W points at the bf16 hi plane (rows of ldw bf16), the lo plane starts w_lo_off elements later
     long w_lo_off;
+    int asplit;        // A is pre-split as well (dense GEMM only): A points at the bf16 hi plane (M rows of lda bf16), lo plane a_lo_off elements later
+    long a_lo_off;
     // implicit-GEMM convolution (cv_ks > 0): A is an NHWC map (H*W rows of lda floats), row m of the GEMM is
     // output pixel (m / Wo, m % Wo), column k is (tap = k / Cin, channel = k % Cin); K = ks*ks*Cin
     int cv_ks, cv_H, cv_W, cv_Cin, cv_Wo, cv_stride, cv_pad;
@@ -475,11 +477,11 @@ __global__ void split_planes_kernel(const float *W, int ldw, int N, int K, unsig
 //        the workgroup folds the producer's statistics partials itself while its first tile is in flight, keeps the per-channel
 //        scale / shift in LDS and normalises every A element on its way into the bf16 planes - the stand-alone normalisation
 //        kernel, its statistics kernel and one round trip of the activation through HBM disappear.
-// PF2:   TWO K-tiles in flight in registers (loads of tile t+2 are issued before tile t is multiplied).  With one tile in flight a
-//        workgroup that has no neighbour on its CU spends a full memory round trip per K-tile (measured ~1.6 us per 32 KB tile on the
-//        320-workgroup M = 20480 launches, whose MFMAs take 0.2 us and whose bytes arrive in 0.5 us): the grids of a single frame
-//        give 1 - 2.5 workgroups per CU, too few for other workgroups to hide it.
-template <int BM, int BN, int TM, int TN, int BK3, int KW = 1, bool WSPLIT = false, int WPE = 1, bool ANORM = false, bool PF2 = false>
+// ASPLIT: the A operand arrives PRE-SPLIT as well (bf16 hi / lo planes written by its producer - the KPConv aggregation, whose
+//        (M, 15 C) output has no other reader): A tiles then travel global -> LDS as plain 16-byte copies like the W tiles, the
+//        conversion instructions (the bulk of the VALU work of a tile) and their registers disappear.  Dense GEMM only.
+//        (An earlier experiment in this slot - two K-tiles in flight in registers - measured 445 vs 457 frames/s and was removed.)
+template <int BM, int BN, int TM, int TN, int BK3, int KW = 1, bool WSPLIT = false, int WPE = 1, bool ANORM = false, bool ASPLIT = false>
 __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
     static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 waves");
     constexpr int NT = 256 * KW;
@@ -489,7 +491,8 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
     constexpr int A_LD4 = BM / RPP, W_LD4 = BN / RPP;            // float4 loads per thread and tile
     static_assert(A_LD4 >= 1 && W_LD4 >= 1 && (BK3 / 16) % KW == 0, "tile too small for this many waves");
     // pre-split W: 16-B chunks of 8 bf16; chunk c of a plane tile = (row c / CPR, k 8 * (c % CPR))
-    constexpr int CPR = BK3 / 8, W_CH = BN * CPR / NT;
+    constexpr int CPR = BK3 / 8, W_CH = BN * CPR / NT, A_CH = BM * CPR / NT;
+    static_assert(!ASPLIT || ((BM * CPR) % NT == 0 && WSPLIT && !ANORM), "pre-split A: plane tile must divide over the threads");
     static_assert(!WSPLIT || (BN * CPR) % NT == 0, "plane tile must divide over the threads");
     constexpr int TLD = BN + 4;
     constexpr int PLANE_A = BM * BROW3, PLANE_W = BN * BROW3;    // bytes
@@ -513,23 +516,32 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
     const int ntiles = (kend - kbeg + BK3 - 1) / BK3;
     const int lrow = tid / LPR, lk = (tid % LPR) * 4;            // LPR lanes cover one row slice; RPP rows per pass
     struct Stage {                                               // one K-tile on its way from global memory to LDS
-        f32x4 ra[A_LD4];                                         // native vectors: plain 16-B loads, no struct copies
+        f32x4 ra[ASPLIT ? 1 : A_LD4];                            // fp32 A: native vectors, plain 16-B loads, no struct copies
+        f32x4 rah[ASPLIT ? A_CH : 1], ral[ASPLIT ? A_CH : 1];   // pre-split A: 16-B chunks (8 bf16) of the hi / lo plane
         f32x4 rw[WSPLIT ? 1 : W_LD4];                            // fp32 W: W_LD4 chunks of 4
         f32x4 rwh[WSPLIT ? W_CH : 1], rwl[WSPLIT ? W_CH : 1];   // pre-split W: 16-B chunks (8 bf16) of the hi / lo plane, as opaque bits
         unsigned amask;                                          // validity of the A values (see gload)
         bool afull;                                              // uniform: the A registers hold a full dense tile (no zeroing needed)
         int achan;                                               // ANORM: first of the 4 channels the staged float4s of this thread belong to
     };
-    Stage st0, st1;                                              // st1 only with PF2 (always indexed statically: registers, never scratch)
+    Stage st0;
     const bool conv = g.cv_ks != 0;
 
     // Addressing: a workgroup-uniform base (scalar registers, advanced by one K-tile per iteration) plus a per-thread 32-bit
     // byte offset that never changes -> the loads of a full tile need NO vector arithmetic at all.  Rows past M / N are
     // clamped to the last row: they only feed output rows / columns that are never stored (MFMA rows and columns are
     // independent), so they need no zeroing; only K tails (and convolution padding) are zeroed, on the A side.
-    unsigned aoff[A_LD4], woff[WSPLIT ? W_CH : W_LD4];
+    unsigned aoff[ASPLIT ? A_CH : A_LD4], woff[WSPLIT ? W_CH : W_LD4];
+    if constexpr (ASPLIT) {
 #pragma unroll
-    for (int j = 0; j < A_LD4; ++j) aoff[j] = ((unsigned)(min(m0 + lrow + RPP * j, g.M - 1) - m0) * (unsigned)g.lda + lk) * 4u;
+        for (int j = 0; j < A_CH; ++j) {
+            const int c = tid + NT * j;
+            aoff[j] = ((unsigned)(min(m0 + c / CPR, g.M - 1) - m0) * (unsigned)g.lda + 8 * (c % CPR)) * 2u;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < A_LD4; ++j) aoff[j] = ((unsigned)(min(m0 + lrow + RPP * j, g.M - 1) - m0) * (unsigned)g.lda + lk) * 4u;
+    }
     if constexpr (WSPLIT) {
 #pragma unroll
         for (int j = 0; j < W_CH; ++j) {
@@ -540,14 +552,16 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
 #pragma unroll
         for (int j = 0; j < W_LD4; ++j) woff[j] = ((unsigned)(min(n0 + lrow + RPP * j, g.N - 1) - n0) * (unsigned)g.ldw + lk) * 4u;
     }
-    const char *abase = reinterpret_cast<const char *>(g.A + (size_t)m0 * g.lda + kbeg);
+    const char *abase = ASPLIT ? reinterpret_cast<const char *>(reinterpret_cast<const uint16_t *>(g.A) + (size_t)m0 * g.lda + kbeg)
+                               : reinterpret_cast<const char *>(g.A + (size_t)m0 * g.lda + kbeg);
+    const size_t alo = (size_t)g.a_lo_off * 2;
     const char *wbase = WSPLIT ? reinterpret_cast<const char *>(reinterpret_cast<const uint16_t *>(g.W) + (size_t)n0 * g.ldw + kbeg)
                                : reinterpret_cast<const char *>(g.W + (size_t)n0 * g.ldw + kbeg);
     const size_t wlo = (size_t)g.w_lo_off * 2;
 
     // conv-mode pixel coordinates of this thread's A rows (row = m0 + lrow + RPP*j)
     int yo[A_LD4], xo[A_LD4], fb[A_LD4];
-    if (conv) {
+    if (!ASPLIT && conv) {
 #pragma unroll
         for (int j = 0; j < A_LD4; ++j) {
             const int r = min(m0 + lrow + RPP * j, g.M - 1);
@@ -563,7 +577,27 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
         const bool full = kbeg + (t + 1) * BK3 <= kend;   // uniform
         const int k = kbeg + t * BK3 + lk;
         const bool kin = k < kend;
-        if (!conv) {
+        if constexpr (ASPLIT) {
+            const char *at = abase + (size_t)t * (BK3 * 2);
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            if (full) {
+#pragma unroll
+                for (int j = 0; j < A_CH; ++j) {
+                    st.rah[j] = *reinterpret_cast<const f32x4 *>(at + aoff[j]);
+                    st.ral[j] = *reinterpret_cast<const f32x4 *>(at + alo + aoff[j]);
+                }
+            } else {   // K tail: chunks past the K range are ZERO (the W side re-reads finite values there); K is a multiple of 8
+#pragma unroll
+                for (int j = 0; j < A_CH; ++j) {
+                    const int c8 = 8 * ((tid + NT * j) % CPR);
+                    const bool cin = kbeg + t * BK3 + c8 < kend;
+                    const char *q = cin ? at + aoff[j] : abase + (aoff[j] - 2u * c8);
+                    const f32x4 h = *reinterpret_cast<const f32x4 *>(q), l = *reinterpret_cast<const f32x4 *>(q + alo);
+                    st.rah[j] = cin ? h : zero;
+                    st.ral[j] = cin ? l : zero;
+                }
+            }
+        } else if (!conv) {
             if constexpr (ANORM) st.achan = kin ? k : 0;
             st.afull = full;
             const char *at = abase + (size_t)t * (BK3 * 4);
@@ -635,7 +669,15 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
                 st.ra[j] = v;
             }
         }
-        if (st.afull) {
+        if constexpr (ASPLIT) {
+#pragma unroll
+            for (int j = 0; j < A_CH; ++j) {
+                const int c = tid + NT * j;
+                unsigned char *p = lds_raw + (c / CPR) * BROW3 + (c % CPR) * 16;
+                *reinterpret_cast<f32x4 *>(p) = st.rah[j];
+                *reinterpret_cast<f32x4 *>(p + PLANE_A) = st.ral[j];
+            }
+        } else if (st.afull) {
 #pragma unroll
             for (int j = 0; j < A_LD4; ++j) {
                 uint2 hi, lo;
@@ -716,9 +758,6 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
     // buffer do NOT shorten the ~1 us a lone workgroup spends per 64 KB tile - that is the CU's L2 fill rate; only spreading
     // the tiles over more CUs does, which is what split-K is tuned for.)
     if (ntiles > 0) gload(0, st0);
-    if constexpr (PF2) {
-        if (ntiles > 1) gload(1, st1);
-    }
     if constexpr (ANORM) {
         // statistics of this tile's frame -> scale / shift table in LDS: copied from the finalized vectors (cofi_norm_finalize) or,
         // without them, folded here from the producer's partials (fold scratch lives in the still unused operand buffer)
@@ -740,25 +779,7 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
     }
     if (ntiles > 0) sstore(st0);
     __syncthreads();
-    if constexpr (PF2) {
-        // tile t is in LDS, tile t+1 in flight in one register stage; the other stage (consumed by the last sstore) takes tile t+2
-        for (int t = 0; t < ntiles; t += 2) {
-            if (t + 2 < ntiles) gload(t + 2, st0);
-            compute();
-            __syncthreads();              // every wave is done reading tile t
-            if (t + 1 < ntiles) {
-                sstore(st1);
-                __syncthreads();          // tile t+1 visible
-                if (t + 3 < ntiles) gload(t + 3, st1);
-                compute();
-                __syncthreads();
-                if (t + 2 < ntiles) {
-                    sstore(st0);
-                    __syncthreads();
-                }
-            }
-        }
-    } else {
+    {
         for (int t = 0; t < ntiles; ++t) {
             if (t + 1 < ntiles) gload(t + 1, st0);
             compute();
@@ -991,24 +1012,16 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
     g.xcd_rcp_gy = grid.y > 1 ? (unsigned)((0x100000000ULL + grid.y - 1) / grid.y) : 0u;   // 0: gy = 1
     if (g.bf16x3) {
         const int kw = (p.bm == 64 && p.bn == 64) ? latency_kw(p, g.M, g.N) : 1;
-        static const bool pf2 = [] { const char *e = getenv("COFI_GEMM_PF2"); return e && atoi(e) != 0; }();
-#define COFI_LAUNCH_BF16X3_P(BM_, BN_, TM_, TN_, BK_, KW_, WPE_, PF2_)                                                                            \
+#define COFI_LAUNCH_BF16X3_W(BM_, BN_, TM_, TN_, BK_, KW_, WPE_)                                                                                  \
     do {                                                                                                                                        \
         if (g.an.part)                                                                                                                          \
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, true, WPE_, true, PF2_>), grid, dim3(256 * KW_), 0, s, g);     \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, true, WPE_, true, false>), grid, dim3(256 * KW_), 0, s, g);    \
+        else if (g.asplit)                                                                                                                      \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, true, WPE_, false, true>), grid, dim3(256 * KW_), 0, s, g);    \
         else if (g.wsplit)                                                                                                                      \
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, true, WPE_, false, PF2_>), grid, dim3(256 * KW_), 0, s, g);    \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, true, WPE_, false, false>), grid, dim3(256 * KW_), 0, s, g);   \
         else                                                                                                                                    \
             hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, false, WPE_, false, false>), grid, dim3(256 * KW_), 0, s, g);  \
-    } while (0)
-/* COFI_GEMM_PF2=1 (A/B runs): the 4-wave 64-row configurations keep two K-tiles in flight.  Measured on MI355X with three frames in
- * flight: 445 vs 457 frames/s - other streams' kernels already hide the load latency, the extra registers cost co-residency. */
-#define COFI_LAUNCH_BF16X3_W(BM_, BN_, TM_, TN_, BK_, KW_, WPE_)                                     \
-    do {                                                                                            \
-        if ((KW_) == 1 && (BM_) == 64 && pf2)                                                       \
-            COFI_LAUNCH_BF16X3_P(BM_, BN_, TM_, TN_, BK_, KW_, WPE_, ((KW_) == 1 && (BM_) == 64));  \
-        else                                                                                        \
-            COFI_LAUNCH_BF16X3_P(BM_, BN_, TM_, TN_, BK_, KW_, WPE_, false);                        \
     } while (0)
 #define COFI_LAUNCH_BF16X3(BM_, BN_, TM_, TN_, BK_, KW_) COFI_LAUNCH_BF16X3_W(BM_, BN_, TM_, TN_, BK_, KW_, 1)
         // K-tile depth per tile shape (measured): the 128x128 tile is register-bound at 2 waves per SIMD either way; the 64x128 and
@@ -1026,7 +1039,6 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
             COFI_LAUNCH_BF16X3(64, 64, 1, 1, 64, 1);
 #undef COFI_LAUNCH_BF16X3
 #undef COFI_LAUNCH_BF16X3_W
-#undef COFI_LAUNCH_BF16X3_P
     } else if (p.bm == 128 && p.bn == 128)
         hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, g);
     else if (p.bm == 64 && p.bn == 128)
@@ -1080,8 +1092,10 @@ int gemm_entry(const float *A, int lda, const cofi_norm_desc_t *a_norm, const fl
     if (M == 0) return 0;
     const int bf16x3 = (act & COFI_GEMM_BF16X3) ? 1 : 0;
     const int wsplit = (act & COFI_GEMM_W_SPLIT) ? 1 : 0;
-    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_W_SPLIT);
+    const int asplit = (act & COFI_GEMM_A_SPLIT) ? 1 : 0;
+    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_W_SPLIT | COFI_GEMM_A_SPLIT);
     if (act < 0 || act > 3 || (wsplit && (!bf16x3 || (ldw & 7))) || frames <= 0) return COFI_EINVAL;
+    if (asplit && (!wsplit || a_norm || (lda & 7) || (K & 7))) return COFI_EINVAL;
     const int sshift = colpart ? stat_shift_of(stat_width, N) : 0;
     if (sshift < 0) return COFI_EINVAL;
     Plan p = make_plan(M, N, K, false);
@@ -1090,6 +1104,7 @@ int gemm_entry(const float *A, int lda, const cofi_norm_desc_t *a_norm, const fl
     g.A = A; g.W = W; g.C = C; g.bias = bias; g.rowdiv = rowdiv; g.ws = (float *)ws; g.colpart = colpart;
     g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.act = act; g.ksplit = 1;
     g.bf16x3 = bf16x3; g.wsplit = wsplit; g.w_lo_off = (long)N * ldw; g.cv_Pout = 1; g.stat_shift = sshift;
+    g.asplit = asplit; g.a_lo_off = (long)M * lda;
     if (int rc = set_a_norm(g, a_norm, K, M / frames, frames, p)) return rc;
     return launch(g, p, cofi_s(stream));
 }

@@ -33,6 +33,8 @@ struct KpArgs {
     int ldf, N, C, M, H, ld_agg;   // N = support rows PER FRAME, M = total query rows
     float sigma;
     int Mpf;                       // query rows per frame (stack mode: frame f owns queries [f*Mpf, ..) and support [f*N, ..))
+    size_t planes_lo;              // 0: agg is fp32 (M, ld_agg); else agg is a bf16 hi plane (M, ld_agg bf16) and the lo plane starts planes_lo
+                                   // elements later - the GEMM that consumes it then needs no conversion (COFI_GEMM_A_SPLIT)
     const int32_t *order;          // optional processing order (frame-local query ids, stacked per frame): wave w of the grid
                                    // handles query order[w].  A spatially sorted order makes the waves resident on one CU work on
                                    // neighbouring queries whose neighbour rows overlap, so the gather is served from L1 instead of L2.
@@ -190,6 +192,41 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
     int npos;
     kp_aggregate_query<VEC, NCH, KP_PHASE_DEFAULT>(a, m, c0, rec_s[wv], acc, npos);
     // D layout 16x16: row (kernel point) = 4*g + r, col = j  ->  channels c .. c+VEC-1 contiguous
+    if (a.planes_lo) {   // bf16 hi / lo planes (same rounding as the GEMM's on-the-fly split: identical products)
+        uint16_t *hrow = reinterpret_cast<uint16_t *>(a.agg) + (size_t)m * a.ld_agg;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = c0 + ch * 16 * VEC + VEC * j;
+            if (c < a.C) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * g + r;
+                    if (k < 15) {
+                        uint16_t *dst = hrow + (size_t)k * a.C + c;
+                        if constexpr (VEC == 4) {
+                            uint2 hi, lo;
+                            cofi_split2(acc[ch][0][r], acc[ch][1][r], hi.x, lo.x);
+                            cofi_split2(acc[ch][2][r], acc[ch][3][r], hi.y, lo.y);
+                            *reinterpret_cast<uint2 *>(dst) = hi;
+                            *reinterpret_cast<uint2 *>(dst + a.planes_lo) = lo;
+                        } else if constexpr (VEC == 2) {
+                            unsigned hi, lo;
+                            cofi_split2(acc[ch][0][r], acc[ch][1][r], hi, lo);
+                            *reinterpret_cast<unsigned *>(dst) = hi;
+                            *reinterpret_cast<unsigned *>(dst + a.planes_lo) = lo;
+                        } else {
+                            unsigned hi, lo;
+                            cofi_split2(acc[ch][0][r], 0.f, hi, lo);
+                            dst[0] = (uint16_t)hi;
+                            dst[a.planes_lo] = (uint16_t)lo;
+                        }
+                    }
+                }
+            }
+        }
+        if (blockIdx.y == 0 && lane == 0) a.cnt[m] = (float)(npos > 1 ? npos : 1);
+        return;
+    }
     float *orow = a.agg + (size_t)m * a.ld_agg;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
@@ -553,13 +590,14 @@ extern "C" int cofi_row_sum_positive(const float *feats, int ld, int N, int C, u
 
 extern "C" int cofi_kpconv_aggregate(const float *feats, int ldf, int N, int C, const float *q_pts, const float *s_pts,
                                      const int32_t *idx, int M, int H, const float *kernel_points, float sigma,
-                                     const uint8_t *row_pos, float *agg, int ld_agg, float *cnt, int frames, const int32_t *order,
+                                     const uint8_t *row_pos, float *agg, int ld_agg, int agg_planes, float *cnt, int frames, const int32_t *order,
                                      cofi_stream_t stream) {
     if (!feats || !q_pts || !s_pts || !idx || !kernel_points || !row_pos || !agg || !cnt) return COFI_EINVAL;
     if (N <= 0 || C <= 0 || M < 0 || H <= 0 || (H & 3) || ldf < C || ld_agg < 15 * C || !(sigma > 0.f) || frames <= 0) return COFI_EINVAL;
+    if (agg_planes && ((ld_agg & 7) || (C & 3) || ((uintptr_t)agg & 15))) return COFI_EINVAL;
     if ((size_t)N * ldf * 4 >= ((size_t)1 << 32) || N >= (1 << 24) || (size_t)ldf * 4 >= (1u << 24)) return COFI_EUNSUPPORTED;  // 24x24-bit row offsets
     if (M == 0) return 0;
-    KpArgs a{feats, q_pts, s_pts, kernel_points, idx, row_pos, agg, cnt, ldf, N, C, M * frames, H, ld_agg, sigma, M, order};
+    KpArgs a{feats, q_pts, s_pts, kernel_points, idx, row_pos, agg, cnt, ldf, N, C, M * frames, H, ld_agg, sigma, M, agg_planes ? (size_t)M * frames * ld_agg : 0, order};
     M *= frames;
     hipStream_t s = cofi_s(stream);
     const int mb = cofi_cdiv(M, 4);
@@ -589,7 +627,7 @@ extern "C" int cofi_kpconv_aggregate_c4(const float *records, int N, int C, cons
     if (!records || !q_pts || !idx || !kernel_points || !agg || !cnt || ((uintptr_t)records & 15)) return COFI_EINVAL;
     if (N <= 0 || C <= 0 || C > 4 || M < 0 || H <= 0 || (H & 3) || ld_agg < 15 * C || !(sigma > 0.f) || frames <= 0) return COFI_EINVAL;
     if (M == 0) return 0;
-    KpArgs a{records, q_pts, nullptr, kernel_points, idx, nullptr, agg, cnt, 8, N, C, M * frames, H, ld_agg, sigma, M, order};
+    KpArgs a{records, q_pts, nullptr, kernel_points, idx, nullptr, agg, cnt, 8, N, C, M * frames, H, ld_agg, sigma, M, 0, order};
     hipLaunchKernelGGL(kpconv_aggregate_c4_kernel, dim3(cofi_cdiv((long)M * frames, 4)), dim3(256), 0, cofi_s(stream), a);
     return cofi_launch_status();
 }
@@ -620,7 +658,7 @@ extern "C" int cofi_kpconv_fused(const float *feats, int ldf, int N, int C, cons
         while ((1 << shift) < stat_width) ++shift;
     }
     KpFusedArgs fa{};
-    fa.a = KpArgs{feats, q_pts, s_pts, kernel_points, idx, row_pos, nullptr, nullptr, ldf, N, C, M * frames, H, 0, sigma, M, order};
+    fa.a = KpArgs{feats, q_pts, s_pts, kernel_points, idx, row_pos, nullptr, nullptr, ldf, N, C, M * frames, H, 0, sigma, M, 0, order};
     fa.w_hi = (const uint16_t *)w_planes;
     fa.w_lo = fa.w_hi + (size_t)C * ldw;
     fa.ldw = ldw; fa.bias = bias; fa.y = y; fa.ldy = ldy; fa.colpart = colpart; fa.stat_shift = shift; fa.qt = qt;

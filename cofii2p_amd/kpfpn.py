@@ -13,6 +13,10 @@ LRELU = 0.1
 # fabric, but measured SLOWER on MI355X (490 vs 503 frames/s): 320-1280 eight-wave workgroups that alternate between a gather phase
 # and a GEMM phase quantise badly on 256 CUs, while the two-kernel form spreads 20 480 one-wave queries evenly.
 FUSED_KPCONV = os.environ.get("COFI_KPCONV_FUSED", "0") == "1"
+# Opt-in (COFI_KPCONV_AGG_PLANES=1): the aggregate is written as bf16 hi / lo planes and its GEMM reads them without conversion
+# (COFI_GEMM_A_SPLIT).  Bit-identical results; measured neutral on MI355X (batch 1: 512 vs 513 f/s, batch 16: 647 vs 652): the conversion
+# instructions were not what these GEMMs wait for.
+AGG_PLANES = os.environ.get("COFI_KPCONV_AGG_PLANES", "0") == "1"
 
 
 def norm_kind(sd) -> str:
@@ -87,7 +91,9 @@ def _kpconv(P, p: str, feats, q_pts, s_pts, idx, sigma: float, frames: int = 1, 
         y, part, sr = ops.kpconv_fused(feats, q_pts, s_pts, idx, P[p + "KPConv.kernel_points"], sigma, w, P[p + "KPConv.bias"], stat_width=sw,
                                        frames=frames, order=order)
         return y, ops.ColStats(part, y.shape[0], GN_GROUPS, frames, width=sw, slab_rows=sr)
-    agg, cnt = ops.kpconv_aggregate(feats, q_pts, s_pts, idx, P[p + "KPConv.kernel_points"], sigma, frames=frames, order=order)
+    # opt-in: the aggregate has one reader, the GEMM below - written as bf16 hi / lo planes it enters that GEMM without conversion work
+    planes = AGG_PLANES and ops.GEMM_MODE == "bf16x3" and isinstance(w, ops.SplitW)
+    agg, cnt = ops.kpconv_aggregate(feats, q_pts, s_pts, idx, P[p + "KPConv.kernel_points"], sigma, frames=frames, order=order, planes=planes)
     y, part = ops.gemm_colstats(agg, w, bias=P[p + "KPConv.bias"], rowdiv=cnt, stat_width=sw)
     return y, _stats(y, part, frames, sw)
 

@@ -273,16 +273,35 @@ def _a_operand(a, M_rows: int, frames: int):
     return a.materialize(), None
 
 
+GEMM_A_SPLIT = 0x400
+
+
+class SplitA:
+    """An activation that its producer already wrote as bf16 hi / lo planes (kpconv_aggregate(planes=True)): planes (2, M, ld) int16,
+    logical shape (M, K).  Only the bf16x3 GEMM with a pre-split weight consumes it (COFI_GEMM_A_SPLIT)."""
+
+    def __init__(self, planes: torch.Tensor, K: int):
+        self.planes, self.K = planes, K
+        self.shape, self.device, self.dtype = (planes.shape[1], K), planes.device, torch.float32
+
+
 def _gemm_impl(a, w, out, bias, rowdiv, act, stat_width, frames):
     lib = _lib.load()
     if isinstance(a, Normed) and not isinstance(w, SplitW) and a.fusable():
         w = SplitW(w)   # the normalising loader lives in the pre-split-weight kernels
     M0 = a.shape[0]
-    a, nd = _a_operand(a, M0, frames)
-    _mat(a, "a")
+    aflag = 0
+    if isinstance(a, SplitA):
+        if GEMM_MODE != "bf16x3" or not isinstance(w, SplitW):
+            raise _lib.CofiError("gemm: a pre-split activation needs the bf16x3 arithmetic and a pre-split weight")
+        asplit, nd, aflag = a, None, GEMM_A_SPLIT
+        a_ptr, a_ld, (M, K) = _p(a.planes), a.planes.shape[2], a.shape
+    else:
+        a, nd = _a_operand(a, M0, frames)
+        _mat(a, "a")
+        a_ptr, a_ld, (M, K) = _p(a), _ld(a), a.shape
     if not isinstance(w, SplitW):
         _mat(w, "w")
-    M, K = a.shape
     N = w.shape[0]
     if w.shape[1] != K:
         raise _lib.CofiError("gemm: K mismatch %s vs %s" % (tuple(a.shape), tuple(w.shape)))
@@ -299,8 +318,8 @@ def _gemm_impl(a, w, out, bias, rowdiv, act, stat_width, frames):
         return out, colpart
     ws = _WS_GEMM.get(lib.cofi_gemm_f32_workspace(M, N, K), a.device)
     wp, wld, wflag = _wargs(w)
-    rc = lib.cofi_gemm_f32_fused(_p(a), _ld(a), None if nd is None else ctypes.byref(nd), wp, wld, _p(out), _ld(out), M, N, K, _p(bias),
-                                 _p(rowdiv), act | _gemm_flag() | wflag, _p(colpart), max(stat_width, 1), _p(ws), 0 if ws is None else ws.numel(),
+    rc = lib.cofi_gemm_f32_fused(a_ptr, a_ld, None if nd is None else ctypes.byref(nd), wp, wld, _p(out), _ld(out), M, N, K, _p(bias),
+                                 _p(rowdiv), act | _gemm_flag() | wflag | aflag, _p(colpart), max(stat_width, 1), _p(ws), 0 if ws is None else ws.numel(),
                                  frames, _stream())
     _lib.check(rc, "cofi_gemm_f32_fused")
     return out, colpart
@@ -375,7 +394,7 @@ def row_sum_positive(feats: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def kpconv_aggregate(feats, q_pts, s_pts, idx, kernel_points, sigma: float, row_pos=None, frames: int = 1, order=None):
+def kpconv_aggregate(feats, q_pts, s_pts, idx, kernel_points, sigma: float, row_pos=None, frames: int = 1, order=None, planes: bool = False):
     """-> agg (M, 15*C), cnt (M,) float.  idx int32 (M,H).  Stack mode: `frames` equally sized frames stacked along
     the rows of every argument, idx frame-local."""
     lib = _lib.load()
@@ -388,7 +407,11 @@ def kpconv_aggregate(feats, q_pts, s_pts, idx, kernel_points, sigma: float, row_
         raise _lib.CofiError("kpconv_aggregate: shape mismatch")
     if row_pos is None:
         row_pos = getattr(feats, "cofi_row_pos", None)   # left there by the group_norm_apply that produced feats
-    agg = torch.empty((M, 15 * C), dtype=torch.float32, device=feats.device)
+    planes = planes and C % 4 == 0 and C > 4 and (15 * C) % 8 == 0
+    if planes:   # bf16 hi / lo planes: the part-2 GEMM takes them without any conversion (SplitA)
+        agg = torch.empty((2, M, 15 * C), dtype=torch.int16, device=feats.device)
+    else:
+        agg = torch.empty((M, 15 * C), dtype=torch.float32, device=feats.device)
     cnt = torch.empty((M,), dtype=torch.float32, device=feats.device)
     if C <= 4 and row_pos is None and M > 0:
         # first layer: [features | position | positive-sum flag] packed into 32-byte records, one gather per neighbour
@@ -401,9 +424,9 @@ def kpconv_aggregate(feats, q_pts, s_pts, idx, kernel_points, sigma: float, row_
     if row_pos is None:
         row_pos = row_sum_positive(feats)
     rc = lib.cofi_kpconv_aggregate(_p(feats), _ld(feats), N // frames, C, _p(q_pts), _p(s_pts), _p(idx), M // frames, H,
-                                   _p(kernel_points), float(sigma), _p(row_pos), _p(agg), 15 * C, _p(cnt), frames, _p(order), _stream())
+                                   _p(kernel_points), float(sigma), _p(row_pos), _p(agg), 15 * C, int(planes), _p(cnt), frames, _p(order), _stream())
     _lib.check(rc, "cofi_kpconv_aggregate")
-    return agg, cnt
+    return (SplitA(agg, 15 * C) if planes else agg), cnt
 
 
 def kpconv_fused_slab_rows(C: int, M: int, frames: int = 1) -> int:

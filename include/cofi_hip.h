@@ -80,6 +80,10 @@ typedef struct cofi_norm_desc {
  * (ldw % 8 == 0, rows zero-padded past K), immediately followed by the lo plane of the same shape.  Weights are static:
  * splitting them once removes half of the on-the-fly conversion work of every launch. */
 #define COFI_GEMM_W_SPLIT 0x200
+/* with COFI_GEMM_W_SPLIT, cofi_gemm_f32_fused only: A is PRE-SPLIT too - `A` points at its bf16 hi plane, M rows of `lda` bf16
+ * (lda % 8 == 0, K % 8 == 0), immediately followed by the lo plane (M * lda elements later): what cofi_kpconv_aggregate writes with
+ * planes = 1.  The operand then needs no conversion on its way into LDS.  Not combinable with a_norm. */
+#define COFI_GEMM_A_SPLIT 0x400
 
 int cofi_abi_version(void);
 /* name of the code object's target, "gfx950" */
@@ -141,7 +145,9 @@ int cofi_kpconv_aggregate_c4(const float *records, int N, int C, const float *q_
                              const int32_t *order, cofi_stream_t stream);
 int cofi_kpconv_aggregate(const float *feats, int ldf, int N, int C, const float *q_pts, const float *s_pts, const int32_t *idx,
                           int M, int H, const float *kernel_points /* (15,3) */, float sigma, const uint8_t *row_pos,
-                          float *agg, int ld_agg, float *cnt, int frames, const int32_t *order /* optional (frames*M) frame-local
+                          float *agg, int ld_agg, int agg_planes /* 0: fp32 (M, ld_agg); 1: bf16 hi plane (M, ld_agg bf16, ld_agg % 8 == 0,
+                          C % 4 == 0) followed by the lo plane - the operand form of COFI_GEMM_A_SPLIT */,
+                          float *cnt, int frames, const int32_t *order /* optional (frames*M) frame-local
                           processing order of the queries, e.g. Morton-sorted: results do not depend on it */,
                           cofi_stream_t stream);
 
