@@ -255,8 +255,13 @@ def main():
     if args.only in (None, "kitti"):
         run_frame(model, "frame_kitti.npz", frame_id=0, num_points=20480, pyr_seed=7, modes=("test",))
     if args.only in (None, "norms"):   # the other two get_norm() configurations of the point encoder (eval mode: BatchNorm = running statistics)
+        import json
+
         for norm in ("bn", "ln"):
             _, m2, _ = build_reference_model(norm)
+            # the reference's own state_dict layout for this option (key order, shapes, dtypes): tests/test_host_cpu.py pins the module to it
+            spec = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m2.state_dict().items()]
+            json.dump(spec, open(os.path.join(GOLD, "state_dict_spec_%s.json" % norm), "w"))
             run_frame(m2, "frame_tiny_%s.npz" % norm, frame_id=1, num_points=2048, pyr_seed=11, modes=("test",))
 
 
