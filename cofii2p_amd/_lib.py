@@ -91,7 +91,7 @@ SIGNATURES = {
     "cofi_voxel_downsample": (_I, [_P, _I, ctypes.c_double, _P, _I, _P, _P, _Z, _P]),
     "cofi_grid_subsample": (_I, [_P, _I, _F, _P, _I, _P, _P, _Z, _P]),
     "cofi_radius_mask": (_I, [_P, _P, _I, _I, _I, _F, ctypes.c_longlong, ctypes.c_longlong, _P, _P, _P]),
-    "cofi_gather_transform": (_I, [_P, _P, _I, _P, _P, _P, _P]),
+    "cofi_gather_transform": (_I, [_P, _P, _I, _P, _P, _P, _I, _P]),
     "cofi_resize_crop_image": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
 }
 

@@ -285,7 +285,7 @@ __global__ void pack_transform_kernel(const float *data, int N, const float *P44
 // rows choice[i] of the (nvox, 8) table -> points (n,3) = R p + t, feats (n,4) = [intensity | R n]     (kitti.py:284-288, 293)
 // The reference multiplies in float64 (np.dot of the float32 4x4 P with float32 arrays promotes nothing: float32 BLAS) - restated as
 // sequential float32 multiply-adds in the order k = 0, 1, 2 (cofii2p_amd/dataside.py documents the same order for the oracle).
-__global__ void gather_transform_kernel(const float *vox, const int32_t *choice, int n, const float *P44, float *points, float *feats) {
+__global__ void gather_transform_kernel(const float *vox, const int32_t *choice, int n, const float *P44, float *points, float *feats, int feats_are_points) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float *r = vox + (size_t)choice[i] * 8;
@@ -302,7 +302,11 @@ __global__ void gather_transform_kernel(const float *vox, const int32_t *choice,
         nn[a] = sn;
     }
     points[3 * i] = p[0]; points[3 * i + 1] = p[1]; points[3 * i + 2] = p[2];
-    feats[4 * i] = r[3]; feats[4 * i + 1] = nn[0]; feats[4 * i + 2] = nn[1]; feats[4 * i + 3] = nn[2];
+    // KITTI: [intensity | R n] (kitti.py:293); nuScenes has no normals: [intensity | transformed point] (nuscenes.py:204)
+    feats[4 * i] = r[3];
+    feats[4 * i + 1] = feats_are_points ? p[0] : nn[0];
+    feats[4 * i + 2] = feats_are_points ? p[1] : nn[1];
+    feats[4 * i + 3] = feats_are_points ? p[2] : nn[2];
 }
 
 // cv2.resize(img, (dw, dh), INTER_LINEAR) on uint8 HWC in OpenCV's fixed-point arithmetic (11-bit coefficients, rounding shift by 22),
@@ -506,9 +510,9 @@ extern "C" int cofi_radius_mask(const int32_t *idx, const float *dist, int M, in
 }
 
 extern "C" int cofi_gather_transform(const float *vox_rows, const int32_t *choice, int n, const float *P44_dev, float *points, float *feats,
-                                     cofi_stream_t stream) {
+                                     int feats_are_points, cofi_stream_t stream) {
     if (!vox_rows || !choice || !P44_dev || !points || !feats || n <= 0) return COFI_EINVAL;
-    hipLaunchKernelGGL(gather_transform_kernel, dim3(cofi_cdiv(n, 256)), dim3(256), 0, cofi_s(stream), vox_rows, choice, n, P44_dev, points, feats);
+    hipLaunchKernelGGL(gather_transform_kernel, dim3(cofi_cdiv(n, 256)), dim3(256), 0, cofi_s(stream), vox_rows, choice, n, P44_dev, points, feats, feats_are_points);
     return cofi_launch_status();
 }
 

@@ -34,8 +34,9 @@ def frame_seed(index: int) -> int:
 class FrameSampler:
     """The random draws of one __getitem__(index) call, in the reference's order."""
 
-    def __init__(self, index: int, seed: Optional[int] = None):
-        self.seed = frame_seed(index) if seed is None else int(seed)
+    def __init__(self, index: int, seed: Optional[int] = None, dataset: str = "kitti"):
+        # kitti.py:261-264 seeds with SeedSequence([index]); nuscenes.py:178-181 with the index itself
+        self.seed = (frame_seed(index) if dataset == "kitti" else int(index)) if seed is None else int(seed)
         self.rs = np.random.RandomState(self.seed)   # the global numpy state after np.random.seed(seed)
         self.rnd = random.Random(self.seed)          # the global `random` state after random.seed(seed)
 
@@ -119,7 +120,8 @@ def intrinsics_and_crop(K: np.ndarray, img_hw, opt, sampler: Optional[FrameSampl
     return scaled(Kc, 0.5), scaled(Kc, 0.125), (dy, dx), (rh, rw)
 
 
-def project_labels(coarse_points: np.ndarray, P: np.ndarray, K_2: np.ndarray, K_4: np.ndarray, opt, sampler: FrameSampler) -> Dict:
+def project_labels(coarse_points: np.ndarray, P: np.ndarray, K_2: np.ndarray, K_4: np.ndarray, opt, sampler: FrameSampler,
+                   dataset: str = "kitti") -> Dict:
     """kitti.py:334-372 on the coarsest-stage points (n, 3): projection to the 1/8 image, in-picture mask, `num_kpt` random in / out
     points, occupied-pixel mask, then the fine (1/2 image) pixel of every kept point.  Plain numpy on 1280 points, written the way
     the reference writes it (same operations, same dtypes): nothing here is worth a kernel launch."""
@@ -131,7 +133,12 @@ def project_labels(coarse_points: np.ndarray, P: np.ndarray, K_2: np.ndarray, K_
     xy = np.floor(proj[0:2, :] + 0.5)
     inpic = (xy[0] >= 1) & (xy[0] <= (opt.img_W * s8 - 3)) & (xy[1] >= 1) & (xy[1] <= (opt.img_H * s8 - 3)) & (proj[2] > 0)
     pc_kpt_idx = np.where(inpic)[0]
-    pc_kpt_idx = pc_kpt_idx[sampler.permutation(len(pc_kpt_idx))[0:opt.num_kpt]]
+    valid_kpt = True
+    if dataset == "kitti" or len(pc_kpt_idx) >= opt.num_kpt:
+        pc_kpt_idx = pc_kpt_idx[sampler.permutation(len(pc_kpt_idx))[0:opt.num_kpt]]
+    else:   # nuscenes.py:262-268: too few points in the picture - no draw, all-zero indices, the sample is flagged
+        valid_kpt = False
+        pc_kpt_idx = np.zeros((opt.num_kpt,), dtype=np.int64)
     pc_outline_idx = np.where(~inpic)[0]
     pc_outline_idx = pc_outline_idx[sampler.permutation(len(pc_outline_idx))[0:opt.num_kpt]]
     H8, W8 = int(opt.img_H * s8), int(opt.img_W * s8)
@@ -144,9 +151,11 @@ def project_labels(coarse_points: np.ndarray, P: np.ndarray, K_2: np.ndarray, K_
     pp[0:2, :] = pp[0:2, :] / pp[2:, :]
     fine_xy = np.floor(pp[0:2, :])
     ok = (fine_xy[0] >= 0) & (fine_xy[0] <= (opt.img_W * 0.5 - 1)) & (fine_xy[1] >= 0) & (fine_xy[1] <= (opt.img_H * 0.5 - 1)) & (pp[2] > 0)
-    if not np.all(ok):
+    if dataset == "kitti" and not np.all(ok):
         raise AssertionError("a coarse in-picture point projects outside the 1/2 image (kitti.py:366)")
+    extra = {} if dataset == "kitti" else {"valid_kpt": valid_kpt}
     return {
+        **extra,
         "coarse_img_mask": mask,
         "pc_kpt_idx": pc_kpt_idx,
         "pc_outline_idx": pc_outline_idx,
@@ -171,9 +180,14 @@ class FramePreparer:
     the tensors on the device (`img` (3,H,W), `pc_data_dict` with int64 tables and `feats`, the label tensors, K / K_4 / P).
     Buffers are cached per input size; one preparer per stream."""
 
-    def __init__(self, opt, device="cuda", mode: str = "val"):
+    def __init__(self, opt, device="cuda", mode: str = "val", dataset: str = "kitti"):
+        """dataset: 'kitti' (data/kitti.py: calibration transform, voxel grid, normals as features) or 'nuscenes' (data/nuscenes.py:177-320:
+        the stored cloud is already in the camera frame and is resampled directly, features = [intensity | point], seed = index)."""
         if mode not in ("val", "train"):
             raise ValueError("mode must be 'val' or 'train'")
+        if dataset not in ("kitti", "nuscenes"):
+            raise ValueError("dataset name invalid, only support KITTI Odometry and Nuscenes now!")   # train.py:130
+        self.dataset = dataset
         if mode == "train":
             # kitti.py:329-330 augments the image with torchvision ColorJitter in train mode: not built (training is out of scope)
             raise NotImplementedError("train-mode image augmentation (ColorJitter, kitti.py:193-201) is not implemented")
@@ -203,14 +217,16 @@ class FramePreparer:
         return vox, int(c[0])
 
     def resample_transform(self, vox: torch.Tensor, choice: np.ndarray, P: np.ndarray):
-        """rows `choice` of the voxel table, x' = R x + t, n' = R n -> points (n, 3), feats (n, 4) (kitti.py:284-288, 293)."""
+        """rows `choice` of the voxel table, x' = R x + t, n' = R n -> points (n, 3), feats (n, 4) = [intensity | n'] (kitti.py:284-288, 293)
+        or [intensity | x'] (nuscenes.py:199-204)."""
         lib = _lib.load()
         n = int(choice.shape[0])
         ch = torch.from_numpy(np.ascontiguousarray(choice, dtype=np.int32)).to(self.device, non_blocking=True)
         Pd = torch.from_numpy(np.ascontiguousarray(P, dtype=np.float32)).to(self.device, non_blocking=True)
         points = torch.empty((n, 3), dtype=torch.float32, device=self.device)
         feats = torch.empty((n, 4), dtype=torch.float32, device=self.device)
-        _lib.check(lib.cofi_gather_transform(_p(vox), _p(ch), n, _p(Pd), _p(points), _p(feats), _stream()), "cofi_gather_transform")
+        _lib.check(lib.cofi_gather_transform(_p(vox), _p(ch), n, _p(Pd), _p(points), _p(feats), int(self.dataset == "nuscenes"), _stream()),
+                   "cofi_gather_transform")
         return points, feats
 
     def image(self, img_u8: torch.Tensor, resized_hw, crop_yx):
@@ -228,11 +244,23 @@ class FramePreparer:
         coarsest-stage points on the host, are produced by calling out["finish_labels"]() later - e.g. after the forward of this
         frame has been submitted, when the points have long arrived - and are then added to the same dict."""
         opt, dev = self.opt, self.device
-        s = FrameSampler(index)
+        s = FrameSampler(index, dataset=self.dataset)
         data = (torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)) if isinstance(data, np.ndarray) else data).to(dev, non_blocking=True)
         img = (torch.from_numpy(np.ascontiguousarray(img)) if isinstance(img, np.ndarray) else img).to(dev, non_blocking=True)
-        Ptr = torch.from_numpy(np.ascontiguousarray(P_Tr, dtype=np.float32)).to(dev, non_blocking=True)
-        vox, nvox = self.voxel_downsample(data, Ptr)
+        if self.dataset == "kitti":
+            Ptr = torch.from_numpy(np.ascontiguousarray(P_Tr, dtype=np.float32)).to(dev, non_blocking=True)
+            vox, nvox = self.voxel_downsample(data, Ptr)
+        else:
+            # nuscenes.py:189-197: (4, N) = [xyz | intensity], already in the camera frame, no voxel grid (commented out in the reference):
+            # the same (N, 8) row layout through the pack kernel with the identity transform and zero normals
+            if data.dim() != 2 or data.shape[0] != 4:
+                raise _lib.CofiError("dataside: a nuScenes cloud is (4, N) = [xyz | intensity]")
+            nvox = data.shape[1]
+            d7 = torch.zeros((7, nvox), dtype=torch.float32, device=dev)
+            d7[:4] = data
+            vox = torch.empty((nvox, 8), dtype=torch.float32, device=dev)
+            eye = torch.eye(4, dtype=torch.float32, device=dev)
+            _lib.check(_lib.load().cofi_pack_transform_scan(_p(d7), nvox, _p(eye), _p(vox), _stream()), "cofi_pack_transform_scan")
         choice = s.downsample_choice(nvox, opt.num_pc)
         P = s.random_transform(opt)
         points, feats = self.resample_transform(vox, choice, P)
@@ -252,11 +280,11 @@ class FramePreparer:
 
         def finish_labels():
             ready.synchronize()
-            lab = project_labels(coarse_host.numpy(), P, K_2, K_4, opt, s)
+            lab = project_labels(coarse_host.numpy(), P, K_2, K_4, opt, s, dataset=self.dataset)
             kpt = torch.from_numpy(lab["pc_kpt_idx"]).to(dev)
             out["fine_pc_inline_index"] = ops.nearest_node(pyr["points"][1], pyr["points"][-1][kpt].contiguous()).to(torch.int64)   # point2node, kitti.py:374
             for k, v in lab.items():
-                out[k] = torch.from_numpy(v).to(dev)
+                out[k] = torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v
             out.pop("finish_labels", None)
             return out
 

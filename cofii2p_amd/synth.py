@@ -130,3 +130,25 @@ def make_raw_scan(frame_id: int = 0, num_points: int = 120000, img_hw=(376, 1241
     data = np.concatenate([pts, inten, nrm], 1)[order].T.astype(np.float32)
     K = np.array([[707.0912, 0.0, 601.8873], [0.0, 707.0912, 183.1104], [0.0, 0.0, 1.0]])
     return np.ascontiguousarray(data), img, K
+
+
+def make_raw_nuscenes(frame_id: int = 0, num_points: int = 26000, img_hw=(900, 1600)):
+    """A nuScenes-style sample as data/nuscenes.py:183-193 reads it: `pc` (4, N) float32 = [xyz | intensity] ALREADY in the camera
+    frame (x right, y down, z forward), `img` (H, W, 3) uint8, `K` (3, 3) float64."""
+    g = np.random.default_rng(4242 + int(frame_id))
+    H, W = img_hw
+    img = g.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    n_ground = int(0.65 * num_points)
+    r = np.exp(g.uniform(np.log(2.5), np.log(60.0), n_ground))
+    az = g.uniform(-np.pi, np.pi, n_ground)
+    ground = np.stack([r * np.sin(az), 1.8 + g.normal(0.0, 0.03, n_ground), r * np.cos(az)], 1)
+    n_wall = num_points - n_ground
+    u = g.uniform(-40.0, 40.0, n_wall)
+    side = g.integers(0, 4, n_wall)
+    d = g.uniform(8.0, 35.0, 4)[side]
+    h = g.uniform(-5.0, 1.8, n_wall)
+    wall = np.where((side % 2 == 0)[:, None], np.stack([np.where(side == 0, d, -d), h, u], 1), np.stack([u, h, np.where(side == 1, d, -d)], 1))
+    pts = np.concatenate([ground, wall], 0)[g.permutation(num_points)]
+    inten = g.uniform(0.0, 255.0, (num_points, 1))
+    K = np.array([[1266.417, 0.0, 816.267], [0.0, 1266.417, 491.507], [0.0, 0.0, 1.0]])
+    return np.ascontiguousarray(np.concatenate([pts, inten], 1).T.astype(np.float32)), img, K

@@ -432,6 +432,7 @@ int cofi_grid_subsample(const float *points, int N, float voxel, float *out_poin
 int cofi_radius_mask(const int32_t *idx, const float *dist, int M, int k, int S, float radius, long long offset, long long fill, long long *out,
                      int32_t *max_count_dev, cofi_stream_t stream);
 int cofi_gather_transform(const float *vox_rows, const int32_t *choice, int n, const float *P44_dev, float *points, float *feats,
+                          int feats_are_points /* 0: feats = [intensity | R n] (kitti.py:293); 1: [intensity | R x + t] (nuscenes.py:204) */,
                           cofi_stream_t stream);
 int cofi_resize_crop_image(const uint8_t *src_hwc, int src_h, int src_w, int dst_h, int dst_w, int crop_y, int crop_x, int H, int W,
                            float *out_chw, cofi_stream_t stream);

@@ -165,8 +165,10 @@ def resize_linear_u8(img, dw, dh):
     return np.clip(v, 0, 255).astype(np.uint8)
 
 
-def project_labels(coarse_points, P, K_2, K_4, img_H, img_W, num_kpt, rs):
-    """kitti.py:334-372: coarse (1/8) and fine (1/2) correspondences of the coarsest-stage points.  coarse_points (3, n) float32."""
+def project_labels(coarse_points, P, K_2, K_4, img_H, img_W, num_kpt, rs, nuscenes=False):
+    """kitti.py:334-372 (nuscenes.py:254-296 with nuscenes=True: too few in-picture points -> zero indices and valid_kpt False instead of
+    a short draw; no assertion on the fine pixels): coarse (1/8) and fine (1/2) correspondences of the coarsest-stage points.
+    coarse_points (3, n) float32."""
     scale_size = 0.125
     Rinv = np.linalg.inv(P[0:3, 0:3])
     proj = np.dot(K_4, np.dot(Rinv, coarse_points) - np.dot(Rinv, P[0:3, 3:]))
@@ -176,7 +178,12 @@ def project_labels(coarse_points, P, K_2, K_4, img_H, img_W, num_kpt, rs):
     inpic = (xy[0] >= 1) & (xy[0] <= (img_W * scale_size - 3)) & (xy[1] >= 1) & (xy[1] <= (img_H * scale_size - 3)) & (proj[2] > 0)
     mask[:, inpic] = 1.0
     pc_kpt_idx = np.where(mask.squeeze() == 1)[0]
-    pc_kpt_idx = pc_kpt_idx[rs.permutation(len(pc_kpt_idx))[0:num_kpt]]
+    valid_kpt = True
+    if not nuscenes or len(pc_kpt_idx) >= num_kpt:
+        pc_kpt_idx = pc_kpt_idx[rs.permutation(len(pc_kpt_idx))[0:num_kpt]]
+    else:
+        valid_kpt = False
+        pc_kpt_idx = np.zeros((num_kpt,), dtype=np.int64)
     pc_outline_idx = np.where(mask.squeeze() == 0)[0]
     pc_outline_idx = pc_outline_idx[rs.permutation(len(pc_outline_idx))[0:num_kpt]]
     xy2 = xy[:, inpic]
@@ -193,8 +200,9 @@ def project_labels(coarse_points, P, K_2, K_4, img_H, img_W, num_kpt, rs):
     pp[0:2, :] = pp[0:2, :] / pp[2:, :]
     fine_xy = np.floor(pp[0:2, :])
     fine_in = (fine_xy[0] >= 0) & (fine_xy[0] <= (img_W * 0.5 - 1)) & (fine_xy[1] >= 0) & (fine_xy[1] <= (img_H * 0.5 - 1)) & (pp[2] > 0)
-    assert np.all(fine_in)
+    assert nuscenes or np.all(fine_in)
     return {
+        **({"valid_kpt": valid_kpt} if nuscenes else {}),
         "coarse_img_mask": img_mask_s8.astype(np.float32),
         "pc_kpt_idx": pc_kpt_idx,
         "pc_outline_idx": pc_outline_idx,
@@ -263,5 +271,48 @@ def prepare_frame(data, img, K, P_Tr, index, opt, mode="val"):
         # intermediates
         "points": points, "feats": feats, "subsample": sub, "choice": choice, "P_random": P,
         "voxel": (vpc, vint, vsn), "crop": (dy, dx), "resized_hw": small.shape[:2],
+    })
+    return out
+
+
+def prepare_frame_nuscenes(pc4, img, K, index, opt, mode="val"):
+    """nuscenes.py:177-320 (val mode) minus the disk reads and the KNN tables: seed = index, the stored (4, N) cloud [xyz | intensity]
+    is already in the camera frame and is resampled directly (the voxel grid is commented out there), features = [intensity | point]."""
+    seed = int(index)
+    rs = np.random.RandomState(seed)
+    rnd = random.Random(seed)
+    intensity, pc = pc4[3, :].reshape(1, -1), pc4[0:3, :]
+    choice = downsample_choice(pc.shape[1], opt.num_pc, rs)
+    pc, intensity = pc[:, choice], intensity[:, choice]
+    amp = (opt.P_tx_amplitude, opt.P_ty_amplitude, opt.P_tz_amplitude, opt.P_Rx_amplitude, opt.P_Ry_amplitude, opt.P_Rz_amplitude)
+    P = random_transform(rnd, amp)
+    pc = rigid(P, pc)
+    sub, n = [], pc.shape[1]
+    for _ in range(NUM_STAGES - 1):
+        sub.append(rs.choice(np.arange(n), size=n // 2))
+        n //= 2
+    points = [np.ascontiguousarray(pc.T)]
+    for s_ in sub:
+        points.append(points[-1][s_])
+    feats = np.concatenate([intensity, pc], axis=0).T.astype(np.float32)
+    small = resize_linear_u8(img, int(round(img.shape[1] * 0.5)), int(round(img.shape[0] * 0.5)))
+    K = camera_matrix_scaling(K, 0.5)
+    if mode == "train":
+        dx = rnd.randint(0, small.shape[1] - opt.img_W)
+        dy = rnd.randint(0, small.shape[0] - opt.img_H)
+    else:
+        dx = int((small.shape[1] - opt.img_W) / 2)
+        dy = int((small.shape[0] - opt.img_H) / 2)
+    crop = small[dy:dy + opt.img_H, dx:dx + opt.img_W, :]
+    K = camera_matrix_cropping(K, dx=dx, dy=dy)
+    K_2 = camera_matrix_scaling(K, 0.5)
+    K_4 = camera_matrix_scaling(K, 0.125)
+    coarse_points = np.array(points[-1], dtype=np.float32).T
+    out = project_labels(coarse_points, P, K_2, K_4, opt.img_H, opt.img_W, opt.num_kpt, rs, nuscenes=True)
+    out["fine_pc_inline_index"] = point2node(points[1], points[-1][out["pc_kpt_idx"]])
+    out.update({
+        "img": np.ascontiguousarray((crop.astype(np.float32) / 255.0).transpose(2, 0, 1)),
+        "K": K_2.astype(np.float32), "K_4": K_4.astype(np.float32), "P": np.linalg.inv(P).astype(np.float32),
+        "points": points, "feats": feats, "subsample": sub, "choice": choice, "P_random": P, "crop": (dy, dx),
     })
     return out

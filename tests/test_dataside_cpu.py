@@ -143,3 +143,50 @@ def test_intrinsics_chain(gold):
     K_2, K_4, (dy, dx), (rh, rw) = dataside.intrinsics_and_crop(K, (376, 1241), kitti_opt(), None)
     assert (rh, rw) == (188, 620) and (dy, dx) == (14, 54)
     assert np.array_equal(K_2.astype(np.float32), gold["i0_K"]) and np.array_equal(K_4.astype(np.float32), gold["i0_K_4"])
+
+
+# ---------------------------------------------------------------------------------------------------------------- nuScenes loader
+NUS_INDICES = (0, 1, 2)
+
+
+def nuscenes_opt():
+    """data/options.py:60-97"""
+    return types.SimpleNamespace(img_H=160, img_W=320, num_pc=20480, num_kpt=32, P_tx_amplitude=10, P_ty_amplitude=0, P_tz_amplitude=10,
+                                 P_Rx_amplitude=0.0, P_Ry_amplitude=2.0 * np.pi, P_Rz_amplitude=0.0)
+
+
+@pytest.mark.parametrize("index", NUS_INDICES)
+def test_oracle_matches_reference_nuscenes_getitem(index):
+    """data/nuscenes.py:177-320 (seed = index, no voxel grid, features = [intensity | point], valid_kpt) against what the reference's own
+    nuscenes_pc_img_dataset.__getitem__ returned (tests/tools/make_golden_dataside_nuscenes.py); index 0 is a sample with fewer than
+    num_kpt coarse points in the picture (valid_kpt False, all-zero indices, no permutation drawn)."""
+    gold = load_golden("dataside_nuscenes_ref.npz")
+    tag = "i%d_" % index
+    fid, n = gold[tag + "frame_points"]
+    pc4, img, K = synth.make_raw_nuscenes(int(fid), int(n))
+    opt = nuscenes_opt()
+    r = D.prepare_frame_nuscenes(pc4, img, K, index, opt)
+    assert bool(r["valid_kpt"]) == bool(gold[tag + "valid_kpt"])
+    for k in INT_KEYS:
+        assert np.array_equal(np.asarray(r[k]), gold[tag + k]), k
+    assert np.array_equal(r["coarse_img_mask"], gold[tag + "coarse_img_mask"])
+    for k in ("K", "K_4", "P"):
+        np.testing.assert_array_equal(r[k], gold[tag + k])
+    np.testing.assert_allclose(r["points"][4], gold[tag + "points4"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(r["points"][0][::64], gold[tag + "points0_rows"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(r["feats"][::64], gold[tag + "feats_rows"], rtol=0, atol=2e-5)
+    q = np.rint(r["img"] * 255.0).astype(np.uint8)
+    assert hashlib.sha256(np.ascontiguousarray(q).tobytes()).hexdigest() == str(gold[tag + "img_sha256"])
+    # the product's host logic (sampler with the nuScenes seed rule, label projection with the valid_kpt branch)
+    s = dataside.FrameSampler(index, dataset="nuscenes")
+    assert s.seed == index
+    assert np.array_equal(s.downsample_choice(int(n), opt.num_pc), r["choice"])
+    assert np.array_equal(s.random_transform(opt), r["P_random"])
+    for a, b in zip(s.subsample_indices(opt.num_pc, 5), r["subsample"]):
+        assert np.array_equal(a, b)
+    K_2, K_4, crop, rhw = dataside.intrinsics_and_crop(K, img.shape[:2], opt, s)
+    assert crop == r["crop"] and rhw == (450, 800)
+    lab = dataside.project_labels(r["points"][4], r["P_random"], K_2, K_4, opt, s, dataset="nuscenes")
+    assert lab["valid_kpt"] == bool(gold[tag + "valid_kpt"])
+    for k in INT_KEYS[:-1]:
+        assert np.array_equal(lab[k], gold[tag + k]), k

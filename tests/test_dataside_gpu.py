@@ -196,3 +196,32 @@ def test_prepared_frame_feeds_the_model(ds):
     for o in list(outs) + list(test):
         if torch.is_tensor(o) and o.is_floating_point():
             assert torch.isfinite(o).all()
+
+
+@pytest.mark.parametrize("index", (0, 1, 2))
+def test_prepared_nuscenes_frame_against_reference_golden(ds, index):
+    """FramePreparer(dataset='nuscenes') against the reference's nuscenes_pc_img_dataset.__getitem__ (labels and index lists exactly,
+    floats to 2e-5) and the oracle (exactly); incl. the sample with valid_kpt False and the cloud with fewer than num_pc points."""
+    from cofii2p_amd import synth
+    from test_dataside_cpu import nuscenes_opt
+
+    gold = load_golden("dataside_nuscenes_ref.npz")
+    tag = "i%d_" % index
+    fid, n = gold[tag + "frame_points"]
+    pc4, img, K = synth.make_raw_nuscenes(int(fid), int(n))
+    opt = nuscenes_opt()
+    out = ds.FramePreparer(opt, DEV, dataset="nuscenes").prepare(pc4, img, K, None, index)
+    want = D.prepare_frame_nuscenes(pc4, img, K, index, opt)
+    assert out["valid_kpt"] == bool(gold[tag + "valid_kpt"])
+    for k in INT_KEYS:
+        assert np.array_equal(out[k].cpu().numpy(), gold[tag + k]), k
+    assert np.array_equal(out["coarse_img_mask"].cpu().numpy(), gold[tag + "coarse_img_mask"])
+    for k in ("K", "K_4", "P"):
+        assert np.array_equal(out[k].cpu().numpy(), gold[tag + k])
+    dd = out["pc_data_dict"]
+    np.testing.assert_allclose(dd["points"][4].cpu().numpy(), gold[tag + "points4"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(dd["feats"].cpu().numpy()[::64], gold[tag + "feats_rows"], rtol=0, atol=2e-5)
+    for i in range(5):
+        assert np.array_equal(dd["points"][i].cpu().numpy(), want["points"][i])
+    assert np.array_equal(dd["feats"].cpu().numpy(), want["feats"])
+    assert np.array_equal(out["img"].cpu().numpy(), want["img"]) and tuple(out["img"].shape) == (3, 160, 320)
