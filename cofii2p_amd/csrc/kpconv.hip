@@ -51,7 +51,8 @@ struct KpArgs {
 // row id - is staged per 64 neighbours with coalesced/gather loads by lane = neighbour, parked in a wave-private LDS
 // record, and fetched back per step with one broadcast ds_read_b128 (4 distinct addresses per wave).
 constexpr int KP_PHASE_DEFAULT = 128;  // neighbour records staged per wave and phase (H <= 128: one phase)
-constexpr int KP_PAD = 32;     // shadow records behind the phase: the pipeline's look-ahead (<= 7 steps) reads them
+constexpr int KP_PAD = 64;     // shadow records behind the (compacted) records of a phase: the round-up to 16 neighbours (<= 15) and the
+                               // pipeline's look-ahead (<= 7 steps = 28) read them
 
 template <int VEC, int NCH>
 struct KpFeat {
@@ -93,8 +94,20 @@ __device__ __forceinline__ void kp_aggregate_query(KpArgs a, const int m, const 
     }
     const char *fbase = reinterpret_cast<const char *>(a.feats);
     const unsigned ldfb = 4u * a.ldf;
-    if (lane < KP_PAD) rec[KP_PHASE + lane] = make_float4(1e18f, 0.f, 0.f, __int_as_float(0));  // look-ahead lands here
     const float inv_sigma = 1.0f / a.sigma;
+    // Support of the kernel: the influence max(0, 1 - |d - k| / sigma) of EVERY kernel point k is exactly 0 for a neighbour at |d| >=
+    // max|k| + sigma.  The k nearest neighbours of the pyramid reach far beyond that (KITTI-shaped frames: 2 - 26 % of the 128 lie
+    // inside), so the staging keeps only the neighbours inside the support (compacted, order preserved) and the MFMA / feature-load
+    // loop runs over those: exact - the dropped terms are zeros - up to the regrouping of the fp32 sums.  (The bound carries a 2e-5
+    // margin: far more than the rounding of the distances on either side.)
+    float rsup;
+    {
+        float kn = j < 15 ? __builtin_amdgcn_sqrtf((kx * kx + ky * ky) + kz * kz) : 0.f;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) kn = fmaxf(kn, __shfl_xor(kn, o, 64));
+        rsup = (kn + a.sigma) * 1.00002f;
+    }
+    const float rsup2 = rsup * rsup;
 
     for (int h0 = 0; h0 < a.H; h0 += KP_PHASE) {
         const int nh = a.H - h0 < KP_PHASE ? a.H - h0 : KP_PHASE;  // multiple of 4
@@ -115,16 +128,22 @@ __device__ __forceinline__ void kp_aggregate_query(KpArgs a, const int m, const 
             px[r] = sp[0]; py[r] = sp[1]; pz[r] = sp[2];
             pos[r] = a.row_pos[idc];
         }
+        int nin = 0;   // neighbours of this phase inside the kernel's support (wave-uniform)
 #pragma unroll
         for (int r = 0; r < KP_PHASE / 64; ++r) {
             const bool valid = (unsigned)idr[r] < (unsigned)a.N;
-            npos += __popcll(__ballot(valid && pos[r] != 0));
-            // kpconv.py:93: neighbours centred on the query.  A shadow neighbour sits 1e18 away (influence exactly 0, as for
-            // the reference's 1e6 shadow point) and points at row 0, so the step loop needs no validity test.
-            rec[r * 64 + lane] = make_float4(valid ? px[r] - qx : 1e18f, py[r] - qy, pz[r] - qz, __int_as_float(valid ? idr[r] : 0));
+            npos += __popcll(__ballot(valid && pos[r] != 0));   // kpconv.py:113-115 counts over ALL neighbours
+            // kpconv.py:93: neighbours centred on the query
+            const float dx = px[r] - qx, dy = py[r] - qy, dz = pz[r] - qz;
+            const bool inside = valid && (dx * dx + dy * dy) + dz * dz < rsup2;
+            const unsigned long long msk = __ballot(inside);
+            if (inside) rec[nin + __popcll(msk & ((1ull << lane) - 1ull))] = make_float4(dx, dy, dz, __int_as_float(idr[r]));
+            nin += __popcll(msk);
         }
+        // shadow records (1e18 away: influence exactly 0, row 0: finite data) behind the list, so the step loop needs no validity test
+        rec[nin + lane] = make_float4(1e18f, 0.f, 0.f, __int_as_float(0));
         __builtin_amdgcn_wave_barrier();
-        const int steps = nh >> 2;
+        const int steps = (nin + 3) >> 2;
         const float4 *rg = rec + g;  // record of neighbour 4t+g = rg[4t]; reads past the phase hit later records or the pad
         // The loads ARE the software pipeline.  Each one is followed by a compiler-level memory barrier (no instruction):
         // without it the optimiser folds the loop-carried loaded values into loop-carried ADDRESSES and re-issues every
@@ -267,8 +286,8 @@ __global__ void kp_pack_c4_kernel(const float *feats, int ldf, int C, const floa
 
 __global__ __launch_bounds__(256) void kpconv_aggregate_c4_kernel(KpArgs a) {   // a.feats = packed records (N, 8)
     constexpr int PH = 128;
-    __shared__ float4 rec_s[4][PH];
-    __shared__ float4 fea_s[4][PH];
+    __shared__ float4 rec_s[4][PH + 4];   // + one step of shadow records behind the compacted list
+    __shared__ float4 fea_s[4][PH + 4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int m = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + wv);
     if (m >= a.M) return;
@@ -279,6 +298,14 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_c4_kernel(KpArgs a) {   
     const int jk = j < 15 ? j : 0;
     const float kx = a.kp[3 * jk], ky = a.kp[3 * jk + 1], kz = a.kp[3 * jk + 2];
     const float inv_sigma = 1.0f / a.sigma;
+    float rsup;   // support of the kernel, as in kp_aggregate_query: same neighbours kept, same order -> identical bits
+    {
+        float kn = j < 15 ? __builtin_amdgcn_sqrtf((kx * kx + ky * ky) + kz * kz) : 0.f;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) kn = fmaxf(kn, __shfl_xor(kn, o, 64));
+        rsup = (kn + a.sigma) * 1.00002f;
+    }
+    const float rsup2 = rsup * rsup;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     int npos = 0;
     const int32_t *irow = a.idx + (size_t)m * a.H;
@@ -300,15 +327,27 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_c4_kernel(KpArgs a) {   
             fr[r] = recs[2 * (size_t)idc];
             pp[r] = recs[2 * (size_t)idc + 1];
         }
+        int nin = 0;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const bool valid = (unsigned)idr[r] < (unsigned)a.N;
             npos += __popcll(__ballot(valid && pp[r].w != 0.f));
-            rec[r * 64 + lane] = make_float4(valid ? pp[r].x - qx : 1e18f, pp[r].y - qy, pp[r].z - qz, 0.f);   // shadow: influence exactly 0
-            fea[r * 64 + lane] = valid ? fr[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float dx = pp[r].x - qx, dy = pp[r].y - qy, dz = pp[r].z - qz;
+            const bool inside = valid && (dx * dx + dy * dy) + dz * dz < rsup2;
+            const unsigned long long msk = __ballot(inside);
+            if (inside) {
+                const int slot = nin + __popcll(msk & ((1ull << lane) - 1ull));
+                rec[slot] = make_float4(dx, dy, dz, 0.f);
+                fea[slot] = fr[r];
+            }
+            nin += __popcll(msk);
+        }
+        if (lane < 4) {   // the last step is filled up with shadow neighbours: influence exactly 0, zero features
+            rec[nin + lane] = make_float4(1e18f, 0.f, 0.f, 0.f);
+            fea[nin + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __builtin_amdgcn_wave_barrier();
-        const int steps = nh >> 2;
+        const int steps = (nin + 3) >> 2;
 #pragma unroll 4
         for (int t = 0; t < steps; ++t) {
             const float4 rc = rec[4 * t + g];
