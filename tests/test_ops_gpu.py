@@ -217,6 +217,33 @@ def test_kpconv_fused_rejects_unsupported_shapes(ops, monkeypatch):
     assert ops.kpconv_fused_slab_rows(64, 20480) == 0
 
 
+@pytest.mark.parametrize("sigma", [0.01, 0.08, 3.0])
+@pytest.mark.parametrize("C,H", [(4, 128), (32, 128), (64, 256), (128, 64)])
+def test_kpconv_support_cut_extremes(ops, C, H, sigma):
+    """The aggregation drops neighbours outside the kernel's support (|d| >= max|k| + sigma: every influence exactly 0).  Extremes:
+    a support so small that only coincident points are inside (incl. queries with NO neighbour inside), one that holds every
+    neighbour, several staging phases (H = 256); kernel points on and beyond the unit scale."""
+    g = np.random.default_rng(C + H)
+    N, M = 1500, 400
+    s_pts = torch.from_numpy(g.uniform(-1, 1, (N, 3)).astype(np.float32))
+    q_pts = s_pts[g.integers(0, N, M)].clone()
+    q_pts[::2] += 0.05          # half of the queries coincide with a support point, the others sit 0.087 away from everything near
+    idx = torch.from_numpy(knn_c.knn(s_pts.numpy(), q_pts.numpy(), H).astype(np.int64))
+    idx[::7, -9:] = N
+    feats = torch.from_numpy(g.standard_normal((N, C)).astype(np.float32))
+    kp = torch.from_numpy((g.uniform(-1, 1, (15, 3)) * 1.5 * sigma).astype(np.float32))
+    kp[0] = 0
+    w = torch.from_numpy((g.standard_normal((15, C, 16)) * 0.1).astype(np.float32))
+    b = torch.from_numpy(g.standard_normal(16).astype(np.float32))
+    ref = O.kpconv(feats, q_pts, s_pts, idx, kp, w, b, sigma)
+    agg, cnt = ops.kpconv_aggregate(G(feats), G(q_pts), G(s_pts), G(idx, torch.int32), G(kp), sigma)
+    out = ops.gemm(agg, G(w.permute(2, 0, 1).reshape(16, -1).contiguous()), bias=G(b), rowdiv=cnt)
+    close(out, ref, 1e-4)
+    if sigma == 0.01:
+        # (almost) nothing lies inside the support of the shifted queries: exact zero rows, bias-only outputs
+        assert float((agg[::2].abs().amax(1) == 0).float().mean()) > 0.8
+
+
 def test_pool_gather(ops, mg):
     idx = G(mg["kp_idx"], torch.int32)
     x = G(mg["pool_x"])
