@@ -348,7 +348,6 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_c4_kernel(KpArgs a) {   
         }
         __builtin_amdgcn_wave_barrier();
         const int steps = (nin + 3) >> 2;
-#pragma unroll 4
         for (int t = 0; t < steps; ++t) {
             const float4 rc = rec[4 * t + g];
             const float f = fsel[(4 * t + g) * 4] * fmask;
