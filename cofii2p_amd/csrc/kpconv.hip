@@ -59,6 +59,66 @@ struct KpFeat {
     float f[NCH][VEC];
 };
 
+// The MFMA / feature-load loop of one wave over the `nin` staged neighbour records of a query (rec: LDS, followed by >= 64 shadow
+// records), channels coffb[] of the rows behind fbase: acc += W^T F.
+template <int VEC, int NCH>
+__device__ __forceinline__ void kp_steps(const char *fbase, const unsigned ldfb, const unsigned (&coffb)[NCH], const float4 *rec, const int nin,
+                                         const float kx, const float ky, const float kz, const float inv_sigma, f32x4 (&acc)[NCH][VEC]) {
+    const int g = (threadIdx.x & 63) >> 4;
+    {
+        const int steps = (nin + 3) >> 2;
+        const float4 *rg = rec + g;  // record of neighbour 4t+g = rg[4t]; reads past the phase hit later records or the pad
+        // The loads ARE the software pipeline.  Each one is followed by a compiler-level memory barrier (no instruction):
+        // without it the optimiser folds the loop-carried loaded values into loop-carried ADDRESSES and re-issues every
+        // load at its use, which serialises the L2 latency into each step.
+        auto fetch = [&](int t) -> float4 {
+            const float4 v = rg[4 * t];
+            asm volatile("" ::: "memory");
+            return v;
+        };
+        auto issue = [&](const float4 &rc, KpFeat<VEC, NCH> &f) {
+            const unsigned id = (unsigned)__float_as_int(rc.w);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                // byte offset of (row, channel chunk): < 4 GiB with id, ldfb < 2^24 (checked by the host) -> one full-rate mad
+                const char *src = fbase + (size_t)(__umul24(id, ldfb) + coffb[ch]);
+                if constexpr (VEC == 4) {
+                    const f32x4 tt = *reinterpret_cast<const f32x4 *>(src);
+                    f.f[ch][0] = tt[0]; f.f[ch][1] = tt[1]; f.f[ch][2] = tt[2]; f.f[ch][3] = tt[3];
+                } else if constexpr (VEC == 2) {
+                    const f32x2 tt = *reinterpret_cast<const f32x2 *>(src);
+                    f.f[ch][0] = tt[0]; f.f[ch][1] = tt[1];
+                } else {
+                    f.f[ch][0] = *reinterpret_cast<const float *>(src);
+                }
+            }
+            asm volatile("" ::: "memory");
+        };
+        auto consume = [&](const float4 &rc, const KpFeat<VEC, NCH> &f) {
+            // kpconv.py:93-99: ((s - q) - kp)^2 summed, sqrt, 1 - d/sigma, clamp at 0 (straight-line: select, no branch)
+            const float dx = rc.x - kx, dy = rc.y - ky, dz = rc.z - kz;
+            const float sq = (dx * dx + dy * dy) + dz * dz;
+            const float w = fmaxf(1.0f - __builtin_amdgcn_sqrtf(sq) * inv_sigma, 0.0f);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    acc[ch][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, f.f[ch][v], acc[ch][v], 0, 0, 0);
+        };
+        // software pipeline: slot k fetches the record of step k+3 (LDS), runs the MFMAs of step k behind it, then issues
+        // the feature loads of step k+3 (L2) - three feature loads stay in flight per wave
+        float4 R0 = fetch(0), R1 = fetch(1), R2 = fetch(2), R3;
+        KpFeat<VEC, NCH> F0, F1, F2, F3;
+        issue(R0, F0); issue(R1, F1); issue(R2, F2);
+        for (int t = 0; t < steps; t += 4) {  // steps in [steps, roundup4) read shadow records and add zero
+            R3 = fetch(t + 3); consume(R0, F0); issue(R3, F3);
+            R0 = fetch(t + 4); consume(R1, F1); issue(R0, F0);
+            R1 = fetch(t + 5); consume(R2, F2); issue(R1, F1);
+            R2 = fetch(t + 6); consume(R3, F3); issue(R2, F2);
+        }
+    }
+}
+
 // The aggregation of ONE query m by one wave (see the file header): acc[ch][v] = MFMA accumulators (rows = kernel points,
 // column j = channel c0 + ch*16*VEC + VEC*j + v), npos = neighbours whose feature row sums to > 0 (kpconv.py:113-114).
 // rec = the wave's private LDS record buffer (PHASE + KP_PAD entries); a is a private copy (frame shift).
@@ -66,7 +126,7 @@ template <int VEC, int NCH, int PHASE>
 __device__ __forceinline__ void kp_aggregate_query(KpArgs a, const int m, const int c0, float4 *rec, f32x4 (&acc)[NCH][VEC], int &npos) {
     constexpr int KP_PHASE = PHASE;
     const int lane = threadIdx.x & 63;
-    const int j = lane & 15, g = lane >> 4;
+    const int j = lane & 15;
     {   // stack mode: shift the support-side bases to this query's frame (indices are frame-local)
         const size_t fo = (size_t)(m / a.Mpf) * a.N;
         a.feats += fo * a.ldf;
@@ -143,56 +203,7 @@ __device__ __forceinline__ void kp_aggregate_query(KpArgs a, const int m, const 
         // shadow records (1e18 away: influence exactly 0, row 0: finite data) behind the list, so the step loop needs no validity test
         rec[nin + lane] = make_float4(1e18f, 0.f, 0.f, __int_as_float(0));
         __builtin_amdgcn_wave_barrier();
-        const int steps = (nin + 3) >> 2;
-        const float4 *rg = rec + g;  // record of neighbour 4t+g = rg[4t]; reads past the phase hit later records or the pad
-        // The loads ARE the software pipeline.  Each one is followed by a compiler-level memory barrier (no instruction):
-        // without it the optimiser folds the loop-carried loaded values into loop-carried ADDRESSES and re-issues every
-        // load at its use, which serialises the L2 latency into each step.
-        auto fetch = [&](int t) -> float4 {
-            const float4 v = rg[4 * t];
-            asm volatile("" ::: "memory");
-            return v;
-        };
-        auto issue = [&](const float4 &rc, KpFeat<VEC, NCH> &f) {
-            const unsigned id = (unsigned)__float_as_int(rc.w);
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                // byte offset of (row, channel chunk): < 4 GiB with id, ldfb < 2^24 (checked by the host) -> one full-rate mad
-                const char *src = fbase + (size_t)(__umul24(id, ldfb) + coffb[ch]);
-                if constexpr (VEC == 4) {
-                    const f32x4 tt = *reinterpret_cast<const f32x4 *>(src);
-                    f.f[ch][0] = tt[0]; f.f[ch][1] = tt[1]; f.f[ch][2] = tt[2]; f.f[ch][3] = tt[3];
-                } else if constexpr (VEC == 2) {
-                    const f32x2 tt = *reinterpret_cast<const f32x2 *>(src);
-                    f.f[ch][0] = tt[0]; f.f[ch][1] = tt[1];
-                } else {
-                    f.f[ch][0] = *reinterpret_cast<const float *>(src);
-                }
-            }
-            asm volatile("" ::: "memory");
-        };
-        auto consume = [&](const float4 &rc, const KpFeat<VEC, NCH> &f) {
-            // kpconv.py:93-99: ((s - q) - kp)^2 summed, sqrt, 1 - d/sigma, clamp at 0 (straight-line: select, no branch)
-            const float dx = rc.x - kx, dy = rc.y - ky, dz = rc.z - kz;
-            const float sq = (dx * dx + dy * dy) + dz * dz;
-            const float w = fmaxf(1.0f - __builtin_amdgcn_sqrtf(sq) * inv_sigma, 0.0f);
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-                for (int v = 0; v < VEC; ++v)
-                    acc[ch][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, f.f[ch][v], acc[ch][v], 0, 0, 0);
-        };
-        // software pipeline: slot k fetches the record of step k+3 (LDS), runs the MFMAs of step k behind it, then issues
-        // the feature loads of step k+3 (L2) - three feature loads stay in flight per wave
-        float4 R0 = fetch(0), R1 = fetch(1), R2 = fetch(2), R3;
-        KpFeat<VEC, NCH> F0, F1, F2, F3;
-        issue(R0, F0); issue(R1, F1); issue(R2, F2);
-        for (int t = 0; t < steps; t += 4) {  // steps in [steps, roundup4) read shadow records and add zero
-            R3 = fetch(t + 3); consume(R0, F0); issue(R3, F3);
-            R0 = fetch(t + 4); consume(R1, F1); issue(R0, F0);
-            R1 = fetch(t + 5); consume(R2, F2); issue(R1, F1);
-            R2 = fetch(t + 6); consume(R3, F3); issue(R2, F2);
-        }
+        kp_steps<VEC, NCH>(fbase, ldfb, coffb, rec, nin, kx, ky, kz, inv_sigma, acc);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -267,6 +278,89 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_kernel(KpArgs a) {
         }
     }
     if (blockIdx.y == 0 && lane == 0) a.cnt[m] = (float)(npos > 1 ? npos : 1);
+}
+
+// Wide layers (C = 256 / 512: NP = C / 128 channel passes) with few queries (1280 ... 2560 at the deep stages): the NP passes of a
+// query are NP waves of ONE workgroup that stage its neighbour records TOGETHER - each wave a 1/NP share of the 128 neighbours,
+// survivors concatenated in neighbour order through LDS - instead of every pass repeating the whole staging.  Same records, same
+// order as kp_aggregate_query: identical bits.
+template <int NP>
+__global__ __launch_bounds__(256) void kpconv_aggregate_shared_kernel(KpArgs a) {
+    constexpr int VEC = 4, NCH = 2, QW = 4 / NP, SH = 128 / NP;   // queries per workgroup, neighbours staged per wave
+    __shared__ float4 rec_s[QW][128 + KP_PAD];
+    __shared__ int cnt_s[QW][NP], pos_s[QW][NP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int qs = wv / NP, p = wv % NP;
+    const int j = lane & 15, g = lane >> 4;
+    int m = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * QW + qs);   // host: M % QW == 0
+    if (a.order) m = (m / a.Mpf) * a.Mpf + a.order[m];
+    {
+        const size_t fo = (size_t)(m / a.Mpf) * a.N;
+        a.feats += fo * a.ldf;
+        a.s_pts += fo * 3;
+        a.row_pos += fo;
+    }
+    const float qx = a.q_pts[3 * m], qy = a.q_pts[3 * m + 1], qz = a.q_pts[3 * m + 2];
+    const int jk = j < 15 ? j : 0;
+    const float kx = a.kp[3 * jk], ky = a.kp[3 * jk + 1], kz = a.kp[3 * jk + 2];
+    const float inv_sigma = 1.0f / a.sigma;
+    float rsup;
+    {
+        float kn = j < 15 ? __builtin_amdgcn_sqrtf((kx * kx + ky * ky) + kz * kz) : 0.f;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) kn = fmaxf(kn, __shfl_xor(kn, o, 64));
+        rsup = (kn + a.sigma) * 1.00002f;
+    }
+    const float rsup2 = rsup * rsup;
+    // ---- this wave's share of the staging: neighbours [p * SH, (p + 1) * SH), lane = neighbour
+    const int hl = p * SH + lane;
+    const bool mine = lane < SH && hl < a.H;
+    const int id = mine ? a.idx[(size_t)m * a.H + hl] : a.N;
+    const bool valid = (unsigned)id < (unsigned)a.N;
+    const int idc = valid ? id : 0;
+    const float *sp = a.s_pts + 3 * (size_t)idc;
+    const float dx = sp[0] - qx, dy = sp[1] - qy, dz = sp[2] - qz;
+    const int rp = a.row_pos[idc];
+    const bool inside = valid && (dx * dx + dy * dy) + dz * dz < rsup2;
+    const unsigned long long msk = __ballot(inside);
+    const int npos_w = __popcll(__ballot(valid && rp != 0));
+    if (lane == 0) { cnt_s[qs][p] = __popcll(msk); pos_s[qs][p] = npos_w; }
+    __syncthreads();
+    int off = 0, nin = 0, npos = 0;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int c = cnt_s[qs][q];
+        off += q < p ? c : 0;
+        nin += c;
+        npos += pos_s[qs][q];
+    }
+    float4 *rec = rec_s[qs];
+    if (inside) rec[off + __popcll(msk & ((1ull << lane) - 1ull))] = make_float4(dx, dy, dz, __int_as_float(id));
+    if (p == 0) rec[nin + lane] = make_float4(1e18f, 0.f, 0.f, __int_as_float(0));   // shadow records behind the list
+    __syncthreads();
+    // ---- this wave's channel pass over the shared records
+    const int c0 = p * (16 * VEC * NCH);
+    unsigned coffb[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) coffb[ch] = 4u * (c0 + ch * 16 * VEC + VEC * j);
+    f32x4 acc[NCH][VEC];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[ch][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    kp_steps<VEC, NCH>(reinterpret_cast<const char *>(a.feats), 4u * a.ldf, coffb, rec, nin, kx, ky, kz, inv_sigma, acc);
+    float *orow = a.agg + (size_t)m * a.ld_agg;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c = c0 + ch * 16 * VEC + VEC * j;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * g + r;
+            if (k < 15)
+                *reinterpret_cast<float4 *>(orow + (size_t)k * a.C + c) = make_float4(acc[ch][0][r], acc[ch][1][r], acc[ch][2][r], acc[ch][3][r]);
+        }
+    }
+    if (p == 0 && lane == 0) a.cnt[m] = (float)(npos > 1 ? npos : 1);
 }
 
 // C <= 4 (the first layer of the encoder: [intensity | normal]).  What a neighbour costs in the staging is the number of distinct
@@ -639,7 +733,13 @@ extern "C" int cofi_kpconv_aggregate(const float *feats, int ldf, int N, int C, 
     M *= frames;
     hipStream_t s = cofi_s(stream);
     const int mb = cofi_cdiv(M, 4);
-    if ((C & 3) == 0 && (ldf & 3) == 0 && C >= 64) {
+    static const bool no_shared = [] { const char *e = getenv("COFI_KP_NO_SHARED_STAGING"); return e && atoi(e) != 0; }();
+    if (!no_shared && !agg_planes && (C == 256 || C == 512) && (ldf & 3) == 0 && H <= 128 && M % (C == 256 ? 2 : 1) == 0) {
+        if (C == 256)
+            hipLaunchKernelGGL(kpconv_aggregate_shared_kernel<2>, dim3(M / 2), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(kpconv_aggregate_shared_kernel<4>, dim3(M), dim3(256), 0, s, a);
+    } else if ((C & 3) == 0 && (ldf & 3) == 0 && C >= 64) {
         if (C % 128 == 0)
             hipLaunchKernelGGL((kpconv_aggregate_kernel<4, 2>), dim3(mb, C / 128), dim3(256), 0, s, a);
         else
