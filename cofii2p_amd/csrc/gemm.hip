@@ -967,12 +967,14 @@ Plan make_plan(int M, int N, int K, bool fused_ln) {
     return p;
 }
 
-// Latency configuration of the 64x64 kernel (8 or 16 waves sharing every K-tile): grids small enough that each workgroup
-// is alone on its CU; 16 waves once a workgroup runs >= 4 K-tiles.  COFI_GEMM_KW = "<kw>:<max blocks>" overrides for A/B
-// runs (kw 0 = the rule above with another bound, "1:0" disables).
+// Latency configuration of the 64x64 kernel (8 or 16 waves sharing every K-tile) for grids small enough that each workgroup is alone
+// on its CU; 16 waves once a workgroup runs >= 4 K-tiles.  It shortens a LONE launch (a single frame at a time: 303 vs 301 frames/s)
+// but its 512 / 1024-thread workgroups take more of the chip per launch, which costs throughput once frames overlap (four frames in
+// flight: 563 vs 583 frames/s) - OFF by default.  COFI_GEMM_KW = "<kw>:<max blocks>": "0:256" = the rule above for grids of <= 256
+// workgroups, "2:256" / "4:256" force 8 / 16 waves, "1:0" (default) = always the 4-wave kernel.
 int latency_kw(const Plan &p, int M, int N) {
     static const struct Cfg { int kw; long max_blocks; } cfg = [] {
-        Cfg c{0, 256};
+        Cfg c{1, 0};
         if (const char *e = getenv("COFI_GEMM_KW")) sscanf(e, "%d:%ld", &c.kw, &c.max_blocks);
         return c;
     }();
