@@ -49,6 +49,12 @@ static inline int attn_forced_wg_per_cu() {
     return n;
 }
 
+// COFI_ATTN_KS_CAP (A/B runs): upper bound on the key ranges per pair (default COFI_ATTN_MAX_KS).  Read once.
+static inline int attn_ks_cap() {
+    static const int n = [] { const char *e = getenv("COFI_ATTN_KS_CAP"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= COFI_ATTN_MAX_KS) ? v : COFI_ATTN_MAX_KS; }();
+    return n;
+}
+
 static inline AttnLayout attn_layout(int L, int S, int H, int frames) {
     AttnLayout a;
     a.P = cofi_cdiv(S, 32);
@@ -62,7 +68,7 @@ static inline AttnLayout attn_layout(int L, int S, int H, int frames) {
     const int ncu = attn_num_cus() * (a.light ? 2 : 1);
     int best = 1;
     double best_cost = 1e30;
-    for (int ks = 1; ks <= COFI_ATTN_MAX_KS && ks <= a.P; ++ks) {
+    for (int ks = 1; ks <= attn_ks_cap() && ks <= a.P; ++ks) {
         const double rounds = (double)cofi_cdiv(sp * ks, ncu);
         const double cost = rounds * (cofi_cdiv(cofi_cdiv(a.P, ks), COFI_ATTN_KPH) + 1.5);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = ks; }
