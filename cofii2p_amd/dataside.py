@@ -196,8 +196,9 @@ class FramePreparer:
         self._rows = self._vox = None
         self.last = {}
 
-    def voxel_downsample(self, data: torch.Tensor, P_Tr: torch.Tensor):
-        """(7, N) raw scan + 4x4 calibration transform (device) -> ((cap, 8) voxel rows, count).  Syncs on the count."""
+    def voxel_downsample(self, data: torch.Tensor, P_Tr: torch.Tensor, wait: bool = True):
+        """(7, N) raw scan + 4x4 calibration transform (device) -> ((cap, 8) voxel rows, count).  wait=True syncs on the count;
+        wait=False returns (rows, pinned host counters, event) - read the counters after event.synchronize()."""
         lib = _lib.load()
         if data.dim() != 2 or data.shape[0] != 7 or data.dtype != torch.float32 or not data.is_contiguous():
             raise _lib.CofiError("dataside: the raw scan must be a contiguous (7, N) float32 tensor")
@@ -211,6 +212,13 @@ class FramePreparer:
         nbytes = lib.cofi_voxel_downsample_workspace(N)
         ws = self._ws.get(nbytes, self.device)
         _lib.check(lib.cofi_voxel_downsample(_p(rows), N, VOXEL_SIZE, _p(vox), N, _p(cnt), _p(ws), ws.numel(), _stream()), "cofi_voxel_downsample")
+        if not wait:
+            if getattr(self, "_cnt_host", None) is None:
+                self._cnt_host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            self._cnt_host.copy_(cnt, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            return vox, self._cnt_host, ev
         c = cnt.cpu()
         if int(c[1]):
             raise _lib.CofiError("dataside: the scan spans more than 8192 voxels along an axis")
@@ -239,17 +247,18 @@ class FramePreparer:
                                               self.opt.img_H, self.opt.img_W, _p(out), _stream()), "cofi_resize_crop_image")
         return out
 
-    def prepare(self, data, img, K: np.ndarray, P_Tr: np.ndarray, index: int, defer_labels: bool = False) -> Dict:
-        """defer_labels=True: the model inputs come back at once (ONE host sync: the voxel count); the label tensors, which need the
-        coarsest-stage points on the host, are produced by calling out["finish_labels"]() later - e.g. after the forward of this
-        frame has been submitted, when the points have long arrived - and are then added to the same dict."""
-        opt, dev = self.opt, self.device
-        s = FrameSampler(index, dataset=self.dataset)
+    def begin(self, data, img, K: np.ndarray, P_Tr: np.ndarray, index: int):
+        """First half of `prepare`: uploads (if needed) and enqueues everything that does not depend on a random draw - calibration
+        transform + voxel grid - WITHOUT waiting for the voxel count.  A loader that keeps several frames in flight calls begin() for a
+        later frame right after submitting the current frame's forward on the same stream, and complete() when it comes back to it:
+        the count has long arrived and the host never blocks on the GPU.  One outstanding begin() per preparer."""
+        dev = self.device
         data = (torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)) if isinstance(data, np.ndarray) else data).to(dev, non_blocking=True)
         img = (torch.from_numpy(np.ascontiguousarray(img)) if isinstance(img, np.ndarray) else img).to(dev, non_blocking=True)
+        h = {"img": img, "K": K, "index": index}
         if self.dataset == "kitti":
             Ptr = torch.from_numpy(np.ascontiguousarray(P_Tr, dtype=np.float32)).to(dev, non_blocking=True)
-            vox, nvox = self.voxel_downsample(data, Ptr)
+            h["vox"], h["cnt_host"], h["event"] = self.voxel_downsample(data, Ptr, wait=False)
         else:
             # nuscenes.py:189-197: (4, N) = [xyz | intensity], already in the camera frame, no voxel grid (commented out in the reference):
             # the same (N, 8) row layout through the pack kernel with the identity transform and zero normals
@@ -261,6 +270,28 @@ class FramePreparer:
             vox = torch.empty((nvox, 8), dtype=torch.float32, device=dev)
             eye = torch.eye(4, dtype=torch.float32, device=dev)
             _lib.check(_lib.load().cofi_pack_transform_scan(_p(d7), nvox, _p(eye), _p(vox), _stream()), "cofi_pack_transform_scan")
+            h["vox"], h["nvox"] = vox, nvox
+        return h
+
+    def prepare(self, data, img, K: np.ndarray, P_Tr: np.ndarray, index: int, defer_labels: bool = False) -> Dict:
+        """defer_labels=True: the model inputs come back at once (ONE host sync: the voxel count); the label tensors, which need the
+        coarsest-stage points on the host, are produced by calling out["finish_labels"]() later - e.g. after the forward of this
+        frame has been submitted, when the points have long arrived - and are then added to the same dict."""
+        return self.complete(self.begin(data, img, K, P_Tr, index), defer_labels)
+
+    def complete(self, h: Dict, defer_labels: bool = False) -> Dict:
+        """Second half of `prepare` (see begin): the draws that need the voxel count, resampling + SE(3), KNN pyramid, image, labels."""
+        opt, dev = self.opt, self.device
+        img, K, index = h["img"], h["K"], h["index"]
+        s = FrameSampler(index, dataset=self.dataset)
+        vox = h["vox"]
+        if "event" in h:
+            h["event"].synchronize()
+            if int(h["cnt_host"][1]):
+                raise _lib.CofiError("dataside: the scan spans more than 8192 voxels along an axis")
+            nvox = int(h["cnt_host"][0])
+        else:
+            nvox = h["nvox"]
         choice = s.downsample_choice(nvox, opt.num_pc)
         P = s.random_transform(opt)
         points, feats = self.resample_transform(vox, choice, P)

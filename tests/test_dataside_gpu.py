@@ -225,3 +225,27 @@ def test_prepared_nuscenes_frame_against_reference_golden(ds, index):
         assert np.array_equal(dd["points"][i].cpu().numpy(), want["points"][i])
     assert np.array_equal(dd["feats"].cpu().numpy(), want["feats"])
     assert np.array_equal(out["img"].cpu().numpy(), want["img"]) and tuple(out["img"].shape) == (3, 160, 320)
+
+
+def test_begin_complete_pipeline_equals_prepare(ds):
+    """FramePreparer.begin / complete (the voxel grid enqueued ahead, no wait on its count) == prepare, also with two frames interleaved
+    on two preparers and the labels deferred."""
+    from cofii2p_amd import synth
+
+    opt = kitti_opt()
+    P_Tr = calib_P_Tr()
+    frames = [synth.make_raw_scan(i) for i in (0, 1)]
+    want = [ds.FramePreparer(opt, DEV).prepare(d, im, K, P_Tr, 10 + i) for i, (d, im, K) in enumerate(frames)]
+    preps = [ds.FramePreparer(opt, DEV) for _ in frames]
+    hs = [p.begin(d, im, K, P_Tr, 10 + i) for i, (p, (d, im, K)) in enumerate(zip(preps, frames))]
+    got = [p.complete(h, defer_labels=True) for p, h in zip(preps, hs)]
+    for g in got:
+        assert "finish_labels" in g and "pc_kpt_idx" not in g
+        g["finish_labels"]()
+    for w, g in zip(want, got):
+        for i in range(5):
+            assert torch.equal(w["pc_data_dict"]["points"][i], g["pc_data_dict"]["points"][i])
+            assert torch.equal(w["pc_data_dict"]["neighbors"][i], g["pc_data_dict"]["neighbors"][i])
+        assert torch.equal(w["img"], g["img"]) and torch.equal(w["pc_data_dict"]["feats"], g["pc_data_dict"]["feats"])
+        for k in INT_KEYS + ("coarse_img_mask", "K", "K_4", "P"):
+            assert torch.equal(w[k], g[k]), k
