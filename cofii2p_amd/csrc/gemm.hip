@@ -58,6 +58,7 @@ struct GemmArgs {
     // frame (tiles never straddle frames: host-checked).
     NormSrc an;
     int an_rows;
+    int abl;   // PROBE (tools/planes_probe.py): bit 0 no compute, bit 1 no tile loads after the prologue, bit 2 fragment reads without MFMAs
 };
 
 // Tile coordinates of this workgroup.  The dispatcher hands workgroup L (x fastest, then y, then the K-split slice z) to XCD
@@ -872,6 +873,8 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
     rowwise_epilogue<BM, BN, false>(g, lds, TLD, m0, n0, bid.y, lds);
 }
 
+#include "gemm_planes.inc"
+
 // split-K tail, same row-wise epilogue reading the partial sums.  Two tilings:
 //   64 rows x 32 columns  (plain / column statistics): slabs of 64 rows keep the statistics table small and
 //                          even M = 1280, N = 256 still gives 160 workgroups;
@@ -888,7 +891,29 @@ __global__ __launch_bounds__(256) void splitk_epilogue_ln_kernel(GemmArgs g) {
 
 struct Plan {
     int bm, bn, ksplit, kchunk;
+    int pcfg;   // >= 0: gemm_planes_kernel configuration (kPlanesCfg) - both operands are bf16 planes; -1: the register-staged kernels
 };
+
+// Configurations of gemm_planes_kernel: tile, K-tile depth, wave grid, LDS stages, workgroups per CU the register budget allows.
+struct PlanesCfg { int bm, bn, bk, wm, wn, nst, minw; };
+#define COFI_PLANES_CFGS(X)          \
+    X(0, 128, 128, 64, 2, 2, 2, 1)   \
+    X(1, 128, 128, 32, 2, 2, 2, 2)   \
+    X(2, 128, 128, 32, 2, 2, 4, 1)   \
+    X(3, 256, 128, 32, 4, 2, 3, 2)   \
+    X(4, 64, 128, 64, 2, 2, 2, 1)    \
+    X(5, 64, 128, 32, 2, 2, 3, 2)    \
+    X(6, 64, 64, 64, 2, 2, 2, 2)     \
+    X(7, 64, 64, 32, 2, 2, 3, 3)     \
+    X(8, 128, 32, 64, 4, 1, 2, 2)    \
+    X(9, 128, 64, 64, 2, 2, 2, 1)    \
+    X(10, 256, 256, 32, 4, 2, 2, 2)
+static const PlanesCfg kPlanesCfg[] = {
+#define X(id, bm, bn, bk, wm, wn, nst, minw) {bm, bn, bk, wm, wn, nst, minw},
+    COFI_PLANES_CFGS(X)
+#undef X
+};
+constexpr int kNumPlanesCfg = sizeof(kPlanesCfg) / sizeof(kPlanesCfg[0]);
 
 // Tuned plans for the shapes of the KITTI / nuScenes-shaped forward (tools/tune_gemm.py on MI355X, bf16x3 kernel):
 // {M, N, K, bm, bn, ksplit}.  Anything not listed falls through to the heuristic below.
@@ -900,6 +925,7 @@ int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;
 
 Plan finish_plan(int K, int bm, int bn, int ks) {
     Plan p;
+    p.pcfg = -1;
     p.bm = bm; p.bn = bn;
     int ktiles = cofi_cdiv(K, BK);
     if (ks < 1) ks = 1;
@@ -914,6 +940,7 @@ Plan finish_plan(int K, int bm, int bn, int ks) {
 // (256 CUs) is covered about twice, keeping >= 2 k-tiles (64 values) per split.
 Plan make_plan(int M, int N, int K, bool fused_ln) {
     Plan p;
+    p.pcfg = -1;
     if (g_force_bm) {
         p = finish_plan(K, g_force_bm, g_force_bn, g_force_ks);
         if (fused_ln && p.ksplit == 1 && p.bn < N) { p.bm = 64; p.bn = 128; }
@@ -967,6 +994,50 @@ Plan make_plan(int M, int N, int K, bool fused_ln) {
     return p;
 }
 
+// ---- plans of gemm_planes_kernel (both operands pre-split): {M, N, K, configuration, split-K}, tuned on MI355X by
+// tools/tune_gemm.py --planes; anything not listed falls through to the heuristic.
+struct TunedPlanes { int M, N, K, cfg, ks; };
+#include "gemm_planes_plans.inc"
+
+// tuning hook (tools/tune_gemm.py only): cfg >= 0 forces that configuration and split, -2 sends pre-split operands to the
+// register-staged kernel instead (the A/B partner of the bit-identity test), -1 restores table + heuristic
+int g_force_pcfg = -1, g_force_pks = 0, g_force_abl = 0;
+
+Plan finish_planes_plan(int K, int cfg, int ks) {
+    Plan p;
+    p.pcfg = cfg;
+    p.bm = kPlanesCfg[cfg].bm;
+    p.bn = kPlanesCfg[cfg].bn;
+    const int ktiles = cofi_cdiv(K, 128);   // K chunks in multiples of 128, as finish_plan: equal splits give equal bits in both kernels
+    if (ks < 1) ks = 1;
+    p.kchunk = cofi_cdiv(ktiles, ks) * 128;
+    p.ksplit = cofi_cdiv(K, p.kchunk);
+    return p;
+}
+
+Plan make_planes_plan(int M, int N, int K) {
+    if (g_force_pcfg >= 0 && g_force_pcfg < kNumPlanesCfg) return finish_planes_plan(K, g_force_pcfg, g_force_pks);
+    for (const TunedPlanes &t : kTunedPlanes)
+        if (t.M == M && t.N == N && t.K == K && t.cfg >= 0 && t.cfg < kNumPlanesCfg) return finish_planes_plan(K, t.cfg, t.ks);
+    auto nblk = [&](int c) { return (long)cofi_cdiv(M, kPlanesCfg[c].bm) * cofi_cdiv(N, kPlanesCfg[c].bn); };
+    const int max_ks = K >= 1024 ? K / 512 : 1;   // >= 512 K values (4 x 128) per split
+    int cfg;
+    if (N <= 32) cfg = 8;
+    else if (N <= 64) cfg = nblk(9) >= 200 ? 9 : 6;
+    else if (nblk(3) >= 1024) cfg = 3;            // 256 x 128, 8 waves: once there are >= 4 rounds of them
+    else if (nblk(0) * max_ks >= 200) cfg = 0;
+    else if (nblk(4) * max_ks >= 200) cfg = 4;
+    else cfg = 6;
+    const long nb = nblk(cfg);
+    int ks = 1;
+    if (nb < 200) {
+        ks = (int)((256 + nb - 1) / nb);
+        if (ks > max_ks) ks = max_ks;
+        if (ks > 32) ks = 32;
+    }
+    return finish_planes_plan(K, cfg, ks);
+}
+
 // Latency configuration of the 64x64 kernel (8 or 16 waves sharing every K-tile) for grids small enough that each workgroup is alone
 // on its CU; 16 waves once a workgroup runs >= 4 K-tiles.  It shortens a LONE launch (a single frame at a time: 303 vs 301 frames/s)
 // but its 512 / 1024-thread workgroups take more of the chip per launch, which costs throughput once frames overlap (four frames in
@@ -1012,7 +1083,18 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
     dim3 grid(cofi_cdiv(g.N, p.bn), cofi_cdiv(g.M, p.bm), p.ksplit);
     g.xcd = xcd_order(g, grid);
     g.xcd_rcp_gy = grid.y > 1 ? (unsigned)((0x100000000ULL + grid.y - 1) / grid.y) : 0u;   // 0: gy = 1
-    if (g.bf16x3) {
+    if (p.pcfg >= 0) {
+        g.abl = g_force_abl;
+        switch (p.pcfg) {
+#define X(id, bm_, bn_, bk_, wm_, wn_, nst_, minw_)                                                                                      \
+    case id:                                                                                                                             \
+        hipLaunchKernelGGL((gemm_planes_kernel<bm_, bn_, bk_, wm_, wn_, nst_, minw_>), grid, dim3(64 * wm_ * wn_), 0, s, g);              \
+        break;
+            COFI_PLANES_CFGS(X)
+#undef X
+        default: return COFI_EINVAL;
+        }
+    } else if (g.bf16x3) {
         const int kw = (p.bm == 64 && p.bn == 64) ? latency_kw(p, g.M, g.N) : 1;
 #define COFI_LAUNCH_BF16X3_W(BM_, BN_, TM_, TN_, BK_, KW_, WPE_)                                                                                  \
     do {                                                                                                                                        \
@@ -1100,7 +1182,7 @@ int gemm_entry(const float *A, int lda, const cofi_norm_desc_t *a_norm, const fl
     if (asplit && (!wsplit || a_norm || (lda & 7) || (K & 7))) return COFI_EINVAL;
     const int sshift = colpart ? stat_shift_of(stat_width, N) : 0;
     if (sshift < 0) return COFI_EINVAL;
-    Plan p = make_plan(M, N, K, false);
+    Plan p = (asplit && g_force_pcfg != -2) ? make_planes_plan(M, N, K) : make_plan(M, N, K, false);
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
     GemmArgs g{};
     g.A = A; g.W = W; g.C = C; g.bias = bias; g.rowdiv = rowdiv; g.ws = (float *)ws; g.colpart = colpart;
@@ -1143,8 +1225,9 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
 
 extern "C" size_t cofi_gemm_f32_workspace(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    Plan p = make_plan(M, N, K, false);
-    return p.ksplit > 1 ? (size_t)p.ksplit * M * N * sizeof(float) : 0;
+    const Plan p = make_plan(M, N, K, false), q = make_planes_plan(M, N, K);   // whichever kernel the operands select
+    const int ks = p.ksplit > q.ksplit ? p.ksplit : q.ksplit;
+    return ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
 }
 
 extern "C" int cofi_gemm_f32_stat_slabs(int M, int N, int K) {
@@ -1211,6 +1294,14 @@ extern "C" int cofi_split_bf16_planes(const float *W, int ldw, int N, int K, voi
 
 // Plan override for tools/tune_gemm.py (not declared in the public header, not used by the product path): force (bm, bn, ksplit)
 // for subsequent plans; (0,0,0) restores the table + heuristic.
+extern "C" int cofi_tune_force_planes(int cfg, int ksplit) {
+    if (cfg < -2 || cfg >= kNumPlanesCfg || ksplit < 0) return COFI_EINVAL;
+    g_force_pcfg = cfg; g_force_pks = ksplit;
+    return 0;
+}
+
+extern "C" int cofi_tune_force_abl(int abl) { g_force_abl = abl; return 0; }
+
 extern "C" int cofi_tune_force_plan(int bm, int bn, int ksplit) {
     const bool ok = (bm == 0 && bn == 0) || ((bm == 64 || bm == 128) && (bn == 64 || bn == 128) && !(bm == 128 && bn == 64));
     if (!ok || ksplit < 0) return COFI_EINVAL;

@@ -349,6 +349,27 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_shared_kernel(KpArgs a) 
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[ch][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
     kp_steps<VEC, NCH>(reinterpret_cast<const char *>(a.feats), 4u * a.ldf, coffb, rec, nin, kx, ky, kz, inv_sigma, acc);
+    if (a.planes_lo) {   // bf16 hi / lo planes, as kpconv_aggregate_kernel writes them
+        uint16_t *hrow = reinterpret_cast<uint16_t *>(a.agg) + (size_t)m * a.ld_agg;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = c0 + ch * 16 * VEC + VEC * j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 4 * g + r;
+                if (k < 15) {
+                    uint16_t *dst = hrow + (size_t)k * a.C + c;
+                    uint2 hi, lo;
+                    cofi_split2(acc[ch][0][r], acc[ch][1][r], hi.x, lo.x);
+                    cofi_split2(acc[ch][2][r], acc[ch][3][r], hi.y, lo.y);
+                    *reinterpret_cast<uint2 *>(dst) = hi;
+                    *reinterpret_cast<uint2 *>(dst + a.planes_lo) = lo;
+                }
+            }
+        }
+        if (p == 0 && lane == 0) a.cnt[m] = (float)(npos > 1 ? npos : 1);
+        return;
+    }
     float *orow = a.agg + (size_t)m * a.ld_agg;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
@@ -734,7 +755,7 @@ extern "C" int cofi_kpconv_aggregate(const float *feats, int ldf, int N, int C, 
     hipStream_t s = cofi_s(stream);
     const int mb = cofi_cdiv(M, 4);
     static const bool no_shared = [] { const char *e = getenv("COFI_KP_NO_SHARED_STAGING"); return e && atoi(e) != 0; }();
-    if (!no_shared && !agg_planes && (C == 256 || C == 512) && (ldf & 3) == 0 && H <= 128 && M % (C == 256 ? 2 : 1) == 0) {
+    if (!no_shared && (C == 256 || C == 512) && (ldf & 3) == 0 && H <= 128 && M % (C == 256 ? 2 : 1) == 0) {
         if (C == 256)
             hipLaunchKernelGGL(kpconv_aggregate_shared_kernel<2>, dim3(M / 2), dim3(256), 0, s, a);
         else

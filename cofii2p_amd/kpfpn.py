@@ -13,10 +13,10 @@ LRELU = 0.1
 # fabric, but measured SLOWER on MI355X (490 vs 503 frames/s): 320-1280 eight-wave workgroups that alternate between a gather phase
 # and a GEMM phase quantise badly on 256 CUs, while the two-kernel form spreads 20 480 one-wave queries evenly.
 FUSED_KPCONV = os.environ.get("COFI_KPCONV_FUSED", "0") == "1"
-# Opt-in (COFI_KPCONV_AGG_PLANES=1): the aggregate is written as bf16 hi / lo planes and its GEMM reads them without conversion
-# (COFI_GEMM_A_SPLIT).  Bit-identical results; measured neutral on MI355X (batch 1: 512 vs 513 f/s, batch 16: 647 vs 652): the conversion
-# instructions were not what these GEMMs wait for.
-AGG_PLANES = os.environ.get("COFI_KPCONV_AGG_PLANES", "0") == "1"
+# The KPConv aggregate (M, 15 C) has ONE reader, the part-2 GEMM: it is written as bf16 hi / lo planes (same rounding as the GEMM's own
+# split: identical products) and that GEMM runs on gemm_planes_kernel - both operands travel global -> LDS by LDS-DMA, no conversion
+# work, no register staging (csrc/gemm_planes.inc).  COFI_KPCONV_AGG_PLANES=0 restores the fp32 aggregate + on-the-fly split.
+AGG_PLANES = os.environ.get("COFI_KPCONV_AGG_PLANES", "1") == "1"
 
 
 def norm_kind(sd) -> str:
