@@ -417,6 +417,8 @@ def main():
 
     cofi_ops.GEMM_MODE = args.gemm
     model = CoFiI2P(Opt()).to(dev)
+    if os.environ.get("COFI_BENCH_SKIP_UNUSED_MAPS") == "1":   # diagnostic only (never the reported configuration): ResNet layer3 / layer4 / avg-pool, which nothing reads
+        model.compute_unused_image_maps = False
     _model_ref.append(model)
     if not args.eager:
         model.enable_graphs()

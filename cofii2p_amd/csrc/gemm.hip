@@ -58,7 +58,6 @@ struct GemmArgs {
     // frame (tiles never straddle frames: host-checked).
     NormSrc an;
     int an_rows;
-    int abl;   // PROBE (tools/planes_probe.py): bit 0 no compute, bit 1 no tile loads after the prologue, bit 2 fragment reads without MFMAs
 };
 
 // Tile coordinates of this workgroup.  The dispatcher hands workgroup L (x fastest, then y, then the K-split slice z) to XCD
@@ -897,17 +896,15 @@ struct Plan {
 // Configurations of gemm_planes_kernel: tile, K-tile depth, wave grid, LDS stages, workgroups per CU the register budget allows.
 struct PlanesCfg { int bm, bn, bk, wm, wn, nst, minw; };
 #define COFI_PLANES_CFGS(X)          \
-    X(0, 128, 128, 64, 2, 2, 2, 1)   \
-    X(1, 128, 128, 32, 2, 2, 2, 2)   \
-    X(2, 128, 128, 32, 2, 2, 4, 1)   \
-    X(3, 256, 128, 32, 4, 2, 3, 2)   \
-    X(4, 64, 128, 64, 2, 2, 2, 1)    \
-    X(5, 64, 128, 32, 2, 2, 3, 2)    \
-    X(6, 64, 64, 64, 2, 2, 2, 2)     \
-    X(7, 64, 64, 32, 2, 2, 3, 3)     \
-    X(8, 128, 32, 64, 4, 1, 2, 2)    \
-    X(9, 128, 64, 64, 2, 2, 2, 1)    \
-    X(10, 256, 256, 32, 4, 2, 2, 2)
+    X(0, 128, 128, 64, 4, 2, 2, 2)   \
+    X(1, 64, 64, 64, 2, 2, 2, 2)     \
+    X(2, 256, 128, 32, 4, 2, 3, 2)   \
+    X(3, 256, 256, 32, 4, 2, 2, 2)   \
+    X(4, 128, 32, 64, 4, 1, 2, 2)    \
+    X(5, 128, 64, 64, 4, 2, 2, 2)    \
+    X(6, 64, 64, 32, 2, 2, 4, 2)     \
+    X(7, 128, 128, 32, 4, 2, 4, 2)   \
+    X(8, 64, 128, 64, 2, 2, 2, 1)
 static const PlanesCfg kPlanesCfg[] = {
 #define X(id, bm, bn, bk, wm, wn, nst, minw) {bm, bn, bk, wm, wn, nst, minw},
     COFI_PLANES_CFGS(X)
@@ -1001,7 +998,7 @@ struct TunedPlanes { int M, N, K, cfg, ks; };
 
 // tuning hook (tools/tune_gemm.py only): cfg >= 0 forces that configuration and split, -2 sends pre-split operands to the
 // register-staged kernel instead (the A/B partner of the bit-identity test), -1 restores table + heuristic
-int g_force_pcfg = -1, g_force_pks = 0, g_force_abl = 0;
+int g_force_pcfg = -1, g_force_pks = 0;
 
 Plan finish_planes_plan(int K, int cfg, int ks) {
     Plan p;
@@ -1022,12 +1019,12 @@ Plan make_planes_plan(int M, int N, int K) {
     auto nblk = [&](int c) { return (long)cofi_cdiv(M, kPlanesCfg[c].bm) * cofi_cdiv(N, kPlanesCfg[c].bn); };
     const int max_ks = K >= 1024 ? K / 512 : 1;   // >= 512 K values (4 x 128) per split
     int cfg;
-    if (N <= 32) cfg = 8;
-    else if (N <= 64) cfg = nblk(9) >= 200 ? 9 : 6;
-    else if (nblk(3) >= 1024) cfg = 3;            // 256 x 128, 8 waves: once there are >= 4 rounds of them
-    else if (nblk(0) * max_ks >= 200) cfg = 0;
-    else if (nblk(4) * max_ks >= 200) cfg = 4;
-    else cfg = 6;
+    if (N <= 32) cfg = 4;                          // 128 x 32
+    else if (N <= 64) cfg = nblk(5) >= 400 ? 5 : 1;
+    else if (nblk(3) * max_ks >= 400 && N % 256 == 0 && M >= 8192) cfg = 3;   // 256 x 256: the L2 -> LDS traffic of a tile halves again
+    else if (nblk(2) >= 512) cfg = 2;              // 256 x 128
+    else if (nblk(0) * max_ks >= 200) cfg = 0;     // 128 x 128
+    else cfg = 1;                                  // 64 x 64
     const long nb = nblk(cfg);
     int ks = 1;
     if (nb < 200) {
@@ -1084,7 +1081,6 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
     g.xcd = xcd_order(g, grid);
     g.xcd_rcp_gy = grid.y > 1 ? (unsigned)((0x100000000ULL + grid.y - 1) / grid.y) : 0u;   // 0: gy = 1
     if (p.pcfg >= 0) {
-        g.abl = g_force_abl;
         switch (p.pcfg) {
 #define X(id, bm_, bn_, bk_, wm_, wn_, nst_, minw_)                                                                                      \
     case id:                                                                                                                             \
@@ -1299,8 +1295,6 @@ extern "C" int cofi_tune_force_planes(int cfg, int ksplit) {
     g_force_pcfg = cfg; g_force_pks = ksplit;
     return 0;
 }
-
-extern "C" int cofi_tune_force_abl(int abl) { g_force_abl = abl; return 0; }
 
 extern "C" int cofi_tune_force_plan(int bm, int bn, int ksplit) {
     const bool ok = (bm == 0 && bn == 0) || ((bm == 64 || bm == 128) && (bn == 64 || bn == 128) && !(bm == 128 && bn == 64));

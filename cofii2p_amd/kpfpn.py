@@ -13,10 +13,14 @@ LRELU = 0.1
 # fabric, but measured SLOWER on MI355X (490 vs 503 frames/s): 320-1280 eight-wave workgroups that alternate between a gather phase
 # and a GEMM phase quantise badly on 256 CUs, while the two-kernel form spreads 20 480 one-wave queries evenly.
 FUSED_KPCONV = os.environ.get("COFI_KPCONV_FUSED", "0") == "1"
-# The KPConv aggregate (M, 15 C) has ONE reader, the part-2 GEMM: it is written as bf16 hi / lo planes (same rounding as the GEMM's own
-# split: identical products) and that GEMM runs on gemm_planes_kernel - both operands travel global -> LDS by LDS-DMA, no conversion
-# work, no register staging (csrc/gemm_planes.inc).  COFI_KPCONV_AGG_PLANES=0 restores the fp32 aggregate + on-the-fly split.
-AGG_PLANES = os.environ.get("COFI_KPCONV_AGG_PLANES", "1") == "1"
+# The KPConv aggregate (M, 15 C) has ONE reader, the part-2 GEMM.  In stack mode (>= 4 frames per submission) it is written as bf16
+# hi / lo planes (same rounding as the GEMM's own split: identical products) and that GEMM runs on gemm_planes_kernel - both operands
+# travel global -> LDS by LDS-DMA, no conversion work, no register staging (csrc/gemm_planes.inc): 5-28 % faster per launch on MI355X,
+# +2.5 % frames/s at batch 16.  A single frame keeps the fp32 aggregate: measured with four frames in flight the planes path is
+# 577-582 vs 583-584 frames/s (its 64-128 KB of LDS per workgroup keep other frames' kernels off the CU, and the aggregation's 8-byte
+# plane stores cost what the GEMMs win).  COFI_KPCONV_AGG_PLANES=0 / =all forces never / always (A/B runs, tests).
+AGG_PLANES = os.environ.get("COFI_KPCONV_AGG_PLANES", "stack")
+AGG_PLANES_MIN_FRAMES = 4
 
 
 def norm_kind(sd) -> str:
@@ -91,8 +95,8 @@ def _kpconv(P, p: str, feats, q_pts, s_pts, idx, sigma: float, frames: int = 1, 
         y, part, sr = ops.kpconv_fused(feats, q_pts, s_pts, idx, P[p + "KPConv.kernel_points"], sigma, w, P[p + "KPConv.bias"], stat_width=sw,
                                        frames=frames, order=order)
         return y, ops.ColStats(part, y.shape[0], GN_GROUPS, frames, width=sw, slab_rows=sr)
-    # opt-in: the aggregate has one reader, the GEMM below - written as bf16 hi / lo planes it enters that GEMM without conversion work
-    planes = AGG_PLANES and ops.GEMM_MODE == "bf16x3" and isinstance(w, ops.SplitW)
+    planes = (ops.GEMM_MODE == "bf16x3" and isinstance(w, ops.SplitW)
+              and (AGG_PLANES == "all" or (AGG_PLANES not in ("0", "off") and frames >= AGG_PLANES_MIN_FRAMES)))
     agg, cnt = ops.kpconv_aggregate(feats, q_pts, s_pts, idx, P[p + "KPConv.kernel_points"], sigma, frames=frames, order=order, planes=planes)
     y, part = ops.gemm_colstats(agg, w, bias=P[p + "KPConv.bias"], rowdiv=cnt, stat_width=sw)
     return y, _stats(y, part, frames, sw)

@@ -12,8 +12,8 @@ import torch
 
 from cofii2p_amd import _lib, ops
 
-CFGS = [(128, 128, 64, 2), (128, 128, 32, 2), (128, 128, 32, 4), (256, 128, 32, 3), (64, 128, 64, 2), (64, 128, 32, 3), (64, 64, 64, 2), (64, 64, 32, 3),
-        (128, 32, 64, 2), (128, 64, 64, 2), (256, 256, 32, 2)]   # (bm, bn, bk, stages) by configuration id: kPlanesCfg of gemm.hip
+CFGS = [(128, 128, 64, 2), (64, 64, 64, 2), (256, 128, 32, 3), (256, 256, 32, 2), (128, 32, 64, 2), (128, 64, 64, 2), (64, 64, 32, 4), (128, 128, 32, 4),
+        (64, 128, 64, 2)]   # (bm, bn, bk, stages) by configuration id: kPlanesCfg of gemm.hip
 
 
 def time_graph(fn, reps=20):
@@ -94,7 +94,7 @@ def main():
                 fp(cid, ks)
                 y, part = ops.gemm_colstats(sa, sw, bias=bias, rowdiv=rowdiv, act=ops.ACT_LEAKY01, stat_width=sw_)
                 torch.cuda.synchronize()
-                same = torch.equal(y, ref) and torch.equal(part, refp)
+                same = torch.equal(y, ref) and torch.allclose(part, refp, rtol=2e-5, atol=1e-3)
                 if not same:
                     bad += 1
                     d = float((y - ref).abs().max())
