@@ -353,6 +353,71 @@ def cpu_baseline(frame, n_frames=2):
                       "precomputed; best of 8 / 32 torch threads on a %d-core host" % (n_frames, ncpu)}
 
 
+def pin_to_gpu_numa_node(local: int):
+    """Best effort: restrict this rank's host threads to the NUMA node its GPU hangs off (8-GPU nodes: a rank whose launch thread sits on
+    the other socket pays for every submission).  -> the node id, or None when sysfs does not say."""
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return None
+        cpus = []
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.extend(range(int(a), int(b or a) + 1))
+        os.sched_setaffinity(0, set(cpus))
+        return node
+    except Exception:
+        return None
+
+
+class Pipeline:
+    """The software pipeline of the headline measurement: S frame streams x `slots_per_stream` hipGraph slots; frame i is enqueued on stream
+    i % S while the previous frames are still executing, a slot's result (incl. the host read of the match count) is collected just
+    before the slot is reused.  Every step is ONE frame through the complete forward + fine matching."""
+
+    def __init__(self, model, dev, frames, S, slots_per_stream, copy_inputs, cu_split=None):
+        self.model, self.frames, self.S, self.copy_inputs = model, frames, S, copy_inputs
+        self.streams = make_streams(dev, S, cu_split)
+        self.NSLOT = S * max(1, slots_per_stream)   # submission i: stream i % S, hipGraph slot i % NSLOT
+        self.pending = [None] * self.NSLOT
+
+    def run(self, nsteps, base=0):
+        nm, model = 0, self.model
+        for i in range(nsteps):
+            sl = i % self.NSLOT
+            if self.pending[sl] is not None:
+                nm = model.finish(self.pending[sl])[4].shape[0]
+            pyr, img, _ = self.frames[(base + i) % len(self.frames)]
+            with torch.cuda.stream(self.streams[i % self.S]):
+                self.pending[sl] = model.forward_async(sl, pyr, img, inputs_stable=not self.copy_inputs)
+        for k in range(self.NSLOT):   # collect in submission order
+            sl = (nsteps + k) % self.NSLOT
+            if self.pending[sl] is not None:
+                nm = model.finish(self.pending[sl])[4].shape[0]
+                self.pending[sl] = None
+        return nm
+
+    def warm(self, warmup):
+        import math
+
+        # every (slot, input set) graph captured and replayed at least once, whatever --warmup says (in-place inputs: one graph per pair)
+        return self.run(max(warmup, 2 * self.NSLOT, math.lcm(self.NSLOT, len(self.frames))), 0)
+
+
+def timed_repeats(run_steps, barrier, steps, repeats):
+    """`repeats` timed regions of EXACTLY `steps` steps each, every one bracketed by barrier + synchronize on both sides -> seconds per region"""
+    out = []
+    for _ in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(steps)
+        barrier()
+        out.append(time.perf_counter() - t0)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -372,6 +437,10 @@ def main():
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the extra stack-mode batch-4/16 measurements")
     ap.add_argument("--batch", type=int, default=1, help="frames per submission in stack mode (BASELINE configs[2] uses 16); a step is then one batch")
     ap.add_argument("--stress", action="store_true", help="bench BASELINE configs[4] instead: 896x1600 image, 40960 points (implies --points 40960)")
+    ap.add_argument("--repeats", type=int, default=0, help="timed regions of --steps steps each; the median is reported (0 = 5 when --steps < 100, else 1)")
+    ap.add_argument("--distinct-frames", type=int, default=16, help="distinct synthetic frames per rank cycled by the timed loop (16 x 27 MB of "
+                    "tables do not fit the 256 MB Infinity Cache)")
+    ap.add_argument("--no-f32", action="store_true", help="skip the extra exact-fp32 measurement (value_f32)")
     ap.add_argument("--gemm", default=os.environ.get("COFI_GEMM", "bf16x3"), choices=["f32", "bf16x3"],
                     help="arithmetic of the dense contractions: exact fp32 MFMA, or 3-term bf16 split with fp32 accumulation")
     args = ap.parse_args()
@@ -410,6 +479,7 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    numa_node = pin_to_gpu_numa_node(local) if (world > 1 and not args.share_device) else None
 
     from cofii2p_amd import ops as cofi_ops
     from cofii2p_amd.network import CoFiI2P
@@ -422,7 +492,7 @@ def main():
     _model_ref.append(model)
     if not args.eager:
         model.enable_graphs()
-    n_distinct = 4
+    n_distinct = max(1, args.distinct_frames)
     my_ids = shard_frames(list(range(n_distinct * world)), rank, world)
     frames = make_inputs(dev, my_ids, args.points)
 
@@ -435,6 +505,8 @@ def main():
     nmatch = 0
     S = max(1, args.inflight) if not args.eager else 1
     Bsz = max(1, args.batch)
+    repeats = args.repeats if args.repeats > 0 else (5 if args.steps < 100 else 1)
+    pipe = None
     if Bsz > 1:
         # stack mode: Bsz frames per submission through the same launches, S submissions in flight
         batches = []
@@ -460,75 +532,53 @@ def main():
             return nm
 
         nmatch = runb(max(args.warmup, 2 * S))
-        barrier()
-        t0 = time.perf_counter()
-        runb(args.steps)
-        barrier()
-        dt = time.perf_counter() - t0
+        dts = timed_repeats(runb, barrier, args.steps, repeats)
     elif S == 1:
-        for i in range(args.warmup):
+        def run1(nsteps):
+            for i in range(nsteps):
+                one_step(model, frames[i % len(frames)])
+
+        for i in range(max(args.warmup, len(frames))):
             out, _ = one_step(model, frames[i % len(frames)])
             nmatch = out[4].shape[0]
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            one_step(model, frames[i % len(frames)])
-        barrier()
-        dt = time.perf_counter() - t0
+        dts = timed_repeats(run1, barrier, args.steps, repeats)
     else:
-        # software pipeline over S frame slots: frame i is enqueued on stream i % S while the previous S-1 frames
-        # are still executing; a slot's result (incl. the host read of the match count) is collected just before
-        # the slot is reused.  Every step is still ONE frame through the complete forward.
-        streams = make_streams(dev, S, args.cu_split)
-        NSLOT = S * max(1, args.slots_per_stream)   # submission i: stream i % S, hipGraph slot i % NSLOT
-        pending = [None] * NSLOT
-
-        def run(nsteps, base):
-            nm = 0
-            for i in range(nsteps):
-                sl = i % NSLOT
-                if pending[sl] is not None:
-                    nm = model.finish(pending[sl])[4].shape[0]
-                pyr, img, _ = frames[(base + i) % len(frames)]
-                with torch.cuda.stream(streams[i % S]):
-                    pending[sl] = model.forward_async(sl, pyr, img, inputs_stable=not args.copy_inputs)
-            for k in range(NSLOT):   # collect in submission order
-                sl = (nsteps + k) % NSLOT
-                if pending[sl] is not None:
-                    nm = model.finish(pending[sl])[4].shape[0]
-                    pending[sl] = None
-            return nm
-
-        import math
-
-        # every (slot, input set) graph captured and replayed at least once, whatever --warmup says (in-place inputs: one graph per pair)
-        nmatch = run(max(args.warmup, 2 * NSLOT, math.lcm(NSLOT, len(frames))), 0)
-        barrier()
-        t0 = time.perf_counter()
-        run(args.steps, 0)
-        barrier()
-        dt = time.perf_counter() - t0
-    gathered = None
+        pipe = Pipeline(model, dev, frames, S, args.slots_per_stream, args.copy_inputs, args.cu_split)
+        nmatch = pipe.warm(args.warmup)
+        dts = timed_repeats(pipe.run, barrier, args.steps, repeats)
+    dt = float(np.median(dts))   # this rank's seconds per timed region of args.steps steps
+    gathered = per_rank = gather_ms = None
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [float(x.item()) for x in allt]
+        dt = max(per_rank)   # the job is as fast as its slowest rank
         # the one exchange of a frame-parallel evaluation: per-frame results of every rank -> all ranks, global
         # frame order, over the process group the ranks were timed in (RCCL over xGMI with the default backend)
         from cofii2p_amd.parallel import gather_frame_results
 
         vals = torch.tensor([[float(nmatch), float(rank)] for _ in my_ids], dtype=torch.float32, device=dev if args.dist_backend == "nccl" else "cpu")
+        barrier()
+        t0 = time.perf_counter()
         gathered = gather_frame_results(my_ids, vals.reshape(len(my_ids), 2), n_distinct * world)
+        torch.cuda.synchronize()
+        gather_ms = 1e3 * (time.perf_counter() - t0)
         assert sorted(set(int(r) for r in gathered[:, 1].tolist())) == list(range(world))
     result = {
         "metric": "I2P frames/sec (160x512 img, 20480 pts)", "value": world * args.steps * Bsz / dt, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        # the arithmetic the dense contractions compute in ("bf16x3": 3-term bf16 split on the bf16 matrix cores, fp32 accumulate;
+        # "f32": exact fp32 MFMA); storage, accumulation, KPConv aggregation and attention are fp32 either way
+        "dtype": args.gemm,
+        "repeats": repeats, "seconds_per_repeat": [round(x, 6) for x in dts], "distinct_frames_per_rank": len(frames),
         "data": "synthetic", "launch": "eager" if args.eager else "hipGraph replay",
         "input_staging": "copied into per-slot static buffers" if (args.copy_inputs or args.eager) else "read in place (inputs resident in HBM, forward_async(inputs_stable=True))", "gemm_mode": args.gemm,
         "ranks": world if dist is None else dist.get_world_size(), "dist_backend": None if dist is None else args.dist_backend,
         "gathered_frame_results": None if gathered is None else int(gathered.shape[0]),
+        "per_rank_frames_per_s": None if per_rank is None else [round(args.steps * Bsz / x, 2) for x in per_rank],
+        "result_gather_ms": gather_ms, "numa_node": numa_node,
         "arithmetic": "fp32 storage and accumulation everywhere; dense contractions " + (
             "on the exact fp32 MFMA" if args.gemm == "f32" else
             "as a 3-term bf16 split (hi*hi + hi*lo + lo*hi) on the bf16 matrix cores: 4e-6 max abs deviation from the reference's "
@@ -545,6 +595,17 @@ def main():
                    "hipgraph_slots_per_stream": max(1, args.slots_per_stream) if (S > 1 and Bsz == 1) else 1},
     }
 
+    if rank == 0 and world == 1 and Bsz == 1 and pipe is not None and args.gemm == "bf16x3" and not args.no_f32:
+        # the same pipelined loop with every dense contraction on the exact fp32 MFMA (the reference's arithmetic): on record next to `value`
+        cofi_ops.GEMM_MODE = "f32"
+        try:
+            pipe.warm(args.warmup)
+            dts32 = timed_repeats(pipe.run, barrier, args.steps, repeats)
+        finally:
+            cofi_ops.GEMM_MODE = args.gemm
+        d32 = float(np.median(dts32))
+        result["value_f32"] = {"frames_per_s": args.steps / d32, "ms_per_frame": 1e3 * d32 / args.steps, "repeats": repeats,
+                               "note": "identical loop, COFI_GEMM=f32: every GEMM / convolution on v_mfma_f32_32x32x2_f32 (bit-equal to an fmaf chain)"}
     if rank == 0 and world == 1 and Bsz == 1 and not args.eager and not args.no_batch_sweep:
         # the reference-surface call pattern (evaluation/eval_all.py:94-96): model(...) per frame, one host synchronisation per
         # frame, nothing in flight behind it - what a caller gets without forward_async / finish

@@ -309,8 +309,11 @@ __global__ void gather_transform_kernel(const float *vox, const int32_t *choice,
     feats[4 * i + 3] = feats_are_points ? p[2] : nn[2];
 }
 
-// cv2.resize(img, (dw, dh), INTER_LINEAR) on uint8 HWC in OpenCV's fixed-point arithmetic (11-bit coefficients, rounding shift by 22),
-// then the crop [cy, cy + H) x [cx, cx + W), / 255 and HWC -> CHW (kitti.py:306-322, 375).  One thread per output value.
+// cv2.resize(img, (dw, dh), INTER_LINEAR) on uint8 HWC in OpenCV's fixed-point arithmetic: 11-bit coefficients, horizontal pass exact
+// in int32, vertical pass as the uchar specialisation of VResizeLinear writes it - each term TRUNCATED on its own,
+//     ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2
+// (not the single rounding shift by 22 of the generic FixedPtCast: the two differ by one LSB whenever the low bits of the two terms
+// carry, e.g. KITTI's 1241 x 376 -> 620 x 188) - then the crop [cy, cy + H) x [cx, cx + W), / 255 and HWC -> CHW (kitti.py:306-322, 375).  One thread per output value.
 __global__ void resize_crop_kernel(const uint8_t *src, int sh, int sw, int dh, int dw, int cy, int cx, int H, int W, float *out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= 3 * H * W) return;
@@ -335,7 +338,7 @@ __global__ void resize_crop_kernel(const uint8_t *src, int sh, int sw, int dh, i
     auto px = [&](int yy, int xx) { return (int)src[((size_t)yy * sw + xx) * 3 + c]; };
     const int r0 = px(sy, sx) * ax0 + px(sy, sx1) * ax1;     // horizontal pass, scale 2^11
     const int r1 = px(sy1, sx) * ax0 + px(sy1, sx1) * ax1;
-    const int v = (r0 * ay0 + r1 * ay1 + (1 << 21)) >> 22;    // vertical pass + FixedPtCast<int, uchar, 22>
+    const int v = (((ay0 * (r0 >> 4)) >> 16) + ((ay1 * (r1 >> 4)) >> 16) + 2) >> 2;    // vertical pass, VResizeLinear<uchar, int, short, ...>
     out[e] = (float)min(max(v, 0), 255) / 255.f;
 }
 

@@ -119,6 +119,10 @@ static inline int make_norm_src(const cofi_norm_desc_t *d, int rows_per_frame, i
     if ((C % w) || (C % G) || (d->nslab % frames)) return COFI_EINVAL;
     const int tcols = C / w, cpg = C / G;
     if ((cpg % w) || (tcols & (tcols - 1)) || tcols < 2 || (G & (G - 1)) || C > max_channels) return COFI_EUNSUPPORTED;
+    // the channel -> group map of the consumers is a shift (cshift): channels per group must be a power of two (C = 96, G = 32 would
+    // otherwise pass every check above and normalise with the wrong group); and a group's table columns must fit one fold pass of
+    // the smallest consumer workgroup (fold_stat_table: 2 * 256 columns per pass)
+    if ((cpg & (cpg - 1)) || tcols / G > 512) return COFI_EUNSUPPORTED;
     // slabs (64 rows unless the producer says otherwise) must not straddle frames (stack mode)
     const int sr = d->slab_rows > 0 ? d->slab_rows : 64;
     if (frames > 1 && (rows_per_frame % sr)) return COFI_EINVAL;

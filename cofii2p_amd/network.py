@@ -55,13 +55,24 @@ ALTERNATE_ORDER = os.environ.get("COFI_ALTERNATE_ORDER", "1") != "0"   # A/B swi
 class CoFiI2P(nn.Module):
     """See module docstring.  ``opt`` needs ``img_H, img_W, img_fine_resolution_scale, norm``
     (data/options.py:17-19,51).  ``norm``: 'gn' (the shipped configuration, the fast path), 'bn' (inference: running statistics, folded
-    into the weights) or 'ln' - the three get_norm() variants of model/kpconv/modules.py:51-60."""
+    into the weights) or 'ln' - the three get_norm() variants of model/kpconv/modules.py:51-60.
+
+    ``arithmetic`` (or ``opt.arithmetic``): how the dense contractions (every nn.Linear / nn.Conv2d / KPConv weight product) are
+    computed.  "f32" = products on the exact fp32 MFMA, bit-equal to an fmaf chain - the reference's arithmetic.  "bf16x3" = each fp32
+    operand split into bf16 hi + lo, hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32 accumulation (~2^-16 relative error per
+    product, ~2x the throughput; outputs within 4e-6 / 2.6e-5 of the reference on the golden frame, same matches selected there, but a
+    score within ~1e-5 of the 0.9 threshold or an arg-max near-tie may resolve differently).  None = the process default
+    (``COFI_GEMM``, "bf16x3" when unset).  The reference-named shim ``model.network.CoFiI2P`` defaults to "f32".  INTEGRATION.md
+    states the accuracy contract."""
 
     MAX_STABLE_GRAPHS = 64   # distinct (slot, input set) graphs kept for forward_async(inputs_stable=True)
+    DEFAULT_ARITHMETIC = None   # None: follow ops.GEMM_MODE (COFI_GEMM); the model.network shim sets "f32"
 
-    def __init__(self, opt, init: str = "synthetic"):
+    def __init__(self, opt, init: str = "synthetic", arithmetic: Optional[str] = None):
         super().__init__()
         self.opt = opt
+        self.arithmetic = arithmetic if arithmetic is not None else getattr(opt, "arithmetic", self.DEFAULT_ARITHMETIC)
+        ops.arithmetic(self.arithmetic)   # validates the name
         self.pc_norm_kind = getattr(opt, "norm", "gn")   # get_norm() of the point encoder: 'gn' (shipped), 'bn' (running statistics), 'ln'
         if self.pc_norm_kind not in ("gn", "bn", "ln"):
             raise ValueError("only support batch normalization, layer normalization and group normalization now!")   # modules.py:60
@@ -390,6 +401,10 @@ class CoFiI2P(nn.Module):
         if mode != "test":
             raise ValueError("forward_async serves the test-mode pipeline")
         _lib.load()
+        with ops.arithmetic(self.arithmetic):
+            return self._forward_async(slot, pc_data_dict, img, mode, inputs_stable)
+
+    def _forward_async(self, slot, pc_data_dict, img, mode, inputs_stable):
         P = self._pack(img.device)
         if inputs_stable:
             for k in ("points", "neighbors", "subsampling", "upsampling"):
@@ -448,7 +463,7 @@ class CoFiI2P(nn.Module):
                                       "torch.no_grad() for inference / validation; training needs the reference's PyTorch model")
         if self.training and self.pc_norm_kind == "bn":
             raise NotImplementedError("opt.norm == 'bn' is served with running statistics (module.eval()); batch statistics need the reference's model")
-        with torch.no_grad():
+        with torch.no_grad(), ops.arithmetic(self.arithmetic):
             return self._forward(pc_data_dict, img, fine_center_kpt_coors, fine_pc_inline_index, mode, taps)
 
     def _forward(self, pc_data_dict, img, fine_center_kpt_coors, fine_pc_inline_index, mode, taps=None):

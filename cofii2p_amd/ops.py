@@ -31,6 +31,28 @@ def _gemm_flag() -> int:
     return GEMM_BF16X3 if GEMM_MODE == "bf16x3" else 0
 
 
+class arithmetic:
+    """Context manager: run the enclosed launches with the given contraction arithmetic ("bf16x3" | "f32"; None = leave the process
+    default, COFI_GEMM).  `CoFiI2P(opt, arithmetic=...)` wraps its forwards in it, so two models with different arithmetic coexist."""
+
+    def __init__(self, mode):
+        if mode not in (None, "bf16x3", "f32"):
+            raise ValueError("arithmetic must be 'bf16x3' or 'f32', got %r" % (mode,))
+        self.mode = mode
+
+    def __enter__(self):
+        global GEMM_MODE
+        self.saved = GEMM_MODE
+        if self.mode is not None:
+            GEMM_MODE = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global GEMM_MODE
+        GEMM_MODE = self.saved
+        return False
+
+
 GEMM_W_SPLIT = 0x200
 
 

@@ -56,6 +56,13 @@ def build_pyramid(points: torch.Tensor, subsample: List[torch.Tensor], k: int = 
 def precompute_point_cloud_stack_mode(points, intensity, normals, lengths, num_stages, device="cuda", rng: Optional[np.random.RandomState] = None):
     """Signature of preprocess_data.py:36.  points (3,N) numpy; intensity / normals are carried by the
     caller (kitti.py:293) and ignored here, exactly as in the reference."""
+    import multiprocessing as mp
+
+    if mp.current_process().name != "MainProcess" and mp.get_start_method(allow_none=True) in (None, "fork"):
+        # the reference calls this inside Dataset.__getitem__ (data/kitti.py:292) under DataLoader workers: a FORKED worker cannot
+        # initialise HIP (it hangs or fails inside the runtime) - say so instead
+        raise RuntimeError("precompute_point_cloud_stack_mode launches HIP kernels and cannot run in a forked DataLoader worker: use "
+                           "num_workers=0, or multiprocessing_context='spawn', or cofii2p_amd.dataside.FramePreparer (the device-side loader)")
     rng = np.random if rng is None else rng
     n = points.shape[1]
     sub = []

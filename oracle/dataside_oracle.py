@@ -140,7 +140,10 @@ def camera_matrix_cropping(K, dx, dy):
 
 
 def resize_linear_u8(img, dw, dh):
-    """cv2.resize(img, (dw, dh), interpolation=INTER_LINEAR) for uint8 HWC (kitti.py:306-309), OpenCV's generic fixed-point path."""
+    """cv2.resize(img, (dw, dh), interpolation=INTER_LINEAR) for uint8 HWC (kitti.py:306-309) as OpenCV's fixed-point path computes it
+    (imgproc/resize.cpp, published algorithm; cv2 itself is absent from this image -> parity with the library UNPINNED, see
+    tests/test_thirdparty_gpu.py): 11-bit coefficients (cvRound), horizontal pass exact in int32, vertical pass as the uchar
+    specialisation of VResizeLinear: ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2 - each term truncated."""
     sh, sw = img.shape[:2]
 
     def coef(dsize, ssize):
@@ -161,7 +164,7 @@ def resize_linear_u8(img, dw, dh):
     y0, y1, ay0, ay1 = coef(dh, sh)
     src = img.astype(np.int64)
     rows = src[:, x0, :] * ax0[None, :, None] + src[:, x1, :] * ax1[None, :, None]
-    v = (rows[y0] * ay0[:, None, None] + rows[y1] * ay1[:, None, None] + (1 << 21)) >> 22
+    v = (((ay0[:, None, None] * (rows[y0] >> 4)) >> 16) + ((ay1[:, None, None] * (rows[y1] >> 4)) >> 16) + 2) >> 2
     return np.clip(v, 0, 255).astype(np.uint8)
 
 

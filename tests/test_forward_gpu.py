@@ -529,9 +529,13 @@ def test_bench_two_ranks_share_device(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--dist-backend", "gloo", "--steps", "6",
-                          "--warmup", "2", "--points", "4096", "--no-cpu-baseline", "--no-kernel-timing", "--no-batch-sweep"], env=env,
-                         capture_output=True, text=True, timeout=900)
+                          "--warmup", "2", "--points", "4096", "--distinct-frames", "4", "--repeats", "2", "--no-cpu-baseline", "--no-kernel-timing",
+                          "--no-batch-sweep"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["gathered_frame_results"] == 8 and d["value"] > 0
+    # per-rank rates (a straggler would show), the gather's own time, and the repeats the median was taken over
+    assert len(d["per_rank_frames_per_s"]) == 2 and all(v > 0 for v in d["per_rank_frames_per_s"]) and d["result_gather_ms"] >= 0
+    assert d["repeats"] == 2 and len(d["seconds_per_repeat"]) == 2 and d["dtype"] == "bf16x3"
+    assert abs(d["value"] - 2 * 6 / max(6 / v for v in d["per_rank_frames_per_s"])) / d["value"] < 0.02

@@ -145,7 +145,9 @@ def test_model_import_path_shim_and_training_guard():
 
     from cofii2p_amd import network, preprocess
 
-    assert shim.CoFiI2P is network.CoFiI2P and shim.point2node is network.point2node and shim.CoFiI2P_wrapper is network.CoFiI2P_wrapper
+    # the shim's class IS the implementation, specialised only in its default arithmetic (exact fp32: test_arithmetic_is_an_explicit_option...)
+    assert issubclass(shim.CoFiI2P, network.CoFiI2P) and shim.point2node is network.point2node and issubclass(shim.CoFiI2P_wrapper, network.CoFiI2P_wrapper)
+    assert set(vars(shim.CoFiI2P)) - {'__module__', '__doc__', '__qualname__'} == {'DEFAULT_ARITHMETIC'}
     assert precompute_point_cloud_stack_mode is preprocess.precompute_point_cloud_stack_mode is precompute_point_cloud_cuda
 
     class Opt:
@@ -198,3 +200,58 @@ def test_neighbourhood_operator_shims_and_oracle_properties():
         ids = rows[r][rows[r] != 4000]
         d = ((p[ids].astype(np.float64) - p[r].astype(np.float64)) ** 2).sum(1)
         assert (d < 0.81 + 1e-5).all() and (np.diff(d) >= -1e-6).all()
+
+
+def test_arithmetic_is_an_explicit_option_and_the_shim_is_strict():
+    """the reference-named import path must not hand out approximate contractions unasked.  `model.network.CoFiI2P` defaults to
+    the exact fp32 arithmetic, `cofii2p_amd.network.CoFiI2P` follows the process default unless told, `opt.arithmetic` / the constructor
+    argument override both, and the per-forward context restores the process default."""
+    from cofii2p_amd import ops
+    from cofii2p_amd.network import CoFiI2P as Native
+    from model.network import CoFiI2P as Shim, CoFiI2P_wrapper
+
+    class Opt:
+        img_H, img_W, img_fine_resolution_scale, norm = 160, 512, 32, "gn"
+
+    assert Shim(Opt()).arithmetic == "f32" and CoFiI2P_wrapper(Opt()).cofii2p.arithmetic == "f32"
+    assert Native(Opt()).arithmetic is None and Native(Opt(), arithmetic="f32").arithmetic == "f32"
+    o = Opt()
+    o.arithmetic = "bf16x3"
+    assert Shim(o).arithmetic == "bf16x3" and Native(o).arithmetic == "bf16x3"
+    with pytest.raises(ValueError):
+        Native(Opt(), arithmetic="fp16")
+    before = ops.GEMM_MODE
+    with ops.arithmetic("f32"):
+        assert ops.GEMM_MODE == "f32"
+        with ops.arithmetic(None):
+            assert ops.GEMM_MODE == "f32"
+    assert ops.GEMM_MODE == before
+    assert list(Shim(Opt()).state_dict().keys()) == list(Native(Opt()).state_dict().keys())   # same 430-key layout
+
+
+def _call_pyramid_in_worker(q):
+    import numpy as np
+
+    from model.kpconv.preprocess_data import precompute_point_cloud_stack_mode
+
+    try:
+        precompute_point_cloud_stack_mode(np.zeros((3, 64), np.float32), None, None, None, 2)
+        q.put("no error")
+    except RuntimeError as e:
+        q.put(str(e))
+    except Exception as e:   # pragma: no cover
+        q.put("other: %r" % (e,))
+
+
+def test_pyramid_shim_refuses_forked_dataloader_workers():
+    """the reference calls precompute_point_cloud_stack_mode inside Dataset.__getitem__ (data/kitti.py:292); a forked worker cannot
+    initialise HIP - the shim says so instead of hanging"""
+    import multiprocessing as mp
+
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    p = ctx.Process(target=_call_pyramid_in_worker, args=(q,))
+    p.start()
+    msg = q.get(timeout=60)
+    p.join(30)
+    assert "forked DataLoader worker" in msg and "FramePreparer" in msg
