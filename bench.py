@@ -66,30 +66,10 @@ def record_kernel_calls(model, dev, points=20480, batch=1):
 _model_ref = []
 
 
-def make_streams(dev, n, cu_split=None):
-    """n HIP streams; cu_split = "even" | "halves": experiment - each stream gets a disjoint CU mask (hipExtStreamCreateWithCUMask)."""
-    if not cu_split or n != 2:
-        # the model hands out the streams the process already owns first (capture + default stream): every extra live stream makes
-        # two frame streams share one of HIP's 4 hardware queues (CoFiI2P.frame_streams)
-        return _model_ref[0].frame_streams(n, dev) if (_model_ref and os.environ.get("COFI_BENCH_STREAMS", "") != "new") else \
-            [torch.cuda.Stream(device=dev) for _ in range(n)]
-    import ctypes
-
-    hip = ctypes.CDLL("libamdhip64.so")
-    streams = []
-    for i in range(2):
-        words = (ctypes.c_uint32 * 8)()
-        for w in range(8):
-            if cu_split == "halves":
-                words[w] = 0xFFFFFFFF if (w < 4) == (i == 0) else 0
-            else:  # alternate CUs
-                words[w] = 0x55555555 if i == 0 else 0xAAAAAAAA
-        st = ctypes.c_void_p()
-        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
-        if rc != 0:
-            raise SystemExit("hipExtStreamCreateWithCUMask failed: %d" % rc)
-        streams.append(torch.cuda.ExternalStream(st.value, device=dev))
-    return streams
+def make_streams(dev, n):
+    """n HIP streams to keep frames in flight on.  The model hands out the streams the process already owns first (capture + default
+    stream): every extra live stream makes two frame streams share one of HIP's 4 hardware queues (CoFiI2P.frame_streams)."""
+    return _model_ref[0].frame_streams(n, dev) if _model_ref else [torch.cuda.Stream(device=dev) for _ in range(n)]
 
 
 def one_step(model, frame):
@@ -377,9 +357,9 @@ class Pipeline:
     i % S while the previous frames are still executing, a slot's result (incl. the host read of the match count) is collected just
     before the slot is reused.  Every step is ONE frame through the complete forward + fine matching."""
 
-    def __init__(self, model, dev, frames, S, slots_per_stream, copy_inputs, cu_split=None):
+    def __init__(self, model, dev, frames, S, slots_per_stream, copy_inputs):
         self.model, self.frames, self.S, self.copy_inputs = model, frames, S, copy_inputs
-        self.streams = make_streams(dev, S, cu_split)
+        self.streams = make_streams(dev, S)
         self.NSLOT = S * max(1, slots_per_stream)   # submission i: stream i % S, hipGraph slot i % NSLOT
         self.pending = [None] * self.NSLOT
 
@@ -431,7 +411,6 @@ def main():
     ap.add_argument("--slots-per-stream", type=int, default=2, help="submissions queued per frame stream: 2 = the next frame is already enqueued behind the running one (no host bubble)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for single-GPU tests of the N > 1 path)")
     ap.add_argument("--share-device", action="store_true", help="test aid: all ranks use cuda:0")
-    ap.add_argument("--cu-split", default=None, choices=[None, "even", "halves"], help="experiment: the two frame streams get disjoint CU masks")
     ap.add_argument("--copy-inputs", action="store_true", help="stage every frame's inputs into per-slot static buffers (one 27 MB copy launch per frame) "
                     "instead of letting the hipGraph read the resident input tensors in place (forward_async(inputs_stable=True))")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the extra stack-mode batch-4/16 measurements")
@@ -487,8 +466,6 @@ def main():
 
     cofi_ops.GEMM_MODE = args.gemm
     model = CoFiI2P(Opt()).to(dev)
-    if os.environ.get("COFI_BENCH_SKIP_UNUSED_MAPS") == "1":   # diagnostic only (never the reported configuration): ResNet layer3 / layer4 / avg-pool, which nothing reads
-        model.compute_unused_image_maps = False
     _model_ref.append(model)
     if not args.eager:
         model.enable_graphs()
@@ -543,7 +520,7 @@ def main():
             nmatch = out[4].shape[0]
         dts = timed_repeats(run1, barrier, args.steps, repeats)
     else:
-        pipe = Pipeline(model, dev, frames, S, args.slots_per_stream, args.copy_inputs, args.cu_split)
+        pipe = Pipeline(model, dev, frames, S, args.slots_per_stream, args.copy_inputs)
         nmatch = pipe.warm(args.warmup)
         dts = timed_repeats(pipe.run, barrier, args.steps, repeats)
     dt = float(np.median(dts))   # this rank's seconds per timed region of args.steps steps

@@ -64,11 +64,9 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nblk) {
 // b128 stores of 8 consecutive query lanes hit 8 different chunk slots (conflict free without padding: 4 KB per state)
 __device__ __forceinline__ int so_off(int q, int chunk) { return q * 32 + ((chunk ^ (q & 7)) << 2); }
 
-// ABL: timing ablations (tools only, COFI_ATTN_ABLATE): 1 no softmax, 2 no PV chain, 4 no QK^T chain, 8 no re-staging after the
-// prologue, 16 no per-step barrier.  0 = the product kernel.
 // LIGHT: two workgroups per CU (<= 128 VGPRs): a wave runs QK^T, softmax and PV of a unit back to back - with four waves per SIMD
 // the other waves' MFMAs cover its softmax - and one workgroup's prologue / merge runs under the other's MFMA phase.
-template <int ABL, bool LIGHT>
+template <bool LIGHT>
 __global__ __launch_bounds__(64 * NW, LIGHT ? 4 : 2) void attention_flat_kernel(AttnArgs a) {
     // LDS carve (floats): two staging buffers of KPH K tiles + KPH V tiles | running max / row sum of the waves | Q scale | fold
     // scratch.  The waves' final O states (s_o) re-use the staging buffers: they are written after the loop's last barrier.  78 KB
@@ -169,10 +167,6 @@ __global__ __launch_bounds__(64 * NW, LIGHT ? 4 : 2) void attention_flat_kernel(
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        if constexpr (ABL & 4) {
-            s[0] = kt[li * TLD + lh];
-            return s;
-        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const f32x4 kf = *reinterpret_cast<const f32x4 *>(kt + li * TLD + 4 * lh + 8 * c);
@@ -192,7 +186,6 @@ __global__ __launch_bounds__(64 * NW, LIGHT ? 4 : 2) void attention_flat_kernel(
             if (k0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= a.S) s[r] = -INFINITY;
     };
     auto softmax = [&](f32x16 &s) {  // online softmax (base 2); returns P in s, rescales o
-        if constexpr (ABL & 1) return;
         float bmax = -1e30f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) bmax = fmaxf(bmax, s[r]);
@@ -211,11 +204,6 @@ __global__ __launch_bounds__(64 * NW, LIGHT ? 4 : 2) void attention_flat_kernel(
         for (int r = 0; r < 16; ++r) o[r] *= alpha;
     };
     auto pv = [&](const f32x16 &p, const float(&vf)[16]) {  // O^T += V^T . P^T in D-layout key order
-        if constexpr (ABL & 2) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] += vf[r] + p[r];
-            return;
-        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], p[r], o, 0, 0, 0);
     };
@@ -239,11 +227,11 @@ __global__ __launch_bounds__(64 * NW, LIGHT ? 4 : 2) void attention_flat_kernel(
                 softmax(sC);
                 pv(sC, vC);
             }
-            if (t + 1 < nsteps && !(ABL & 8)) {
+            if (t + 1 < nsteps) {
                 stage_store((t + 1) & 1);
                 if (t + 2 < nsteps) stage_load(t + 2);
             }
-            if constexpr (!(ABL & 16)) __syncthreads();
+            __syncthreads();
         }
     } else {
     f32x16 sC;
@@ -283,11 +271,11 @@ __global__ __launch_bounds__(64 * NW, LIGHT ? 4 : 2) void attention_flat_kernel(
                 kbC = kb;
             }
         }
-        if (t + 1 < nsteps && !(ABL & 8)) {
+        if (t + 1 < nsteps) {
             stage_store((t + 1) & 1);
             if (t + 2 < nsteps) stage_load(t + 2);
         }
-        if constexpr (!(ABL & 16)) __syncthreads();
+        __syncthreads();
     }
     if (kbC >= 0) {
         if (tail_keys && kbC == lay.P - 1) mask_tail(kbC, sC);
@@ -357,24 +345,11 @@ int attention_check(const float *Q, int ldq, const float *K, int ldk, const floa
 
 int launch_parts(AttnArgs a, int frames, hipStream_t stream) {
     a.lay = attn_layout(a.L, a.S, a.H, frames);
-    static const int abl = [] { const char *e = getenv("COFI_ATTN_ABLATE"); return e ? atoi(e) : 0; }();   // timing experiments only
     const dim3 grid(a.lay.nwg), block(64 * NW);
-    if (a.lay.light) {
-        switch (abl) {
-            case 7: hipLaunchKernelGGL((attention_flat_kernel<7, true>), grid, block, 0, stream, a); break;
-            case 31: hipLaunchKernelGGL((attention_flat_kernel<31, true>), grid, block, 0, stream, a); break;
-            default: hipLaunchKernelGGL((attention_flat_kernel<0, true>), grid, block, 0, stream, a);
-        }
-        return cofi_launch_status();
-    }
-    switch (abl) {
-        case 1: hipLaunchKernelGGL((attention_flat_kernel<1, false>), grid, block, 0, stream, a); break;
-        case 2: hipLaunchKernelGGL((attention_flat_kernel<2, false>), grid, block, 0, stream, a); break;
-        case 4: hipLaunchKernelGGL((attention_flat_kernel<4, false>), grid, block, 0, stream, a); break;
-        case 7: hipLaunchKernelGGL((attention_flat_kernel<7, false>), grid, block, 0, stream, a); break;
-        case 31: hipLaunchKernelGGL((attention_flat_kernel<31, false>), grid, block, 0, stream, a); break;
-        default: hipLaunchKernelGGL((attention_flat_kernel<0, false>), grid, block, 0, stream, a);
-    }
+    if (a.lay.light)
+        hipLaunchKernelGGL((attention_flat_kernel<true>), grid, block, 0, stream, a);
+    else
+        hipLaunchKernelGGL((attention_flat_kernel<false>), grid, block, 0, stream, a);
     return cofi_launch_status();
 }
 

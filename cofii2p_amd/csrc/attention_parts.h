@@ -43,18 +43,7 @@ static inline int attn_num_cus() {
 // K / V tiles, Q-norm fold - and merge run under the other's MFMA phase).  Measured on MI355X (us per launch, heavy / light): one
 // KITTI cross-attention call (80 query super blocks) 14.9 / 16.3, the joint self-attention call (160) 28.3 / 24.6, 16 stacked
 // frames 158.9 / 150.0 - light wins once there are enough super blocks to give every CU two workgroups without splitting the keys
-// further.  COFI_ATTN_WG_PER_CU = 1 / 2 forces a variant (A/B runs).  Read once: producer and consumers always agree.
-static inline int attn_forced_wg_per_cu() {
-    static const int n = [] { const char *e = getenv("COFI_ATTN_WG_PER_CU"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2) ? v : 0; }();
-    return n;
-}
-
-// COFI_ATTN_KS_CAP (A/B runs): upper bound on the key ranges per pair (default COFI_ATTN_MAX_KS).  Read once.
-static inline int attn_ks_cap() {
-    static const int n = [] { const char *e = getenv("COFI_ATTN_KS_CAP"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= COFI_ATTN_MAX_KS) ? v : COFI_ATTN_MAX_KS; }();
-    return n;
-}
-
+// further.
 static inline AttnLayout attn_layout(int L, int S, int H, int frames) {
     AttnLayout a;
     a.P = cofi_cdiv(S, 32);
@@ -63,12 +52,11 @@ static inline AttnLayout attn_layout(int L, int S, int H, int frames) {
     const long sp = (long)frames * H * a.QSB;   // workgroups per key range
     // Cost of a split in "steps" (one 32 x 32 unit per wave): waves of workgroups the chip runs one after the other, each
     // ceil(blocks / KPH) steps long plus a fixed prologue + merge cost of about 1.5 steps.
-    const int forced = attn_forced_wg_per_cu();
-    a.light = forced ? forced == 2 : sp * 2 >= attn_num_cus();
+    a.light = sp * 2 >= attn_num_cus();
     const int ncu = attn_num_cus() * (a.light ? 2 : 1);
     int best = 1;
     double best_cost = 1e30;
-    for (int ks = 1; ks <= attn_ks_cap() && ks <= a.P; ++ks) {
+    for (int ks = 1; ks <= COFI_ATTN_MAX_KS && ks <= a.P; ++ks) {
         const double rounds = (double)cofi_cdiv(sp * ks, ncu);
         const double cost = rounds * (cofi_cdiv(cofi_cdiv(a.P, ks), COFI_ATTN_KPH) + 1.5);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = ks; }

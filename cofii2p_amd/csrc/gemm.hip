@@ -468,11 +468,8 @@ __global__ void split_planes_kernel(const float *W, int ldw, int N, int K, unsig
 // and needs 4x fewer barriers.  One LDS buffer + a register-staged next tile:
 //   issue global loads (t+1) -> MFMAs on tile t from LDS -> barrier -> split + write tile t+1 -> barrier.
 // (The 128x128 tile uses BK3 = 64: 128 would need 139 KB of LDS and the whole VGPR file for one workgroup.)
-// KW = 1: 4 waves (2x2 over the tile), up to 2 workgroups per CU - the throughput configuration.
-// KW = 2/4: 8/16 waves; wave group kq = wave / 4 multiplies only the kq-th 1/KW of every K-tile and the KW partial
-//           accumulators are summed through LDS in a fixed order at the end.  A workgroup that is alone on its CU (small
-//           grids) is bound by the serial chain load -> split -> LDS -> MFMA of ONE wave per SIMD (~2 us per 128-deep tile,
-//           measured); KW waves per SIMD split the conversion work KW ways and overlap each other's phases.
+// 4 waves (2x2 over the tile), up to 2-3 workgroups per CU.  (An 8 / 16-wave variant that split every K-tile over wave groups shortened a
+// LONE launch but cost throughput with frames in flight - 563 vs 583 frames/s - and was removed in round 3)
 // ANORM: the A operand carries a pending GroupNorm / InstanceNorm (+ affine + LeakyReLU) of the producing layer (GemmArgs::an):
 //        the workgroup folds the producer's statistics partials itself while its first tile is in flight, keeps the per-channel
 //        scale / shift in LDS and normalises every A element on its way into the bf16 planes - the stand-alone normalisation
@@ -481,15 +478,15 @@ __global__ void split_planes_kernel(const float *W, int ldw, int N, int K, unsig
 //        (M, 15 C) output has no other reader): A tiles then travel global -> LDS as plain 16-byte copies like the W tiles, the
 //        conversion instructions (the bulk of the VALU work of a tile) and their registers disappear.  Dense GEMM only.
 //        (An earlier experiment in this slot - two K-tiles in flight in registers - measured 445 vs 457 frames/s and was removed.)
-template <int BM, int BN, int TM, int TN, int BK3, int KW = 1, bool WSPLIT = false, int WPE = 1, bool ANORM = false, bool ASPLIT = false>
-__global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
+template <int BM, int BN, int TM, int TN, int BK3, bool WSPLIT = false, int WPE = 1, bool ANORM = false, bool ASPLIT = false>
+__global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
     static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 waves");
-    constexpr int NT = 256 * KW;
+    constexpr int NT = 256;
     constexpr int BROW3 = BK3 * 2 + 16;   // bytes per LDS row: bf16 values + 16 B pad (68 / 36 dwords: conflict-free b128 reads)
     constexpr int LPR = BK3 / 4;          // lanes per row slice (float4 each)
     constexpr int RPP = NT / LPR;         // rows per staging pass
     constexpr int A_LD4 = BM / RPP, W_LD4 = BN / RPP;            // float4 loads per thread and tile
-    static_assert(A_LD4 >= 1 && W_LD4 >= 1 && (BK3 / 16) % KW == 0, "tile too small for this many waves");
+    static_assert(A_LD4 >= 1 && W_LD4 >= 1, "tile too small for 256 threads");
     // pre-split W: 16-B chunks of 8 bf16; chunk c of a plane tile = (row c / CPR, k 8 * (c % CPR))
     constexpr int CPR = BK3 / 8, W_CH = BN * CPR / NT, A_CH = BM * CPR / NT;
     static_assert(!ASPLIT || ((BM * CPR) % NT == 0 && WSPLIT && !ANORM), "pre-split A: plane tile must divide over the threads");
@@ -497,8 +494,8 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
     constexpr int TLD = BN + 4;
     constexpr int PLANE_A = BM * BROW3, PLANE_W = BN * BROW3;    // bytes
     constexpr int BUF = 2 * (PLANE_A + PLANE_W);                 // hi+lo of A and W
-    // the epilogue re-uses the operand buffer as a row-major fp32 tile (+ the column-statistics scratch behind it when KW > 1)
-    constexpr int EPI = (BM == 128 ? 64 : BM) * TLD * 4 + (KW > 1 ? (NT / (BN / 4)) * BN * 2 * 4 : 0);   // BM = 128: two 64-row halves
+    // the epilogue re-uses the operand buffer as a row-major fp32 tile
+    constexpr int EPI = (BM == 128 ? 64 : BM) * TLD * 4;   // BM = 128: two 64-row halves
     constexpr int LDS_BYTES = BUF > EPI ? BUF : EPI;
     static_assert((NT / (BN / 4)) * BN * 2 * 4 <= LDS_BYTES, "column-statistics scratch must fit");
     constexpr int AN_MAXC = 512;                                 // channels of a normalised A operand (scale + shift table behind the buffers)
@@ -507,8 +504,7 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
     float *nsc = reinterpret_cast<float *>(lds_raw + LDS_BYTES), *nsh = nsc + AN_MAXC;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kq = wave >> 2, wq = wave & 3;   // K share, position in the 2x2 wave grid
-    const int wm = wq >> 1, wn = wq & 1;
+    const int wm = wave >> 1, wn = wave & 1;   // position in the 2x2 wave grid
     const BlockId bid = gemm_block_id(g);
     const int m0 = bid.y * BM, n0 = bid.x * BN;
     const int kbeg = bid.z * g.kchunk;
@@ -726,12 +722,12 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
 
     const int li = lane & 31, lh = lane >> 5;
     union Frag { uint4 u; bf16x8 v; };
-    constexpr int STEPS = BK3 / 16 / KW;   // 16-deep MFMA steps of this wave per tile
-    const unsigned char *as = lds_raw + (wm * 32 * TM + li) * BROW3 + lh * 16 + kq * STEPS * 32;
-    const unsigned char *bs = lds_raw + 2 * PLANE_A + (wn * 32 * TN + li) * BROW3 + lh * 16 + kq * STEPS * 32;
+    constexpr int STEPS = BK3 / 16;   // 16-deep MFMA steps per tile
+    const unsigned char *as = lds_raw + (wm * 32 * TM + li) * BROW3 + lh * 16;
+    const unsigned char *bs = lds_raw + 2 * PLANE_A + (wn * 32 * TN + li) * BROW3 + lh * 16;
     auto compute = [&]() {
 #pragma unroll
-        for (int s2 = 0; s2 < STEPS; ++s2) {  // lane (i,h) owns k = 16*(kq*STEPS + s2) + 8h .. +7
+        for (int s2 = 0; s2 < STEPS; ++s2) {  // lane (i,h) owns k = 16*s2 + 8h .. +7
             Frag ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -792,38 +788,6 @@ __global__ __launch_bounds__(256 * KW, WPE) void gemm_bf16x3_kernel(GemmArgs g) 
     }
 
     float *lds = reinterpret_cast<float *>(lds_raw);
-    if constexpr (KW > 1) {
-        // sum of the KW partial accumulators in ascending kq order (fixed -> deterministic): wave group q adds its share to the
-        // row-major LDS tile in round q; after the last round group 0 holds ... the tile itself is what the epilogue reads
-#pragma unroll
-        for (int q = 0; q < KW; ++q) {
-            if (kq == q) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int rl = wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                            float *p = lds + rl * TLD + wn * 32 * TN + j * 32 + li;
-                            *p = (q == 0) ? acc[i][j][r] : *p + acc[i][j][r];
-                        }
-            }
-            __syncthreads();
-        }
-        if (g.ksplit > 1) {
-            // partial sums of this K chunk: the tile goes out row by row (float per thread, coalesced 256-B segments)
-            for (int e = tid; e < BM * BN; e += NT) {
-                const int rl = e / BN, cl = e - rl * BN;
-                const int row = m0 + rl, col = n0 + cl;
-                if (row < g.M && col < g.N) g.ws[((size_t)bid.z * g.M + row) * g.N + col] = lds[rl * TLD + cl];
-            }
-            return;
-        }
-        // `red` of the epilogue aliases the tile: park it behind the tile instead (BUF >= tile + red, checked below)
-        rowwise_epilogue<BM, BN, false, NT>(g, lds, TLD, m0, n0, bid.y, lds + BM * TLD);
-        return;
-    }
     if (g.ksplit > 1) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -943,17 +907,9 @@ Plan make_plan(int M, int N, int K, bool fused_ln) {
         if (fused_ln && p.ksplit == 1 && p.bn < N) { p.bm = 64; p.bn = 128; }
         return p;
     }
-    // COFI_GEMM_KS_SCALE (A/B runs): scales the split-K factor of the tuned plans (0 = never split)
-    static const float ks_scale = [] { const char *e = getenv("COFI_GEMM_KS_SCALE"); return e ? (float)atof(e) : 1.0f; }();
     for (const TunedPlan &t : kTunedPlans)
         if (t.M == M && t.N == N && t.K == K) {
-            int ks = t.ks;
-            if (ks_scale != 1.0f && ks > 1) ks = (int)(ks * ks_scale + 0.5f) < 1 ? 1 : (int)(ks * ks_scale + 0.5f);
-            // COFI_GEMM_MAX_TILE = "<bm>x<bn>" (A/B runs): caps the tuned tile (e.g. 64x64: smallest register / LDS footprint)
-            static const struct Cap { int bm, bn; } cap = [] { Cap c{128, 128}; if (const char *e = getenv("COFI_GEMM_MAX_TILE")) sscanf(e, "%dx%d", &c.bm, &c.bn); return c; }();
-            int bm = t.bm < cap.bm ? t.bm : cap.bm, bn = t.bn < cap.bn ? t.bn : cap.bn;
-            if (bm == 128 && bn == 64) bm = 64;
-            p = finish_plan(K, bm, bn, ks);
+            p = finish_plan(K, t.bm, t.bn, t.ks);
             if (fused_ln && p.ksplit == 1 && p.bn < N) { p.bm = 64; p.bn = 128; }
             return p;
         }
@@ -1035,30 +991,10 @@ Plan make_planes_plan(int M, int N, int K) {
     return finish_planes_plan(K, cfg, ks);
 }
 
-// Latency configuration of the 64x64 kernel (8 or 16 waves sharing every K-tile) for grids small enough that each workgroup is alone
-// on its CU; 16 waves once a workgroup runs >= 4 K-tiles.  It shortens a LONE launch (a single frame at a time: 303 vs 301 frames/s)
-// but its 512 / 1024-thread workgroups take more of the chip per launch, which costs throughput once frames overlap (four frames in
-// flight: 563 vs 583 frames/s) - OFF by default.  COFI_GEMM_KW = "<kw>:<max blocks>": "0:256" = the rule above for grids of <= 256
-// workgroups, "2:256" / "4:256" force 8 / 16 waves, "1:0" (default) = always the 4-wave kernel.
-int latency_kw(const Plan &p, int M, int N) {
-    static const struct Cfg { int kw; long max_blocks; } cfg = [] {
-        Cfg c{1, 0};
-        if (const char *e = getenv("COFI_GEMM_KW")) sscanf(e, "%d:%ld", &c.kw, &c.max_blocks);
-        return c;
-    }();
-    const long nb = (long)cofi_cdiv(M, p.bm) * cofi_cdiv(N, p.bn) * p.ksplit;
-    if (p.bm != 64 || p.bn != 64 || nb > cfg.max_blocks) return 1;
-    return cfg.kw ? cfg.kw : (p.kchunk >= 4 * 128 ? 4 : 2);
-}
-
 // Tile order (GemmArgs::xcd): estimate the bytes both orders pull over the fabric — every XCD that touches a row panel of A
-// or a column panel of W reads it through its own L2 — and take the cheaper one.  COFI_GEMM_XCD = 0 / 1 forces hardware /
-// XCD-contiguous order for A/B runs.
+// or a column panel of W reads it through its own L2 — and take the cheaper one.
 int xcd_order(const GemmArgs &g, const dim3 &grid) {
-    static const int mode = [] {
-        const char *e = getenv("COFI_GEMM_XCD");
-        return e ? atoi(e) : 2;
-    }();
+    const int mode = 2;   // 0 / 1 would force hardware / XCD-contiguous order; 2 picks per launch from the traffic estimate below
     const long gx = grid.x, gy = grid.y, gz = grid.z, nblk = gx * gy * gz;
     if (mode == 0 || (gx & (gx - 1)) || nblk < 16 || gy * gz >= 65536) return 0;
     const int enc = 1 + __builtin_ctzl(gx);
@@ -1091,34 +1027,26 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
         default: return COFI_EINVAL;
         }
     } else if (g.bf16x3) {
-        const int kw = (p.bm == 64 && p.bn == 64) ? latency_kw(p, g.M, g.N) : 1;
-#define COFI_LAUNCH_BF16X3_W(BM_, BN_, TM_, TN_, BK_, KW_, WPE_)                                                                                  \
-    do {                                                                                                                                        \
-        if (g.an.part)                                                                                                                          \
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, true, WPE_, true, false>), grid, dim3(256 * KW_), 0, s, g);    \
-        else if (g.asplit)                                                                                                                      \
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, true, WPE_, false, true>), grid, dim3(256 * KW_), 0, s, g);    \
-        else if (g.wsplit)                                                                                                                      \
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, true, WPE_, false, false>), grid, dim3(256 * KW_), 0, s, g);   \
-        else                                                                                                                                    \
-            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, KW_, false, WPE_, false, false>), grid, dim3(256 * KW_), 0, s, g);  \
+#define COFI_LAUNCH_BF16X3(BM_, BN_, TM_, TN_, BK_)                                                                        \
+    do {                                                                                                                  \
+        if (g.an.part)                                                                                                    \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, true, 1, true, false>), grid, dim3(256), 0, s, g);    \
+        else if (g.asplit)                                                                                                \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, true, 1, false, true>), grid, dim3(256), 0, s, g);    \
+        else if (g.wsplit)                                                                                                \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, true, 1, false, false>), grid, dim3(256), 0, s, g);   \
+        else                                                                                                              \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, false, 1, false, false>), grid, dim3(256), 0, s, g);  \
     } while (0)
-#define COFI_LAUNCH_BF16X3(BM_, BN_, TM_, TN_, BK_, KW_) COFI_LAUNCH_BF16X3_W(BM_, BN_, TM_, TN_, BK_, KW_, 1)
-        // K-tile depth per tile shape (measured): the 128x128 tile is register-bound at 2 waves per SIMD either way; the 64x128 and
-        // the throughput 64x64 tile run 1.4x / 1.05x faster with 64-deep K-tiles (2-3 workgroups per CU instead of 1-2) than with
-        // 128-deep ones; the small-grid 8/16-wave configurations keep 128 (fewer barriers for a lone workgroup).
+        // K-tile depth 64 for every tile shape (measured: the 64x128 and 64x64 tiles run 1.4x / 1.05x faster with 64-deep K-tiles -
+        // 2-3 workgroups per CU instead of 1-2 - than with 128-deep ones; the 128x128 tile is register-bound at 2 waves per SIMD either way)
         if (p.bm == 128 && p.bn == 128)
-            COFI_LAUNCH_BF16X3(128, 128, 2, 2, 64, 1);   // (32-deep K-tiles at 3 waves per SIMD, 168 VGPRs with spills: no faster)
+            COFI_LAUNCH_BF16X3(128, 128, 2, 2, 64);
         else if (p.bm == 64 && p.bn == 128)
-            COFI_LAUNCH_BF16X3(64, 128, 1, 2, 64, 1);
-        else if (kw == 4)
-            COFI_LAUNCH_BF16X3(64, 64, 1, 1, 128, 4);
-        else if (kw == 2)
-            COFI_LAUNCH_BF16X3(64, 64, 1, 1, 128, 2);
+            COFI_LAUNCH_BF16X3(64, 128, 1, 2, 64);
         else
-            COFI_LAUNCH_BF16X3(64, 64, 1, 1, 64, 1);
+            COFI_LAUNCH_BF16X3(64, 64, 1, 1, 64);
 #undef COFI_LAUNCH_BF16X3
-#undef COFI_LAUNCH_BF16X3_W
     } else if (p.bm == 128 && p.bn == 128)
         hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, g);
     else if (p.bm == 64 && p.bn == 128)

@@ -318,9 +318,8 @@ extern "C" int cofi_knn_grid_build(const float *support, int S, void *ws, size_t
     int *start = (int *)(base + grid_off_start()), *cursor = (int *)(base + grid_off_cursor());
     float4 *sorted = (float4 *)(base + grid_off_sorted());
     const int nb = min(cofi_cdiv(S, 256), 1024), nb_box = min(cofi_cdiv(S, 1024), 64);
-    // tuning knobs (results never depend on them): points per cell, size of a query's first block in units of k
-    static const float target_occ = [] { const char *e = getenv("COFI_KNN_OCC"); return e ? fmaxf((float)atof(e), 0.5f) : 12.0f; }();
-    static const float first_block = [] { const char *e = getenv("COFI_KNN_FIRST"); return e ? fmaxf((float)atof(e), 0.1f) : 0.8f; }();
+    // tuned on MI355X (results never depend on them): points per cell, size of a query's first block in units of k
+    const float target_occ = 12.0f, first_block = 0.8f;
     hipLaunchKernelGGL(grid_init_kernel, dim3(1), dim3(1024), 0, s, hd, start, S, target_occ, first_block);
     hipLaunchKernelGGL(grid_bbox_kernel, dim3(nb_box), dim3(256), 0, s, support, S, hd);
     hipLaunchKernelGGL(grid_count_kernel, dim3(nb), dim3(256), 0, s, support, S, hd, start);

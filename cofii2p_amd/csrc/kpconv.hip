@@ -754,8 +754,7 @@ extern "C" int cofi_kpconv_aggregate(const float *feats, int ldf, int N, int C, 
     M *= frames;
     hipStream_t s = cofi_s(stream);
     const int mb = cofi_cdiv(M, 4);
-    static const bool no_shared = [] { const char *e = getenv("COFI_KP_NO_SHARED_STAGING"); return e && atoi(e) != 0; }();
-    if (!no_shared && (C == 256 || C == 512) && (ldf & 3) == 0 && H <= 128 && M % (C == 256 ? 2 : 1) == 0) {
+    if ((C == 256 || C == 512) && (ldf & 3) == 0 && H <= 128 && M % (C == 256 ? 2 : 1) == 0) {
         if (C == 256)
             hipLaunchKernelGGL(kpconv_aggregate_shared_kernel<2>, dim3(M / 2), dim3(256), 0, s, a);
         else
@@ -795,8 +794,6 @@ extern "C" int cofi_kpconv_aggregate_c4(const float *records, int N, int C, cons
 // divides M and still gives >= 256 workgroups; 0 = shape not supported (use cofi_kpconv_aggregate + cofi_gemm_f32_fused)
 extern "C" int cofi_kpconv_fused_slab_rows(int C, int M, int frames) {
     if ((C != 32 && C != 64) || M <= 0 || frames <= 0 || (M % 16)) return 0;
-    static const int forced = [] { const char *e = getenv("COFI_KPF_QT"); return e ? atoi(e) : 0; }();
-    if ((forced == 16 || forced == 32 || forced == 64) && M % forced == 0) return forced;   // A/B runs
     for (int q = 64; q >= 32; q >>= 1)
         if (M % q == 0 && (long)M * frames / q >= 256) return q;
     return 16;

@@ -115,9 +115,6 @@ __device__ __forceinline__ void gemm_stage(f32x16 (&acc)[NT], const unsigned cha
     }
 }
 
-// ABL: timing ablations (tools only, COFI_TAIL_ABLATE): 1 / 2 / 4 skip the GEMM of stage 1 / 2 / 3, 8 skip both LayerNorms,
-// 16 read zeros instead of msg.  0 = the product kernel.
-template <int ABL>
 __global__ __launch_bounds__(256) void loftr_tail_kernel(TailArgs a) {
     // LDS carve (bytes): msg planes 2*R*S128 | cat planes 2*R*S256 | h planes 2*R*S256 | fp32 staging R*FLD*4
     constexpr int OFF_MSG = 0, OFF_CAT = OFF_MSG + 2 * R * S128, OFF_H = OFF_CAT + 2 * R * S256, OFF_F = OFF_H + 2 * R * S256;
@@ -138,9 +135,7 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailArgs a) {
         for (int p = 0; p < R / 8; ++p) {
             const int rl = lr + 8 * p, row = min(r0 + rl, a.L - 1);
             float4 mv;
-            if constexpr (ABL & 16) {
-                mv = make_float4(0.f, 0.f, 0.f, 0.f);
-            } else if (a.parts) {
+            if (a.parts) {
                 const int f = row / a.Lf;
                 mv = attn_merged_chunk(a.parts, a.lay, f, a.H, lk >> 5, row - f * a.Lf, (lk & 31) >> 2);
             } else {
@@ -161,7 +156,6 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailArgs a) {
     // LayerNorm of the staged (R x 128) tile: wave w owns rows 8w .. 8w+7, lane owns columns lane, lane+64
     auto row_layernorm = [&](int rl, const float *g, const float *b, float &o0, float &o1) {
         const float v0 = stage[rl * FLD + lane], v1 = stage[rl * FLD + 64 + lane];
-        if constexpr (ABL & 8) { o0 = v0; o1 = v1; return; }
         const float mean = wave_sum(v0 + v1) * (1.0f / C);
         const float d0 = v0 - mean, d1 = v1 - mean;
         const float rstd = 1.0f / sqrtf(wave_sum(d0 * d0 + d1 * d1) * (1.0f / C) + a.eps);
@@ -174,7 +168,7 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailArgs a) {
         f32x16 acc[1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-        if constexpr (!(ABL & 1)) gemm_stage<1, 8, 2>(acc, msg_hi, msg_lo, S128, a.wm_hi, a.wm_lo, C, wave * 32, li, lh);
+        gemm_stage<1, 8, 2>(acc, msg_hi, msg_lo, S128, a.wm_hi, a.wm_lo, C, wave * 32, li, lh);
         acc_to_stage(acc[0], wave * 32);
     }
     __syncthreads();
@@ -195,7 +189,7 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailArgs a) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        if constexpr (!(ABL & 2)) gemm_stage<2, 16, 2>(acc, cat_hi, cat_lo, S256, a.w0_hi, a.w0_lo, 2 * C, wave * 64, li, lh);
+        gemm_stage<2, 16, 2>(acc, cat_hi, cat_lo, S256, a.w0_hi, a.w0_lo, 2 * C, wave * 64, li, lh);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -211,7 +205,7 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailArgs a) {
         f32x16 acc[1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-        if constexpr (!(ABL & 4)) gemm_stage<1, 16, 4>(acc, h_hi, h_lo, S256, a.w2_hi, a.w2_lo, 2 * C, wave * 32, li, lh);
+        gemm_stage<1, 16, 4>(acc, h_hi, h_lo, S256, a.w2_hi, a.w2_lo, 2 * C, wave * 32, li, lh);
         acc_to_stage(acc[0], wave * 32);
     }
     __syncthreads();
@@ -230,17 +224,7 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailArgs a) {
 }
 
 void launch_tail(const TailArgs &a, int nwg, hipStream_t s) {
-    static const int abl = [] { const char *e = getenv("COFI_TAIL_ABLATE"); return e ? atoi(e) : 0; }();   // timing experiments only
-    switch (abl) {
-        case 1: hipLaunchKernelGGL(loftr_tail_kernel<1>, dim3(nwg), dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(loftr_tail_kernel<2>, dim3(nwg), dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL(loftr_tail_kernel<4>, dim3(nwg), dim3(256), 0, s, a); break;
-        case 7: hipLaunchKernelGGL(loftr_tail_kernel<7>, dim3(nwg), dim3(256), 0, s, a); break;
-        case 8: hipLaunchKernelGGL(loftr_tail_kernel<8>, dim3(nwg), dim3(256), 0, s, a); break;
-        case 16: hipLaunchKernelGGL(loftr_tail_kernel<16>, dim3(nwg), dim3(256), 0, s, a); break;
-        case 31: hipLaunchKernelGGL(loftr_tail_kernel<31>, dim3(nwg), dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(loftr_tail_kernel<0>, dim3(nwg), dim3(256), 0, s, a);
-    }
+    hipLaunchKernelGGL(loftr_tail_kernel, dim3(nwg), dim3(256), 0, s, a);
 }
 
 }  // namespace

@@ -49,7 +49,7 @@ def score_thresholds(n: int = 64) -> np.ndarray:
     return np.asarray(out, dtype=np.float64).astype(np.float32)
 
 
-ALTERNATE_ORDER = os.environ.get("COFI_ALTERNATE_ORDER", "1") != "0"   # A/B switch: odd forward_async slots run the point encoder first (515-518 vs 510 f/s)
+ALTERNATE_ORDER = True   # odd forward_async slots run the point encoder first (measured 515-518 vs 510 frames/s)
 
 
 class CoFiI2P(nn.Module):
@@ -96,7 +96,7 @@ class CoFiI2P(nn.Module):
 
         # intra-frame fork/join slots captured by forward_async (bit 0 image branch, 1 residual shortcuts, 2 attention streams,
         # 3 the ResNet tail nothing reads)
-        self.async_branch_mask = int(os.environ.get("COFI_ASYNC_BRANCH_MASK", "0"))
+        self.async_branch_mask = 0
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
         self.eval()
 
@@ -419,7 +419,7 @@ class CoFiI2P(nn.Module):
         # fork/join only adds join latency then — measured 254 vs 331 frames/s at two frames in flight)
         outs = self._graph_forward(P, points, tabs[0], tabs[1], tabs[2], pc_data_dict["feats"].contiguous(), img.contiguous(), mode, None,
                                    None, slot=slot, branch_mask=self.async_branch_mask,
-                                   order=None if os.environ.get("COFI_NO_ORDER") else pc_data_dict.get("order"), inputs_stable=inputs_stable)
+                                   order=pc_data_dict.get("order"), inputs_stable=inputs_stable)
         hosts = self.__dict__.setdefault("_count_host", {})   # one pinned landing buffer per slot (a slot is finished before it is reused)
         host = hosts.get((slot, len(outs)))
         if host is None:

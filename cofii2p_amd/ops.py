@@ -24,7 +24,7 @@ GEMM_MODE = os.environ.get("COFI_GEMM", "bf16x3")
 
 # Which intra-frame fork/join branches are taken (see Branch).  With >= 2 frames in flight the frames themselves fill
 # the GPU and intra-frame forks only add join overhead; with one frame in flight they shorten the critical path.
-BRANCH_MASK = int(os.environ.get("COFI_BRANCH_MASK", "7"))
+BRANCH_MASK = 7
 
 
 def _gemm_flag() -> int:
@@ -199,10 +199,9 @@ def set_workspace_slot(slot: int):
     Workspace.slot = int(slot)
 
 
-# Who turns statistics partials into per-channel scale / shift: "kernel" = one small cofi_norm_finalize launch per
-# normalisation, consumers read the finished vectors; "inline" = every consumer workgroup folds the table itself (no extra
-# launch; the default - measured equal within noise, 443 vs 446 frames/s, and it keeps ~80 launches out of a frame).  COFI_NORM_FOLD selects.
-NORM_FOLD = os.environ.get("COFI_NORM_FOLD", "inline")
+# Statistics partials -> per-channel scale / shift: every consumer workgroup folds the table itself (stat_fold.h).  A separate
+# cofi_norm_finalize launch per normalisation + consumers reading the finished vectors measured equal within noise (443 vs 446
+# frames/s) for ~80 more launches per frame; the entry point stays for callers that want the vectors (ColStats.scale_shift).
 
 
 # ------------------------------------------------------------------------------------------ dense
@@ -242,8 +241,6 @@ class ColStats:
         d.eps, d.slope = self.eps, slope
         d.slab_rows = self.slab_rows
         d.scale_shift = None
-        if NORM_FOLD == "kernel":
-            d.scale_shift = self.scale_shift(d, gamma, beta).data_ptr()
         return d
 
     def scale_shift(self, d, gamma, beta) -> torch.Tensor:
@@ -812,7 +809,7 @@ def loftr_tail(msg, x, w, out, eps: float = 1e-5):
     return out
 
 
-MULTI_COPY_BLOCKS = int(os.environ.get("COFI_COPY_BLOCKS", "64"))   # workgroups per record (the largest record of a frame is ~10 MB)
+MULTI_COPY_BLOCKS = 64   # workgroups per record (the largest record of a frame is ~10 MB)
 
 
 class MultiCopy:
@@ -845,7 +842,7 @@ class MultiCopy:
 
 
 # ------------------------------------------------------------------------------------------ KNN / indices
-KNN_GRID_MIN_SUPPORT = int(os.environ.get("COFI_KNN_GRID_MIN", "1024"))   # smaller support sets: brute force
+KNN_GRID_MIN_SUPPORT = 1024   # smaller support sets: brute force
 
 
 def _check_xyz(t, name):

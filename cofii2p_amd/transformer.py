@@ -12,7 +12,7 @@ import os
 
 from . import ops
 
-JOINT_SELF = os.environ.get("COFI_JOINT_SELF", "1") != "0"  # A/B switch for the joint self-attention layers
+JOINT_SELF = True   # the four self layers run ONCE over [image | point] tokens (shared weights); tests flip it for the per-stream form
 
 
 def pack_layer(sd: Dict[str, torch.Tensor], p: str) -> Dict[str, torch.Tensor]:
