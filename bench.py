@@ -664,12 +664,18 @@ def main():
         result["knn_pyramid"] = {"ms_per_frame": grid_ms, "brute_force_ms_per_frame": brute_ms,
                                  "note": "build_pyramid (5 stages, 13 searches, k = 128) as called from Python, one stream; not part of `value`"}
         if S > 1 and not args.eager:
-            # ... and the whole chain on this GPU: every frame's pyramid is built on its frame stream right before its forward
+            # ... and the whole chain on this GPU: every frame's pyramid is built on its frame stream right before its forward - the ~40
+            # launches of a pyramid as ONE hipGraph per slot (preprocess.PyramidGraph), its tables read in place by the forward's graph
+            from cofii2p_amd.preprocess import PyramidGraph
+
             model.enable_graphs(True)
             st = make_streams(dev, S)
             NSL = S * max(1, args.slots_per_stream)
             pend = [None] * NSL
-            feats0, img0 = frames[0][0]["feats"], frames[0][1]
+            feats0 = frames[0][0]["feats"]
+            sub_sizes = [int(t.shape[0]) for t in sub]
+            pgs = [PyramidGraph(args.points, sub_sizes, dev, capture_stream=st[0]) for _ in range(NSL)]
+            imgs = [frames[0][1].clone() for _ in range(NSL)]   # static per slot, like the tables
             for phase in range(2):   # 0 = warm-up (captures the graphs of these slots), 1 = timed
                 nfr = max(args.steps, 3 * NSL)
                 torch.cuda.synchronize()
@@ -679,9 +685,9 @@ def main():
                     if pend[sl] is not None:
                         model.finish(pend[sl])
                     with torch.cuda.stream(st[i % S]):
-                        pyr = build_pyramid(p0, sub)
+                        pyr = dict(pgs[sl].run(p0, sub))
                         pyr["feats"] = feats0
-                        pend[sl] = model.forward_async(30 + sl, pyr, img0)
+                        pend[sl] = model.forward_async(30 + sl, pyr, imgs[sl], inputs_stable=True)
                 for sl in range(NSL):
                     if pend[sl] is not None:
                         model.finish(pend[sl])
@@ -689,7 +695,9 @@ def main():
                 torch.cuda.synchronize()
                 dte = time.perf_counter() - t0
             result["with_pyramid_build"] = {"frames_per_s": nfr / dte, "ms_per_frame": 1e3 * dte / nfr,
-                                            "note": "pyramid construction (KNN) + forward + fine matching per frame on the same GPU; not the headline"}
+                                            "note": "pyramid construction (5 cell grids + 13 KNN-128 searches, one hipGraph) + forward + fine matching per "
+                                                    "frame on the same GPU; not the headline"}
+            del pgs
     if rank == 0 and world == 1 and Bsz == 1 and not args.no_batch_sweep and not args.eager:
         # row f2: the whole data side of a frame on this GPU (data/kitti.py:259-393: calibration transform, 0.1 m voxel grid, resample to
         # num_pc, random SE(3), KNN pyramid, image resize / crop, labels) from a raw 120 000-point scan + 376 x 1241 image already in
@@ -704,43 +712,68 @@ def main():
         for k_, v_ in dict(num_pc=args.points, num_kpt=64, P_tx_amplitude=10, P_ty_amplitude=0, P_tz_amplitude=10, P_Rx_amplitude=0.0, P_Ry_amplitude=2.0 * np.pi, P_Rz_amplitude=0.0).items():
             setattr(opt_ds, k_, v_)
         st = make_streams(dev, max(S, 1))
-        preps = [dataside.FramePreparer(opt_ds, dev) for _ in st]
+        prep0 = dataside.FramePreparer(opt_ds, dev)
         for i in range(3):
-            preps[0].prepare(raw_d, img_d, rK, P_Tr, i)
+            prep0.prepare(raw_d, img_d, rK, P_Tr, i)
         torch.cuda.synchronize()
         nl = 20
         t0 = time.perf_counter()
         for i in range(nl):
-            preps[0].prepare(raw_d, img_d, rK, P_Tr, i)
+            prep0.prepare(raw_d, img_d, rK, P_Tr, i)
         torch.cuda.synchronize()
         loader_ms = 1e3 * (time.perf_counter() - t0) / nl
+        voxels = prep0.last["voxels"]
+        del prep0
+        # the pipelined loader (cofii2p_amd/loader.py): voxel grid enqueued LOOK frames ahead, draws in worker processes, resample +
+        # pyramid + image as one hipGraph per slot, tables read in place by the forward's graph; INFL forwards in flight
+        from cofii2p_amd.loader import FrameLoader
+
         model.enable_graphs(True)
-        NSL = len(st) * max(1, args.slots_per_stream)
+        LOOK, INFL = len(st), len(st) * max(1, args.slots_per_stream)
+        NSL = INFL + LOOK
+        loader = FrameLoader(opt_ds, dev, slots=NSL, workers=4, capture_stream=st[0])
         pend = [None] * NSL
-        for phase in range(2):
-            nfr = max(args.steps, 3 * NSL)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(nfr):
-                sl = i % NSL
-                if pend[sl] is not None:
-                    model.finish(pend[sl][0])
-                    pend[sl][1]["finish_labels"]()
-                with torch.cuda.stream(st[i % len(st)]):
-                    smp = preps[i % len(st)].prepare(raw_d, img_d, rK, P_Tr, i, defer_labels=True)
-                    pend[sl] = (model.forward_async(60 + sl, smp["pc_data_dict"], smp["img"][None]), smp)
-            for sl in range(NSL):
-                if pend[sl] is not None:
-                    model.finish(pend[sl][0])
-                    pend[sl][1]["finish_labels"]()
-                    pend[sl] = None
-            torch.cuda.synchronize()
-            dtl = time.perf_counter() - t0
+
+        def collect(sl):
+            h, smp = pend[sl]
+            model.finish(h)
+            smp["finish_labels"]()
+            loader.release(sl)
+            pend[sl] = None
+
+        try:
+            for phase in range(2):
+                nfr = max(args.steps, 3 * NSL)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for j in range(min(LOOK, nfr)):
+                    with torch.cuda.stream(st[j % len(st)]):
+                        loader.begin(j % NSL, raw_d, img_d, rK, P_Tr, j)
+                for i in range(nfr):
+                    sl, nxt = i % NSL, i + LOOK
+                    with torch.cuda.stream(st[i % len(st)]):
+                        if nxt < nfr:   # the voxel grid of frame i + LOOK goes onto this stream AHEAD of frame i's own work
+                            if pend[nxt % NSL] is not None:
+                                collect(nxt % NSL)
+                            loader.begin(nxt % NSL, raw_d, img_d, rK, P_Tr, nxt)
+                        loader.poll()
+                        smp = loader.complete(sl)
+                        pend[sl] = (model.forward_async(60 + sl, smp["pc_data_dict"], smp["img"][None], inputs_stable=True), smp)
+                    loader.poll()
+                for k in range(NSL):
+                    if pend[(nfr + k) % NSL] is not None:
+                        collect((nfr + k) % NSL)
+                torch.cuda.synchronize()
+                dtl = time.perf_counter() - t0
+        finally:
+            loader.close()
         result["with_dataside"] = {"loader_ms_per_frame": loader_ms, "loader_frames_per_s": 1e3 / loader_ms, "frames_per_s": nfr / dtl,
-                                   "ms_per_frame": 1e3 * dtl / nfr, "voxels": preps[0].last["voxels"], "raw_points": int(raw.shape[1]),
+                                   "ms_per_frame": 1e3 * dtl / nfr, "voxels": voxels, "raw_points": int(raw.shape[1]),
+                                   "frames_in_flight": INFL, "voxel_grids_ahead": LOOK, "draw_workers": 4,
                                    "note": "kitti.py:259-393 on the device (voxel grid + resample + SE(3) + KNN pyramid + image + labels) in front of the "
-                                           "forward + fine matching; raw scan and image resident in HBM; one blocking host sync per frame (voxel count), the labels are "
-                                           "finished when the frame's forward is collected; not the headline"}
+                                           "forward + fine matching, pipelined (cofii2p_amd/loader.py): raw scan and image resident in HBM, voxel count "
+                                           "read asynchronously, Mersenne-Twister draws in worker processes, labels finished when the frame's forward is "
+                                           "collected; loader_ms_per_frame = the synchronous FramePreparer.prepare() alone; not the headline"}
     if rank == 0 and world == 1 and Bsz == 1 and not args.eager and not args.no_batch_sweep and not args.stress:
         result["stress_config"] = stress_summary(dev, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -8,9 +8,13 @@
 
 The reference seeds the GLOBAL numpy and `random` generators per frame index and draws from them in a fixed order
 (kitti.py:261-264, then :170/:175, :220-229, preprocess_data.py:58 four times, :313-314 in train mode, :345/:349/:358);
-`FrameSampler` makes the same draws in the same order from private generators, so a frame prepared here gets the reference's
-choice indices, SE(3) and label permutations.  The draws are host-side by nature (Mersenne Twister streams); they are handed
-to the kernels as plain index arrays / a 4x4 matrix.  One host sync per frame: the voxel count (the resampling draw depends on it).
+`FrameSampler` (cofii2p_amd/sampler.py) makes the same draws in the same order from private generators, so a frame prepared here
+gets the reference's choice INDICES, SE(3) and label permutations.  Caveat: the voxel table those indices select from is in ascending
+voxel-index order here, in open3d's hash-map order in the reference - the same index therefore names a different voxel and the
+resampled cloud equals the reference's in distribution, not point for point (exactly equal whenever the voxel table is, e.g. the
+nuScenes path, which has no voxel grid).  The draws are host-side by nature (Mersenne Twister streams); they are handed to the
+kernels as plain index arrays / a 4x4 matrix.  `prepare()` syncs once per frame on the voxel count (the resampling draw depends on
+it); cofii2p_amd/loader.py pipelines frames so that nothing waits.
 """
 import random
 from typing import Dict, Optional
@@ -21,68 +25,10 @@ import torch
 from . import _lib, ops
 from .preprocess import build_pyramid
 
-NUM_STAGES = 5
 VOXEL_SIZE = 0.1   # kitti.py:283
 
 
-def frame_seed(index: int) -> int:
-    """kitti.py:261-262"""
-    (seed,) = np.random.SeedSequence([index]).generate_state(1)
-    return int(seed)
-
-
-class FrameSampler:
-    """The random draws of one __getitem__(index) call, in the reference's order."""
-
-    def __init__(self, index: int, seed: Optional[int] = None, dataset: str = "kitti"):
-        # kitti.py:261-264 seeds with SeedSequence([index]); nuscenes.py:178-181 with the index itself
-        self.seed = (frame_seed(index) if dataset == "kitti" else int(index)) if seed is None else int(seed)
-        self.rs = np.random.RandomState(self.seed)   # the global numpy state after np.random.seed(seed)
-        self.rnd = random.Random(self.seed)          # the global `random` state after random.seed(seed)
-
-    def downsample_choice(self, n: int, num_pc: int) -> np.ndarray:
-        """kitti.py:168-176"""
-        if n >= num_pc:
-            return self.rs.choice(n, num_pc, replace=False)
-        fix = np.arange(n)
-        while n + fix.shape[0] < num_pc:
-            fix = np.concatenate((fix, np.arange(n)), axis=0)
-        return np.concatenate((fix, self.rs.choice(n, num_pc - fix.shape[0], replace=False)), axis=0)
-
-    def random_transform(self, opt) -> np.ndarray:
-        """kitti.py:216-235 (+ :203-214): t, then the angles; R = Rz Ry Rx; 4x4 float32."""
-        u = self.rnd.uniform
-        t = [u(-opt.P_tx_amplitude, opt.P_tx_amplitude), u(-opt.P_ty_amplitude, opt.P_ty_amplitude), u(-opt.P_tz_amplitude, opt.P_tz_amplitude)]
-        a = [u(-opt.P_Rx_amplitude, opt.P_Rx_amplitude), u(-opt.P_Ry_amplitude, opt.P_Ry_amplitude), u(-opt.P_Rz_amplitude, opt.P_Rz_amplitude)]
-        Rx = np.array([[1, 0, 0], [0, np.cos(a[0]), -np.sin(a[0])], [0, np.sin(a[0]), np.cos(a[0])]])
-        Ry = np.array([[np.cos(a[1]), 0, np.sin(a[1])], [0, 1, 0], [-np.sin(a[1]), 0, np.cos(a[1])]])
-        Rz = np.array([[np.cos(a[2]), -np.sin(a[2]), 0], [np.sin(a[2]), np.cos(a[2]), 0], [0, 0, 1]])
-        P = np.identity(4, dtype=np.float32)
-        P[0:3, 0:3] = np.dot(Rz, np.dot(Ry, Rx))
-        P[0:3, 3] = t
-        return P
-
-    def subsample_indices(self, n: int, num_stages: int = NUM_STAGES):
-        """preprocess_data.py:55-59: half of the previous stage, WITH replacement."""
-        out = []
-        for _ in range(num_stages - 1):
-            out.append(self.rs.choice(np.arange(n), size=n // 2))
-            n //= 2
-        return out
-
-    def crop_offsets(self, small_hw, opt, mode: str):
-        """kitti.py:312-317: random crop in train mode, centred otherwise."""
-        h, w = small_hw
-        if mode == "train":
-            dx = self.rnd.randint(0, w - opt.img_W)
-            dy = self.rnd.randint(0, h - opt.img_H)
-        else:
-            dx = int((w - opt.img_W) / 2)
-            dy = int((h - opt.img_H) / 2)
-        return dy, dx
-
-    def permutation(self, n: int) -> np.ndarray:
-        return self.rs.permutation(n)
+from .sampler import NUM_STAGES, FrameSampler, frame_seed  # noqa: E402,F401  (torch-free module: the loader's worker processes import it alone)
 
 
 def calib_matrices(lines: Dict[str, str]) -> Dict[str, np.ndarray]:
@@ -227,10 +173,14 @@ class FramePreparer:
     def resample_transform(self, vox: torch.Tensor, choice: np.ndarray, P: np.ndarray):
         """rows `choice` of the voxel table, x' = R x + t, n' = R n -> points (n, 3), feats (n, 4) = [intensity | n'] (kitti.py:284-288, 293)
         or [intensity | x'] (nuscenes.py:199-204)."""
-        lib = _lib.load()
-        n = int(choice.shape[0])
         ch = torch.from_numpy(np.ascontiguousarray(choice, dtype=np.int32)).to(self.device, non_blocking=True)
         Pd = torch.from_numpy(np.ascontiguousarray(P, dtype=np.float32)).to(self.device, non_blocking=True)
+        return self.resample_transform_dev(vox, ch, Pd)
+
+    def resample_transform_dev(self, vox: torch.Tensor, ch: torch.Tensor, Pd: torch.Tensor):
+        """the same with the draw already on the device (int32 indices, 4x4 float32): no host work, capturable in a hipGraph"""
+        lib = _lib.load()
+        n = int(ch.shape[0])
         points = torch.empty((n, 3), dtype=torch.float32, device=self.device)
         feats = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         _lib.check(lib.cofi_gather_transform(_p(vox), _p(ch), n, _p(Pd), _p(points), _p(feats), int(self.dataset == "nuscenes"), _stream()),
@@ -253,6 +203,10 @@ class FramePreparer:
         later frame right after submitting the current frame's forward on the same stream, and complete() when it comes back to it:
         the count has long arrived and the host never blocks on the GPU.  One outstanding begin() per preparer."""
         dev = self.device
+        if getattr(self, "_outstanding", False):
+            raise _lib.CofiError("FramePreparer.begin: the previous begin() of this preparer has not been complete()d - its voxel table and "
+                                 "count buffer would be overwritten (one preparer per frame in flight)")
+        self._outstanding = True
         data = (torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)) if isinstance(data, np.ndarray) else data).to(dev, non_blocking=True)
         img = (torch.from_numpy(np.ascontiguousarray(img)) if isinstance(img, np.ndarray) else img).to(dev, non_blocking=True)
         h = {"img": img, "K": K, "index": index}
@@ -282,6 +236,7 @@ class FramePreparer:
     def complete(self, h: Dict, defer_labels: bool = False) -> Dict:
         """Second half of `prepare` (see begin): the draws that need the voxel count, resampling + SE(3), KNN pyramid, image, labels."""
         opt, dev = self.opt, self.device
+        self._outstanding = False
         img, K, index = h["img"], h["K"], h["index"]
         s = FrameSampler(index, dataset=self.dataset)
         vox = h["vox"]

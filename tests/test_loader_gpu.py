@@ -1,0 +1,106 @@
+"""The pipelined loader (cofii2p_amd/loader.py: voxel grids enqueued ahead, draws in worker processes, resample + pyramid + image as one
+hipGraph per slot) against the synchronous FramePreparer.prepare, which tests/test_dataside_gpu.py pins to the reference's own
+__getitem__ (tests/golden/dataside_ref.npz): identical bits for every tensor, labels included, with slots reused and frames
+interleaved; and PyramidGraph against build_pyramid.  Needs a real MI355X."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_dataside_cpu import INT_KEYS, kitti_opt  # noqa: E402
+from test_dataside_gpu import calib_P_Tr  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def test_pipelined_loader_equals_prepare():
+    from cofii2p_amd import dataside, synth
+    from cofii2p_amd.loader import FrameLoader
+
+    opt, P_Tr = kitti_opt(), calib_P_Tr()
+    frames = [synth.make_raw_scan(i) for i in (0, 1)]
+    ids = [10, 11, 12, 13, 14, 15, 16]                      # 7 frames through 3 slots: every slot is reused, two raw scans alternate
+    want = [dataside.FramePreparer(opt, DEV).prepare(*frames[k % 2], P_Tr, ids[k]) for k in range(len(ids))]
+    cap = torch.cuda.Stream(device=DEV)
+    loader = FrameLoader(opt, DEV, slots=3, workers=2, capture_stream=cap)
+    try:
+        got = [None] * len(ids)
+        LOOK = 2
+        for k in range(min(LOOK, len(ids))):
+            loader.begin(k % 3, *frames[k % 2], P_Tr, ids[k])
+        for k in range(len(ids)):
+            loader.poll()
+            smp = loader.complete(k % 3)
+            smp["finish_labels"]()
+            # the slot's tensors are static: snapshot before the slot is reused
+            got[k] = {"img": smp["img"].clone(), "feats": smp["pc_data_dict"]["feats"].clone(),
+                      "points": [t.clone() for t in smp["pc_data_dict"]["points"]],
+                      "neighbors": [t.clone() for t in smp["pc_data_dict"]["neighbors"]],
+                      "subsampling": [t.clone() for t in smp["pc_data_dict"]["subsampling"]],
+                      "upsampling": [t.clone() for t in smp["pc_data_dict"]["upsampling"]],
+                      **{key: smp[key].clone() if torch.is_tensor(smp[key]) else smp[key] for key in INT_KEYS + ("coarse_img_mask", "K", "K_4", "P")}}
+            assert smp["pc_data_dict"]["neighbors"][0].dtype == torch.int32
+            loader.release(k % 3)
+            if k + LOOK < len(ids):
+                loader.begin((k + LOOK) % 3, *frames[(k + LOOK) % 2], P_Tr, ids[k + LOOK])
+        torch.cuda.synchronize()
+    finally:
+        loader.close()
+    for w, g in zip(want, got):
+        assert torch.equal(w["img"], g["img"]) and torch.equal(w["pc_data_dict"]["feats"], g["feats"])
+        for i in range(5):
+            assert torch.equal(w["pc_data_dict"]["points"][i], g["points"][i])
+            assert torch.equal(w["pc_data_dict"]["neighbors"][i], g["neighbors"][i].long())     # the reference's dtype is int64
+        for i in range(4):
+            assert torch.equal(w["pc_data_dict"]["subsampling"][i], g["subsampling"][i].long())
+            assert torch.equal(w["pc_data_dict"]["upsampling"][i], g["upsampling"][i].long())
+        for key in INT_KEYS + ("coarse_img_mask", "K", "K_4", "P"):
+            assert torch.equal(w[key], g[key]), key
+
+
+def test_loader_feeds_the_model_in_place():
+    """a loader sample goes straight into forward_async(inputs_stable=True) - the graph reads the slot's tensors where they lie - and gives
+    what the synchronous path gives"""
+    import bench
+    from cofii2p_amd import dataside, synth
+    from cofii2p_amd.loader import FrameLoader
+    from cofii2p_amd.network import CoFiI2P
+
+    opt, P_Tr = kitti_opt(), calib_P_Tr()
+    raw, img, K = synth.make_raw_scan(0)
+    model = CoFiI2P(bench.Opt()).to(DEV)
+    ref_smp = dataside.FramePreparer(opt, DEV).prepare(raw, img, K, P_Tr, 5)
+    ref = model(ref_smp["pc_data_dict"], ref_smp["img"][None], None, None, None, "test")
+    st = model.frame_streams(1)[0]
+    loader = FrameLoader(opt, DEV, slots=2, workers=1, capture_stream=st)
+    try:
+        for rep in range(2):   # second round replays the captured graphs
+            with torch.cuda.stream(st):
+                loader.begin(0, raw, img, K, P_Tr, 5)
+                smp = loader.complete(0)
+                out = model.finish(model.forward_async(0, smp["pc_data_dict"], smp["img"][None], inputs_stable=True))
+            for a, b in zip(ref[:6], out[:6]):
+                assert torch.equal(a, b)
+            assert torch.equal(ref[7], out[7])
+            loader.release(0)
+    finally:
+        loader.close()
+
+
+def test_pyramid_graph_equals_build_pyramid():
+    from cofii2p_amd.preprocess import PyramidGraph, build_pyramid
+    from cofii2p_amd.synth import make_frame, subsample_indices
+
+    cap = torch.cuda.Stream(device=DEV)
+    pg = PyramidGraph(4096, [2048, 1024, 512, 256], DEV, capture_stream=cap)
+    for fid in (3, 4, 5):   # first call captures, the next two replay with other data
+        fr = make_frame(fid, 4096)
+        pts = torch.from_numpy(fr.points).to(DEV)
+        sub = [torch.from_numpy(s).to(DEV) for s in subsample_indices(4096, 5, seed=fid)]
+        want = build_pyramid(pts, sub)
+        got = pg.run(pts, sub)
+        torch.cuda.synchronize()
+        for key in ("points", "neighbors", "subsampling", "upsampling", "order"):
+            for a, b in zip(want[key], got[key]):
+                assert torch.equal(a, b), key
