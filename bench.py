@@ -734,6 +734,14 @@ def main():
         loader = FrameLoader(opt_ds, dev, slots=NSL, workers=4, capture_stream=st[0])
         pend = [None] * NSL
 
+        host = {"begin": 0.0, "complete": 0.0, "forward": 0.0, "collect": 0.0}   # host seconds inside each call (timed phase)
+
+        def timed(name, fn, *a, **k):
+            t_ = time.perf_counter()
+            r = fn(*a, **k)
+            host[name] += time.perf_counter() - t_
+            return r
+
         def collect(sl):
             h, smp = pend[sl]
             model.finish(h)
@@ -744,6 +752,8 @@ def main():
         try:
             for phase in range(2):
                 nfr = max(args.steps, 3 * NSL)
+                for k_ in host:
+                    host[k_] = 0.0
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for j in range(min(LOOK, nfr)):
@@ -754,15 +764,15 @@ def main():
                     with torch.cuda.stream(st[i % len(st)]):
                         if nxt < nfr:   # the voxel grid of frame i + LOOK goes onto this stream AHEAD of frame i's own work
                             if pend[nxt % NSL] is not None:
-                                collect(nxt % NSL)
-                            loader.begin(nxt % NSL, raw_d, img_d, rK, P_Tr, nxt)
+                                timed("collect", collect, nxt % NSL)
+                            timed("begin", loader.begin, nxt % NSL, raw_d, img_d, rK, P_Tr, nxt)
                         loader.poll()
-                        smp = loader.complete(sl)
-                        pend[sl] = (model.forward_async(60 + sl, smp["pc_data_dict"], smp["img"][None], inputs_stable=True), smp)
+                        smp = timed("complete", loader.complete, sl)
+                        pend[sl] = (timed("forward", model.forward_async, 60 + sl, smp["pc_data_dict"], smp["img"][None], inputs_stable=True), smp)
                     loader.poll()
                 for k in range(NSL):
                     if pend[(nfr + k) % NSL] is not None:
-                        collect((nfr + k) % NSL)
+                        timed("collect", collect, (nfr + k) % NSL)
                 torch.cuda.synchronize()
                 dtl = time.perf_counter() - t0
         finally:
@@ -770,6 +780,7 @@ def main():
         result["with_dataside"] = {"loader_ms_per_frame": loader_ms, "loader_frames_per_s": 1e3 / loader_ms, "frames_per_s": nfr / dtl,
                                    "ms_per_frame": 1e3 * dtl / nfr, "voxels": voxels, "raw_points": int(raw.shape[1]),
                                    "frames_in_flight": INFL, "voxel_grids_ahead": LOOK, "draw_workers": 4,
+                                   "host_ms_per_frame_in": {k_: round(1e3 * v_ / nfr, 4) for k_, v_ in host.items()},
                                    "note": "kitti.py:259-393 on the device (voxel grid + resample + SE(3) + KNN pyramid + image + labels) in front of the "
                                            "forward + fine matching, pipelined (cofii2p_amd/loader.py): raw scan and image resident in HBM, voxel count "
                                            "read asynchronously, Mersenne-Twister draws in worker processes, labels finished when the frame's forward is "

@@ -43,7 +43,11 @@ def build_pyramid(points: torch.Tensor, subsample: List[torch.Tensor], k: int = 
     for i in range(len(pts)):
         neighbors.append(ops.knn(pts[i], pts[i], k, grid=grids[i], qorder=qord[i] if grids[i] is not None else None))
         if i < len(pts) - 1:
-            subsampling.append(ops.knn(pts[i], pts[i + 1], k, grid=grids[i], qorder=qord[i + 1] if grids[i] is not None else None))
+            # subsampling[i] = the k nearest stage-i points of every stage-(i+1) point.  Stage i+1 is a SELECTION of stage i (point m is
+            # stage-i point subsample[i][m], bit for bit), so that row is exactly row subsample[i][m] of neighbors[i] - same coordinates,
+            # same canonical distances, same (distance, lowest index) order: 4 of the 13 searches of a pyramid are row gathers
+            # (tests/test_ops_gpu.py::test_gpu_pyramid_bit_exact_and_int64_contract holds the tables to the searching oracle)
+            subsampling.append(neighbors[i][subsample[i].long()].contiguous())
             upsampling.append(ops.knn(pts[i + 1], pts[i], k, grid=grids[i + 1], qorder=qord[i] if grids[i + 1] is not None else None))
     conv = ops.idx_to_int64 if int64 else (lambda t: t)
     return {"points": pts, "lengths": [int(p.shape[0]) for p in pts], "neighbors": [conv(t) for t in neighbors],

@@ -101,6 +101,10 @@ def test_pyramid_graph_equals_build_pyramid():
         want = build_pyramid(pts, sub)
         got = pg.run(pts, sub)
         torch.cuda.synchronize()
-        for key in ("points", "neighbors", "subsampling", "upsampling", "order"):
+        for key in ("points", "neighbors", "subsampling", "upsampling"):
             for a, b in zip(want[key], got[key]):
                 assert torch.equal(a, b), key
+        # `order` is only a PROCESSING order (the cell order of a grid: points of one cell land in it in arrival order, which the
+        # counting sort's cursors do not fix): each must be a permutation of its stage, results never depend on it
+        for a, b in zip(want["order"], got["order"]):
+            assert torch.equal(torch.sort(a)[0], torch.sort(b)[0]) and torch.equal(torch.sort(b)[0].long(), torch.arange(b.numel(), device=DEV))
