@@ -82,7 +82,9 @@ typedef struct cofi_norm_desc {
 #define COFI_GEMM_W_SPLIT 0x200
 /* with COFI_GEMM_W_SPLIT, cofi_gemm_f32_fused only: A is PRE-SPLIT too - `A` points at its bf16 hi plane, M rows of `lda` bf16
  * (lda % 8 == 0, K % 8 == 0), immediately followed by the lo plane (M * lda elements later): what cofi_kpconv_aggregate writes with
- * planes = 1.  The operand then needs no conversion on its way into LDS.  Not combinable with a_norm. */
+ * planes = 1.  Both operands then travel global -> LDS by LDS-DMA (global_load_lds) through a software-pipelined multi-stage ring
+ * (csrc/gemm_planes.inc: 9 tile configurations, plans tuned on MI355X); same products, same K order as the other bf16x3 kernels - equal
+ * split-K gives equal bits.  Not combinable with a_norm. */
 #define COFI_GEMM_A_SPLIT 0x400
 
 int cofi_abi_version(void);

@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-kernel-timing --no-batch-sweep"
+BENCH="python $R/bench.py --steps 20 --warmup 4 --repeats 1 --no-f32 --no-cpu-baseline --no-kernel-timing --no-batch-sweep"
 run_trace() {  # name, extra bench args
   rocprofv3 --kernel-trace --stats -d /tmp/prof_$1 -o x -- $BENCH $2 > $OUT/$1.log 2>&1
   DB=$(find /tmp/prof_$1 -name '*_results.db' | head -1)
