@@ -468,8 +468,9 @@ def test_eval_all_shaped_caller(model, tmp_path, monkeypatch):
     from cofii2p_amd.network import CoFiI2P, fine_matching
     from cofii2p_amd.pose import get_P_diff, pose_matrix, solve_pnp_ransac
 
-    assert ShimCoFiI2P is CoFiI2P
-    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x3")   # what a caller gets by default
+    # the reference-named class IS the implementation with the exact-fp32 contractions as its default: what an unchanged caller gets
+    assert issubclass(ShimCoFiI2P, CoFiI2P) and ShimCoFiI2P(Opt()).arithmetic == "f32"
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x3")   # the process default must not leak into the strict shim
     gold = load_golden("frame_kitti.npz")
     fr, data = frame_inputs(int(gold["frame_id"]), int(gold["num_points"]), int(gold["pyr_seed"]))
     batched = {k: [t[None] for t in data[k]] for k in ("points", "neighbors", "subsampling", "upsampling")}   # DataLoader adds a batch axis of 1

@@ -77,3 +77,43 @@ def test_planes_gemm_is_deterministic_and_leaves_neighbours_alone(hooks):
     for _ in range(3):
         assert torch.equal(ops.gemm(sa, sw, out=buf[:, 128:384]), y0)
     assert float((buf[:, :128] - 7.0).abs().max()) == 0.0 and float((buf[:, 384:] - 7.0).abs().max()) == 0.0
+
+
+def test_splitk_gemms_are_bit_reproducible_under_concurrent_load(hooks):
+    """Split-K GEMMs (slabs + the fixed-order reduction launch) of both kernels, several tile shapes, 150 launches on four streams at
+    once - every stream with its own workspace: each output must equal, bit for bit, the one computed alone.  (Round 3 also tried the
+    reduction INSIDE the launch - last-arriving workgroup, agent-scope release / acquire; it passed this test and lost 17 % of the
+    frame rate: the per-workgroup L2 write-back of the release hits the other frames' kernels.  DESIGN.md section 6.)"""
+    ops, fp, fo = hooks
+    g = torch.Generator(device=DEV).manual_seed(11)
+    probs = []
+    for (M, N, K, cfg, ks) in ((1280, 512, 7680, 0, 6), (1280, 256, 3840, 1, 6), (2560, 256, 3840, 1, 3), (320, 256, 2304, 1, 6), (2560, 128, 1920, 6, 3)):
+        a = torch.randn((M, K), device=DEV, generator=g)
+        w = torch.randn((N, K), device=DEV, generator=g) / K ** 0.5
+        probs.append((a, split_a(ops, a), ops.SplitW(w), torch.randn((N,), device=DEV, generator=g), cfg, ks))
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(4)]
+
+    def run(pr, planes):
+        a, sa, sw, bias, cfg, ks = pr
+        if planes:
+            fp(cfg, ks)
+            return ops.gemm_colstats(sa, sw, bias=bias, act=ops.ACT_LEAKY01, stat_width=32)
+        fo(64, 64, ks)
+        return ops.gemm_colstats(a, sw, bias=bias, act=ops.ACT_LEAKY01, stat_width=32)
+
+    try:
+        want = {}
+        for i, pr in enumerate(probs):
+            for planes in (False, True):
+                want[(i, planes)] = [t.clone() for t in run(pr, planes)]
+        torch.cuda.synchronize()
+        outs = []
+        for rep in range(150):
+            i, planes = rep % len(probs), bool((rep // len(probs)) & 1)
+            with torch.cuda.stream(streams[rep % 4]):
+                outs.append(((i, planes), run(probs[i], planes)))
+        torch.cuda.synchronize()
+        for key, (y, part) in outs:
+            assert torch.equal(y, want[key][0]) and torch.equal(part, want[key][1]), key
+    finally:
+        fp(-1, 0), fo(0, 0, 0)
