@@ -446,18 +446,24 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.share_device:  # test aid: every rank on cuda:0 (with --dist-backend gloo; RCCL refuses two ranks on one GPU)
+        local = 0
+    if local >= torch.cuda.device_count():
+        raise SystemExit("rank %d wants cuda:%d but this node exposes %d GPU(s)" % (rank, local, torch.cuda.device_count()))
+    torch.cuda.set_device(local)   # BEFORE the process group exists: RCCL binds its communicator to the current device
+    dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this host driver only supports dmabuf IPC (RCCL / xGMI peer access)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
         if dist.get_world_size() != args.gpus:
             raise SystemExit("--gpus %d but the process group has %d ranks" % (args.gpus, dist.get_world_size()))
-    if args.share_device:  # test aid: every rank on cuda:0 (with --dist-backend gloo; RCCL refuses two ranks on one GPU)
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
     numa_node = pin_to_gpu_numa_node(local) if (world > 1 and not args.share_device) else None
 
     from cofii2p_amd import ops as cofi_ops
