@@ -82,6 +82,10 @@ SIGNATURES = {
     "cofi_gather_rows_sel": (_I, [_P, _I, _I, _P, _P, _I, _P, _I, _P]),
     "cofi_multi_copy": (_I, [_P, _I, _I, _P]),
     "cofi_pnp_ransac_workspace": (_Z, [_I]),
+    "cofi_desc_loss_workspace": (_Z, [_I]),
+    "cofi_desc_loss": (_I, [_P, _I, _P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _I, _P, _I, _P, _Z, _P]),
+    "cofi_fine_circle_loss": (_I, [_P, _P, _I, _P, _I, _I, _F, _F, _P, _P, _P, _P, _P, _I, _P]),
+    "cofi_overlap_loss": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P]),
     "cofi_pnp_ransac": (_I, [_P, _P, _P, _I, _F, _F, _F, _F, _I, _F, ctypes.c_uint, _I, _P, _Z, _P, _P, _P, _P]),
     "cofi_fine_match": (_I, [_P, _P, _I, _I, _P, _I, _F, _P, _I, _P, _P, _P]),
     "cofi_kpconv_fused_slab_rows": (_I, [_I, _I, _I]),

@@ -385,6 +385,25 @@ int cofi_fine_match(const float *patches, const float *pc_feats, int ldp, int C,
                     float center_scale, const int32_t *count_dev, int cap, float *fine_xy, int32_t *best, cofi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Row f3, first part: the training losses of model/loss.py with their gradients w.r.t. the network outputs
+ * (the backward of the network itself is not built: DESIGN.md section 8).  grad_out = d(total)/d(loss), a device scalar; gradient
+ * pointers may be NULL (forward only).  All fp32, fixed-order reductions (bit-reproducible).
+ * cofi_desc_loss      loss.py:69-93: img / pc (C, K) with leading dimensions ldi / ldp (column = key point), mask (K, K);
+ *                     -> loss[1], dists (K, K) = 1 - img^T pc (the reference returns it too); ws from cofi_desc_loss_workspace(K).
+ * cofi_fine_circle_loss loss.py:9-51 (m = 0.2, gamma = 5 there): patches (K, C, 16), pc (K, C) rows of ldp, relative_index (K) int64
+ *                     -> loss[1], per_kpt (K) scratch/output = log(1 + loss_n loss_p) per key point.
+ * cofi_overlap_loss   loss.py:53-60: BCELoss(mean) of the in-picture scores against 1 and the out-of-picture scores against 0. */
+size_t cofi_desc_loss_workspace(int K);
+int cofi_desc_loss(const float *img, int ldi, const float *pc, int ldp, const float *mask, int C, int K, float pos_margin, float neg_margin,
+                   float log_scale, float *loss, float *dists, const float *grad_out, float *grad_img, int ldgi, float *grad_pc, int ldgp,
+                   void *ws, size_t ws_bytes, cofi_stream_t stream);
+int cofi_fine_circle_loss(const float *patches, const float *pc, int ldp, const int64_t *relative_index, int K, int C, float m, float gamma,
+                          float *loss, float *per_kpt, const float *grad_out, float *grad_patches, float *grad_pc, int ldg,
+                          cofi_stream_t stream);
+int cofi_overlap_loss(const float *inline_score, int n_in, const float *outline_score, int n_out, float *loss, const float *grad_out,
+                      float *grad_in, float *grad_outline, cofi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Row f1: camera pose from the fine matches, replacing the reference's
  *   cv2.solvePnPRansac(cameraMatrix=K, imagePoints=fine_xy.T, objectPoints=coarse_pc_points, iterationsCount=10000,
  *                      distCoeffs=None)                                   (evaluation/eval_all.py:107)
