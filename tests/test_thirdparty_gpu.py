@@ -4,6 +4,7 @@ DESIGN.md declares unpinned.  Each test skips when its library is absent and pin
   * cv2.solvePnPRansac(iterationsCount=10000)  vs  cofi_pnp_ransac          (evaluation/eval_all.py:107-117, row f1)
   * cv2.resize(INTER_LINEAR)                   vs  cofi_resize_crop_image   (data/kitti.py:306-309, row f2)
   * open3d voxel_down_sample(0.1)              vs  cofi_voxel_downsample    (data/kitti.py:145-166,283, row f2)
+  * geotransformer.ext radius_neighbors / grid_subsampling  vs  cofii2p_amd.neighbors  (model/kpconv/ops, row g)
 
 Needs a real MI355X:  python -m pytest tests -m gpu"""
 import numpy as np
@@ -92,3 +93,32 @@ def test_voxel_grid_against_open3d():
     a = got[np.lexsort(got[:, :3].T[::-1])][:, :7]
     b = ref[np.lexsort(ref[:, :3].T[::-1])]
     np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6)
+
+
+def test_radius_search_and_grid_subsample_against_geotransformer_ext():
+    """model/kpconv/ops/radius_search.py:24 and grid_subsample.py:21 forward to `geotransformer.ext` (un-vendored, CPU): when the
+    extension is importable, the same calls through cofii2p_amd.neighbors must give the same neighbour sets / the same cell barycentres
+    (the extension leaves the order of equidistant neighbours and of the cells unspecified: rows compared as distance-sorted sets,
+    cells as lexicographically sorted rows)."""
+    ext = pytest.importorskip("geotransformer.ext")
+    from cofii2p_amd import neighbors
+
+    g = np.random.default_rng(5)
+    pts = torch.from_numpy(np.concatenate([g.uniform(-3, 3, (1500, 3)), g.uniform(-2, 2, (900, 3))]).astype(np.float32))
+    lengths = torch.tensor([1500, 900])
+    ref_pts, ref_len = ext.grid_subsampling(pts, lengths, 0.3)
+    got_pts, got_len = neighbors.grid_subsample(pts.to(DEV), lengths, 0.3)
+    assert torch.equal(ref_len.cpu().long(), got_len.cpu().long())
+    s0 = 0
+    for n in ref_len.tolist():
+        a, b = ref_pts[s0:s0 + n].numpy(), got_pts[s0:s0 + n].cpu().numpy()
+        np.testing.assert_allclose(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])], rtol=0, atol=1e-6)
+        s0 += n
+    radius, limit = 0.6, 32
+    ref = ext.radius_neighbors(ref_pts, pts, ref_len, lengths, radius)[:, :limit]
+    got = neighbors.radius_search(ref_pts.to(DEV), pts.to(DEV), ref_len, lengths, radius, limit).cpu()
+    total = pts.shape[0]
+    for r in range(ref.shape[0]):
+        a = set(int(v) for v in ref[r].tolist() if v < total)
+        b = set(int(v) for v in got[r].tolist() if v < total)
+        assert a == b or (len(a) == limit and len(b) == limit), r   # a full row may differ only in which equidistant tail entries it keeps
