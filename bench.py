@@ -530,6 +530,7 @@ def main():
         nmatch = pipe.warm(args.warmup)
         dts = timed_repeats(pipe.run, barrier, args.steps, repeats)
     dt = float(np.median(dts))   # this rank's seconds per timed region of args.steps steps
+    peak_headline_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30   # weights + planes + inputs + one private pool per captured hipGraph
     gathered = per_rank = gather_ms = None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
@@ -556,6 +557,7 @@ def main():
         # "f32": exact fp32 MFMA); storage, accumulation, KPConv aggregation and attention are fp32 either way
         "dtype": args.gemm,
         "repeats": repeats, "seconds_per_repeat": [round(x, 6) for x in dts], "distinct_frames_per_rank": len(frames),
+        "peak_mem_GB": round(peak_headline_gb, 2),
         "data": "synthetic", "launch": "eager" if args.eager else "hipGraph replay",
         "input_staging": "copied into per-slot static buffers" if (args.copy_inputs or args.eager) else "read in place (inputs resident in HBM, forward_async(inputs_stable=True))", "gemm_mode": args.gemm,
         "ranks": world if dist is None else dist.get_world_size(), "dist_backend": None if dist is None else args.dist_backend,

@@ -65,7 +65,10 @@ class CoFiI2P(nn.Module):
     (``COFI_GEMM``, "bf16x3" when unset).  The reference-named shim ``model.network.CoFiI2P`` defaults to "f32".  INTEGRATION.md
     states the accuracy contract."""
 
-    MAX_STABLE_GRAPHS = 64   # distinct (slot, input set) graphs kept for forward_async(inputs_stable=True)
+    # distinct (slot, input set) graphs kept for forward_async(inputs_stable=True).  Every captured graph owns a private memory pool with a
+    # full frame of intermediates (≈ 0.7 GB for a KITTI frame, `peak_mem_GB` of the bench line / graphs captured): a loader should recycle
+    # a RING of input buffers - one graph per (slot, ring entry) - not allocate fresh inputs per frame; past the limit forward_async raises
+    MAX_STABLE_GRAPHS = 64
     DEFAULT_ARITHMETIC = None   # None: follow ops.GEMM_MODE (COFI_GEMM); the model.network shim sets "f32"
 
     def __init__(self, opt, init: str = "synthetic", arithmetic: Optional[str] = None):
