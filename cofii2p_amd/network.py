@@ -66,7 +66,8 @@ class CoFiI2P(nn.Module):
     states the accuracy contract."""
 
     # distinct (slot, input set) graphs kept for forward_async(inputs_stable=True).  Every captured graph owns a private memory pool with a
-    # full frame of intermediates (≈ 0.7 GB for a KITTI frame, `peak_mem_GB` of the bench line / graphs captured): a loader should recycle
+    # full frame of intermediates (≈ 0.1 GB for a KITTI frame: the bench's 16 graphs + weights + planes + inputs peak at 2.35 GB, `peak_mem_GB`;
+    # the stress configuration ≈ 20 GB): a loader should recycle
     # a RING of input buffers - one graph per (slot, ring entry) - not allocate fresh inputs per frame; past the limit forward_async raises
     MAX_STABLE_GRAPHS = 64
     DEFAULT_ARITHMETIC = None   # None: follow ops.GEMM_MODE (COFI_GEMM); the model.network shim sets "f32"
