@@ -228,7 +228,8 @@ def kernel_rooflines(model, dev, args, Bsz, frame=None, batch=None):
                            "traffic": None if pmc is None else pmc.get("traffic_bytes_per_launch"),
                            "traffic_collected_on": None if pmc is None else pmc.get("collected_on"),
                            "algorithmic_bytes_per_launch": d["bytes_per_frame"] / d["launches_per_frame"],
-                           "launches_per_frame": d["launches_per_frame"], "avg_launch_us": 1e6 * d["seconds_per_frame"] / d["launches_per_frame"]}
+                           "launches_per_frame": d["launches_per_frame"], "avg_launch_us": 1e6 * d["seconds_per_frame"] / d["launches_per_frame"],
+                           "algorithmic_gflop_per_frame": d["flops_per_frame"] / 1e9}
     else:
         ach = d["bytes_per_frame"] / d["seconds_per_frame"] / 1e9
         out["roofline"] = {"kernel": "cofi_" + dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -612,6 +613,11 @@ def main():
             result.update(kernel_rooflines(model, dev, args, 1, frame=frames[0]))
         else:
             result.update(kernel_rooflines(model, dev, args, Bsz, batch=batches[0]))
+        rf = result.get("roofline", {})
+        if rf.get("bound") == "mfma" and "algorithmic_gflop_per_frame" in rf:
+            # `frac` prices one launch at a time (isolated replay); with frames in flight the kernels share the chip, so the family's
+            # share of the chip over the whole timed region is its work per frame x frames/s (per GPU) over the same peak
+            rf["chip_level_frac"] = rf["algorithmic_gflop_per_frame"] * 1e9 * (result["value"] / world) / (rf["peak"] * 1e12)
     if rank == 0 and world == 1 and Bsz == 1 and not args.eager and not args.no_batch_sweep:
         # additional information (BASELINE configs[2]): the same frames in stack-mode batches through the same kernels
         model.enable_graphs(True)
