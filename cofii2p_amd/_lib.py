@@ -86,6 +86,14 @@ SIGNATURES = {
     "cofi_desc_loss": (_I, [_P, _I, _P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _I, _P, _I, _P, _Z, _P]),
     "cofi_fine_circle_loss": (_I, [_P, _P, _I, _P, _I, _I, _F, _F, _P, _P, _P, _P, _P, _I, _P]),
     "cofi_overlap_loss": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P]),
+    "cofi_kpconv_aggregate_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _F, _P, _I, _P]),
+    "cofi_neighbor_maxpool_arg": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _P, _P]),
+    "cofi_neighbor_maxpool_bwd": (_I, [_P, _I, _P, _I, _I, _P, _P, _I, _P, _I, _P]),
+    "cofi_gather_rows_bwd": (_I, [_P, _I, _I, _P, _P, _I, _P, _I, _P]),
+    "cofi_im2col_nhwc": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "cofi_col2im_nhwc": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "cofi_attention_bwd_workspace": (_Z, [_I, _I]),
+    "cofi_attention_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _I, _P, _I, _P, _I, _P, _Z, _P]),
     "cofi_pnp_ransac": (_I, [_P, _P, _P, _I, _F, _F, _F, _F, _I, _F, ctypes.c_uint, _I, _P, _Z, _P, _P, _P, _P]),
     "cofi_fine_match": (_I, [_P, _P, _I, _I, _P, _I, _F, _P, _I, _P, _P, _P]),
     "cofi_kpconv_fused_slab_rows": (_I, [_I, _I, _I]),

@@ -1,0 +1,410 @@
+// Backward kernels of the training path: the adjoints of the three operators that carry the gradient
+// through the network - KPConv aggregation, attention, convolution (as im2col / col2im around the GEMM) - and of the two neighbour
+// gathers.  The GEMMs of the backward are the forward's own kernel on transposed operands (cofii2p_amd/autograd.py).
+// Reference: what torch.autograd derives for model/kpconv/kpconv.py:91-116, model/transformer/linear_attention.py:56-79,
+// model/kpconv/functional.py:5-21,53-66 when train.py:285 calls loss.backward().
+//
+// SCATTER-FREE.  Every forward gather  y[m] = f(x[idx[m, h]])  has the adjoint  dx[j] = sum over the pairs (m, h) with idx[m, h] == j.
+// Instead of float atomics (order-dependent sums) the host hands over the TRANSPOSED table of idx in CSR form - pair ids m * H + h
+// sorted by (j, m, h), offsets per j - and one wave per support row j walks its own list in that fixed order: every gradient row is
+// written once, coalesced, and the result is bit-reproducible.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// KPConv aggregation, adjoint w.r.t. the support features:
+//   forward   agg[m, k, c] = sum_h w(m, h, k) f[idx[m, h], c],   w = max(1 - |(s[idx] - q[m]) - kp[k]| / sigma, 0)   (kpconv.py:93-105)
+//   adjoint   df[j, c]     = sum_{(m, h): idx[m, h] = j} sum_k w(m, h, k) dagg[m, k, c]
+// One wave per (support row j, chunk of 64 channels), lane = channel.  The influence weights of a pair are recomputed from the
+// geometry (uniform over the wave); only kernel points with w > 0 - typically 1-3 of 15 - cost a (coalesced, 256-byte) load of dagg.
+// C = 32: the two half-waves take alternate pairs and are folded once at the end (fixed order).
+struct KpBwdArgs {
+    const float *dagg, *q_pts, *s_pts, *kp;
+    const int32_t *pairs, *offsets;
+    float *dfeats;
+    int ldd, ldf, N, C, H;
+    float inv_sigma;
+};
+
+__global__ __launch_bounds__(256) void kpconv_aggregate_bwd_kernel(KpBwdArgs a) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int CW = a.C >= 64 ? 64 : a.C;          // channels a wave covers per pass (C < 64: 64 / CW pairs side by side)
+    const int chunks = (a.C + CW - 1) / CW;
+    const int j = wave / chunks, ch = wave - j * chunks;
+    if (j >= a.N) return;
+    const int NS = 64 / CW, sub = lane / CW, c = ch * CW + (lane - sub * CW);
+    const bool c_ok = c < a.C && sub < NS;
+    const float sx = a.s_pts[3 * j], sy = a.s_pts[3 * j + 1], sz = a.s_pts[3 * j + 2];
+    const int p0 = a.offsets[j], p1 = a.offsets[j + 1];
+    float acc = 0.f;
+    for (int p = p0 + sub; p < p1; p += NS) {
+        const int pair = a.pairs[p];
+        const int m = pair / a.H;
+        const float ox = sx - a.q_pts[3 * m], oy = sy - a.q_pts[3 * m + 1], oz = sz - a.q_pts[3 * m + 2];
+        const float *d = a.dagg + (size_t)m * a.ldd + c;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) {
+            const float dx = ox - a.kp[3 * k], dy = oy - a.kp[3 * k + 1], dz = oz - a.kp[3 * k + 2];
+            const float sq = (dx * dx + dy * dy) + dz * dz;
+            const float w = fmaxf(1.0f - __builtin_amdgcn_sqrtf(sq) * a.inv_sigma, 0.0f);
+            if (w > 0.f && c_ok) acc = fmaf(w, d[(size_t)k * a.C], acc);
+        }
+    }
+    // fold the NS side-by-side partial sums (lanes with equal channel) in a fixed order
+    for (int o = 32; o >= CW; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (c_ok && sub == 0) a.dfeats[(size_t)j * a.ldf + c] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Neighbour max-pool with the arg-max (functional.py:53-66: x padded with a zero row, max over the H neighbours; the first
+// neighbour attaining the maximum receives the gradient).  One thread per (query, channel).
+__global__ void neighbor_maxpool_arg_kernel(const float *x, int ldx, int N, int C, const int32_t *idx, int M, int H, float *out, int ldo,
+                                            int32_t *arg) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)M * C) return;
+    const int m = (int)(t / C), c = (int)(t - (size_t)m * C);
+    float best = -INFINITY;
+    int bh = 0;
+    for (int h = 0; h < H; ++h) {
+        const int id = idx[(size_t)m * H + h];
+        const float v = (id >= 0 && id < N) ? x[(size_t)id * ldx + c] : 0.f;
+        if (v > best) { best = v; bh = h; }
+    }
+    out[(size_t)m * ldo + c] = best;
+    arg[(size_t)m * C + c] = bh;
+}
+
+// dx[j, c] = sum over the pairs (m, h) of row j with arg[m, c] == h of dy[m, c]; one wave per (j, 64-channel chunk)
+__global__ __launch_bounds__(256) void neighbor_maxpool_bwd_kernel(const float *dy, int ldy, const int32_t *arg, int C, int H, const int32_t *pairs,
+                                                                   const int32_t *offsets, int N, float *dx, int ldx) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int chunks = (C + 63) / 64;
+    const int j = wave / chunks, c = (wave - j * chunks) * 64 + lane;
+    if (j >= N || c >= C) return;
+    float acc = 0.f;
+    for (int p = offsets[j]; p < offsets[j + 1]; ++p) {
+        const int pair = pairs[p], m = pair / H, h = pair - m * H;
+        if (arg[(size_t)m * C + c] == h) acc += dy[(size_t)m * ldy + c];
+    }
+    dx[(size_t)j * ldx + c] = acc;
+}
+
+// adjoint of out[m] = x[idx[m * stride]] (functional.py:5-21 nearest_upsample; any row gather): dx[j] = sum over the rows m of
+// list j of dy[m].  pairs = row ids m sorted by (j, m).
+__global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float *dy, int ldy, int C, const int32_t *pairs, const int32_t *offsets, int N,
+                                                              float *dx, int ldx) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int chunks = (C + 63) / 64;
+    const int j = wave / chunks, c = (wave - j * chunks) * 64 + lane;
+    if (j >= N || c >= C) return;
+    float acc = 0.f;
+    for (int p = offsets[j]; p < offsets[j + 1]; ++p) acc += dy[(size_t)pairs[p] * ldy + c];
+    dx[(size_t)j * ldx + c] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Convolution as a GEMM with an explicit operand (training only: the weight gradient needs the unfolded input anyway).
+//   col[(oy, ox), (dy * ks + dx) * C + c] = x[(oy * stride + dy - pad, ox * stride + dx - pad), c]   (0 outside the map)
+// and its adjoint in gather form (one thread per input pixel and 4 channels sums the taps that touched it: no atomics).
+__global__ void im2col_nhwc_kernel(const float *x, int ldx, int H, int W, int C, int ks, int stride, int pad, int Ho, int Wo, float *col, int ldc) {
+    const int C4 = C >> 2, taps = ks * ks;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)Ho * Wo * taps * C4) return;
+    const int c4 = (int)(t % C4);
+    const int tap = (int)((t / C4) % taps);
+    const int m = (int)(t / ((size_t)C4 * taps));
+    const int oy = m / Wo, ox = m - oy * Wo, dy = tap / ks, dx = tap - dy * ks;
+    const int y = oy * stride + dy - pad, xx = ox * stride + dx - pad;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (y >= 0 && y < H && xx >= 0 && xx < W) v = *reinterpret_cast<const f32x4 *>(x + ((size_t)y * W + xx) * ldx + 4 * c4);
+    *reinterpret_cast<f32x4 *>(col + (size_t)m * ldc + (size_t)tap * C + 4 * c4) = v;
+}
+
+__global__ void col2im_nhwc_kernel(const float *dcol, int ldc, int H, int W, int C, int ks, int stride, int pad, int Ho, int Wo, float *dx, int ldx) {
+    const int C4 = C >> 2;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)H * W * C4) return;
+    const int c4 = (int)(t % C4);
+    const int pix = (int)(t / C4);
+    const int y = pix / W, xx = pix - y * W;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int dy = 0; dy < ks; ++dy) {
+        const int ny = y + pad - dy;
+        if (ny < 0 || ny % stride) continue;
+        const int oy = ny / stride;
+        if (oy >= Ho) continue;
+        for (int dxx = 0; dxx < ks; ++dxx) {
+            const int nx = xx + pad - dxx;
+            if (nx < 0 || nx % stride) continue;
+            const int ox = nx / stride;
+            if (ox >= Wo) continue;
+            acc += *reinterpret_cast<const f32x4 *>(dcol + ((size_t)oy * Wo + ox) * ldc + (size_t)(dy * ks + dxx) * C + 4 * c4);
+        }
+    }
+    *reinterpret_cast<f32x4 *>(dx + (size_t)pix * ldx + 4 * c4) = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Attention backward (recompute style: the (L, S) probability matrix is never stored) on the exact fp32 matrix instruction
+// v_mfma_f32_32x32x2_f32, head dimension 32.  With P = softmax(scale Q K^T), O = P V:
+//   delta_i = dO_i . O_i,   dP = dO V^T,   dS = P o (dP - delta) scale,   dQ = dS K,   dK = dS^T Q,   dV = P^T dO.
+// Two kernels, one wave per 32-row block of one head:
+//   attention_bwd_dq_kernel   (query block)  pass 1 recomputes the row log-sum-exp, pass 2 accumulates dQ; writes {lse, delta} per
+//                                            query to the workspace,
+//   attention_bwd_dkv_kernel  (key block)    loops over the query blocks with that workspace and accumulates dK, dV.
+// Operand layouts follow the forward kernel (attention.hip): a score tile is computed TRANSPOSED so that one lane owns one row of the
+// block it accumulates for (the query in the dQ kernel, the key in the dK/dV kernel) - softmax statistics are per-lane scalars - and
+// the MFMA D layout of that tile is directly the B operand of the second product.  MFMA 32x32x2: lane l supplies A[l & 31][l >> 5] and
+// B[l >> 5][l & 31]; D register r of lane l is D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31].
+constexpr int AD = 32, ALD = AD + 4;   // head dimension; LDS tile row stride (floats): b128 rows and b32 columns both conflict free
+
+struct AttnBwdArgs {
+    const float *Q, *K, *V, *O, *dO;
+    float *dQ, *dK, *dV, *stat;   // stat (H, L, 2) = {lse in log2 units, delta}
+    int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, L, S, H;
+    float scale, scale_log2e;
+};
+
+__device__ __forceinline__ float bw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// stage rows [r0, r0 + 32) (clamped to nrows - 1) x 32 columns starting at `src` into an LDS tile; one wave
+__device__ __forceinline__ void stage_tile(float *tile, const float *src, int ld, int r0, int nrows, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = lane + 64 * i, r = e >> 3, c4 = e & 7;
+        const int row = min(r0 + r, nrows - 1);
+        *reinterpret_cast<f32x4 *>(tile + r * ALD + 4 * c4) = *reinterpret_cast<const f32x4 *>(src + (size_t)row * ld + 4 * c4);
+    }
+}
+
+// acc(32 x 32) = T . F^T: T = LDS tile rows (A operand, row = lane & 31), F = per-lane fragments frag[c][e] = X[row(lane & 31)][8c + 4 (lane >> 5) + e]
+__device__ __forceinline__ f32x16 tile_dot(const float *tile, const f32x4 (&frag)[4], int li, int lh) {
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(tile + li * ALD + 8 * c + 4 * lh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t[e], frag[c][e], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// acc(32 x 32)[d][col = lane & 31] += sum_t tile[row_t][d] * b[t], row_t = (t & 3) + 8 (t >> 2) + 4 (lane >> 5): the transposed tile times a
+// D-layout operand
+__device__ __forceinline__ void tile_t_dot_acc(f32x16 &acc, const float *tile, const f32x16 &b, int li, int lh) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int row = (t & 3) + 8 * (t >> 2) + 4 * lh;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[row * ALD + li], b[t], acc, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void load_frag(f32x4 (&frag)[4], const float *row_ptr, int lh) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) frag[c] = *reinterpret_cast<const f32x4 *>(row_ptr + 8 * c + 4 * lh);
+}
+
+// rows d = 8 g + 4 lh + e of the transposed accumulator are 4 contiguous columns of the output row this lane owns
+__device__ __forceinline__ void store_acc_t(float *row_ptr, const f32x16 &acc, int lh) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        *reinterpret_cast<f32x4 *>(row_ptr + 8 * g + 4 * lh) = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void attention_bwd_dq_kernel(AttnBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_k[32 * ALD], s_v[32 * ALD];
+    const int lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
+    const int qb = blockIdx.x, h = blockIdx.y;
+    const int q = min(qb * 32 + li, a.L - 1);
+    const bool q_ok = qb * 32 + li < a.L;
+    f32x4 qf[4], dof[4], of[4];
+    load_frag(qf, a.Q + (size_t)q * a.ldq + h * AD, lh);
+    load_frag(dof, a.dO + (size_t)q * a.lddo + h * AD, lh);
+    load_frag(of, a.O + (size_t)q * a.ldo + h * AD, lh);
+    float delta = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) delta = fmaf(dof[c][e], of[c][e], delta);
+    delta += __shfl_xor(delta, 32, 64);
+    const int nkb = (a.S + 31) / 32;
+    // ---- pass 1: row maximum and sum of exponentials (log2 domain), this lane's 16 keys of every block
+    float mx = -INFINITY, sum = 0.f;
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();
+        stage_tile(s_k, a.K + h * AD, a.ldk, kb * 32, a.S, lane);
+        __syncthreads();
+        const f32x16 st = tile_dot(s_k, qf, li, lh);
+        float sv[16], bm = mx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            sv[r] = key < a.S ? st[r] * a.scale_log2e : -INFINITY;
+            bm = fmaxf(bm, sv[r]);
+        }
+        if (bm > -INFINITY) {
+            sum *= bw_exp2(mx - bm);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += bw_exp2(sv[r] - bm);
+            mx = bm;
+        }
+    }
+    {   // join the two halves of the query's keys
+        const float om = __shfl_xor(mx, 32, 64), os = __shfl_xor(sum, 32, 64);
+        const float m2 = fmaxf(mx, om);
+        const float s0 = mx > -INFINITY ? sum * bw_exp2(mx - m2) : 0.f, s1 = om > -INFINITY ? os * bw_exp2(om - m2) : 0.f;
+        sum = lh == 0 ? s0 + s1 : s1 + s0;   // the same association in both halves
+        mx = m2;
+    }
+    const float lse = mx + __builtin_amdgcn_logf(sum);   // v_log_f32 = log2
+    if (q_ok && lh == 0) {
+        float *st = a.stat + ((size_t)h * a.L + q) * 2;
+        st[0] = lse;
+        st[1] = delta;
+    }
+    // ---- pass 2: dQ^T[d, q] += K^T dS^T
+    f32x16 dq = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();
+        stage_tile(s_k, a.K + h * AD, a.ldk, kb * 32, a.S, lane);
+        stage_tile(s_v, a.V + h * AD, a.ldv, kb * 32, a.S, lane);
+        __syncthreads();
+        const f32x16 st = tile_dot(s_k, qf, li, lh);
+        const f32x16 dp = tile_dot(s_v, dof, li, lh);
+        f32x16 ds;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float p = key < a.S ? bw_exp2(st[r] * a.scale_log2e - lse) : 0.f;
+            ds[r] = p * (dp[r] - delta) * a.scale;
+        }
+        tile_t_dot_acc(dq, s_k, ds, li, lh);
+    }
+    if (q_ok) store_acc_t(a.dQ + (size_t)q * a.lddq + h * AD, dq, lh);
+}
+
+__global__ __launch_bounds__(64) void attention_bwd_dkv_kernel(AttnBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_q[32 * ALD], s_do[32 * ALD], s_stat[64];
+    const int lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
+    const int kb = blockIdx.x, h = blockIdx.y;
+    const int key = min(kb * 32 + li, a.S - 1);
+    const bool k_ok = kb * 32 + li < a.S;
+    f32x4 kf[4], vf[4];
+    load_frag(kf, a.K + (size_t)key * a.ldk + h * AD, lh);
+    load_frag(vf, a.V + (size_t)key * a.ldv + h * AD, lh);
+    f32x16 dk = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dv = dk;
+    const int nqb = (a.L + 31) / 32;
+    for (int qb = 0; qb < nqb; ++qb) {
+        __syncthreads();
+        stage_tile(s_q, a.Q + h * AD, a.ldq, qb * 32, a.L, lane);
+        stage_tile(s_do, a.dO + h * AD, a.lddo, qb * 32, a.L, lane);
+        {
+            const int qi = min(qb * 32 + (lane >> 1), a.L - 1);
+            s_stat[lane] = a.stat[((size_t)h * a.L + qi) * 2 + (lane & 1)];
+        }
+        __syncthreads();
+        const f32x16 s = tile_dot(s_q, kf, li, lh);      // S[i][j]: rows = queries, column = this lane's key
+        const f32x16 dp = tile_dot(s_do, vf, li, lh);    // dP[i][j] = dO_i . V_j
+        f32x16 p, ds;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float pv = qb * 32 + i < a.L ? bw_exp2(s[r] * a.scale_log2e - s_stat[2 * i]) : 0.f;
+            p[r] = pv;
+            ds[r] = pv * (dp[r] - s_stat[2 * i + 1]) * a.scale;
+        }
+        tile_t_dot_acc(dv, s_do, p, li, lh);    // dV^T[d, j] += dO^T P
+        tile_t_dot_acc(dk, s_q, ds, li, lh);    // dK^T[d, j] += Q^T dS
+    }
+    if (k_ok) {
+        store_acc_t(a.dK + (size_t)key * a.lddk + h * AD, dk, lh);
+        store_acc_t(a.dV + (size_t)key * a.lddv + h * AD, dv, lh);
+    }
+}
+
+inline bool bad_mat(const void *p, int ld, int cols) { return !p || ld < cols || (ld & 3) || ((uintptr_t)p & 15); }
+
+}  // namespace
+
+extern "C" int cofi_kpconv_aggregate_bwd(const float *dagg, int ldd, const float *q_pts, const float *s_pts, const int32_t *pairs,
+                                         const int32_t *offsets, int N, int C, int H, const float *kernel_points, float sigma, float *dfeats,
+                                         int ldf, cofi_stream_t stream) {
+    if (!dagg || !q_pts || !s_pts || !pairs || !offsets || !kernel_points || !dfeats || N <= 0 || C <= 0 || H <= 0 || ldd < 15 * C || ldf < C ||
+        !(sigma > 0.f))
+        return COFI_EINVAL;
+    if (C < 64 && (C & (C - 1))) return COFI_EUNSUPPORTED;   // narrow layers: a power of two (the network has 32)
+    KpBwdArgs a{dagg, q_pts, s_pts, kernel_points, pairs, offsets, dfeats, ldd, ldf, N, C, H, 1.0f / sigma};
+    const int CW = C >= 64 ? 64 : C, chunks = (C + CW - 1) / CW;
+    const long waves = (long)N * chunks;
+    hipLaunchKernelGGL(kpconv_aggregate_bwd_kernel, dim3(cofi_cdiv(waves, 4)), dim3(256), 0, cofi_s(stream), a);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_neighbor_maxpool_arg(const float *x, int ldx, int N, int C, const int32_t *idx, int M, int H, float *out, int ldo, int32_t *arg,
+                                         cofi_stream_t stream) {
+    if (!x || !idx || !out || !arg || N <= 0 || C <= 0 || M < 0 || H <= 0 || ldx < C || ldo < C) return COFI_EINVAL;
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(neighbor_maxpool_arg_kernel, dim3(cofi_cdiv((long)M * C, 256)), dim3(256), 0, cofi_s(stream), x, ldx, N, C, idx, M, H, out, ldo,
+                       arg);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_neighbor_maxpool_bwd(const float *dy, int ldy, const int32_t *arg, int C, int H, const int32_t *pairs, const int32_t *offsets,
+                                         int N, float *dx, int ldx, cofi_stream_t stream) {
+    if (!dy || !arg || !pairs || !offsets || !dx || N <= 0 || C <= 0 || H <= 0 || ldy < C || ldx < C) return COFI_EINVAL;
+    const long waves = (long)N * ((C + 63) / 64);
+    hipLaunchKernelGGL(neighbor_maxpool_bwd_kernel, dim3(cofi_cdiv(waves, 4)), dim3(256), 0, cofi_s(stream), dy, ldy, arg, C, H, pairs, offsets, N, dx,
+                       ldx);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_gather_rows_bwd(const float *dy, int ldy, int C, const int32_t *pairs, const int32_t *offsets, int N, float *dx, int ldx,
+                                    cofi_stream_t stream) {
+    if (!dy || !pairs || !offsets || !dx || N <= 0 || C <= 0 || ldy < C || ldx < C) return COFI_EINVAL;
+    const long waves = (long)N * ((C + 63) / 64);
+    hipLaunchKernelGGL(gather_rows_bwd_kernel, dim3(cofi_cdiv(waves, 4)), dim3(256), 0, cofi_s(stream), dy, ldy, C, pairs, offsets, N, dx, ldx);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_im2col_nhwc(const float *x, int ldx, int H, int W, int C, int ks, int stride, int pad, float *col, int ldc,
+                                cofi_stream_t stream) {
+    if (H <= 0 || W <= 0 || C <= 0 || (C & 3) || ks <= 0 || stride <= 0 || pad < 0 || bad_mat(x, ldx, C) || bad_mat(col, ldc, ks * ks * C))
+        return COFI_EINVAL;
+    const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return COFI_EINVAL;
+    const long n = (long)Ho * Wo * ks * ks * (C / 4);
+    hipLaunchKernelGGL(im2col_nhwc_kernel, dim3(cofi_cdiv(n, 256)), dim3(256), 0, cofi_s(stream), x, ldx, H, W, C, ks, stride, pad, Ho, Wo, col, ldc);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_col2im_nhwc(const float *dcol, int ldc, int H, int W, int C, int ks, int stride, int pad, float *dx, int ldx,
+                                cofi_stream_t stream) {
+    if (H <= 0 || W <= 0 || C <= 0 || (C & 3) || ks <= 0 || stride <= 0 || pad < 0 || bad_mat(dx, ldx, C) || bad_mat(dcol, ldc, ks * ks * C))
+        return COFI_EINVAL;
+    const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return COFI_EINVAL;
+    const long n = (long)H * W * (C / 4);
+    hipLaunchKernelGGL(col2im_nhwc_kernel, dim3(cofi_cdiv(n, 256)), dim3(256), 0, cofi_s(stream), dcol, ldc, H, W, C, ks, stride, pad, Ho, Wo, dx, ldx);
+    return cofi_launch_status();
+}
+
+extern "C" size_t cofi_attention_bwd_workspace(int L, int H) { return (size_t)L * H * 2 * sizeof(float); }
+
+extern "C" int cofi_attention_bwd(const float *q, int ldq, const float *k, int ldk, const float *v, int ldv, const float *o, int ldo,
+                                  const float *d_o, int lddo, int L, int S, int H, int D, float scale, float *dq, int lddq, float *dk, int lddk,
+                                  float *dv, int lddv, void *ws, size_t ws_bytes, cofi_stream_t stream) {
+    if (L <= 0 || S <= 0 || H <= 0) return COFI_EINVAL;
+    if (D != AD) return COFI_EUNSUPPORTED;
+    const int HD = H * D;
+    if (bad_mat(q, ldq, HD) || bad_mat(k, ldk, HD) || bad_mat(v, ldv, HD) || bad_mat(o, ldo, HD) || bad_mat(d_o, lddo, HD) || bad_mat(dq, lddq, HD) ||
+        bad_mat(dk, lddk, HD) || bad_mat(dv, lddv, HD))
+        return COFI_EINVAL;
+    if (!ws || ws_bytes < cofi_attention_bwd_workspace(L, H)) return COFI_EWORKSPACE;
+    AttnBwdArgs a{q, k, v, o, d_o, dq, dk, dv, (float *)ws, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, L, S, H, scale, scale * 1.4426950408889634f};
+    hipLaunchKernelGGL(attention_bwd_dq_kernel, dim3((L + 31) / 32, H), dim3(64), 0, cofi_s(stream), a);
+    hipLaunchKernelGGL(attention_bwd_dkv_kernel, dim3((S + 31) / 32, H), dim3(64), 0, cofi_s(stream), a);
+    return cofi_launch_status();
+}

@@ -4,8 +4,9 @@
 layout (model/network.py:14-164; 430 tensors, strict-loadable: evaluation/eval_all.py:49), so it
 drops into `evaluation/eval_all.py` / `train.py`-style callers under PyTorch-ROCm.  Underneath,
 forward enqueues hand-written gfx950 kernels through the C ABI of libcofi_hip.so
-(include/cofi_hip.h).  Inference only (`torch.no_grad()` semantics): there is no autograd (mode='train' with
-gradients enabled raises) and no CPU path — the module raises if the HIP library is missing or a tensor is not on the GPU.
+(include/cofi_hip.h).  Inference runs the fused kernel sequence (no graph behind the outputs); mode='train' with autograd enabled runs
+the differentiable form of the same network (train_forward.py: HIP kernels forward and backward).  There is no CPU path — the module
+raises if the HIP library is missing or a tensor is not on the GPU.
 """
 import os
 from typing import Dict, List, Optional
@@ -36,7 +37,7 @@ def _attach(root: nn.Module, name: str, shape, dtype: str):
     if is_buffer(name):
         node.register_buffer(parts[-1], t)
     else:
-        node.register_parameter(parts[-1], nn.Parameter(t, requires_grad=False))
+        node.register_parameter(parts[-1], nn.Parameter(t))   # learnable, as in the reference (train.py:163 filters on requires_grad)
 
 
 def score_thresholds(n: int = 64) -> np.ndarray:
@@ -92,6 +93,7 @@ class CoFiI2P(nn.Module):
             self.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(norm=self.pc_norm_kind).items()}, strict=True)
         self._packed: Optional[Dict[str, torch.Tensor]] = None
         self._packed_key = None
+        self._trained = False   # set by the first differentiable forward: from then on _pack() watches the parameters' version counters
         self.compute_unused_image_maps = True  # layer3/layer4/avg-pool of the ResNet (network.py:87-89)
         self._use_graphs = False
         self._graphs = {}
@@ -114,9 +116,18 @@ class CoFiI2P(nn.Module):
         self._graphs = {}
         return super()._apply(fn, *a, **k)
 
+    def _param_versions(self) -> int:
+        return sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
+
     def _pack(self, device) -> Dict[str, torch.Tensor]:
-        if self._packed is not None and self._packed_key == device:
+        # the packed (folded, pre-split) weights are a function of the parameters: an optimizer step (in-place update, train.py:286)
+        # bumps the tensors' version counters, and the next inference forward (train.py's validation pass) packs again
+        # (checked only once the training path has run: the serving loop does not pay for 430 version reads per frame)
+        stamp = (device, self._param_versions() if self._trained else 0)
+        if self._packed is not None and self._packed_key == stamp:
             return self._packed
+        if self._packed is not None:
+            self._graphs = {}
         sd = {k: v.detach() for k, v in self.state_dict().items()}
         for k, v in sd.items():
             if v.device != device:
@@ -142,7 +153,7 @@ class CoFiI2P(nn.Module):
             for k in list(d):
                 if gemm_weight(k, d[k]):
                     d[k] = ops.presplit(d[k])
-        self._packed, self._packed_key = P, device
+        self._packed, self._packed_key = P, stamp
         return P
 
     # ------------------------------------------------------------------ forward pieces
@@ -458,13 +469,28 @@ class CoFiI2P(nn.Module):
     def forward(self, pc_data_dict, img, fine_center_kpt_coors, fine_xy, fine_pc_inline_index, mode, taps=None):
         """model/network.py:74-164.  ``fine_xy`` is unused (as in the reference).
 
-        Inference only: the HIP kernels have no backward (SURVEY.md §8 row f3 is not built).  A caller that expects a graph -
-        mode='train' with autograd enabled (train.py:224-226 followed by loss.backward(), train.py:285), or any input that
-        requires grad - gets an error instead of tensors that silently carry no gradient; train.py's validation pass
-        (mode='val' under torch.no_grad(), train.py:66-70) and evaluation/eval_all.py are served."""
-        if torch.is_grad_enabled() and (mode == "train" or img.requires_grad or pc_data_dict["feats"].requires_grad):
-            raise NotImplementedError("cofii2p_amd.CoFiI2P is forward-only (no autograd through the HIP kernels): call it under "
-                                      "torch.no_grad() for inference / validation; training needs the reference's PyTorch model")
+        TRAINING (train.py:224-226 followed by loss.backward(), train.py:285): mode='train' with autograd enabled - or mode 'train' /
+        'val' on a module in train() mode - runs `train_forward.forward_train`: the same network as a torch.autograd graph over this
+        module's parameters whose operators (every weight contraction, the KPConv aggregation, attention, the neighbour gathers) are
+        HIP kernels in both directions; BatchNorm of the up-sampler then uses batch statistics and updates its running buffers, as the
+        reference's module does under train().  norm == 'gn' only.
+        INFERENCE: everything else - evaluation/eval_all.py, train.py's validation pass (model.eval(), mode='val' under
+        torch.no_grad(), train.py:66-70) - runs the fused, folded kernel sequence (optionally a hipGraph) and returns tensors without a
+        graph.  mode='test' is never differentiable (its match selection is a host-visible count, network.py:145-151): inputs that
+        require grad are refused there instead of silently losing their gradient."""
+        if mode in ("train", "val") and (self.training or (mode == "train" and torch.is_grad_enabled())
+                                         or (torch.is_grad_enabled() and (img.requires_grad or pc_data_dict["feats"].requires_grad))):
+            from . import train_forward
+
+            self._trained = True
+            # gradients amplify the arithmetic's rounding (measured on the tiny frame: the 3-term bf16 split's 2^-16 per product becomes
+            # up to 1e-2 in a parameter gradient, exact fp32 stays at the reference's own fp32 level): training computes in "f32"
+            # unless the module was explicitly built with arithmetic="bf16x3"
+            with ops.arithmetic(self.arithmetic if self.arithmetic is not None else "f32"):
+                return train_forward.forward_train(self, pc_data_dict, img, fine_center_kpt_coors, fine_pc_inline_index)
+        if torch.is_grad_enabled() and (img.requires_grad or pc_data_dict["feats"].requires_grad):
+            raise NotImplementedError("mode='test' is not differentiable (host-side match selection, network.py:145-151): call it under "
+                                      "torch.no_grad(); gradients flow through mode='train'")
         if self.training and self.pc_norm_kind == "bn":
             raise NotImplementedError("opt.norm == 'bn' is served with running statistics (module.eval()); batch statistics need the reference's model")
         with torch.no_grad(), ops.arithmetic(self.arithmetic):

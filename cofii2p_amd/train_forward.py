@@ -1,0 +1,247 @@
+"""CoFiI2P.forward(mode='train') with autograd enabled: the differentiable form of the forward.
+
+The same network as `network.CoFiI2P._run_device`, expressed as a torch.autograd graph over the module's own nn.Parameters so that
+train.py:224-288 (forward -> losses -> loss.backward() -> optimizer.step()) runs on this module.  Everything that carries weight or
+moves data between rows - every nn.Linear / nn.Conv2d / KPConv contraction, the KPConv neighbour aggregation, attention, the
+neighbour max-pool and up-sample gathers - is a `cofii2p_amd.autograd` Function whose forward AND backward are hand-written gfx950
+kernels.  The row-local glue between them (normalisations, activations, the bilinear x2, the 3x3 max-pool of the ResNet stem) is
+written with torch's differentiable tensor ops on the same device buffers: the "torch fallback" SURVEY.md row f3 allows for the parts
+that carry no weight.  Activations are pixel-major / point-major (rows, C) matrices as in the inference path.
+
+Differences from the inference path, all the reference's own train()-mode semantics:
+  * BatchNorm2d of the two ImageUpSample stages uses BATCH statistics and updates running_mean / running_var / num_batches_tracked
+    (imagenet.py:381-394 under model.train(), train.py:188);
+  * nothing is folded, fused across layers or captured in a hipGraph; ResNet layer3 / layer4 / avg-pool, which feed nothing
+    (network.py:87-89) and hold no state, are skipped.
+One frame per call (train.py's batch: `torch.squeeze` of a batch of 1).  norm == 'gn' only (the shipped configuration).
+"""
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, autograd as ag, ops
+from .spec import D_MODEL, DECODERS, ENCODER, GN_GROUPS, LAYER_KINDS, N_HEAD, RESNET_LAYERS
+
+LRELU = 0.1
+
+
+# ------------------------------------------------------------------------------------------ row-local glue
+def group_norm_rows(x, w, b, groups: int = GN_GROUPS, eps: float = 1e-5):
+    """modules.py:45-49: nn.GroupNorm over (1, C, N) - statistics over all rows and the channels of a group."""
+    return F.group_norm(x.t().unsqueeze(0), groups, w, b, eps).squeeze(0).t()
+
+
+def instance_norm_rows(x, eps: float = 1e-5):
+    """affine-less nn.InstanceNorm over the positions of one map = per-column normalisation of a (positions, C) matrix."""
+    var, mean = torch.var_mean(x, dim=0, unbiased=False, keepdim=True)
+    return (x - mean) * torch.rsqrt(var + eps)
+
+
+def batch_norm_rows(x, P, B, p: str, training: bool):
+    """nn.BatchNorm2d on a (1, C, H, W) map = BatchNorm over the rows of (H W, C); train mode: batch statistics + running update."""
+    nbt = B.get(p + "num_batches_tracked")
+    if training and nbt is not None:
+        nbt.add_(1)
+    return F.batch_norm(x, B[p + "running_mean"], B[p + "running_var"], P[p + "weight"], P[p + "bias"], training, 0.1, 1e-5)
+
+
+def pos_sine_table(coords: torch.Tensor) -> torch.Tensor:
+    """position_encoding.py:7-50 as a constant (no parameters, inputs need no gradient): (T, n) -> (T, 128)."""
+    out = torch.zeros((coords.shape[0], D_MODEL), dtype=torch.float32, device=coords.device)
+    return ops.pos_sine(coords.contiguous(), out, accumulate=False)
+
+
+# ------------------------------------------------------------------------------------------ point encoder (kp_backbone.py:79-128)
+def _unary(P, p, x, relu: bool = True, norm: bool = True):
+    y = ag.linear(x, P[p + "mlp.weight"], P[p + "mlp.bias"])
+    if norm:
+        y = group_norm_rows(y, P[p + "norm.norm.weight"], P[p + "norm.norm.bias"])
+    return F.leaky_relu(y, LRELU) if relu else y
+
+
+def _kpconv(P, B, p, feats, q_pts, s_pts, idx, sigma, tables):
+    """kpconv.py:79-122: aggregate, contract with the (15, Cin, Cout) weights, divide by the neighbour count, add the bias."""
+    w = P[p + "KPConv.weights"]
+    agg, cnt = ag.kpconv_aggregate(feats, q_pts, s_pts, idx, B[p + "KPConv.kernel_points"], sigma, tables)
+    w2 = w.permute(2, 0, 1).reshape(w.shape[2], -1)     # (Cout, 15 Cin): column k Cin + c, the aggregate's layout
+    return ag.linear(agg, w2, P[p + "KPConv.bias"], rowdiv=cnt)
+
+
+def _block(P, B, blk, feats, q_pts, s_pts, idx, tables):
+    p = "pc_encoder.%s." % blk.name
+    if blk.kind == "conv":   # modules.py:155-159
+        y = _kpconv(P, B, p, feats, q_pts, s_pts, idx, blk.sigma, tables)
+        return F.leaky_relu(group_norm_rows(y, P[p + "norm.norm.weight"], P[p + "norm.norm.bias"]), LRELU)
+    x = _unary(P, p + "unary1.", feats) if blk.cin != blk.mid else feats   # modules.py:222-240
+    x = _kpconv(P, B, p, x, q_pts, s_pts, idx, blk.sigma, tables)
+    x = F.leaky_relu(group_norm_rows(x, P[p + "norm_conv.norm.weight"], P[p + "norm_conv.norm.bias"]), LRELU)
+    x = _unary(P, p + "unary2.", x, relu=False)
+    sc = ag.neighbor_maxpool(feats, idx, tables) if blk.strided else feats
+    if blk.has_shortcut_unary:
+        sc = _unary(P, p + "unary_shortcut.", sc, relu=False)
+    return F.leaky_relu(x + sc, LRELU)
+
+
+def kpconv_fpn(P, B, points, neighbors, subsampling, upsampling, feats, tables) -> List[torch.Tensor]:
+    x = feats
+    stage_out = {}
+    for blk in ENCODER:
+        st = blk.stage
+        if blk.strided:
+            q, s, idx = points[st], points[st - 1], subsampling[st - 1]
+        else:
+            q, s, idx = points[st], points[st], neighbors[st]
+        x = _block(P, B, blk, x, q, s, idx, tables)
+        stage_out[st] = x
+    s5 = stage_out[4]
+    dec = {name: norm for name, _, _, norm in DECODERS}
+    l4 = _unary(P, "pc_encoder.decoder4.", torch.cat([ag.gather_rows(s5, upsampling[3], tables), stage_out[3]], 1), norm=dec["decoder4"])
+    l3 = _unary(P, "pc_encoder.decoder3.", torch.cat([ag.gather_rows(l4, upsampling[2], tables), stage_out[2]], 1), norm=dec["decoder3"])
+    l2 = ag.linear(torch.cat([ag.gather_rows(l3, upsampling[1], tables), stage_out[1]], 1), P["pc_encoder.decoder2.mlp.weight"],
+                   P["pc_encoder.decoder2.mlp.bias"])
+    return [l2, l3, l4, s5]
+
+
+# ------------------------------------------------------------------------------------------ image encoder (imagenet.py:119-217)
+def _nchw(x, H, W):
+    return x.t().reshape(1, x.shape[1], H, W)
+
+
+def _rows(x):
+    return x.reshape(x.shape[1], -1).t()
+
+
+def resnet34_s8(P, img: torch.Tensor):
+    """-> (s2, s4, s8) pixel-major maps with their (H, W): the stem, the max-pool and layer1 / layer2 of the ResNet-34."""
+    p = "img_encoder.backbone."
+    col, H, W = ops.im2col_stem(img.contiguous())                  # (Ho Wo, 160): 7 x 7 x 3 = 147 columns, zero padded
+    w = P[p + "conv1.weight"]
+    w2 = F.pad(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1), (0, col.shape[1] - 147))
+    x = F.relu(instance_norm_rows(ag.linear(col, w2)))
+    outs = [(x, H, W)]
+    x4 = F.max_pool2d(_nchw(x, H, W), 3, 2, 1)
+    H, W = x4.shape[2:]
+    x = _rows(x4)
+    for li, (planes, blocks, stride) in enumerate(RESNET_LAYERS[:2], start=1):
+        for b in range(blocks):
+            q = "%slayer%d.%d." % (p, li, b)
+            st = stride if b == 0 else 1
+            y, Ho, Wo = ag.conv2d(x, H, W, P[q + "conv1.weight"], st)
+            y = F.relu(instance_norm_rows(y))
+            y, _, _ = ag.conv2d(y, Ho, Wo, P[q + "conv2.weight"], 1)
+            y = instance_norm_rows(y)
+            if (q + "downsample.0.weight") in P:
+                d, _, _ = ag.conv2d(x, H, W, P[q + "downsample.0.weight"], st, pad=0)
+                x = F.relu(y + instance_norm_rows(d))
+            else:
+                x = F.relu(y + x)
+            H, W = Ho, Wo
+        outs.append((x, H, W))
+    return outs
+
+
+def _residual_conv(P, B, p, x, H, W, training):
+    """imagenet.py:377-411."""
+    identity = batch_norm_rows(ag.conv2d(x, H, W, P[p + "conv_skip.0.weight"])[0], P, B, p + "conv_skip.1.", training)
+    out = F.relu(batch_norm_rows(ag.conv2d(x, H, W, P[p + "conv1.weight"])[0], P, B, p + "bn1.", training))
+    out = batch_norm_rows(ag.conv2d(out, H, W, P[p + "conv2.weight"])[0], P, B, p + "bn2.", training)
+    return F.relu(out + identity)
+
+
+def image_upsample(P, B, name, low, h, w, skip, training):
+    """imagenet.py:431-444: bilinear x2 (align_corners=False), concat with the skip map, two ResidualConv."""
+    up = F.interpolate(_nchw(low, h, w), scale_factor=2, mode="bilinear", align_corners=False)
+    x = torch.cat([_rows(up), skip], 1)
+    x = _residual_conv(P, B, name + ".conv.0.", x, 2 * h, 2 * w, training)
+    return _residual_conv(P, B, name + ".conv.1.", x, 2 * h, 2 * w, training)
+
+
+# ------------------------------------------------------------------------------------------ transformer (transformer.py:43-104)
+def loftr_layer(P, p, x, src, nhead: int = N_HEAD):
+    q = ag.linear(x, P[p + "q_proj.weight"])
+    k = ag.linear(src, P[p + "k_proj.weight"])
+    v = ag.linear(src, P[p + "v_proj.weight"])
+    q = F.normalize(q, dim=0)   # transformer.py:53: F.normalize's default dim=1 on (1, L, H, D) = over the L tokens
+    msg = ag.attention(q, k, v, nhead)
+    C = x.shape[1]
+    msg = F.layer_norm(ag.linear(msg, P[p + "merge.weight"]), (C,), P[p + "norm1.weight"], P[p + "norm1.bias"])
+    h = ag.linear(F.relu(ag.linear(torch.cat([x, msg], 1), P[p + "mlp.0.weight"])), P[p + "mlp.2.weight"])
+    return x + F.layer_norm(h, (C,), P[p + "norm2.weight"], P[p + "norm2.bias"])
+
+
+def transformer(P, tok_img, tok_pc):
+    for l, kind in enumerate(LAYER_KINDS):
+        p = "transformer.layers.%d." % l
+        if kind == "self":
+            tok_img = loftr_layer(P, p, tok_img, tok_img)
+            tok_pc = loftr_layer(P, p, tok_pc, tok_pc)
+        else:   # the point stream attends to the ALREADY UPDATED image stream (transformer.py:99-100)
+            tok_img = loftr_layer(P, p, tok_img, tok_pc)
+            tok_pc = loftr_layer(P, p, tok_pc, tok_img)
+    return tok_img, tok_pc
+
+
+def score_head(P, head, tokens):
+    """network.py:42-43 on token-major data."""
+    w0, w3, w6 = (P["%s.%d.weight" % (head, i)] for i in (0, 3, 6))
+    y = F.relu(instance_norm_rows(ag.linear(tokens, w0.reshape(w0.shape[0], -1))))
+    y = F.relu(instance_norm_rows(ag.linear(y, w3.reshape(w3.shape[0], -1))))
+    return torch.sigmoid(ag.linear(y, w6.reshape(w6.shape[0], -1)))   # (T, 1)
+
+
+def pc_feature_mlp(P, x):
+    """network.py:29."""
+    p = "pc_feature_layer."
+    x = F.relu(F.layer_norm(ag.linear(x, P[p + "0.weight"]), (1024,), P[p + "1.weight"], P[p + "1.bias"]))
+    x = F.relu(F.layer_norm(ag.linear(x, P[p + "3.weight"]), (512,), P[p + "4.weight"], P[p + "4.bias"]))
+    return ag.linear(x, P[p + "6.weight"])
+
+
+# ------------------------------------------------------------------------------------------ network.py:74-164, train / val branch
+def forward_train(model, pc_data_dict: Dict, img: torch.Tensor, fine_center_kpt_coors: torch.Tensor, fine_pc_inline_index: torch.Tensor):
+    """-> the reference's 8-tuple (fine_center_xy = coarse_pc_points = None) with a graph behind every tensor."""
+    if not img.is_cuda:
+        raise _lib.CofiError("CoFiI2P.forward needs CUDA (HIP) tensors: there is no CPU path")
+    if model.pc_norm_kind != "gn":
+        raise NotImplementedError("the training path serves opt.norm == 'gn' (the shipped configuration)")
+    if img.dim() != 4 or img.shape[0] != 1:
+        raise ValueError("training runs one frame per forward (train.py squeezes a batch of 1)")
+    _lib.load()
+    P = dict(model.named_parameters())
+    B = dict(model.named_buffers())
+    training = model.training
+    as32 = model._as_idx32
+    points = [p.contiguous() for p in pc_data_dict["points"]]
+    neighbors = [as32(t) for t in pc_data_dict["neighbors"]]
+    subsampling = [as32(t) for t in pc_data_dict["subsampling"]]
+    upsampling = [as32(t) for t in pc_data_dict["upsampling"]]
+    feats = pc_data_dict["feats"].contiguous()
+    tables = ag.TableCache()
+
+    pc_set = kpconv_fpn(P, B, points, neighbors, subsampling, upsampling, feats, tables)
+    (s2, H2, W2), (s4, H4, W4), (s8, H8, W8) = resnet34_s8(P, img)
+    fine_pc = F.normalize(pc_set[0], dim=1)                                   # network.py:83
+    pc_mid = F.normalize(pc_feature_mlp(P, pc_set[-1]), dim=1)                # network.py:84
+    s8n = F.normalize(s8, dim=1)                                              # network.py:90
+    tok_img = s8n + pos_sine_table(model._pixel_grid(H8, W8, 1, img.device))  # network.py:104-110
+    tok_pc = pc_mid + pos_sine_table(points[-1])                              # network.py:107,111
+    tok_img, tok_pc = transformer(P, tok_img, tok_pc)
+    pc_score = score_head(P, "pc_score_layer", tok_pc)
+    img_score = score_head(P, "img_score_layer", tok_img)
+    pc_desc = F.normalize(tok_pc, dim=1).t()                                  # (C, N4)  network.py:125
+    img_desc = F.normalize(tok_img, dim=1).t().reshape(1, D_MODEL, H8, W8)    # network.py:126
+    up4 = image_upsample(P, B, "img_upsample_1", s8n, H8, W8, s4, training)
+    up2 = F.normalize(image_upsample(P, B, "img_upsample_2", up4, H4, W4, s2, training), dim=1)   # (H2 W2, 64)
+    # network.py:137-141: fine point descriptors of the labelled points, 4 x 4 patches around the labelled pixels
+    fine_feat = ag.gather_rows(fine_pc, as32(fine_pc_inline_index.reshape(-1)), tables)
+    ctr = fine_center_kpt_coors.to(device=img.device)
+    lt = torch.floor(ctr.to(torch.float32) - 2.0).to(torch.int64)             # network.py:213: left/top = floor(centre - size / 2)
+    ar = torch.arange(4, device=img.device)
+    rows, cols = lt[1][:, None] + ar[None], lt[0][:, None] + ar[None]         # (K, 4)
+    if bool(((rows < 0) | (rows >= H2)).any()) or bool(((cols < 0) | (cols >= W2)).any()):
+        raise AssertionError("patch leaves the feature map (network.py:222)")
+    pix = (rows[:, :, None] * W2 + cols[:, None, :]).reshape(-1)             # (K 16,)
+    patches = ag.gather_rows(up2, pix.to(torch.int32), tables).reshape(ctr.shape[1], 4, 4, -1).permute(0, 3, 1, 2)
+    N4 = points[-1].shape[0]
+    return (img_desc, pc_desc, img_score.reshape(1, 1, H8, W8), pc_score.reshape(1, 1, N4), patches, fine_feat, None, None)

@@ -386,7 +386,7 @@ int cofi_fine_match(const float *patches, const float *pc_feats, int ldp, int C,
 
 /* ---------------------------------------------------------------------------------------------
  * Row f3, first part: the training losses of model/loss.py with their gradients w.r.t. the network outputs
- * (the backward of the network itself is not built: DESIGN.md section 8).  grad_out = d(total)/d(loss), a device scalar; gradient
+ * (the backward of the network itself: second part, below).  grad_out = d(total)/d(loss), a device scalar; gradient
  * pointers may be NULL (forward only).  All fp32, fixed-order reductions (bit-reproducible).
  * cofi_desc_loss      loss.py:69-93: img / pc (C, K) with leading dimensions ldi / ldp (column = key point), mask (K, K);
  *                     -> loss[1], dists (K, K) = 1 - img^T pc (the reference returns it too); ws from cofi_desc_loss_workspace(K).
@@ -402,6 +402,35 @@ int cofi_fine_circle_loss(const float *patches, const float *pc, int ldp, const 
                           cofi_stream_t stream);
 int cofi_overlap_loss(const float *inline_score, int n_in, const float *outline_score, int n_out, float *loss, const float *grad_out,
                       float *grad_in, float *grad_outline, cofi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row f3, second part: the backward of the network (what torch.autograd derives for the reference's modules when train.py:285 calls
+ * loss.backward()).  The dense contractions of the backward are cofi_gemm_f32* on transposed operands (cofi_transpose); these entry
+ * points are the adjoints of the gathers.  A forward gather y[m] = f(x[idx[m, h]]) has the adjoint dx[j] = sum over the pairs (m, h)
+ * with idx[m, h] == j: the caller passes the TRANSPOSED index table in CSR form - `pairs` = the ids m * H + h (for a row gather: m)
+ * sorted by (j, id), `offsets` (N + 1) - and a wave per row j sums its list in that order: no float atomics, bit-reproducible.
+ * cofi_kpconv_aggregate_bwd  model/kpconv/kpconv.py:91-105: dfeats[j, c] = sum_{(m,h)} sum_k w(m, h, k) dagg[m, k C + c] with the kernel-point
+ *                            influences w recomputed from q_pts (M, 3), s_pts (N, 3), kernel_points (15, 3), sigma.  C >= 64 or a power of 2.
+ * cofi_neighbor_maxpool_arg  functional.py:53-66 with the index h of the first neighbour attaining the maximum (arg (M, C) int32);
+ * cofi_neighbor_maxpool_bwd  its adjoint.   cofi_gather_rows_bwd: adjoint of cofi_gather_rows (functional.py:5-21).
+ * cofi_im2col_nhwc / cofi_col2im_nhwc: a convolution of the image branch in training = im2col + GEMM (the weight gradient needs the
+ *                            unfolded input): col (Ho Wo, ks ks C) with column (dy ks + dx) C + c; col2im is the adjoint (gather form).
+ * cofi_attention_bwd         linear_attention.py:56-79, recompute style (no (L, S) matrix stored): q, k, v, o, d_o -> dq, dk, dv; exact fp32
+ *                            matrix instruction; D == 32; ws of cofi_attention_bwd_workspace(L, H) bytes. */
+int cofi_kpconv_aggregate_bwd(const float *dagg, int ldd, const float *q_pts, const float *s_pts, const int32_t *pairs, const int32_t *offsets,
+                              int N, int C, int H, const float *kernel_points, float sigma, float *dfeats, int ldf, cofi_stream_t stream);
+int cofi_neighbor_maxpool_arg(const float *x, int ldx, int N, int C, const int32_t *idx, int M, int H, float *out, int ldo, int32_t *arg,
+                              cofi_stream_t stream);
+int cofi_neighbor_maxpool_bwd(const float *dy, int ldy, const int32_t *arg, int C, int H, const int32_t *pairs, const int32_t *offsets, int N,
+                              float *dx, int ldx, cofi_stream_t stream);
+int cofi_gather_rows_bwd(const float *dy, int ldy, int C, const int32_t *pairs, const int32_t *offsets, int N, float *dx, int ldx,
+                         cofi_stream_t stream);
+int cofi_im2col_nhwc(const float *x, int ldx, int H, int W, int C, int ks, int stride, int pad, float *col, int ldc, cofi_stream_t stream);
+int cofi_col2im_nhwc(const float *dcol, int ldc, int H, int W, int C, int ks, int stride, int pad, float *dx, int ldx, cofi_stream_t stream);
+size_t cofi_attention_bwd_workspace(int L, int H);
+int cofi_attention_bwd(const float *q, int ldq, const float *k, int ldk, const float *v, int ldv, const float *o, int ldo, const float *d_o,
+                       int lddo, int L, int S, int H, int D, float scale, float *dq, int lddq, float *dk, int lddk, float *dv, int lddv, void *ws,
+                       size_t ws_bytes, cofi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row f1: camera pose from the fine matches, replacing the reference's

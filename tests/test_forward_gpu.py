@@ -514,9 +514,9 @@ def test_eval_all_shaped_caller(model, tmp_path, monkeypatch):
     back = metrics.load_frame_result(path)
     assert set(back) == set(metrics.FRAME_KEYS) and back["fine_xy"].shape == fine_xy.shape
     assert fine_xy.shape[1] == coarse_pc_points.shape[0] >= 4
-    # the forward refuses to pretend it can train (train.py:224-226 + loss.backward() at :285 would get no gradient)
-    with pytest.raises(NotImplementedError):
-        net(pc_data_dict, img, torch.zeros(2, 4, device=DEV), None, torch.zeros(4, dtype=torch.int64, device=DEV), "train")
+    # mode='train' with autograd enabled hands back tensors with a graph (train.py:224-226 + loss.backward() at :285; tests/test_train_gpu.py)
+    tr = net(pc_data_dict, img, torch.full((2, 4), 8, device=DEV), None, torch.zeros(4, dtype=torch.int64, device=DEV), "train")
+    assert tr[0].requires_grad and tr[4].shape == (4, 64, 4, 4) and tr[6] is None
 
 
 def test_bench_two_ranks_share_device(tmp_path):

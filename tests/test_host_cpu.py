@@ -154,8 +154,11 @@ def test_model_import_path_shim_and_training_guard():
         img_H, img_W, img_fine_resolution_scale, norm = 160, 512, 32, "gn"
 
     m = network.CoFiI2P(Opt())
-    with pytest.raises(NotImplementedError):
+    from cofii2p_amd import _lib
+
+    with pytest.raises(_lib.CofiError):   # the training path has no CPU form either
         m({"feats": torch.zeros(4, 4)}, torch.zeros(1, 3, 160, 512), None, None, None, "train")
+    assert all(p.requires_grad for p in m.parameters())   # learnable, as train.py:163 expects
 
 
 def test_bench_refuses_more_ranks_than_gpus():

@@ -1,0 +1,326 @@
+"""Row f3 of SURVEY.md section 8: the training path.  (a) every autograd Function of cofii2p_amd/autograd.py - forward value and
+gradients - against the same operator written with plain torch ops and differentiated by torch.autograd; (b) one optimisation step
+shaped like train.py:186-285 on the tiny frame against tests/golden/train_ref.npz, recorded from the REFERENCE's model in train() mode
+(tests/tools/make_golden_train.py): train-mode outputs, the three losses, the gradient of every parameter, the BatchNorm running
+statistics.  Needs a real MI355X:  python -m pytest tests -m gpu"""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+from common import frame_inputs, load_golden, sha  # noqa: E402
+
+DEV = "cuda:0"
+GRAD_TOL = 1e-3   # VERDICT r2 / north star: parameter gradients within 1e-3 relative of the reference's
+
+
+def G(a, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV) if isinstance(a, np.ndarray) else a.to(DEV)
+    return t.requires_grad_() if grad else t
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(autouse=True)
+def f32_arithmetic(monkeypatch):
+    from cofii2p_amd import ops
+
+    monkeypatch.setattr(ops, "GEMM_MODE", "f32")
+
+
+# ------------------------------------------------------------------------------------------ (a) operators
+@pytest.mark.parametrize("M,K,N,bias,rowdiv", [(200, 96, 64, True, False), (130, 15 * 32, 32, True, True), (77, 64, 1, False, False), (50, 6, 10, True, False)])
+def test_linear_function(M, K, N, bias, rowdiv):
+    from cofii2p_amd import autograd as ag
+
+    g = torch.Generator(device=DEV).manual_seed(M)
+    x, w = torch.randn((M, K), device=DEV, generator=g), torch.randn((N, K), device=DEV, generator=g) / math.sqrt(K)
+    b = torch.randn((N,), device=DEV, generator=g) if bias else None
+    rd = torch.randint(1, 9, (M,), device=DEV, generator=g).float() if rowdiv else None
+    dy = torch.randn((M, N), device=DEV, generator=g)
+    ins = [t.clone().requires_grad_() for t in (x, w)] + ([b.clone().requires_grad_()] if bias else [])
+    y = ag.linear(ins[0], ins[1], ins[2] if bias else None, rd)
+    y.backward(dy)
+    ref_in = [t.double().clone().requires_grad_() for t in (x, w)] + ([b.double().clone().requires_grad_()] if bias else [])
+    yr = ref_in[0] @ ref_in[1].t()
+    if rowdiv:
+        yr = yr / rd.double()[:, None]
+    if bias:
+        yr = yr + ref_in[2]
+    yr.backward(dy.double())
+    assert rel_err(y, yr) < 1e-5
+    for a, r in zip(ins, ref_in):
+        assert rel_err(a.grad, r.grad) < 1e-5
+
+
+def _kpconv_agg_torch(feats, q_pts, s_pts, idx, kp, sigma):
+    """kpconv.py:89-105 with plain torch ops (differentiable in feats)."""
+    N = feats.shape[0]
+    sp = torch.cat([s_pts, torch.full((1, 3), 1e6, device=feats.device, dtype=s_pts.dtype)], 0)
+    sf = torch.cat([feats, torch.zeros((1, feats.shape[1]), device=feats.device, dtype=feats.dtype)], 0)
+    ii = idx.long()
+    rel = sp[ii] - q_pts[:, None, :]
+    infl = (1.0 - (rel[:, :, None, :] - kp[None, None]).pow(2).sum(-1).sqrt() / sigma).clamp_min(0.0)   # (M, H, K)
+    nf = sf[ii]
+    agg = infl.transpose(1, 2) @ nf                                                                        # (M, K, C)
+    return agg.reshape(agg.shape[0], -1)
+
+
+@pytest.mark.parametrize("C", [32, 64, 128, 16])
+def test_kpconv_aggregate_function(C):
+    from cofii2p_amd import autograd as ag
+    from cofii2p_amd.weights import kernel_point_table
+
+    g = np.random.default_rng(C)
+    N, M, H, sigma = 300, 180, 24, 0.3
+    s_pts = G((g.random((N, 3)) * 1.2).astype(np.float32))
+    q_pts = G((s_pts[:M].cpu().numpy() + g.normal(0, 0.02, (M, 3))).astype(np.float32))
+    idx_np = g.integers(0, N, (M, H))
+    idx_np[::9, -2:] = N        # shadow neighbours (kpconv.py:89)
+    idx_np[3, :] = N
+    idx_np[5, :4] = idx_np[5, 4]   # one support row several times in a neighbourhood (duplicates of the sub-sampling with replacement)
+    idx = G(idx_np.astype(np.int32))
+    kp = G(kernel_point_table(15, 0.425 * sigma / 0.2))
+    feats = G(g.standard_normal((N, C)).astype(np.float32))
+    dagg = G(g.standard_normal((M, 15 * C)).astype(np.float32))
+    f1 = feats.clone().requires_grad_()
+    agg, cnt = ag.kpconv_aggregate(f1, q_pts, s_pts, idx, kp, sigma, ag.TableCache())
+    agg.backward(dagg)
+    f2 = feats.double().clone().requires_grad_()
+    ref = _kpconv_agg_torch(f2, q_pts.double(), s_pts.double(), idx, kp.double(), sigma)
+    ref.backward(dagg.double())
+    assert rel_err(agg, ref) < 1e-5
+    assert rel_err(f1.grad, f2.grad) < 1e-5
+    # bit-reproducible: the transposed-table walk has a fixed summation order
+    f3 = feats.clone().requires_grad_()
+    ag.kpconv_aggregate(f3, q_pts, s_pts, idx, kp, sigma, ag.TableCache())[0].backward(dagg)
+    assert torch.equal(f1.grad, f3.grad)
+
+
+def test_neighbor_maxpool_and_gather_functions():
+    from cofii2p_amd import autograd as ag
+
+    g = np.random.default_rng(3)
+    N, M, H, C = 150, 90, 16, 96
+    x = G(g.standard_normal((N, C)).astype(np.float32))
+    x[10] = x[11]                      # duplicate rows: a tie, one of them takes the gradient
+    idx_np = g.integers(0, N, (M, H))
+    idx_np[::7, -3:] = N
+    idx_np[4, :] = N                   # only the zero pad row: output 0, no gradient anywhere
+    idx_np[6, 0], idx_np[6, 1] = 10, 11
+    idx = G(idx_np.astype(np.int32))
+    dy = G(g.standard_normal((M, C)).astype(np.float32))
+    x1 = x.clone().requires_grad_()
+    tables = ag.TableCache()
+    y = ag.neighbor_maxpool(x1, idx, tables)
+    y.backward(dy)
+    x2 = x.clone().requires_grad_()
+    xp = torch.cat([x2, torch.zeros((1, C), device=DEV)], 0)
+    yr = xp[idx.long()].max(1)[0]
+    yr.backward(dy)
+    assert torch.equal(y, yr)
+    # ties may send the gradient to another of the equal rows: compare with the tied rows folded together
+    ga, gb = x1.grad.clone(), x2.grad.clone()
+    ga[10] += ga[11]; gb[10] += gb[11]; ga[11] = 0; gb[11] = 0
+    assert rel_err(ga, gb) < 1e-6
+    # nearest up-sample: column 0 of the table (functional.py:20)
+    x3, x4 = x.clone().requires_grad_(), x.clone().requires_grad_()
+    y = ag.gather_rows(x3, idx, tables)
+    y.backward(dy)
+    yr = torch.cat([x4, torch.zeros((1, C), device=DEV)], 0)[idx[:, 0].long()]
+    yr.backward(dy)
+    assert torch.equal(y, yr) and rel_err(x3.grad, x4.grad) < 1e-6
+    # 1-D index list with repeats (the fine key-point selection, network.py:137)
+    sel = G(g.integers(0, N, 40).astype(np.int32))
+    x5, x6 = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ag.gather_rows(x5, sel, ag.TableCache()).backward(dy[:40])
+    x6[sel.long()].backward(dy[:40])
+    assert rel_err(x5.grad, x6.grad) < 1e-6
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout,ks,stride,pad", [(12, 20, 8, 16, 3, 1, 1), (13, 21, 8, 12, 3, 2, 1), (10, 16, 16, 8, 1, 2, 0), (9, 11, 4, 8, 1, 1, 0)])
+def test_conv2d_function(H, W, Cin, Cout, ks, stride, pad):
+    from cofii2p_amd import autograd as ag
+
+    g = torch.Generator(device=DEV).manual_seed(H * W)
+    x = torch.randn((1, Cin, H, W), device=DEV, generator=g)
+    w = torch.randn((Cout, Cin, ks, ks), device=DEV, generator=g) / math.sqrt(Cin * ks * ks)
+    x1, w1 = x.reshape(Cin, -1).t().contiguous().requires_grad_(), w.clone().requires_grad_()
+    y, Ho, Wo = ag.conv2d(x1, H, W, w1, stride, pad)
+    x2, w2 = x.double().clone().requires_grad_(), w.double().clone().requires_grad_()
+    yr = F.conv2d(x2, w2, None, stride, pad)
+    assert yr.shape[2:] == (Ho, Wo)
+    dy = torch.randn((Ho * Wo, Cout), device=DEV, generator=g)
+    y.backward(dy)
+    yr.backward(dy.t().reshape(1, Cout, Ho, Wo).double())
+    assert rel_err(y, yr[0].reshape(Cout, -1).t()) < 1e-5
+    assert rel_err(w1.grad, w2.grad) < 1e-5
+    assert rel_err(x1.grad, x2.grad[0].reshape(Cin, -1).t()) < 1e-5
+
+
+@pytest.mark.parametrize("L,S", [(64, 96), (70, 45), (1280, 128), (33, 1280)])
+def test_attention_function(L, S):
+    from cofii2p_amd import autograd as ag
+
+    H, D = 4, 32
+    g = torch.Generator(device=DEV).manual_seed(L + S)
+    q = torch.randn((L, H * D), device=DEV, generator=g) * 0.7
+    k, v = torch.randn((S, H * D), device=DEV, generator=g), torch.randn((S, H * D), device=DEV, generator=g)
+    do = torch.randn((L, H * D), device=DEV, generator=g)
+    a = [t.clone().requires_grad_() for t in (q, k, v)]
+    o = ag.attention(*a, nhead=H)
+    o.backward(do)
+    r = [t.double().clone().requires_grad_() for t in (q, k, v)]
+    qh, kh, vh = (t.reshape(-1, H, D) for t in r)
+    A = torch.softmax(torch.einsum("lhd,shd->hls", qh, kh) / math.sqrt(D), dim=-1)    # linear_attention.py:70-76
+    orf = torch.einsum("hls,shd->lhd", A, vh).reshape(L, H * D)
+    orf.backward(do.double())
+    assert rel_err(o, orf) < 1e-5
+    for x, y, n in zip(a, r, "qkv"):
+        assert rel_err(x.grad, y.grad) < 2e-5, n
+
+
+# ------------------------------------------------------------------------------------------ (b) one step of train.py vs the reference
+class Opt:
+    img_H, img_W, img_fine_resolution_scale, norm = 160, 512, 32, "gn"
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return load_golden("train_ref.npz")
+
+
+def _train_inputs(gold):
+    fr, data = frame_inputs(int(gold["frame_id"]), int(gold["num_points"]), int(gold["pyr_seed"]))
+    assert sha(fr.points) == str(gold["sha_points"]) and sha(fr.img) == str(gold["sha_img"])
+    dd = {k: [t.to(DEV) for t in v] for k, v in data.items() if k in ("points", "neighbors", "subsampling", "upsampling")}
+    dd["feats"] = data["feats"].to(DEV)
+    img = torch.from_numpy(fr.img)[None].to(DEV)
+    batch = {k[4:]: G(gold[k]) for k in gold.files if k.startswith("lab_")}
+
+    class StepOpt:
+        dist_thres, pos_margin, neg_margin = float(gold["dist_thres"]), float(gold["pos_margin"]), float(gold["neg_margin"])
+
+    return dd, img, batch, StepOpt
+
+
+# "bf16x3" (opt-in for training: CoFiI2P(opt, arithmetic="bf16x3")): the split's 2^-16 per product is amplified by the cancellations of the
+# backward to ~1e-2 in individual gradients - measured, documented in INTEGRATION.md, bounded here
+@pytest.mark.parametrize("arith,tol", [("f32", GRAD_TOL), (None, GRAD_TOL), ("bf16x3", 3e-2)])
+def test_train_step_matches_reference(gold, arith, tol, monkeypatch):
+    """forward(mode='train') -> losses -> backward: train-mode outputs, losses, every parameter gradient (norm-relative error of the 96
+    recorded entries, gradient norm, sum), presence / absence of a gradient, BatchNorm running statistics - against the reference."""
+    from cofii2p_amd import ops
+    from cofii2p_amd.network import CoFiI2P
+    from cofii2p_amd.train_step import step_losses
+
+    monkeypatch.setattr(ops, "GEMM_MODE", arith or "bf16x3")   # arithmetic=None: the process default is bf16x3, training still computes in f32
+    dd, img, batch, sopt = _train_inputs(gold)
+    m = CoFiI2P(Opt(), arithmetic=arith).to(DEV)
+    m.train()
+    outs, mask, (l_desc, l_coarse, l_fine) = step_losses(m, dd, img, batch, sopt)
+    assert np.array_equal(mask.cpu().numpy(), gold["mask"])
+    for n_, t in zip(("img_desc", "pc_desc", "img_score", "pc_score", "patches", "fine_pc"), outs[:6]):
+        ref = gold["train_" + n_]
+        assert tuple(t.shape) == ref.shape, n_
+        assert float((t.detach().cpu() - torch.from_numpy(ref)).abs().max()) < 1e-3, n_    # the forward's own budget (north star)
+    for name, val in (("loss_desc", l_desc), ("loss_coarse", l_coarse), ("loss_fine", l_fine)):
+        assert abs(float(val.detach()) - float(gold[name])) < 1e-3 * max(1.0, abs(float(gold[name]))), name
+    (l_desc + l_coarse + l_fine).backward()
+    names = [str(n) for n in gold["g_names"]]
+    params = dict(m.named_parameters())
+    assert names == list(params)
+    # Judged against the reference's formulas evaluated in float64 (g_val64 / g_norm64).  The reference's own fp32 gradients are not a
+    # usable yardstick everywhere: g_err32 records how far THEY are from the fp64 values - 2e-3 ... 5e-3 for the ResNet filters behind
+    # InstanceNorm (ill-conditioned: a large common component cancels), ~1e-4 elsewhere.  A parameter passes when its gradient is within
+    # `tol` of the fp64 gradient, or - where fp32 cannot do that - no further from it than the reference's own fp32 result was.
+    total = float(np.sqrt((gold["g_norm64"] ** 2).sum()))
+    zero_floor = 1e-6 * total   # biases in front of a one-channel-per-group GroupNorm: exactly zero gradient, fp32 leaves rounding noise
+    worst = (0.0, None)
+    beyond = 0
+    for i, name in enumerate(names):
+        p = params[name]
+        if not int(gold["g_has"][i]):
+            assert p.grad is None, "%s: the reference leaves this parameter without a gradient" % name
+            continue
+        assert p.grad is not None, name
+        flat = p.grad.detach().double().reshape(-1).cpu()
+        norm_ref = float(gold["g_norm64"][i])
+        if norm_ref < zero_floor:
+            assert float(flat.norm()) < 1e-5 * total, "%s: mathematically zero gradient, got |g| = %.3g" % (name, float(flat.norm()))
+            continue
+        got = flat[torch.from_numpy(gold["g_pos"][i])].numpy()
+        ref = gold["g_val64"][i]
+        scale = max(np.linalg.norm(ref), norm_ref * math.sqrt(len(ref) / flat.numel()))   # the sampled entries' own size / the tensor's typical size
+        e_samp = float(np.linalg.norm(got - ref) / scale)
+        e_norm = abs(float(flat.norm()) - norm_ref) / norm_ref
+        allow = max(tol, 2.5 * float(gold["g_err32"][i]))   # same rounding noise, another summation order: within 2.5x of the reference's own deviation
+        beyond += e_samp > tol
+        worst = max(worst, (max(e_samp, e_norm), name))
+        assert e_samp < allow and e_norm < max(tol, GRAD_TOL), "%s: sampled entries off by %.3g (allowed %.3g), norm by %.3g (relative)" % (name, e_samp, allow, e_norm)
+    print("worst parameter gradient error %.3g (%s); %d parameters beyond %.0e, all of them where the reference's own fp32 gradient is" % (worst + (beyond, tol)))
+    bufs = dict(m.named_buffers())
+    for k in gold.files:
+        if k.startswith("buf/"):
+            b = bufs[k[4:]].detach().cpu()
+            ref = torch.from_numpy(np.asarray(gold[k]))
+            assert torch.allclose(b.double(), ref.double(), rtol=1e-4, atol=1e-5), k
+
+
+def test_training_changes_the_served_weights(gold):
+    """train.py's loop: optimisation steps, then the validation pass (model.eval(), mode='val' under no_grad, train.py:66-70) must see
+    the UPDATED weights - the packed / folded inference weights are re-derived once the parameters' versions moved - and the loss of
+    the same batch goes down over a few Adam steps."""
+    from cofii2p_amd.network import CoFiI2P
+    from cofii2p_amd.train_step import step_losses, train_step
+
+    dd, img, batch, sopt = _train_inputs(gold)
+    m = CoFiI2P(Opt(), arithmetic="f32").to(DEV)
+    kpt, inl = batch["fine_center_kpt_coors"], batch["fine_pc_inline_index"]
+    m.eval()
+    with torch.no_grad():
+        before = [t.clone() for t in m(dd, img, kpt, None, inl, "val")[:6]]
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, m.parameters()), lr=1e-3)   # train.py:163-164
+    losses = [float(sum(train_step(m, opt, dd, img, batch, sopt))) for _ in range(4)]
+    assert losses[-1] < losses[0], losses
+    m.eval()
+    with torch.no_grad():
+        after = m(dd, img, kpt, None, inl, "val")[:6]
+    assert any(float((a - b).abs().max()) > 1e-4 for a, b in zip(before, after))
+    # the differentiable forward in eval() mode (BatchNorm on its running statistics) is the same function as the inference path
+    from cofii2p_amd import train_forward
+
+    graph = train_forward.forward_train(m, dd, img, kpt, inl)[:6]
+    assert graph[0].requires_grad
+    for a, b, n_ in zip(after, graph, ("img_desc", "pc_desc", "img_score", "pc_score", "patches", "fine_pc")):
+        assert float((a - b.detach()).abs().max()) < 2e-4, n_
+
+
+def test_train_mode_refusals():
+    from cofii2p_amd import _lib
+    from cofii2p_amd.network import CoFiI2P
+
+    class OptLn(Opt):
+        norm = "ln"
+
+    m = CoFiI2P(OptLn()).to(DEV)
+    dd = {"points": [torch.zeros((8, 3), device=DEV)], "neighbors": [], "subsampling": [], "upsampling": [], "feats": torch.zeros((8, 4), device=DEV)}
+    with pytest.raises(NotImplementedError):
+        m(dd, torch.zeros((1, 3, 160, 512), device=DEV), None, None, None, "train")
+    m = CoFiI2P(Opt()).to(DEV)
+    with pytest.raises(ValueError):
+        m(dd, torch.zeros((2, 3, 160, 512), device=DEV), None, None, None, "train")
+    with pytest.raises(NotImplementedError):   # mode='test' has no gradient to give
+        m(dd, torch.zeros((1, 3, 160, 512), device=DEV, requires_grad=True), None, None, None, "test")
+    with pytest.raises(_lib.CofiError):
+        m(dd, torch.zeros((1, 3, 160, 512)), None, None, None, "train")

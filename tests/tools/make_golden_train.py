@@ -1,0 +1,181 @@
+"""Generate tests/golden/train_ref.npz by RUNNING THE REFERENCE in train() mode (development container only):
+
+    python tests/tools/make_golden_train.py
+
+One optimisation step of train.py:186-285 on the tiny synthetic frame (2048 points, 160 x 512 image, name-keyed synthetic weights):
+model.train(); forward(mode='train'); the caller-side gathers / projection / correspondence mask of train.py:233-251; the three losses
+of model/loss.py; loss.backward().  train.py is a script (argparse + dataset construction at import), so its statements between the
+forward and the backward are evaluated here with the same torch calls on the reference's model and the reference's loss functions.
+
+Recorded: the labels, the loss values, samples of the train-mode outputs, and for every parameter of the model a FINGERPRINT of its
+gradient - present or not, L2 norm and sum, and the values at 96 seeded positions, once as the reference computes them (fp32) and once
+from the same module run in float64 (g_norm64 / g_val64; g_err32 = how far the reference's fp32 gradient is from its fp64 one) - plus
+the BatchNorm running statistics after the step (train mode updates them).  The full gradients are ~100 MB and stay out of the repository.  The fixture is data: inputs and
+expected outputs of the reference, nothing else."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+import ref_shims  # noqa: E402
+from make_golden import build_reference_model, frame_inputs, sha  # noqa: E402
+
+NUM_KPT = 32
+SAMPLES = 96
+
+
+def make_labels(points4: np.ndarray, n1: int, seed: int):
+    """A train.py-shaped label set for the tiny frame (data/kitti.py:305-420 builds the real one from the ground-truth pose):
+    K_4 = intrinsics of the 1/8 map, P = pose, key-point index lists, fine centres / pixels / point indices."""
+    g = np.random.default_rng(seed)
+    K_4 = np.array([[20.0, 0.0, 32.0], [0.0, 20.0, 10.0], [0.0, 0.0, 1.0]], dtype=np.float32)
+    ang = 0.05
+    P = np.eye(4, dtype=np.float32)
+    P[:3, :3] = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], dtype=np.float32)
+    P[:3, 3] = [0.3, -0.1, 0.5]
+    cam = points4 @ P[:3, :3].T + P[:3, 3]
+    uvw = cam @ K_4.T
+    u, v = uvw[:, 0] / uvw[:, 2], uvw[:, 1] / uvw[:, 2]
+    inside = (cam[:, 2] > 0.5) & (u >= 0) & (u < 64) & (v >= 0) & (v < 20)
+    inl, outl = np.nonzero(inside)[0], np.nonzero(~inside)[0]
+    assert len(inl) >= 8 and len(outl) >= 8, (len(inl), len(outl))
+    pc_kpt_idx = g.choice(inl, NUM_KPT, replace=len(inl) < NUM_KPT)
+    pc_outline_idx = g.choice(outl, NUM_KPT, replace=len(outl) < NUM_KPT)
+    # the pixel each key point projects to, jittered by up to one coarse pixel so that the mask has near misses
+    pu = np.clip(np.floor(u[pc_kpt_idx]) + g.integers(-1, 2, NUM_KPT), 0, 63)
+    pv = np.clip(np.floor(v[pc_kpt_idx]) + g.integers(-1, 2, NUM_KPT), 0, 19)
+    coarse_img_kpt_idx = (pv * 64 + pu).astype(np.int64)
+    fine_center = np.stack([g.integers(2, 254, NUM_KPT), g.integers(2, 78, NUM_KPT)]).astype(np.int64)   # (x, y) on the 1/2 map
+    fine_xy = fine_center + g.integers(-2, 2, (2, NUM_KPT))
+    fine_inl = g.integers(0, n1, NUM_KPT).astype(np.int64)
+    return dict(K_4=K_4, P=P, pc_kpt_idx=pc_kpt_idx.astype(np.int64), pc_outline_idx=pc_outline_idx.astype(np.int64),
+                coarse_img_kpt_idx=coarse_img_kpt_idx, fine_center_kpt_coors=fine_center, fine_xy=fine_xy, fine_pc_inline_index=fine_inl)
+
+
+def train_step(model, data, img, lab, opt, losses):
+    """train.py:224-283 on already-loaded tensors.  `losses` = (desc_loss, overlap_loss, fine_circle_loss)."""
+    desc_loss, overlap_loss, fine_circle_loss = losses
+    device = "cpu"
+    K = NUM_KPT
+    outs = model(data, img, lab["fine_center_kpt_coors"], lab["fine_xy"], lab["fine_pc_inline_index"], "train")
+    img_features, pc_features, coarse_img_score, coarse_pc_score, fine_patch, fine_pc_feat = outs[:6]
+    pc_kpt_idx, pc_outline_idx = lab["pc_kpt_idx"], lab["pc_outline_idx"]
+    pc_features_inline = torch.gather(pc_features, index=pc_kpt_idx.expand(pc_features.size(0), K), dim=-1)
+    pc_xyz_inline = torch.gather(data["points"][-1].T, index=pc_kpt_idx.unsqueeze(0).expand(3, K), dim=-1)
+    img_features_flatten = img_features.contiguous().view(img_features.size(1), -1)
+    H8, W8 = img_features.shape[2:]
+    img_x = torch.linspace(0, W8 - 1, W8).view(1, -1).expand(H8, W8).unsqueeze(0)
+    img_y = torch.linspace(0, H8 - 1, H8).view(-1, 1).expand(H8, W8).unsqueeze(0)
+    img_xy_flatten = torch.cat((img_x, img_y), dim=0).contiguous().view(2, -1)
+    cidx = lab["coarse_img_kpt_idx"]
+    img_features_flatten_inline = torch.gather(img_features_flatten, index=cidx.unsqueeze(0).expand(img_features_flatten.size(0), K), dim=-1)
+    img_xy_flatten_inline = torch.gather(img_xy_flatten, index=cidx.unsqueeze(0).expand(2, K), dim=-1)
+    P, K_4 = lab["P"], lab["K_4"]
+    proj = torch.mm(K_4, (torch.mm(P[0:3, 0:3], pc_xyz_inline) + P[0:3, 3:]))
+    pc_xy = proj[0:2, :] / proj[2:, :]
+    mask = (torch.sqrt(torch.sum(torch.square(img_xy_flatten_inline.unsqueeze(-1) - pc_xy.unsqueeze(-2)), dim=0)) <= opt.dist_thres).float()
+    loss_desc, dists = desc_loss(device, img_features_flatten_inline, pc_features_inline, mask, pos_margin=opt.pos_margin, neg_margin=opt.neg_margin)
+    s_in = torch.squeeze(coarse_pc_score[:, :, pc_kpt_idx])
+    s_out = torch.squeeze(coarse_pc_score[:, :, pc_outline_idx])
+    loss_coarse = overlap_loss(device, s_in, s_out)
+    rel = lab["fine_xy"] - lab["fine_center_kpt_coors"] + 2
+    rel_index = rel[1, :] * 4 + rel[0, :]
+    loss_fine = fine_circle_loss(device, fine_patch, fine_pc_feat, rel_index, K)
+    return outs, mask, (loss_desc, loss_coarse, loss_fine)
+
+
+def fingerprint(name: str, g: torch.Tensor):
+    flat = g.detach().double().reshape(-1)
+    rs = np.random.default_rng(abs(hash_name(name)) % (2 ** 32))
+    pos = rs.integers(0, flat.numel(), SAMPLES)
+    return float(flat.norm()), float(flat.sum()), pos.astype(np.int64), flat[torch.from_numpy(pos)].float().numpy()
+
+
+def hash_name(name: str) -> int:
+    import hashlib
+
+    return int(hashlib.sha256(name.encode()).hexdigest()[:8], 16)
+
+
+def main():
+    import importlib
+
+    torch.manual_seed(0)
+    net, model, sd = build_reference_model("gn")
+    loss_mod = importlib.import_module("model.loss")
+    opt = ref_shims.reference_options()
+    frame_id, num_points, pyr_seed = 1, 2048, 11
+    fr, data = frame_inputs(frame_id, num_points, pyr_seed)
+    img = torch.from_numpy(fr.img)[None]
+    lab_np = make_labels(data["points"][-1].numpy(), data["points"][1].shape[0], seed=5)
+    lab = {k: torch.from_numpy(v) for k, v in lab_np.items()}
+    model.train()   # train.py:188
+    outs, mask, (l_desc, l_coarse, l_fine) = train_step(model, data, img, lab, opt, (loss_mod.desc_loss, loss_mod.overlap_loss, loss_mod.fine_circle_loss))
+    loss = l_desc + l_coarse + l_fine   # train.py:283
+    loss.backward()
+    grads32 = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in model.named_parameters()}
+    bufs32 = {n: b.detach().clone() for n, b in model.named_buffers()}
+    # the same step with every tensor in float64: the reference's own formulas without its fp32 rounding.  Several gradients of this
+    # network are ill-conditioned in fp32 (the ResNet filters behind InstanceNorm: the reference's fp32 gradient is 2e-3 ... 5e-3 away
+    # from its fp64 gradient; biases in front of a one-channel-per-group GroupNorm have an exactly zero gradient, fp32 leaves 1e-8
+    # noise), so the fixture records both and tests judge an implementation against the fp64 values
+    torch.set_default_dtype(torch.float64)
+    _, model64, _ = build_reference_model("gn")
+    model64 = model64.double()
+    model64.train()
+    dbl = lambda t: t.double() if torch.is_tensor(t) and t.is_floating_point() else t
+    data64 = {k: ([dbl(t) for t in v] if isinstance(v, list) else dbl(v)) for k, v in data.items()}
+    _, mask64, l64 = train_step(model64, data64, img.double(), {k: dbl(v) for k, v in lab.items()}, opt,
+                                (loss_mod.desc_loss, loss_mod.overlap_loss, loss_mod.fine_circle_loss))
+    sum(l64).backward()
+    torch.set_default_dtype(torch.float32)
+    assert torch.equal(mask64.float(), mask)
+    grads64 = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in model64.named_parameters()}
+    out = {"frame_id": frame_id, "num_points": num_points, "pyr_seed": pyr_seed, "num_kpt": NUM_KPT, "sha_points": sha(fr.points), "sha_img": sha(fr.img),
+           "loss_desc": float(l_desc), "loss_coarse": float(l_coarse), "loss_fine": float(l_fine), "mask": mask.numpy(),
+           "pos_margin": opt.pos_margin, "neg_margin": opt.neg_margin, "dist_thres": opt.dist_thres}
+    out.update({"lab_" + k: v for k, v in lab_np.items()})
+    names = ("img_desc", "pc_desc", "img_score", "pc_score", "patches", "fine_pc")
+    for n_, t in zip(names, outs[:6]):
+        out["train_" + n_] = t.detach().numpy()
+    n_grad = 0
+    g_names, g_has, g_norm, g_sum, g_pos, g_val, g_norm64, g_val64, g_err32 = [], [], [], [], [], [], [], [], []
+    for name, p in model.named_parameters():
+        g_names.append(name)
+        g32, g64 = grads32[name], grads64[name]
+        g_has.append(int(g32 is not None))
+        assert (g32 is None) == (g64 is None)
+        if g32 is None:
+            norm, s, pos, val = 0.0, 0.0, np.zeros(SAMPLES, np.int64), np.zeros(SAMPLES, np.float32)
+            norm64, val64, err = 0.0, np.zeros(SAMPLES, np.float64), 0.0
+        else:
+            n_grad += 1
+            norm, s, pos, val = fingerprint(name, g32)
+            norm64 = float(g64.norm())
+            val64 = g64.reshape(-1)[torch.from_numpy(pos)].numpy()
+            err = float((g32.double() - g64).norm() / max(norm64, 1e-300))
+        g_norm.append(norm), g_sum.append(s), g_pos.append(pos), g_val.append(val), g_norm64.append(norm64), g_val64.append(val64), g_err32.append(err)
+    out.update(g_names=np.array(g_names), g_has=np.array(g_has, np.int64), g_norm=np.array(g_norm, np.float64), g_sum=np.array(g_sum, np.float64),
+               g_pos=np.stack(g_pos), g_val=np.stack(g_val), g_norm64=np.array(g_norm64), g_val64=np.stack(g_val64), g_err32=np.array(g_err32),
+               loss64=np.array([float(v) for v in l64]))
+    for name, b in bufs32.items():   # BatchNorm running statistics after the train-mode forward
+        if name.startswith("img_upsample") and ("running" in name or "num_batches" in name):
+            out["buf/" + name] = b.detach().numpy()
+    np.savez_compressed(os.path.join(GOLD, "train_ref.npz"), **out)
+    tot = float(np.sqrt((out["g_norm"] ** 2).sum()))
+    print("train_ref.npz: %d arrays; losses desc %.6f coarse %.6f fine %.6f; %d parameters with a gradient of %d; |grad| %.4e; mask positives %d"
+          % (len(out), l_desc, l_coarse, l_fine, n_grad, len(list(model.named_parameters())), tot, int(mask.sum())))
+    zero = [n for n, p in model.named_parameters() if p.grad is not None and float(p.grad.abs().max()) == 0.0]
+    print("parameters with an all-zero gradient:", len(zero), zero[:8])
+
+
+if __name__ == "__main__":
+    main()
