@@ -45,6 +45,70 @@ def make_inputs(model_dev, frame_ids, num_points):
     return frames
 
 
+def train_labels(pyr, dev, num_kpt=64, seed=0):
+    """train.py-shaped labels for a synthetic frame (data/kitti.py:305-420 derives the real ones from the ground-truth pose)."""
+    g = np.random.default_rng(seed)
+    pts = pyr["points"][-1].cpu().numpy()
+    K_4 = np.array([[20.0, 0.0, 32.0], [0.0, 20.0, 10.0], [0.0, 0.0, 1.0]], dtype=np.float32)
+    uvw = pts @ K_4.T
+    u, v = uvw[:, 0] / uvw[:, 2], uvw[:, 1] / uvw[:, 2]
+    inside = (pts[:, 2] > 0.5) & (u >= 0) & (u < 64) & (v >= 0) & (v < 20)
+    inl, outl = np.nonzero(inside)[0], np.nonzero(~inside)[0]
+    kpt = g.choice(inl, num_kpt, replace=len(inl) < num_kpt)
+    out = g.choice(outl, num_kpt, replace=len(outl) < num_kpt)
+    cidx = (np.clip(np.floor(v[kpt]), 0, 19) * 64 + np.clip(np.floor(u[kpt]), 0, 63)).astype(np.int64)
+    ctr = np.stack([g.integers(2, 254, num_kpt), g.integers(2, 78, num_kpt)]).astype(np.int64)
+    b = dict(K_4=K_4, P=np.eye(4, dtype=np.float32), pc_kpt_idx=kpt.astype(np.int64), pc_outline_idx=out.astype(np.int64), coarse_img_kpt_idx=cidx,
+             fine_center_kpt_coors=ctr, fine_xy=ctr + g.integers(-2, 2, (2, num_kpt)),
+             fine_pc_inline_index=g.integers(0, pyr["points"][1].shape[0], num_kpt).astype(np.int64))
+    return {k: torch.from_numpy(v_).to(dev) for k, v_ in b.items()}
+
+
+class StepOpt:
+    dist_thres, pos_margin, neg_margin = 1.0, 0.2, 1.8   # data/options.py:39,42-43
+
+
+def train_step_summary(dev, frame, steps=8, warmup=3, arith="f32"):
+    """ms per optimisation step (device events around forward / backward / optimizer), peak memory, loss trajectory."""
+    from cofii2p_amd.network import CoFiI2P
+    from cofii2p_amd.train_step import step_losses
+
+    pyr, img, _fr = frame
+    model = CoFiI2P(Opt(), arithmetic=arith).to(dev)
+    batch = train_labels(pyr, dev)
+    optim = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-3)   # train.py:163-164
+    model.train()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    t = [0.0, 0.0, 0.0]
+    losses = []
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    torch.cuda.reset_peak_memory_stats()
+    for it in range(warmup + steps):
+        optim.zero_grad()
+        ev[0].record()
+        _o, _m, ls = step_losses(model, pyr, img, batch, StepOpt)
+        loss = ls[0] + ls[1] + ls[2]
+        ev[1].record()
+        loss.backward()
+        ev[2].record()
+        optim.step()
+        ev[3].record()
+        torch.cuda.synchronize()
+        losses.append(round(float(loss.detach()), 4))
+        if it >= warmup:
+            for j in range(3):
+                t[j] += ev[j].elapsed_time(ev[j + 1])
+    peak = torch.cuda.max_memory_allocated() - base
+    del model, optim
+    torch.cuda.empty_cache()
+    return {"ms_per_step": sum(t) / steps, "forward_ms": t[0] / steps, "backward_ms": t[1] / steps, "optimizer_ms": t[2] / steps, "steps": steps,
+            "arithmetic": arith, "num_kpt": 64, "peak_mem_GB": peak / 2 ** 30, "loss": losses,
+            "note": "train.py:186-286 on the bench frame: model.train(); forward(mode='train'); desc / overlap / fine-circle losses; backward; Adam. "
+                    "HIP kernels in both directions for every weight contraction, KPConv aggregation, attention and neighbour gather "
+                    "(cofii2p_amd/autograd.py); not part of `value`"}
+
+
 def record_kernel_calls(model, dev, points=20480, batch=1):
     """KernelTimer holding every C-ABI call of one submission (one frame, or a stack-mode batch) - used by tools/."""
     from cofii2p_amd.network import CoFiI2P
@@ -801,6 +865,13 @@ def main():
                                            "collected; loader_ms_per_frame = the synchronous FramePreparer.prepare() alone; not the headline"}
     if rank == 0 and world == 1 and Bsz == 1 and not args.eager and not args.no_batch_sweep and not args.stress:
         result["stress_config"] = stress_summary(dev, args)
+    if rank == 0 and world == 1 and Bsz == 1 and not args.no_batch_sweep and not args.stress:
+        # row f3, outside `value`: one optimisation step of train.py:186-286 on the same frame (forward(mode='train') -> the three losses ->
+        # backward -> Adam), exact fp32 contractions; a separate module instance so the served one keeps its weights
+        try:
+            result["train_step"] = train_step_summary(dev, frames[0])
+        except Exception as e:   # additional information only: never costs the line
+            result["train_step"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(frames[0])
     if rank == 0:

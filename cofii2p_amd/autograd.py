@@ -67,7 +67,14 @@ def _gemm_nt(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
 
 
 def col_sum(x: torch.Tensor) -> torch.Tensor:
-    return ops.col_mean(x)[0] * float(x.shape[0])
+    """out[c] = sum over the rows of x[:, c] (a bias gradient), fixed summation order."""
+    lib = _lib.load()
+    _mat(x, "x")
+    M, C = x.shape
+    out = torch.empty((C,), dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.cofi_col_sum_workspace(M, C), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.cofi_col_sum(_p(x), _ld(x), M, C, _p(out), _p(ws), ws.numel(), _stream()), "cofi_col_sum")
+    return out
 
 
 # ------------------------------------------------------------------------------------------ Linear
@@ -78,7 +85,7 @@ class _Linear(torch.autograd.Function):
         y = ops.gemm(_pad4_cols(xd), _pad4_cols(wd), bias=None if bias is None else bias.detach().contiguous(),
                      rowdiv=None if rowdiv is None else rowdiv.contiguous())
         ctx.save_for_backward(xd, wd, rowdiv)
-        ctx.has_bias = bias is not None
+        ctx.has_bias, ctx.arith = bias is not None, ops.GEMM_MODE   # the backward (run later, by the caller's loss.backward()) computes in the same arithmetic
         return y
 
     @staticmethod
@@ -90,10 +97,11 @@ class _Linear(torch.autograd.Function):
             db = col_sum(dy)                                                             # the bias is added after the division
         if rowdiv is not None:
             dy = dy / rowdiv[:, None]
-        if ctx.needs_input_grad[0]:
-            dx = _gemm_nt(dy, ops.transpose(w.contiguous()))[:, :x.shape[1]]             # dY W
-        if ctx.needs_input_grad[1]:
-            dw = _gemm_nt(ops.transpose(dy), ops.transpose(x.contiguous()))              # dY^T X
+        with ops.arithmetic(ctx.arith):
+            if ctx.needs_input_grad[0]:
+                dx = _gemm_nt(dy, ops.transpose(w.contiguous()))[:, :x.shape[1]]         # dY W
+            if ctx.needs_input_grad[1]:
+                dw = _gemm_nt(ops.transpose(dy), ops.transpose(x.contiguous()))          # dY^T X
         return dx, dw, db, None
 
 

@@ -34,21 +34,38 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_bwd_kernel(KpBwdArgs a) 
     const int j = wave / chunks, ch = wave - j * chunks;
     if (j >= a.N) return;
     const int NS = 64 / CW, sub = lane / CW, c = ch * CW + (lane - sub * CW);
-    const bool c_ok = c < a.C && sub < NS;
+    const bool c_ok = c < a.C;
     const float sx = a.s_pts[3 * j], sy = a.s_pts[3 * j + 1], sz = a.s_pts[3 * j + 2];
     const int p0 = a.offsets[j], p1 = a.offsets[j + 1];
     float acc = 0.f;
-    for (int p = p0 + sub; p < p1; p += NS) {
-        const int pair = a.pairs[p];
-        const int m = pair / a.H;
-        const float ox = sx - a.q_pts[3 * m], oy = sy - a.q_pts[3 * m + 1], oz = sz - a.q_pts[3 * m + 2];
-        const float *d = a.dagg + (size_t)m * a.ldd + c;
+    // 64 pairs per round, lane = pair: one coalesced read of the pair ids, one gather of the query positions, all 15 influence
+    // weights of the pair in this lane's registers.  The accumulation loop then takes pair i's row id and weights from lane i
+    // (wave-uniform values) - its only memory traffic is the dagg rows with a non-zero weight, addresses known up front.
+    for (int base = p0; base < p1; base += 64) {
+        const int cnt = min(64, p1 - base);
+        int m = 0;
+        float w[15];
 #pragma unroll
-        for (int k = 0; k < 15; ++k) {
-            const float dx = ox - a.kp[3 * k], dy = oy - a.kp[3 * k + 1], dz = oz - a.kp[3 * k + 2];
-            const float sq = (dx * dx + dy * dy) + dz * dz;
-            const float w = fmaxf(1.0f - __builtin_amdgcn_sqrtf(sq) * a.inv_sigma, 0.0f);
-            if (w > 0.f && c_ok) acc = fmaf(w, d[(size_t)k * a.C], acc);
+        for (int k = 0; k < 15; ++k) w[k] = 0.f;
+        if (lane < cnt) {
+            m = a.pairs[base + lane] / a.H;
+            const float ox = sx - a.q_pts[3 * m], oy = sy - a.q_pts[3 * m + 1], oz = sz - a.q_pts[3 * m + 2];
+#pragma unroll
+            for (int k = 0; k < 15; ++k) {
+                const float dx = ox - a.kp[3 * k], dy = oy - a.kp[3 * k + 1], dz = oz - a.kp[3 * k + 2];
+                const float sq = (dx * dx + dy * dy) + dz * dz;
+                w[k] = fmaxf(1.0f - __builtin_amdgcn_sqrtf(sq) * a.inv_sigma, 0.0f);
+            }
+        }
+        for (int i = 0; i < cnt; i += NS) {
+            const int src = i + sub;                      // the pair this lane group works on (uniform when NS == 1)
+            const int mi = __shfl(m, src, 64);
+            const float *d = a.dagg + (size_t)mi * a.ldd + c;
+#pragma unroll
+            for (int k = 0; k < 15; ++k) {
+                const float wk = __shfl(w[k], src, 64);   // lanes past cnt hold w = 0
+                if (wk > 0.f && c_ok) acc = fmaf(wk, d[(size_t)k * a.C], acc);
+            }
         }
     }
     // fold the NS side-by-side partial sums (lanes with equal channel) in a fixed order
@@ -214,9 +231,38 @@ __device__ __forceinline__ void store_acc_t(float *row_ptr, const f32x16 &acc, i
     }
 }
 
-__global__ __launch_bounds__(64) void attention_bwd_dq_kernel(AttnBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_k[32 * ALD], s_v[32 * ALD];
-    const int lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
+constexpr int ABW = 4;   // waves per workgroup: each takes every ABW-th block of the loop axis; partial results are folded through LDS in wave order
+
+// Wave-private LDS tiles: a wave only reads what it wrote itself, and the LDS executes one wave's instructions in order, so the loops
+// need no workgroup barrier (their trip counts differ between waves); this fence only pins the compiler's ordering.
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// sum the ABW waves' transposed accumulators (lane (li, lh) register r = element [d = (r & 3) + 8 (r >> 2) + 4 lh][row li]) through LDS;
+// wave 0 returns the total.  red: ABW x 32 x 33 floats.
+__device__ __forceinline__ f32x16 fold_waves(float *red, const f32x16 &acc, int wave, int li, int lh) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = acc[r];
+    __syncthreads();
+    f32x16 tot = acc;
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float t = red[d * 33 + li];
+#pragma unroll
+            for (int w = 1; w < ABW; ++w) t += red[(w * 32 + d) * 33 + li];
+            tot[r] = t;
+        }
+    }
+    return tot;
+}
+
+__global__ __launch_bounds__(64 * ABW) void attention_bwd_dq_kernel(AttnBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_tiles[ABW][2][32 * ALD];
+    __shared__ float s_red[ABW * 32 * 33], s_ml[ABW][2][32];
+    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *s_k = s_tiles[wave][0], *s_v = s_tiles[wave][1];
     const int qb = blockIdx.x, h = blockIdx.y;
     const int q = min(qb * 32 + li, a.L - 1);
     const bool q_ok = qb * 32 + li < a.L;
@@ -231,12 +277,12 @@ __global__ __launch_bounds__(64) void attention_bwd_dq_kernel(AttnBwdArgs a) {
         for (int e = 0; e < 4; ++e) delta = fmaf(dof[c][e], of[c][e], delta);
     delta += __shfl_xor(delta, 32, 64);
     const int nkb = (a.S + 31) / 32;
-    // ---- pass 1: row maximum and sum of exponentials (log2 domain), this lane's 16 keys of every block
+    // ---- pass 1: row maximum and sum of exponentials (log2 domain) over this wave's key blocks, this lane's 16 keys of each
     float mx = -INFINITY, sum = 0.f;
-    for (int kb = 0; kb < nkb; ++kb) {
-        __syncthreads();
+    for (int kb = wave; kb < nkb; kb += ABW) {
+        wave_lds_fence();
         stage_tile(s_k, a.K + h * AD, a.ldk, kb * 32, a.S, lane);
-        __syncthreads();
+        wave_lds_fence();
         const f32x16 st = tile_dot(s_k, qf, li, lh);
         float sv[16], bm = mx;
 #pragma unroll
@@ -252,26 +298,35 @@ __global__ __launch_bounds__(64) void attention_bwd_dq_kernel(AttnBwdArgs a) {
             mx = bm;
         }
     }
-    {   // join the two halves of the query's keys
+    {   // join the two halves of the query's keys, then the waves (fixed order)
         const float om = __shfl_xor(mx, 32, 64), os = __shfl_xor(sum, 32, 64);
         const float m2 = fmaxf(mx, om);
-        const float s0 = mx > -INFINITY ? sum * bw_exp2(mx - m2) : 0.f, s1 = om > -INFINITY ? os * bw_exp2(om - m2) : 0.f;
-        sum = lh == 0 ? s0 + s1 : s1 + s0;   // the same association in both halves
+        sum = (mx > -INFINITY ? sum * bw_exp2(mx - m2) : 0.f) + (om > -INFINITY ? os * bw_exp2(om - m2) : 0.f);
         mx = m2;
+        if (lh == 0) { s_ml[wave][0][li] = mx; s_ml[wave][1][li] = sum; }
+        __syncthreads();
+        float mt = s_ml[0][0][li];
+#pragma unroll
+        for (int w = 1; w < ABW; ++w) mt = fmaxf(mt, s_ml[w][0][li]);
+        float stt = 0.f;
+#pragma unroll
+        for (int w = 0; w < ABW; ++w) stt += s_ml[w][0][li] > -INFINITY ? s_ml[w][1][li] * bw_exp2(s_ml[w][0][li] - mt) : 0.f;
+        mx = mt;
+        sum = stt;
     }
     const float lse = mx + __builtin_amdgcn_logf(sum);   // v_log_f32 = log2
-    if (q_ok && lh == 0) {
+    if (q_ok && lh == 0 && wave == 0) {
         float *st = a.stat + ((size_t)h * a.L + q) * 2;
         st[0] = lse;
         st[1] = delta;
     }
-    // ---- pass 2: dQ^T[d, q] += K^T dS^T
+    // ---- pass 2: dQ^T[d, q] += K^T dS^T over this wave's key blocks
     f32x16 dq = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int kb = 0; kb < nkb; ++kb) {
-        __syncthreads();
+    for (int kb = wave; kb < nkb; kb += ABW) {
+        wave_lds_fence();
         stage_tile(s_k, a.K + h * AD, a.ldk, kb * 32, a.S, lane);
         stage_tile(s_v, a.V + h * AD, a.ldv, kb * 32, a.S, lane);
-        __syncthreads();
+        wave_lds_fence();
         const f32x16 st = tile_dot(s_k, qf, li, lh);
         const f32x16 dp = tile_dot(s_v, dof, li, lh);
         f32x16 ds;
@@ -283,12 +338,16 @@ __global__ __launch_bounds__(64) void attention_bwd_dq_kernel(AttnBwdArgs a) {
         }
         tile_t_dot_acc(dq, s_k, ds, li, lh);
     }
-    if (q_ok) store_acc_t(a.dQ + (size_t)q * a.lddq + h * AD, dq, lh);
+    dq = fold_waves(s_red, dq, wave, li, lh);
+    if (q_ok && wave == 0) store_acc_t(a.dQ + (size_t)q * a.lddq + h * AD, dq, lh);
 }
 
-__global__ __launch_bounds__(64) void attention_bwd_dkv_kernel(AttnBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_q[32 * ALD], s_do[32 * ALD], s_stat[64];
-    const int lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
+__global__ __launch_bounds__(64 * ABW) void attention_bwd_dkv_kernel(AttnBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_tiles[ABW][2][32 * ALD];
+    __shared__ float s_red[ABW * 32 * 33], s_stats[ABW][64];
+    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *s_q = s_tiles[wave][0], *s_do = s_tiles[wave][1], *s_stat = s_stats[wave];
     const int kb = blockIdx.x, h = blockIdx.y;
     const int key = min(kb * 32 + li, a.S - 1);
     const bool k_ok = kb * 32 + li < a.S;
@@ -297,15 +356,15 @@ __global__ __launch_bounds__(64) void attention_bwd_dkv_kernel(AttnBwdArgs a) {
     load_frag(vf, a.V + (size_t)key * a.ldv + h * AD, lh);
     f32x16 dk = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dv = dk;
     const int nqb = (a.L + 31) / 32;
-    for (int qb = 0; qb < nqb; ++qb) {
-        __syncthreads();
+    for (int qb = wave; qb < nqb; qb += ABW) {
+        wave_lds_fence();
         stage_tile(s_q, a.Q + h * AD, a.ldq, qb * 32, a.L, lane);
         stage_tile(s_do, a.dO + h * AD, a.lddo, qb * 32, a.L, lane);
         {
             const int qi = min(qb * 32 + (lane >> 1), a.L - 1);
             s_stat[lane] = a.stat[((size_t)h * a.L + qi) * 2 + (lane & 1)];
         }
-        __syncthreads();
+        wave_lds_fence();
         const f32x16 s = tile_dot(s_q, kf, li, lh);      // S[i][j]: rows = queries, column = this lane's key
         const f32x16 dp = tile_dot(s_do, vf, li, lh);    // dP[i][j] = dO_i . V_j
         f32x16 p, ds;
@@ -319,10 +378,36 @@ __global__ __launch_bounds__(64) void attention_bwd_dkv_kernel(AttnBwdArgs a) {
         tile_t_dot_acc(dv, s_do, p, li, lh);    // dV^T[d, j] += dO^T P
         tile_t_dot_acc(dk, s_q, ds, li, lh);    // dK^T[d, j] += Q^T dS
     }
-    if (k_ok) {
+    dk = fold_waves(s_red, dk, wave, li, lh);
+    __syncthreads();
+    dv = fold_waves(s_red, dv, wave, li, lh);
+    if (k_ok && wave == 0) {
         store_acc_t(a.dK + (size_t)key * a.lddk + h * AD, dk, lh);
         store_acc_t(a.dV + (size_t)key * a.lddv + h * AD, dv, lh);
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Column sums of a (M, C) matrix - the bias gradients - in two fixed-order stages: partial sums of row blocks, then their fold.
+__global__ __launch_bounds__(256) void col_sum_partial_kernel(const float *x, int ldx, int M, int C, int rows_per_block, float *part) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    if (c < C)
+        for (int m = r0 + ph; m < r1; m += 4) s += x[(size_t)m * ldx + c];
+    red[ph][cl] = s;
+    __syncthreads();
+    if (ph == 0 && c < C) part[(size_t)blockIdx.y * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
+__global__ void col_sum_final_kernel(const float *part, int RB, int C, float *out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < RB; ++b) s += part[(size_t)b * C + c];
+    out[c] = s;
 }
 
 inline bool bad_mat(const void *p, int ld, int cols) { return !p || ld < cols || (ld & 3) || ((uintptr_t)p & 15); }
@@ -391,6 +476,19 @@ extern "C" int cofi_col2im_nhwc(const float *dcol, int ldc, int H, int W, int C,
     return cofi_launch_status();
 }
 
+static int col_sum_blocks(int M) { return M <= 256 ? 1 : (M / 128 > 256 ? 256 : M / 128); }
+
+extern "C" size_t cofi_col_sum_workspace(int M, int C) { return (size_t)col_sum_blocks(M) * C * sizeof(float); }
+
+extern "C" int cofi_col_sum(const float *x, int ldx, int M, int C, float *out, void *ws, size_t ws_bytes, cofi_stream_t stream) {
+    if (!x || !out || M <= 0 || C <= 0 || ldx < C) return COFI_EINVAL;
+    const int RB = col_sum_blocks(M);
+    if (!ws || ws_bytes < cofi_col_sum_workspace(M, C)) return COFI_EWORKSPACE;
+    hipLaunchKernelGGL(col_sum_partial_kernel, dim3(cofi_cdiv(C, 64), RB), dim3(256), 0, cofi_s(stream), x, ldx, M, C, cofi_cdiv(M, RB), (float *)ws);
+    hipLaunchKernelGGL(col_sum_final_kernel, dim3(cofi_cdiv(C, 256)), dim3(256), 0, cofi_s(stream), (const float *)ws, RB, C, out);
+    return cofi_launch_status();
+}
+
 extern "C" size_t cofi_attention_bwd_workspace(int L, int H) { return (size_t)L * H * 2 * sizeof(float); }
 
 extern "C" int cofi_attention_bwd(const float *q, int ldq, const float *k, int ldk, const float *v, int ldv, const float *o, int ldo,
@@ -404,7 +502,7 @@ extern "C" int cofi_attention_bwd(const float *q, int ldq, const float *k, int l
         return COFI_EINVAL;
     if (!ws || ws_bytes < cofi_attention_bwd_workspace(L, H)) return COFI_EWORKSPACE;
     AttnBwdArgs a{q, k, v, o, d_o, dq, dk, dv, (float *)ws, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, L, S, H, scale, scale * 1.4426950408889634f};
-    hipLaunchKernelGGL(attention_bwd_dq_kernel, dim3((L + 31) / 32, H), dim3(64), 0, cofi_s(stream), a);
-    hipLaunchKernelGGL(attention_bwd_dkv_kernel, dim3((S + 31) / 32, H), dim3(64), 0, cofi_s(stream), a);
+    hipLaunchKernelGGL(attention_bwd_dq_kernel, dim3((L + 31) / 32, H), dim3(64 * ABW), 0, cofi_s(stream), a);
+    hipLaunchKernelGGL(attention_bwd_dkv_kernel, dim3((S + 31) / 32, H), dim3(64 * ABW), 0, cofi_s(stream), a);
     return cofi_launch_status();
 }

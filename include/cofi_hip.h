@@ -427,6 +427,8 @@ int cofi_gather_rows_bwd(const float *dy, int ldy, int C, const int32_t *pairs, 
                          cofi_stream_t stream);
 int cofi_im2col_nhwc(const float *x, int ldx, int H, int W, int C, int ks, int stride, int pad, float *col, int ldc, cofi_stream_t stream);
 int cofi_col2im_nhwc(const float *dcol, int ldc, int H, int W, int C, int ks, int stride, int pad, float *dx, int ldx, cofi_stream_t stream);
+size_t cofi_col_sum_workspace(int M, int C);   /* out[c] = sum_m x[m, c] (bias gradients), two fixed-order stages */
+int cofi_col_sum(const float *x, int ldx, int M, int C, float *out, void *ws, size_t ws_bytes, cofi_stream_t stream);
 size_t cofi_attention_bwd_workspace(int L, int H);
 int cofi_attention_bwd(const float *q, int ldq, const float *k, int ldk, const float *v, int ldv, const float *o, int ldo, const float *d_o,
                        int lddo, int L, int S, int H, int D, float scale, float *dq, int lddq, float *dk, int lddk, float *dv, int lddv, void *ws,
