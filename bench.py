@@ -68,7 +68,7 @@ class StepOpt:
     dist_thres, pos_margin, neg_margin = 1.0, 0.2, 1.8   # data/options.py:39,42-43
 
 
-def train_step_summary(dev, frame, steps=8, warmup=3, arith="f32"):
+def train_step_summary(dev, frame, steps=8, warmup=3, arith="bf16x6"):
     """ms per optimisation step (device events around forward / backward / optimizer), peak memory, loss trajectory."""
     from cofii2p_amd.network import CoFiI2P
     from cofii2p_amd.train_step import step_losses
@@ -485,8 +485,8 @@ def main():
     ap.add_argument("--distinct-frames", type=int, default=16, help="distinct synthetic frames per rank cycled by the timed loop (16 x 27 MB of "
                     "tables do not fit the 256 MB Infinity Cache)")
     ap.add_argument("--no-f32", action="store_true", help="skip the extra exact-fp32 measurement (value_f32)")
-    ap.add_argument("--gemm", default=os.environ.get("COFI_GEMM", "bf16x3"), choices=["f32", "bf16x3"],
-                    help="arithmetic of the dense contractions: exact fp32 MFMA, or 3-term bf16 split with fp32 accumulation")
+    ap.add_argument("--gemm", default=os.environ.get("COFI_GEMM", "bf16x3"), choices=["f32", "bf16x3", "bf16x6"],
+                    help="arithmetic of the dense contractions: exact fp32 MFMA, 3-term bf16 split, or 6-term bf16 split (fp32-grade), all with fp32 accumulation")
     args = ap.parse_args()
     if args.stress:
         Opt.img_H, Opt.img_W, args.points = 896, 1600, 40960
@@ -646,16 +646,20 @@ def main():
     }
 
     if rank == 0 and world == 1 and Bsz == 1 and pipe is not None and args.gemm == "bf16x3" and not args.no_f32:
-        # the same pipelined loop with every dense contraction on the exact fp32 MFMA (the reference's arithmetic): on record next to `value`
-        cofi_ops.GEMM_MODE = "f32"
-        try:
-            pipe.warm(args.warmup)
-            dts32 = timed_repeats(pipe.run, barrier, args.steps, repeats)
-        finally:
-            cofi_ops.GEMM_MODE = args.gemm
-        d32 = float(np.median(dts32))
-        result["value_f32"] = {"frames_per_s": args.steps / d32, "ms_per_frame": 1e3 * d32 / args.steps, "repeats": repeats,
-                               "note": "identical loop, COFI_GEMM=f32: every GEMM / convolution on v_mfma_f32_32x32x2_f32 (bit-equal to an fmaf chain)"}
+        # the same pipelined loop in the two fp32-grade arithmetics, on record next to `value`: every dense contraction on the exact fp32
+        # MFMA (bit-equal to an fmaf chain), and on the 6-term bf16 split (three planes per operand: the same error against fp64 as the
+        # fp32 kernel, tools/x6_probe.py)
+        for key, mode, note in (("value_f32", "f32", "identical loop, COFI_GEMM=f32: every GEMM / convolution on v_mfma_f32_32x32x2_f32 (bit-equal to an fmaf chain)"),
+                                ("value_bf16x6", "bf16x6", "identical loop, COFI_GEMM=bf16x6: hi/mid/lo bf16 planes of both operands, six products on "
+                                                           "v_mfma_f32_32x32x16_bf16, fp32 accumulation - fp32-grade results (the reference-named shim's default)")):
+            cofi_ops.GEMM_MODE = mode
+            try:
+                pipe.warm(args.warmup)
+                dts32 = timed_repeats(pipe.run, barrier, args.steps, repeats)
+            finally:
+                cofi_ops.GEMM_MODE = args.gemm
+            d32 = float(np.median(dts32))
+            result[key] = {"frames_per_s": args.steps / d32, "ms_per_frame": 1e3 * d32 / args.steps, "repeats": repeats, "note": note}
     if rank == 0 and world == 1 and Bsz == 1 and not args.eager and not args.no_batch_sweep:
         # the reference-surface call pattern (evaluation/eval_all.py:94-96): model(...) per frame, one host synchronisation per
         # frame, nothing in flight behind it - what a caller gets without forward_async / finish
@@ -867,7 +871,7 @@ def main():
         result["stress_config"] = stress_summary(dev, args)
     if rank == 0 and world == 1 and Bsz == 1 and not args.no_batch_sweep and not args.stress:
         # row f3, outside `value`: one optimisation step of train.py:186-286 on the same frame (forward(mode='train') -> the three losses ->
-        # backward -> Adam), exact fp32 contractions; a separate module instance so the served one keeps its weights
+        # backward -> Adam), fp32-grade contractions (bf16x6); a separate module instance so the served one keeps its weights
         try:
             result["train_step"] = train_step_summary(dev, frames[0])
         except Exception as e:   # additional information only: never costs the line

@@ -439,6 +439,17 @@ __device__ __forceinline__ void split4(const f32x4 v, uint2 &hi, uint2 &lo) {
     lo.x = cvt_pk_bf16(rx, ry);
     lo.y = cvt_pk_bf16(rz, rw);
 }
+// three planes: hi + mid + lo carry all 24 mantissa bits of an fp32 value (the bf16x6 arithmetic)
+__device__ __forceinline__ void split4x3(const f32x4 v, uint2 &hi, uint2 &mid, uint2 &lo) {
+    hi.x = cvt_pk_bf16(v[0], v[1]);
+    hi.y = cvt_pk_bf16(v[2], v[3]);
+    const float rx = v[0] - __uint_as_float(hi.x << 16), ry = v[1] - __uint_as_float(hi.x & 0xffff0000u);
+    const float rz = v[2] - __uint_as_float(hi.y << 16), rw = v[3] - __uint_as_float(hi.y & 0xffff0000u);
+    mid.x = cvt_pk_bf16(rx, ry);
+    mid.y = cvt_pk_bf16(rz, rw);
+    lo.x = cvt_pk_bf16(rx - __uint_as_float(mid.x << 16), ry - __uint_as_float(mid.x & 0xffff0000u));
+    lo.y = cvt_pk_bf16(rz - __uint_as_float(mid.y << 16), rw - __uint_as_float(mid.y & 0xffff0000u));
+}
 __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
     hi.x = cvt_pk_bf16(v.x, v.y);
     hi.y = cvt_pk_bf16(v.z, v.w);
@@ -478,9 +489,15 @@ __global__ void split_planes_kernel(const float *W, int ldw, int N, int K, unsig
 //        (M, 15 C) output has no other reader): A tiles then travel global -> LDS as plain 16-byte copies like the W tiles, the
 //        conversion instructions (the bulk of the VALU work of a tile) and their registers disappear.  Dense GEMM only.
 //        (An earlier experiment in this slot - two K-tiles in flight in registers - measured 445 vs 457 frames/s and was removed.)
-template <int BM, int BN, int TM, int TN, int BK3, bool WSPLIT = false, int WPE = 1, bool ANORM = false, bool ASPLIT = false>
+// X6 (COFI_GEMM_BF16X6): THREE bf16 planes per operand - hi + mid + lo hold all 24 mantissa bits of an fp32 value - and the six
+//        products hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi (what is dropped is below 2^-24 of |a||b|): fp32-grade results
+//        (the error is that of the fp32 accumulation, as in the exact-fp32 kernel) at 16/6 = 2.7x the fp32 MFMA rate.  Operands are
+//        split on the fly (no pre-split planes); the normalising loader (ANORM) works as in the 3-term kernel.
+template <int BM, int BN, int TM, int TN, int BK3, bool WSPLIT = false, int WPE = 1, bool ANORM = false, bool ASPLIT = false, bool X6 = false>
 __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
     static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 waves");
+    static_assert(!X6 || (!WSPLIT && !ASPLIT), "bf16x6 splits both operands on the fly");
+    constexpr int NPL = X6 ? 3 : 2;   // bf16 planes per operand
     constexpr int NT = 256;
     constexpr int BROW3 = BK3 * 2 + 16;   // bytes per LDS row: bf16 values + 16 B pad (68 / 36 dwords: conflict-free b128 reads)
     constexpr int LPR = BK3 / 4;          // lanes per row slice (float4 each)
@@ -493,7 +510,7 @@ __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
     static_assert(!WSPLIT || (BN * CPR) % NT == 0, "plane tile must divide over the threads");
     constexpr int TLD = BN + 4;
     constexpr int PLANE_A = BM * BROW3, PLANE_W = BN * BROW3;    // bytes
-    constexpr int BUF = 2 * (PLANE_A + PLANE_W);                 // hi+lo of A and W
+    constexpr int BUF = NPL * (PLANE_A + PLANE_W);               // hi + lo (+ mid) of A and W
     // the epilogue re-uses the operand buffer as a row-major fp32 tile
     constexpr int EPI = (BM == 128 ? 64 : BM) * TLD * 4;   // BM = 128: two 64-row halves
     constexpr int LDS_BYTES = BUF > EPI ? BUF : EPI;
@@ -673,30 +690,29 @@ __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
                 *reinterpret_cast<f32x4 *>(p) = st.rah[j];
                 *reinterpret_cast<f32x4 *>(p + PLANE_A) = st.ral[j];
             }
-        } else if (st.afull) {
-#pragma unroll
-            for (int j = 0; j < A_LD4; ++j) {
-                uint2 hi, lo;
-                split4(st.ra[j], hi, lo);
-                unsigned char *p = lds_raw + (lrow + RPP * j) * BROW3 + lk * 2;
-                *reinterpret_cast<uint2 *>(p) = hi;
-                *reinterpret_cast<uint2 *>(p + PLANE_A) = lo;
-            }
         } else {
 #pragma unroll
             for (int j = 0; j < A_LD4; ++j) {
-                uint2 hi, lo;
-                split4(((st.amask >> j) & 1u) ? st.ra[j] : zero, hi, lo);
+                const f32x4 v = (st.afull || ((st.amask >> j) & 1u)) ? st.ra[j] : zero;
                 unsigned char *p = lds_raw + (lrow + RPP * j) * BROW3 + lk * 2;
+                uint2 hi, lo;
+                if constexpr (X6) {   // planes: hi | mid | lo
+                    uint2 mid;
+                    split4x3(v, hi, mid, lo);
+                    *reinterpret_cast<uint2 *>(p + PLANE_A) = mid;
+                    *reinterpret_cast<uint2 *>(p + 2 * PLANE_A) = lo;
+                } else {
+                    split4(v, hi, lo);
+                    *reinterpret_cast<uint2 *>(p + PLANE_A) = lo;
+                }
                 *reinterpret_cast<uint2 *>(p) = hi;
-                *reinterpret_cast<uint2 *>(p + PLANE_A) = lo;
             }
         }
         if constexpr (WSPLIT) {
 #pragma unroll
             for (int j = 0; j < W_CH; ++j) {
                 const int c = tid + NT * j;
-                unsigned char *p = lds_raw + 2 * PLANE_A + (c / CPR) * BROW3 + (c % CPR) * 16;
+                unsigned char *p = lds_raw + NPL * PLANE_A + (c / CPR) * BROW3 + (c % CPR) * 16;
                 *reinterpret_cast<f32x4 *>(p) = st.rwh[j];
                 *reinterpret_cast<f32x4 *>(p + PLANE_W) = st.rwl[j];
             }
@@ -704,10 +720,17 @@ __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < W_LD4; ++j) {
                 uint2 hi, lo;
-                split4(st.rw[j], hi, lo);
-                unsigned char *p = lds_raw + 2 * PLANE_A + (lrow + RPP * j) * BROW3 + lk * 2;
+                unsigned char *p = lds_raw + NPL * PLANE_A + (lrow + RPP * j) * BROW3 + lk * 2;
+                if constexpr (X6) {
+                    uint2 mid;
+                    split4x3(st.rw[j], hi, mid, lo);
+                    *reinterpret_cast<uint2 *>(p + PLANE_W) = mid;
+                    *reinterpret_cast<uint2 *>(p + 2 * PLANE_W) = lo;
+                } else {
+                    split4(st.rw[j], hi, lo);
+                    *reinterpret_cast<uint2 *>(p + PLANE_W) = lo;
+                }
                 *reinterpret_cast<uint2 *>(p) = hi;
-                *reinterpret_cast<uint2 *>(p + PLANE_W) = lo;
             }
         }
     };
@@ -724,28 +747,39 @@ __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
     union Frag { uint4 u; bf16x8 v; };
     constexpr int STEPS = BK3 / 16;   // 16-deep MFMA steps per tile
     const unsigned char *as = lds_raw + (wm * 32 * TM + li) * BROW3 + lh * 16;
-    const unsigned char *bs = lds_raw + 2 * PLANE_A + (wn * 32 * TN + li) * BROW3 + lh * 16;
+    const unsigned char *bs = lds_raw + NPL * PLANE_A + (wn * 32 * TN + li) * BROW3 + lh * 16;
     auto compute = [&]() {
 #pragma unroll
         for (int s2 = 0; s2 < STEPS; ++s2) {  // lane (i,h) owns k = 16*s2 + 8h .. +7
-            Frag ah[TM], al[TM], bh[TN], bl[TN];
+            Frag ah[TM], al[TM], bh[TN], bl[TN], am[X6 ? TM : 1], bm[X6 ? TN : 1];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 ah[i].u = *reinterpret_cast<const uint4 *>(as + i * 32 * BROW3 + s2 * 32);
-                al[i].u = *reinterpret_cast<const uint4 *>(as + PLANE_A + i * 32 * BROW3 + s2 * 32);
+                al[i].u = *reinterpret_cast<const uint4 *>(as + (NPL - 1) * PLANE_A + i * 32 * BROW3 + s2 * 32);
+                if constexpr (X6) am[i].u = *reinterpret_cast<const uint4 *>(as + PLANE_A + i * 32 * BROW3 + s2 * 32);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 bh[j].u = *reinterpret_cast<const uint4 *>(bs + j * 32 * BROW3 + s2 * 32);
-                bl[j].u = *reinterpret_cast<const uint4 *>(bs + PLANE_W + j * 32 * BROW3 + s2 * 32);
+                bl[j].u = *reinterpret_cast<const uint4 *>(bs + (NPL - 1) * PLANE_W + j * 32 * BROW3 + s2 * 32);
+                if constexpr (X6) bm[j].u = *reinterpret_cast<const uint4 *>(bs + PLANE_W + j * 32 * BROW3 + s2 * 32);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].v, bh[j].v, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bl[j].v, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bh[j].v, acc[i][j], 0, 0, 0);
+                    if constexpr (X6) {   // smallest terms first: 2^-16 (lo*hi, hi*lo, mid*mid), 2^-8 (mid*hi, hi*mid), 1 (hi*hi)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].v, bh[j].v, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bl[j].v, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i].v, bm[j].v, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i].v, bh[j].v, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bm[j].v, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bh[j].v, acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].v, bh[j].v, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bl[j].v, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bh[j].v, acc[i][j], 0, 0, 0);
+                    }
                 }
         }
     };
@@ -1026,6 +1060,22 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
 #undef X
         default: return COFI_EINVAL;
         }
+    } else if (g.bf16x3 == 2) {
+        // bf16x6: three planes per operand; K-tiles of 64 (64 x 64 tile: 54 KB of LDS) / 32 (wider tiles: 41 / 60 KB)
+#define COFI_LAUNCH_BF16X6(BM_, BN_, TM_, TN_, BK_)                                                                        \
+    do {                                                                                                                  \
+        if (g.an.part)                                                                                                    \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, false, 1, true, false, true>), grid, dim3(256), 0, s, g);   \
+        else                                                                                                              \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, false, 1, false, false, true>), grid, dim3(256), 0, s, g);  \
+    } while (0)
+        if (p.bm == 128 && p.bn == 128)
+            COFI_LAUNCH_BF16X6(128, 128, 2, 2, 32);
+        else if (p.bm == 64 && p.bn == 128)
+            COFI_LAUNCH_BF16X6(64, 128, 1, 2, 32);
+        else
+            COFI_LAUNCH_BF16X6(64, 64, 1, 1, 64);
+#undef COFI_LAUNCH_BF16X6
     } else if (g.bf16x3) {
 #define COFI_LAUNCH_BF16X3(BM_, BN_, TM_, TN_, BK_)                                                                        \
     do {                                                                                                                  \
@@ -1080,10 +1130,10 @@ int stat_shift_of(int width, int N) {
 }
 
 // the pending normalisation of the A operand; channels = columns of a dense A / input channels of a convolution.
-// Runs on the bf16x3 kernels with pre-split weights only.
+// Runs on the bf16x3 kernels with pre-split weights and on the bf16x6 kernels.
 int set_a_norm(GemmArgs &g, const cofi_norm_desc_t *a_norm, int channels, int a_rows_per_frame, int frames, const Plan &p) {
     if (!a_norm) return 0;
-    if (!g.bf16x3 || !g.wsplit) return COFI_EUNSUPPORTED;
+    if (!(g.bf16x3 == 1 && g.wsplit) && g.bf16x3 != 2) return COFI_EUNSUPPORTED;   // 3-term kernel: pre-split weights; 6-term kernel: fp32 weights
     if (a_norm->channels != channels) return COFI_EINVAL;
     if (int rc = make_norm_src(a_norm, a_rows_per_frame, frames, 512, &g.an)) return rc;
     if (!(g.an.slope >= 0.f && g.an.slope <= 1.f)) return COFI_EINVAL;
@@ -1098,11 +1148,11 @@ int gemm_entry(const float *A, int lda, const cofi_norm_desc_t *a_norm, const fl
                cofi_stream_t stream) {
     if (int rc = check_common(A, lda, W, ldw, C, ldc, M, N, K)) return rc;
     if (M == 0) return 0;
-    const int bf16x3 = (act & COFI_GEMM_BF16X3) ? 1 : 0;
+    const int bf16x3 = (act & COFI_GEMM_BF16X6) ? 2 : ((act & COFI_GEMM_BF16X3) ? 1 : 0);
     const int wsplit = (act & COFI_GEMM_W_SPLIT) ? 1 : 0;
     const int asplit = (act & COFI_GEMM_A_SPLIT) ? 1 : 0;
-    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_W_SPLIT | COFI_GEMM_A_SPLIT);
-    if (act < 0 || act > 3 || (wsplit && (!bf16x3 || (ldw & 7))) || frames <= 0) return COFI_EINVAL;
+    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT | COFI_GEMM_A_SPLIT);
+    if (act < 0 || act > 3 || (wsplit && (bf16x3 != 1 || (ldw & 7))) || frames <= 0) return COFI_EINVAL;
     if (asplit && (!wsplit || a_norm || (lda & 7) || (K & 7))) return COFI_EINVAL;
     const int sshift = colpart ? stat_shift_of(stat_width, N) : 0;
     if (sshift < 0) return COFI_EINVAL;
@@ -1125,10 +1175,10 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
     const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
     if (frames <= 0) return COFI_EINVAL;
     const int M = Ho * Wo * frames, K = ks * ks * Cin;
-    const int bf16x3 = (act & COFI_GEMM_BF16X3) ? 1 : 0;
+    const int bf16x3 = (act & COFI_GEMM_BF16X6) ? 2 : ((act & COFI_GEMM_BF16X3) ? 1 : 0);
     const int wsplit = (act & COFI_GEMM_W_SPLIT) ? 1 : 0;
-    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_W_SPLIT);
-    if (act < 0 || act > 3 || (wsplit && !bf16x3) || act_col0 < 0 || act_col0 > Cout) return COFI_EINVAL;
+    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT);
+    if (act < 0 || act > 3 || (wsplit && bf16x3 != 1) || act_col0 < 0 || act_col0 > Cout) return COFI_EINVAL;
     const int sshift = colpart ? stat_shift_of(stat_width, Cout) : 0;
     if (sshift < 0) return COFI_EINVAL;
     const int ldw = wsplit ? (K + 7) / 8 * 8 : K;   // pre-split planes: rows padded to 8 values
@@ -1184,10 +1234,10 @@ extern "C" int cofi_gemm_f32_layernorm(const float *A, int lda, const float *W, 
     if (M == 0) return 0;
     Plan p = make_plan(M, N, K, true);
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
-    const int bf16x3 = (relu & COFI_GEMM_BF16X3) ? 1 : 0;
+    const int bf16x3 = (relu & COFI_GEMM_BF16X6) ? 2 : ((relu & COFI_GEMM_BF16X3) ? 1 : 0);
     const int wsplit = (relu & COFI_GEMM_W_SPLIT) ? 1 : 0;
-    relu &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_W_SPLIT);
-    if (wsplit && (!bf16x3 || (ldw & 7))) return COFI_EINVAL;
+    relu &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT);
+    if (wsplit && (bf16x3 != 1 || (ldw & 7))) return COFI_EINVAL;
     GemmArgs g{};
     g.A = A; g.W = W; g.C = C; g.bias = bias; g.ws = (float *)ws; g.ln_gamma = gamma; g.ln_beta = beta; g.res = res;
     g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr; g.M = M; g.N = N; g.K = K; g.ksplit = 1; g.ln_relu = relu; g.ln_eps = eps;

@@ -59,12 +59,16 @@ class CoFiI2P(nn.Module):
     into the weights) or 'ln' - the three get_norm() variants of model/kpconv/modules.py:51-60.
 
     ``arithmetic`` (or ``opt.arithmetic``): how the dense contractions (every nn.Linear / nn.Conv2d / KPConv weight product) are
-    computed.  "f32" = products on the exact fp32 MFMA, bit-equal to an fmaf chain - the reference's arithmetic.  "bf16x3" = each fp32
-    operand split into bf16 hi + lo, hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32 accumulation (~2^-16 relative error per
-    product, ~2x the throughput; outputs within 4e-6 / 2.6e-5 of the reference on the golden frame, same matches selected there, but a
-    score within ~1e-5 of the 0.9 threshold or an arg-max near-tie may resolve differently).  None = the process default
-    (``COFI_GEMM``, "bf16x3" when unset).  The reference-named shim ``model.network.CoFiI2P`` defaults to "f32".  INTEGRATION.md
-    states the accuracy contract."""
+    computed; storage and accumulation are fp32 in all three.
+      "f32"     products on the exact fp32 MFMA, bit-equal to an fmaf chain.
+      "bf16x6"  each fp32 operand split into THREE bf16 planes (hi + mid + lo = all 24 mantissa bits), six products on the bf16 matrix
+                cores: fp32-GRADE - the same error against fp64 as "f32" (what is dropped is below 2^-24 of |a||b|; golden frame 1.9e-6 vs
+                2.0e-6, same matches) at ~1.9x its frame rate.  The default of the reference-named shim ``model.network.CoFiI2P`` and of
+                the training path.
+      "bf16x3"  two planes (hi + lo), three products: ~2^-16 relative error per product, the fastest (outputs within 2e-5 of the
+                reference on the golden frame, same matches selected there, but a score within ~1e-5 of the 0.9 threshold or an arg-max
+                near-tie may resolve differently).
+    None = the process default (``COFI_GEMM``, "bf16x3" when unset).  INTEGRATION.md states the accuracy contract."""
 
     # distinct (slot, input set) graphs kept for forward_async(inputs_stable=True).  Every captured graph owns a private memory pool with a
     # full frame of intermediates (≈ 0.1 GB for a KITTI frame: the bench's 16 graphs + weights + planes + inputs peak at 2.35 GB, `peak_mem_GB`;
@@ -484,9 +488,9 @@ class CoFiI2P(nn.Module):
 
             self._trained = True
             # gradients amplify the arithmetic's rounding (measured on the tiny frame: the 3-term bf16 split's 2^-16 per product becomes
-            # up to 1e-2 in a parameter gradient, exact fp32 stays at the reference's own fp32 level): training computes in "f32"
-            # unless the module was explicitly built with arithmetic="bf16x3"
-            with ops.arithmetic(self.arithmetic if self.arithmetic is not None else "f32"):
+            # up to 1e-2 in a parameter gradient; the fp32-grade arithmetics stay at the reference's own fp32 level): training computes
+            # in "bf16x6" unless the module was built with an explicit arithmetic
+            with ops.arithmetic(self.arithmetic if self.arithmetic is not None else "bf16x6"):
                 return train_forward.forward_train(self, pc_data_dict, img, fine_center_kpt_coors, fine_pc_inline_index)
         if torch.is_grad_enabled() and (img.requires_grad or pc_data_dict["feats"].requires_grad):
             raise NotImplementedError("mode='test' is not differentiable (host-side match selection, network.py:145-151): call it under "

@@ -17,6 +17,7 @@ import os
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_LEAKY01 = 0, 1, 2, 3
 GEMM_BF16X3 = 0x100
+GEMM_BF16X6 = 0x800
 # arithmetic of the dense contractions: "bf16x3" (default) = 3-term bf16 split (hi*hi + hi*lo + lo*hi) on the bf16 matrix cores
 # with fp32 accumulation, ~2^-16 relative error per product; "f32" = exact fp32 MFMA (COFI_GEMM=f32)
 GEMM_MODE = os.environ.get("COFI_GEMM", "bf16x3")
@@ -28,16 +29,17 @@ BRANCH_MASK = 7
 
 
 def _gemm_flag() -> int:
-    return GEMM_BF16X3 if GEMM_MODE == "bf16x3" else 0
+    return GEMM_BF16X3 if GEMM_MODE == "bf16x3" else (GEMM_BF16X6 if GEMM_MODE == "bf16x6" else 0)
 
 
 class arithmetic:
-    """Context manager: run the enclosed launches with the given contraction arithmetic ("bf16x3" | "f32"; None = leave the process
-    default, COFI_GEMM).  `CoFiI2P(opt, arithmetic=...)` wraps its forwards in it, so two models with different arithmetic coexist."""
+    """Context manager: run the enclosed launches with the given contraction arithmetic ("bf16x3" | "bf16x6" | "f32"; None = leave the
+    process default, COFI_GEMM).  "bf16x6": three bf16 planes per operand, six products - fp32-grade results on the bf16 matrix cores
+    (include/cofi_hip.h COFI_GEMM_BF16X6).  `CoFiI2P(opt, arithmetic=...)` wraps its forwards in it, so two models with different arithmetic coexist."""
 
     def __init__(self, mode):
-        if mode not in (None, "bf16x3", "f32"):
-            raise ValueError("arithmetic must be 'bf16x3' or 'f32', got %r" % (mode,))
+        if mode not in (None, "bf16x3", "bf16x6", "f32"):
+            raise ValueError("arithmetic must be 'bf16x3', 'bf16x6' or 'f32', got %r" % (mode,))
         self.mode = mode
 
     def __enter__(self):
@@ -271,7 +273,7 @@ class Normed:
         return self.y.numel()
 
     def fusable(self, tile_rows_ok: bool = True) -> bool:
-        return (GEMM_MODE == "bf16x3" and self.stats.fusable() and self.y.shape[1] <= self.MAX_FUSED_CHANNELS and 0.0 <= self.slope <= 1.0
+        return (GEMM_MODE in ("bf16x3", "bf16x6") and self.stats.fusable() and self.y.shape[1] <= self.MAX_FUSED_CHANNELS and 0.0 <= self.slope <= 1.0
                 and tile_rows_ok)
 
     def desc(self):

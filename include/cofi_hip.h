@@ -86,6 +86,12 @@ typedef struct cofi_norm_desc {
  * (csrc/gemm_planes.inc: 9 tile configurations, plans tuned on MI355X); same products, same K order as the other bf16x3 kernels - equal
  * split-K gives equal bits.  Not combinable with a_norm. */
 #define COFI_GEMM_A_SPLIT 0x400
+/* fp32-GRADE arithmetic on the bf16 matrix cores: every fp32 operand is split on the fly into THREE bf16 planes (hi + mid + lo = all 24
+ * mantissa bits) and the product formed as hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi with fp32 accumulation - what is dropped is
+ * below 2^-24 of |a||b|, so the result differs from an exact-fp32 contraction only by accumulation-order rounding (measured: same error
+ * against fp64 as the fp32 MFMA kernel) at 16/6 = 2.7x its matrix rate.  Plain fp32 operands only (no COFI_GEMM_W_SPLIT / A_SPLIT, no
+ * normalising loader).  Accepted by cofi_gemm_f32*, cofi_conv2d_nhwc*. */
+#define COFI_GEMM_BF16X6 0x800
 
 int cofi_abi_version(void);
 /* name of the code object's target, "gfx950" */

@@ -1,16 +1,18 @@
 """`model.network` of the reference (model/network.py): same names, served by cofii2p_amd.network.
 
-The class exported here is the strict drop-in: unless the caller asks otherwise (`opt.arithmetic = "bf16x3"`, or the constructor
-argument) its dense contractions run on the exact fp32 MFMA - the reference's arithmetic - so `evaluation/eval_all.py` / `train.py`
-(validation) callers that only swap the import get fp32 products, not the faster 3-term bf16 split `cofii2p_amd.network.CoFiI2P`
-defaults to (INTEGRATION.md "Arithmetic")."""
+The class exported here is the strict drop-in: unless the caller asks otherwise (`opt.arithmetic`, or the constructor argument) its
+dense contractions are fp32-GRADE - "bf16x6": three bf16 planes per operand, six products, fp32 accumulation; the same error against
+fp64 as an exact-fp32 contraction (tools/x6_probe.py, tests/test_forward_gpu.py::test_kitti_frame_bf16x6_is_fp32_grade) - so
+`evaluation/eval_all.py` / `train.py` callers that only swap the import get fp32-level results, not the faster but coarser 3-term
+split `cofii2p_amd.network.CoFiI2P` defaults to.  `opt.arithmetic = "f32"` selects the exact fp32 MFMA (products bit-equal
+to an fmaf chain) at about half the frame rate.  INTEGRATION.md "Arithmetic"."""
 from cofii2p_amd import network as _net
 from cofii2p_amd.network import (CoFiI2P_wrapper as _Wrapper, extract_patch, fine_matching, fine_process, point2node,  # noqa: F401
                                  score_thresholds, square_distance)
 
 
 class CoFiI2P(_net.CoFiI2P):
-    DEFAULT_ARITHMETIC = "f32"
+    DEFAULT_ARITHMETIC = "bf16x6"
 
 
 class CoFiI2P_wrapper(_Wrapper):

@@ -255,6 +255,28 @@ def test_kitti_frame_bf16x3_gemms_within_tolerance(model, monkeypatch):
     assert abs(res[6].shape[1] - gold["test_center_xy"].shape[1]) <= 3  # a score may cross the 0.9 threshold
 
 
+def test_kitti_frame_bf16x6_is_fp32_grade(model, monkeypatch):
+    """"bf16x6" (three bf16 planes per operand, six products): the golden frame as close to the reference as the exact-fp32 arithmetic
+    is - the same comparison, each arithmetic's worst output deviation printed side by side - and the same matches selected."""
+    from cofii2p_amd import ops
+
+    model.enable_graphs(False)
+    gold = load_golden("frame_kitti.npz")
+    fr, data = frame_inputs(int(gold["frame_id"]), int(gold["num_points"]), int(gold["pyr_seed"]))
+    dd, img = to_dev(data), torch.from_numpy(fr.img)[None].to(DEV)
+    names = ("img_desc", "pc_desc", "img_score", "pc_score")
+    worst, sel = {}, {}
+    for mode in ("f32", "bf16x6", "bf16x3"):
+        monkeypatch.setattr(ops, "GEMM_MODE", mode)
+        res = model(dd, img, None, None, None, "test")
+        worst[mode] = max(maxdiff(t, gold["test_" + n]) for n, t in zip(names, res[:4]))
+        sel[mode] = model.last_match["sel"].cpu()
+    print("max abs diff vs the reference's outputs:", worst)
+    assert worst["bf16x6"] <= max(2.0 * worst["f32"], 2e-6), worst      # fp32-grade: within rounding of the exact-fp32 run
+    assert worst["bf16x6"] < 0.5 * worst["bf16x3"], worst               # ... and well below the 3-term split
+    assert torch.equal(sel["bf16x6"], sel["f32"])
+
+
 @pytest.mark.parametrize("norm", ["bn", "ln"])
 def test_tiny_frame_other_point_encoder_norms(norm, monkeypatch):
     """opt.norm = 'bn' / 'ln' (get_norm(), modules.py:51-60) against the reference built with that option: BatchNorm (running
@@ -468,8 +490,8 @@ def test_eval_all_shaped_caller(model, tmp_path, monkeypatch):
     from cofii2p_amd.network import CoFiI2P, fine_matching
     from cofii2p_amd.pose import get_P_diff, pose_matrix, solve_pnp_ransac
 
-    # the reference-named class IS the implementation with the exact-fp32 contractions as its default: what an unchanged caller gets
-    assert issubclass(ShimCoFiI2P, CoFiI2P) and ShimCoFiI2P(Opt()).arithmetic == "f32"
+    # the reference-named class IS the implementation with the fp32-grade contractions (bf16x6) as its default: what an unchanged caller gets
+    assert issubclass(ShimCoFiI2P, CoFiI2P) and ShimCoFiI2P(Opt()).arithmetic == "bf16x6"
     monkeypatch.setattr(ops, "GEMM_MODE", "bf16x3")   # the process default must not leak into the strict shim
     gold = load_golden("frame_kitti.npz")
     fr, data = frame_inputs(int(gold["frame_id"]), int(gold["num_points"]), int(gold["pyr_seed"]))

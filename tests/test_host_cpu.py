@@ -207,7 +207,8 @@ def test_neighbourhood_operator_shims_and_oracle_properties():
 
 def test_arithmetic_is_an_explicit_option_and_the_shim_is_strict():
     """the reference-named import path must not hand out approximate contractions unasked.  `model.network.CoFiI2P` defaults to
-    the exact fp32 arithmetic, `cofii2p_amd.network.CoFiI2P` follows the process default unless told, `opt.arithmetic` / the constructor
+    the fp32-grade arithmetic ("bf16x6": same error against fp64 as exact fp32, tests/test_forward_gpu.py::test_kitti_frame_bf16x6_is_fp32_grade;
+    "f32" on request), `cofii2p_amd.network.CoFiI2P` follows the process default unless told, `opt.arithmetic` / the constructor
     argument override both, and the per-forward context restores the process default."""
     from cofii2p_amd import ops
     from cofii2p_amd.network import CoFiI2P as Native
@@ -216,8 +217,8 @@ def test_arithmetic_is_an_explicit_option_and_the_shim_is_strict():
     class Opt:
         img_H, img_W, img_fine_resolution_scale, norm = 160, 512, 32, "gn"
 
-    assert Shim(Opt()).arithmetic == "f32" and CoFiI2P_wrapper(Opt()).cofii2p.arithmetic == "f32"
-    assert Native(Opt()).arithmetic is None and Native(Opt(), arithmetic="f32").arithmetic == "f32"
+    assert Shim(Opt()).arithmetic == "bf16x6" and CoFiI2P_wrapper(Opt()).cofii2p.arithmetic == "bf16x6"
+    assert Native(Opt()).arithmetic is None and Native(Opt(), arithmetic="f32").arithmetic == "f32" and Shim(Opt(), arithmetic="f32").arithmetic == "f32"
     o = Opt()
     o.arithmetic = "bf16x3"
     assert Shim(o).arithmetic == "bf16x3" and Native(o).arithmetic == "bf16x3"

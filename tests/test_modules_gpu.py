@@ -11,8 +11,9 @@ pytestmark = pytest.mark.gpu
 from common import load_golden  # noqa: E402
 
 DEV = "cuda:0"
-# (arithmetic, tolerance): exact fp32 MFMA to the fixtures' own 5e-5; the 3-term bf16 split (2^-16 per product) a decade looser
-MODES = [("f32", 5e-5), ("bf16x3", 5e-4)]
+# (arithmetic, tolerance): exact fp32 MFMA and the 6-term bf16 split (fp32-grade) to the fixtures' own 5e-5; the 3-term bf16 split
+# (2^-16 per product) a decade looser
+MODES = [("f32", 5e-5), ("bf16x6", 5e-5), ("bf16x3", 5e-4)]
 
 
 class Opt:

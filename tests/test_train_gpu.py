@@ -216,7 +216,7 @@ def _train_inputs(gold):
 
 # "bf16x3" (opt-in for training: CoFiI2P(opt, arithmetic="bf16x3")): the split's 2^-16 per product is amplified by the cancellations of the
 # backward to ~1e-2 in individual gradients - measured, documented in INTEGRATION.md, bounded here
-@pytest.mark.parametrize("arith,tol", [("f32", GRAD_TOL), (None, GRAD_TOL), ("bf16x3", 3e-2)])
+@pytest.mark.parametrize("arith,tol", [("f32", GRAD_TOL), ("bf16x6", GRAD_TOL), (None, GRAD_TOL), ("bf16x3", 3e-2)])
 def test_train_step_matches_reference(gold, arith, tol, monkeypatch):
     """forward(mode='train') -> losses -> backward: train-mode outputs, losses, every parameter gradient (norm-relative error of the 96
     recorded entries, gradient norm, sum), presence / absence of a gradient, BatchNorm running statistics - against the reference."""
