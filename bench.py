@@ -756,30 +756,37 @@ def main():
             pend = [None] * NSL
             feats0 = frames[0][0]["feats"]
             sub_sizes = [int(t.shape[0]) for t in sub]
-            pgs = [PyramidGraph(args.points, sub_sizes, dev, capture_stream=st[0]) for _ in range(NSL)]
-            imgs = [frames[0][1].clone() for _ in range(NSL)]   # static per slot, like the tables
-            for phase in range(2):   # 0 = warm-up (captures the graphs of these slots), 1 = timed
-                nfr = max(args.steps, 3 * NSL)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for i in range(nfr):
-                    sl = i % NSL
-                    if pend[sl] is not None:
-                        model.finish(pend[sl])
-                    with torch.cuda.stream(st[i % S]):
-                        pyr = dict(pgs[sl].run(p0, sub))
-                        pyr["feats"] = feats0
-                        pend[sl] = model.forward_async(30 + sl, pyr, imgs[sl], inputs_stable=True)
-                for sl in range(NSL):
-                    if pend[sl] is not None:
-                        model.finish(pend[sl])
-                        pend[sl] = None
-                torch.cuda.synchronize()
-                dte = time.perf_counter() - t0
-            result["with_pyramid_build"] = {"frames_per_s": nfr / dte, "ms_per_frame": 1e3 * dte / nfr,
-                                            "note": "pyramid construction (5 cell grids + 13 KNN-128 searches, one hipGraph) + forward + fine matching per "
+            rates = {}
+            for upk in (None, 1):   # the reference's (N, 128) up-sampling tables / their first column only (all the forward reads), derived without a search
+                pgs = [PyramidGraph(args.points, sub_sizes, dev, capture_stream=st[0], upsample_k=upk) for _ in range(NSL)]
+                imgs = [frames[0][1].clone() for _ in range(NSL)]   # static per slot, like the tables
+                for phase in range(2):   # 0 = warm-up (captures the graphs of these slots), 1 = timed
+                    nfr = max(args.steps, 3 * NSL)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(nfr):
+                        sl = i % NSL
+                        if pend[sl] is not None:
+                            model.finish(pend[sl])
+                        with torch.cuda.stream(st[i % S]):
+                            pyr = dict(pgs[sl].run(p0, sub))
+                            pyr["feats"] = feats0
+                            pend[sl] = model.forward_async((30 if upk is None else 45) + sl, pyr, imgs[sl], inputs_stable=True)
+                    for sl in range(NSL):
+                        if pend[sl] is not None:
+                            model.finish(pend[sl])
+                            pend[sl] = None
+                    torch.cuda.synchronize()
+                    dte = time.perf_counter() - t0
+                rates[upk] = (nfr / dte, 1e3 * dte / nfr)
+                del pgs
+            result["with_pyramid_build"] = {"frames_per_s": rates[None][0], "ms_per_frame": rates[None][1],
+                                            "nearest_only_upsampling": {"frames_per_s": rates[1][0], "ms_per_frame": rates[1][1],
+                                                                        "note": "build_pyramid(upsample_k=1): the four up-sampling tables hold their first column only - "
+                                                                                "all the forward reads (functional.py:20) - derived from neighbors[i] without a search; "
+                                                                                "outputs bit-identical"},
+                                            "note": "pyramid construction (5 cell grids + 9 KNN-128 searches + 4 row gathers, one hipGraph) + forward + fine matching per "
                                                     "frame on the same GPU; not the headline"}
-            del pgs
     if rank == 0 and world == 1 and Bsz == 1 and not args.no_batch_sweep and not args.eager:
         # row f2: the whole data side of a frame on this GPU (data/kitti.py:259-393: calibration transform, 0.1 m voxel grid, resample to
         # num_pc, random SE(3), KNN pyramid, image resize / crop, labels) from a raw 120 000-point scan + 376 x 1241 image already in
@@ -813,55 +820,60 @@ def main():
         model.enable_graphs(True)
         LOOK, INFL = len(st), len(st) * max(1, args.slots_per_stream)
         NSL = INFL + LOOK
-        loader = FrameLoader(opt_ds, dev, slots=NSL, workers=4, capture_stream=st[0])
-        pend = [None] * NSL
+        ds_rates = {}
+        for upk in (None, 1):   # the reference's (N, 128) up-sampling tables / nearest-only tables derived without a search (outputs bit-identical)
+            loader = FrameLoader(opt_ds, dev, slots=NSL, workers=4, capture_stream=st[0], upsample_k=upk)
+            pend = [None] * NSL
 
-        host = {"begin": 0.0, "complete": 0.0, "forward": 0.0, "collect": 0.0}   # host seconds inside each call (timed phase)
+            host = {"begin": 0.0, "complete": 0.0, "forward": 0.0, "collect": 0.0}   # host seconds inside each call (timed phase)
 
-        def timed(name, fn, *a, **k):
-            t_ = time.perf_counter()
-            r = fn(*a, **k)
-            host[name] += time.perf_counter() - t_
-            return r
+            def timed(name, fn, *a, **k):
+                t_ = time.perf_counter()
+                r = fn(*a, **k)
+                host[name] += time.perf_counter() - t_
+                return r
 
-        def collect(sl):
-            h, smp = pend[sl]
-            model.finish(h)
-            smp["finish_labels"]()
-            loader.release(sl)
-            pend[sl] = None
+            def collect(sl):
+                h, smp = pend[sl]
+                model.finish(h)
+                smp["finish_labels"]()
+                loader.release(sl)
+                pend[sl] = None
 
-        try:
-            for phase in range(2):
-                nfr = max(args.steps, 3 * NSL)
-                for k_ in host:
-                    host[k_] = 0.0
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for j in range(min(LOOK, nfr)):
-                    with torch.cuda.stream(st[j % len(st)]):
-                        loader.begin(j % NSL, raw_d, img_d, rK, P_Tr, j)
-                for i in range(nfr):
-                    sl, nxt = i % NSL, i + LOOK
-                    with torch.cuda.stream(st[i % len(st)]):
-                        if nxt < nfr:   # the voxel grid of frame i + LOOK goes onto this stream AHEAD of frame i's own work
-                            if pend[nxt % NSL] is not None:
-                                timed("collect", collect, nxt % NSL)
-                            timed("begin", loader.begin, nxt % NSL, raw_d, img_d, rK, P_Tr, nxt)
+            try:
+                for phase in range(2):
+                    nfr = max(args.steps, 3 * NSL)
+                    for k_ in host:
+                        host[k_] = 0.0
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for j in range(min(LOOK, nfr)):
+                        with torch.cuda.stream(st[j % len(st)]):
+                            loader.begin(j % NSL, raw_d, img_d, rK, P_Tr, j)
+                    for i in range(nfr):
+                        sl, nxt = i % NSL, i + LOOK
+                        with torch.cuda.stream(st[i % len(st)]):
+                            if nxt < nfr:   # the voxel grid of frame i + LOOK goes onto this stream AHEAD of frame i's own work
+                                if pend[nxt % NSL] is not None:
+                                    timed("collect", collect, nxt % NSL)
+                                timed("begin", loader.begin, nxt % NSL, raw_d, img_d, rK, P_Tr, nxt)
+                            loader.poll()
+                            smp = timed("complete", loader.complete, sl)
+                            pend[sl] = (timed("forward", model.forward_async, (60 if upk is None else 80) + sl, smp["pc_data_dict"], smp["img"][None], inputs_stable=True), smp)
                         loader.poll()
-                        smp = timed("complete", loader.complete, sl)
-                        pend[sl] = (timed("forward", model.forward_async, 60 + sl, smp["pc_data_dict"], smp["img"][None], inputs_stable=True), smp)
-                    loader.poll()
-                for k in range(NSL):
-                    if pend[(nfr + k) % NSL] is not None:
-                        timed("collect", collect, (nfr + k) % NSL)
-                torch.cuda.synchronize()
-                dtl = time.perf_counter() - t0
-        finally:
-            loader.close()
+                    for k in range(NSL):
+                        if pend[(nfr + k) % NSL] is not None:
+                            timed("collect", collect, (nfr + k) % NSL)
+                    torch.cuda.synchronize()
+                    dtl = time.perf_counter() - t0
+            finally:
+                loader.close()
+            ds_rates[upk] = (nfr / dtl, dict(host))
+        dtl, host = nfr / ds_rates[None][0], ds_rates[None][1]
         result["with_dataside"] = {"loader_ms_per_frame": loader_ms, "loader_frames_per_s": 1e3 / loader_ms, "frames_per_s": nfr / dtl,
                                    "ms_per_frame": 1e3 * dtl / nfr, "voxels": voxels, "raw_points": int(raw.shape[1]),
                                    "frames_in_flight": INFL, "voxel_grids_ahead": LOOK, "draw_workers": 4,
+                                   "nearest_only_upsampling_frames_per_s": ds_rates[1][0],
                                    "host_ms_per_frame_in": {k_: round(1e3 * v_ / nfr, 4) for k_, v_ in host.items()},
                                    "note": "kitti.py:259-393 on the device (voxel grid + resample + SE(3) + KNN pyramid + image + labels) in front of the "
                                            "forward + fine matching, pipelined (cofii2p_amd/loader.py): raw scan and image resident in HBM, voxel count "

@@ -29,6 +29,7 @@ SIGNATURES = {
     "cofi_abi_version": (_I, []),
     "cofi_target_arch": (ctypes.c_char_p, []),
     "cofi_knn_topk": (_I, [_P, _I, _P, _I, _I, _P, _P, _P]),
+    "cofi_knn_up_nearest": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P]),
     "cofi_knn_grid_workspace": (_Z, [_I]),
     "cofi_knn_grid_build": (_I, [_P, _I, _P, _Z, _P, _P]),
     "cofi_knn_topk_grid": (_I, [_P, _Z, _I, _P, _P, _I, _I, _P, _P, _P]),

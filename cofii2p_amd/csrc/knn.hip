@@ -126,6 +126,45 @@ __global__ __launch_bounds__(256) void nearest_kernel(const float *nodes, int S,
     if (lane == 0) out_idx[q] = (int)(unsigned)(best & 0xffffffffu);
 }
 
+
+// ---- nearest stage-(i+1) point of every stage-i point WITHOUT a search (column 0 of upsampling[i], the only column the forward reads:
+// model/kpconv/functional.py:20).  Stage i+1 is a selection WITH replacement of stage i (point j = stage-i point sub[j], bit for bit), so
+// the nearest selected point of p is the first entry of p's own sorted neighbour row neighbors[i][p] that was selected - exactly, ties
+// included: the candidates at the minimal canonical distance are walked and the lowest stage-(i+1) copy index among them wins, the
+// (distance, lowest index) order of the search this replaces.  first_copy[q] = lowest j with sub[j] == q (INT_MAX: not selected).
+// A row none of whose k entries was selected (degenerate clouds only) scans all stage-(i+1) points instead.
+__global__ void first_copy_kernel(const int32_t *sub, int S1, int32_t *first_copy) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < S1) atomicMin(&first_copy[sub[j]], j);   // integer min: order-free, deterministic
+}
+
+__global__ void up_nearest_kernel(const float *pts, int N, const int32_t *nbr, int k, const int32_t *first_copy, const int32_t *sub, int S1,
+                                  int32_t *out, int ldo) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const float qx = pts[3 * p], qy = pts[3 * p + 1], qz = pts[3 * p + 2];
+    const float qq = canon_sqnorm(qx, qy, qz);
+    u64 best = KEY_INF;
+    for (int h = 0; h < k; ++h) {
+        const int q = nbr[(size_t)p * k + h];
+        if (q < 0 || q >= N) break;   // shadow entries close a row
+        const float sx = pts[3 * q], sy = pts[3 * q + 1], sz = pts[3 * q + 2];
+        const float d = canon_dist(qx, qy, qz, qq, sx, sy, sz, canon_sqnorm(sx, sy, sz));
+        if (best != KEY_INF && __float_as_uint(d) > (unsigned)(best >> 32)) break;   // ascending row: nothing closer or equal follows
+        const int j = first_copy[q];
+        if (j != 0x7fffffff) best = umin64(best, ((u64)__float_as_uint(d) << 32) | (unsigned)j);
+    }
+    if (best == KEY_INF) {
+        for (int j = 0; j < S1; ++j) {
+            const int q = sub[j];
+            const float sx = pts[3 * q], sy = pts[3 * q + 1], sz = pts[3 * q + 2];
+            const float d = canon_dist(qx, qy, qz, qq, sx, sy, sz, canon_sqnorm(sx, sy, sz));
+            best = umin64(best, ((u64)__float_as_uint(d) << 32) | (unsigned)j);
+        }
+    }
+    out[(size_t)p * ldo] = (int)(unsigned)(best & 0xffffffffu);
+}
+
 __global__ void idx64_to_32_kernel(const int64_t *src, int32_t *dst, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (int32_t)src[i];
 }
@@ -158,6 +197,16 @@ extern "C" int cofi_nearest_node_sel(const float *nodes, int S, const float *poi
     if (max_count == 0) return 0;
     hipLaunchKernelGGL(nearest_kernel, dim3(cofi_cdiv(max_count, 4)), dim3(256), 0, cofi_s(stream), nodes, S, points_all, sel,
                        count_dev, max_count, out_idx);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_knn_up_nearest(const float *points, int N, const int32_t *neighbors, int k, const int32_t *sub, int S1, int32_t *first_copy,
+                                   int32_t *out_idx, int ldo, cofi_stream_t stream) {
+    if (!points || !neighbors || !sub || !first_copy || !out_idx || N <= 0 || k <= 0 || S1 <= 0 || ldo < 1) return COFI_EINVAL;
+    if (hipError_t e = hipMemsetD32Async((hipDeviceptr_t)first_copy, 0x7fffffff, (size_t)N, cofi_s(stream)); e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(first_copy_kernel, dim3(cofi_cdiv(S1, 256)), dim3(256), 0, cofi_s(stream), sub, S1, first_copy);
+    hipLaunchKernelGGL(up_nearest_kernel, dim3(cofi_cdiv(N, 256)), dim3(256), 0, cofi_s(stream), points, N, neighbors, k, first_copy, sub, S1, out_idx,
+                       ldo);
     return cofi_launch_status();
 }
 

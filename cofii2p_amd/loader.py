@@ -36,11 +36,15 @@ class _Slot:
 
 
 class FrameLoader:
-    def __init__(self, opt, device="cuda", slots: int = 8, workers: int = 4, dataset: str = "kitti", capture_stream: Optional[torch.cuda.Stream] = None):
+    def __init__(self, opt, device="cuda", slots: int = 8, workers: int = 4, dataset: str = "kitti", capture_stream: Optional[torch.cuda.Stream] = None,
+                 upsample_k: Optional[int] = None):
         """slots: frames that can be in preparation / flight at once (a slot is reusable once the forward that read its tensors has been
         collected).  capture_stream: the stream hipGraphs are captured on (pass the model's: `model.frame_streams(n)[0]`); capture
         needs a non-default stream and every extra stream costs a hardware queue."""
         self.opt, self.device, self.dataset = opt, torch.device(device), dataset
+        # upsample_k=1: the up-sampling tables hold their first column only (all the forward reads), derived without a search
+        # (preprocess.build_pyramid); None: the reference's (N, 128) tables
+        self.upsample_k = upsample_k
         self.preps = [dataside.FramePreparer(opt, device, dataset=dataset) for _ in range(slots)]
         self.slots = [_Slot() for _ in range(slots)]
         self.pool = ProcessPoolExecutor(max_workers=max(1, workers), mp_context=mp.get_context("spawn"), initializer=worker_init)
@@ -93,7 +97,7 @@ class FrameLoader:
         """resample + SE(3) + KNN pyramid + image, all from device-resident inputs: the body of the slot's hipGraph"""
         buf = st.stage["dev"]
         points, feats = prep.resample_transform_dev(st.h["vox"], buf[0], buf[-1])
-        pyr = build_pyramid(points, buf[1:-1], int64=False)
+        pyr = build_pyramid(points, buf[1:-1], int64=False, upsample_k=self.upsample_k)
         pyr["feats"] = feats
         image = prep.image(img_dev, rhw, crop)
         st.stage["coarse_host"].copy_(pyr["points"][-1], non_blocking=True)

@@ -900,6 +900,24 @@ def knn(support, query, k: int, return_dist: bool = False, grid=None, qorder=Non
     return (idx, dist) if return_dist else idx
 
 
+def knn_up_nearest(points, neighbors, sub, out=None):
+    """-> (N, 1) int32: for every stage-i point the nearest stage-(i+1) point = column 0 of `knn(points[sub], points, k)`, derived from the
+    point's own neighbour row (cofi_knn_up_nearest) instead of searched.  points (N, 3), neighbors (N, k) int32 into the same points,
+    sub (S1,) int32: stage-(i+1) point j is stage-i point sub[j]."""
+    lib = _lib.load()
+    _check_xyz(points, "points")
+    _mat(neighbors, "neighbors", torch.int32)
+    if sub.dtype != torch.int32 or not sub.is_cuda or not sub.is_contiguous() or not neighbors.is_contiguous():
+        raise _lib.CofiError("knn_up_nearest: contiguous CUDA int32 tables expected")
+    N, k = neighbors.shape
+    if out is None:
+        out = torch.empty((N, 1), dtype=torch.int32, device=points.device)
+    scratch = torch.empty((N,), dtype=torch.int32, device=points.device)
+    _lib.check(lib.cofi_knn_up_nearest(_p(points), N, _p(neighbors), k, _p(sub), sub.numel(), _p(scratch), _p(out), out.stride(0), _stream()),
+               "cofi_knn_up_nearest")
+    return out
+
+
 def nearest_node(nodes, points):
     lib = _lib.load()
     out = torch.empty((points.shape[0],), dtype=torch.int32, device=points.device)

@@ -27,11 +27,17 @@ def morton_order(points: torch.Tensor) -> torch.Tensor:
     return torch.argsort(code).to(torch.int32).contiguous()
 
 
-def build_pyramid(points: torch.Tensor, subsample: List[torch.Tensor], k: int = NUM_NEIGHBORS, int64: bool = False) -> Dict:
+def build_pyramid(points: torch.Tensor, subsample: List[torch.Tensor], k: int = NUM_NEIGHBORS, int64: bool = False, upsample_k: Optional[int] = None) -> Dict:
     """points (N,3) CUDA fp32; subsample[i] = indices (CUDA int64/int32) into stage i selecting stage
     i+1 (the reference draws them with np.random.choice WITH replacement, preprocess_data.py:58).
     Returns the reference's dict layout: neighbors[i] (N_i,k) into stage i, subsampling[i] (N_{i+1},k)
-    into stage i, upsampling[i] (N_i,k) into stage i+1 — int32 (device native) or int64."""
+    into stage i, upsampling[i] (N_i,k) into stage i+1 — int32 (device native) or int64.
+    upsample_k=1: upsampling[i] holds ONLY its first column, (N_i, 1) - the nearest stage-(i+1) point, all the forward reads of these
+    tables (nearest_upsample, functional.py:20) - and is derived from neighbors[i] without a search (ops.knn_up_nearest: the same index
+    the search returns, ties included).  The four up-searches are 48 % of a pyramid's kernel time; the forward's outputs do not change by
+    a bit.  None / k: the reference's full (N_i, k) tables."""
+    if upsample_k not in (None, 1, k):
+        raise ValueError("upsample_k must be 1 (nearest only) or k (the reference's tables)")
     pts = [points.contiguous()]
     for sel in subsample:
         pts.append(pts[-1][sel.long()].contiguous())
@@ -48,7 +54,10 @@ def build_pyramid(points: torch.Tensor, subsample: List[torch.Tensor], k: int = 
             # same canonical distances, same (distance, lowest index) order: 4 of the 13 searches of a pyramid are row gathers
             # (tests/test_ops_gpu.py::test_gpu_pyramid_bit_exact_and_int64_contract holds the tables to the searching oracle)
             subsampling.append(neighbors[i][subsample[i].long()].contiguous())
-            upsampling.append(ops.knn(pts[i + 1], pts[i], k, grid=grids[i + 1], qorder=qord[i] if grids[i + 1] is not None else None))
+            if upsample_k == 1:
+                upsampling.append(ops.knn_up_nearest(pts[i], neighbors[i], ops.idx_to_int32(subsample[i]).contiguous()))
+            else:
+                upsampling.append(ops.knn(pts[i + 1], pts[i], k, grid=grids[i + 1], qorder=qord[i] if grids[i + 1] is not None else None))
     conv = ops.idx_to_int64 if int64 else (lambda t: t)
     return {"points": pts, "lengths": [int(p.shape[0]) for p in pts], "neighbors": [conv(t) for t in neighbors],
             "subsampling": [conv(t) for t in subsampling], "upsampling": [conv(t) for t in upsampling],
@@ -63,8 +72,10 @@ class PyramidGraph:
     and one graph launch, and the tables come out in static int32 tensors a `forward_async(..., inputs_stable=True)` reads in place.
     One instance per frame in flight (its outputs are overwritten by the next run)."""
 
-    def __init__(self, num_points: int, sub_sizes, device, capture_stream: Optional[torch.cuda.Stream] = None, k: int = NUM_NEIGHBORS):
+    def __init__(self, num_points: int, sub_sizes, device, capture_stream: Optional[torch.cuda.Stream] = None, k: int = NUM_NEIGHBORS,
+                 upsample_k: Optional[int] = None):
         self.device = torch.device(device)
+        self.upsample_k = upsample_k
         self.points = torch.empty((num_points, 3), dtype=torch.float32, device=self.device)
         self.sub = [torch.empty((n,), dtype=torch.int32, device=self.device) for n in sub_sizes]
         self.k, self.graph, self.out = k, None, None
@@ -81,12 +92,12 @@ class PyramidGraph:
             cap.wait_stream(cur)
             with torch.cuda.stream(cap):
                 for _ in range(2):
-                    build_pyramid(self.points, self.sub, self.k)
+                    build_pyramid(self.points, self.sub, self.k, upsample_k=self.upsample_k)
             cur.wait_stream(cap)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=cap):
-                self.out = build_pyramid(self.points, self.sub, self.k)
+                self.out = build_pyramid(self.points, self.sub, self.k, upsample_k=self.upsample_k)
         self.graph.replay()
         return self.out
 

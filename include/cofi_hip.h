@@ -118,6 +118,12 @@ int cofi_knn_topk(const float *support, int S, const float *query, int Q, int k,
  *   cofi_knn_topk_grid(...)      wave per query against a built grid; qorder (Q) optional: wave w handles query qorder[w]
  * One grid serves every search against that support set (neighbors[i], subsampling[i], upsampling[i-1] of
  * preprocess_data.py:60-99 share stage i).  Worth it from a few thousand support points on; below that cofi_knn_topk. */
+/* Column 0 of upsampling[i] (the nearest stage-(i+1) point of every stage-i point; the only column the forward reads, functional.py:20)
+ * WITHOUT a search: stage i+1 is a selection with replacement of stage i (sub[j] = stage-i index of point j, S1 entries), so the answer
+ * is the first selected entry of the point's own sorted row neighbors[i] (N, k) - ties at the minimal canonical distance resolved to the
+ * lowest stage-(i+1) index, exactly as cofi_knn_topk* would.  first_copy: N int32 of scratch.  out_idx[p * ldo] = that index. */
+int cofi_knn_up_nearest(const float *points, int N, const int32_t *neighbors, int k, const int32_t *sub, int S1, int32_t *first_copy,
+                        int32_t *out_idx, int ldo, cofi_stream_t stream);
 size_t cofi_knn_grid_workspace(int S);
 int cofi_knn_grid_build(const float *support, int S, void *ws, size_t ws_bytes, int32_t *order_out, cofi_stream_t stream);
 int cofi_knn_topk_grid(const void *ws, size_t ws_bytes, int S, const float *query, const int32_t *qorder, int Q, int k,

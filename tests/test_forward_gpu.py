@@ -122,6 +122,47 @@ def test_gpu_pyramid_bit_exact_and_int64_contract(model):
     assert out[4].shape[0] >= 4 and out[4].shape[1:] == (64, 16)
 
 
+def test_nearest_only_upsampling_tables_are_exact(model):
+    """build_pyramid(upsample_k=1): the (N, 1) up-sampling tables derived from the points' own neighbour rows equal column 0 of the
+    SEARCHED tables bit for bit - a lattice cloud full of exact distance ties and duplicates (sub-sampling with replacement), a KITTI-shaped
+    pyramid, and a degenerate selection where no neighbour of most points was selected (full scan) - and the forward's outputs do not
+    change by a bit."""
+    from cofii2p_amd import ops
+    from cofii2p_amd.preprocess import build_pyramid
+    from cofii2p_amd.synth import make_frame, subsample_indices
+
+    g = np.random.default_rng(8)
+    lattice = (g.integers(0, 12, (3000, 3)) * 0.1).astype(np.float32)          # many coincident points, many equal distances
+    for pts_np, subs in ((lattice, subsample_indices(3000, 3, seed=1)), (make_frame(5, 4096).points, subsample_indices(4096, 5, seed=3))):
+        pts = torch.from_numpy(pts_np).to(DEV)
+        sub = [torch.from_numpy(s_).to(DEV) for s_ in subs]
+        full = build_pyramid(pts, sub)
+        near = build_pyramid(pts, sub, upsample_k=1)
+        for a, b in zip(full["upsampling"], near["upsampling"]):
+            assert b.shape == (a.shape[0], 1) and torch.equal(a[:, :1], b)
+        for k_ in ("neighbors", "subsampling"):
+            assert all(torch.equal(a, b) for a, b in zip(full[k_], near[k_]))
+    # degenerate: stage 1 = 64 copies of ONE far corner point -> almost no row of neighbors[0] holds a selected point
+    far = torch.from_numpy(np.concatenate([g.random((1500, 3)).astype(np.float32), np.full((1, 3), 50.0, np.float32)])).to(DEV)
+    sel = torch.full((64,), 1500, dtype=torch.int32, device=DEV)
+    nb = ops.knn(far, far, 128)
+    got = ops.knn_up_nearest(far, nb, sel)
+    want = ops.knn(far[sel.long()].contiguous(), far, 64)[:, :1]
+    assert torch.equal(got, want) and int(got.max()) == 0
+    # the forward reads column 0 only (functional.py:20): identical outputs
+    fr = make_frame(5, 4096)
+    sub = [torch.from_numpy(s_).to(DEV) for s_ in subsample_indices(4096, 5, seed=3)]
+    img = torch.from_numpy(fr.img)[None].to(DEV)
+    outs = []
+    model.enable_graphs(False)
+    for kk in (None, 1):
+        pyr = build_pyramid(torch.from_numpy(fr.points).to(DEV), sub, upsample_k=kk)
+        pyr["feats"] = torch.from_numpy(fr.feats).to(DEV)
+        outs.append([t.clone() for t in model(pyr, img, None, None, None, "test")])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_product_refuses_cpu_tensors(model):
     from cofii2p_amd._lib import CofiError
 
