@@ -621,6 +621,68 @@ def test_gemm_bf16x3_split(ops, M, N, K, monkeypatch):
         close(ln, torch.nn.functional.layer_norm(ref.float(), (N,)), 2e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (1280, 512, 7680), (77, 33, 60), (2560, 1024, 3072), (20480, 32, 480), (100, 64, 1000), (64, 480, 20480),
+                                   (4700, 512, 64), (1350, 1024, 256)])
+def test_gemm_bf16x6_is_fp32_grade(ops, M, N, K, monkeypatch):
+    """6-term bf16 split (three planes per operand): against fp64 the contraction is as accurate as the exact-fp32 MFMA kernel on the same
+    operands - what the split drops is below 2^-24 of |a||b|, the rest is fp32 accumulation - on every tile configuration / split-K plan,
+    with the fused epilogues (column statistics, LayerNorm) and the implicit-GEMM convolution."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * 3
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    ref = a.double() @ w.double().t() + bias.double()
+    scale = (a.double().abs() @ w.double().abs().t())
+    err = {}
+    for mode in ("f32", "bf16x6", "bf16x3"):
+        monkeypatch.setattr(ops, "GEMM_MODE", mode)
+        out = ops.gemm(G(a), G(w), bias=G(bias)).cpu().double()
+        err[mode] = (float(((out - ref).abs() / scale).max()), float((out - ref).pow(2).mean().sqrt()))
+    assert err["bf16x6"][0] < max(2.0 * err["f32"][0], 2e-7) and err["bf16x6"][1] < 1.5 * err["f32"][1], err
+    assert err["bf16x6"][1] < 0.3 * err["bf16x3"][1], err
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x6")
+    y, part = ops.gemm_colstats(G(a), G(w), bias=G(bias))
+    st = ops.group_stats_from_colpart(part, M, N).cpu()
+    assert float((st[:, 0].double() - ref.mean(0)).abs().max()) < 1e-4
+    assert torch.equal(y, ops.gemm(G(a), ops.presplit(G(w)), bias=G(bias)))   # a pre-split weight object hands its fp32 original to this arithmetic
+    if N <= 128:
+        ln = ops.gemm_layernorm(G(a), G(w), G(torch.ones(N)), G(torch.zeros(N)), bias=G(bias))
+        close(ln, torch.nn.functional.layer_norm(ref.float(), (N,)), 2e-5)
+
+
+def test_bf16x6_normalising_loader_and_convolution(ops, monkeypatch):
+    """the pending-normalisation loader and the implicit-GEMM convolution in the 6-term arithmetic: fused == apply kernel + plain launch bit
+    for bit, and the results at the exact-fp32 kernel's distance from torch's fp64 reference"""
+    import torch.nn.functional as F
+
+    from cofii2p_amd.image import _nhwc_weight
+
+    g = torch.Generator().manual_seed(5)
+    M, Kc, N, groups = 1280, 128, 512, 32
+    x0, w0 = torch.randn(M, 96, generator=g) * 1.5 + 0.2, torch.randn(Kc, 96, generator=g) / 9.0
+    w1, b1 = torch.randn(N, Kc, generator=g) / Kc ** 0.5, torch.randn(N, generator=g)
+    ga, be = 1 + 0.2 * torch.randn(Kc, generator=g), 0.3 * torch.randn(Kc, generator=g)
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x6")
+    y, part = ops.gemm_colstats(G(x0), ops.presplit(G(w0)), stat_width=4)
+    nm = ops.Normed(y, ops.ColStats(part, M, groups, 1, width=4), G(ga), G(be), 0.1)
+    assert nm.fusable()
+    fused = ops.gemm(nm, ops.presplit(G(w1)), bias=G(b1))
+    plain = ops.gemm(nm.materialize(), G(w1), bias=G(b1))
+    assert torch.equal(fused, plain)
+    ref = F.leaky_relu(F.group_norm((x0.double() @ w0.double().t()).t()[None], groups, ga.double(), be.double(), 1e-5)[0].t(), 0.1) @ w1.double().t() + b1.double()
+    close(fused, ref.float(), 2e-5)
+    Cin, Cout, H, W = 64, 128, 20, 32
+    x = torch.randn(1, Cin, H, W, generator=g)
+    wa = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    refc = F.conv2d(x.double(), wa.double(), stride=2, padding=1)
+    errs = {}
+    for mode in ("f32", "bf16x6"):
+        monkeypatch.setattr(ops, "GEMM_MODE", mode)
+        out = ops.conv2d_nhwc(G(_nhwc(x)), H, W, G(_nhwc_weight(wa)), 3, 2, 1)[0]
+        errs[mode] = float((out.cpu().double() - _nhwc(refc)).abs().max())
+    assert errs["bf16x6"] < max(2.0 * errs["f32"], 1e-6), errs
+
+
 def _nhwc(t):  # (1,C,H,W) -> (H*W, C)
     return t[0].permute(1, 2, 0).reshape(-1, t.shape[1]).contiguous()
 
