@@ -394,10 +394,11 @@ class CoFiI2P(nn.Module):
     def frame_streams(self, n: int, device=None):
         """The HIP streams to keep n frames in flight on (one `forward_async` slot - or two, alternating - per stream).
         HIP multiplexes all streams of a process onto GPU_MAX_HW_QUEUES (default 4) hardware queues, and the command processor serves
-        them best one queue per frame stream: measured on MI355X, four frame streams on the four default queues run 495 frames/s,
-        while every EXTRA live stream (a dedicated capture stream, torch's default stream next to four others) makes two of them share
-        a queue (319 frames/s).  So the streams handed out here are the ones the process already owns - the graph-capture stream and
-        the device's default stream - before any new one is created; more than 4 lose again (5: 341, 6: 379 frames/s)."""
+        them best one queue per frame stream: four frame streams run 575-585 frames/s, five 341, six 379 (two then share a queue), and
+        raising GPU_MAX_HW_QUEUES does not help (8 queues / 8 streams: 462).  The streams handed out are the ones the process already
+        owns - the graph-capture stream and the device's default stream - before new ones are created.  With the default queue
+        configuration this is a convenience, not a requirement: four FRESH streams, or a fifth stream that a loader / RCCL uses next to
+        the four, run at the same rate (profiles/r03_fifth_stream.md; the round-2 pipeline lost 45 % there)."""
         dev = torch.device(device) if device is not None else next(self.parameters()).device
         if getattr(self, "_capture_stream", None) is None or self._capture_stream.device != dev:
             self._capture_stream = torch.cuda.Stream(device=dev)
