@@ -54,6 +54,7 @@ SIGNATURES = {
     "cofi_col_inv_norm_from_colpart": (_I, [_P, _I, _I, _I, _I, _F, _P, _I, _P]),
     "cofi_group_stats_workspace": (_Z, [_I, _I, _I, _I]),
     "cofi_group_stats": (_I, [_P, _I, _I, _I, _I, _F, _P, _P, _Z, _I, _P]),
+    "cofi_group_stats_exact": (_I, [_P, _I, _I, _I, _I, _F, _P, _P, _Z, _I, _P]),
     "cofi_group_norm_apply": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _F, _P, _I, _P, _I, _P]),
     "cofi_norm_finalize": (_I, [_N, _I, _I, _P, _P]),
     "cofi_group_norm_apply_partials": (_I, [_P, _I, _I, _I, _N, _P, _I, _N, _P, _I, _P, _I, _P]),
@@ -93,6 +94,8 @@ SIGNATURES = {
     "cofi_gather_rows_bwd": (_I, [_P, _I, _I, _P, _P, _I, _P, _I, _P]),
     "cofi_im2col_nhwc": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "cofi_col2im_nhwc": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "cofi_group_norm_bwd_workspace": (_Z, [_I, _I, _I]),
+    "cofi_group_norm_bwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _P, _P, _I, _P, _Z, _P]),
     "cofi_col_sum_workspace": (_Z, [_I, _I]),
     "cofi_col_sum": (_I, [_P, _I, _I, _I, _P, _P, _Z, _P]),
     "cofi_attention_bwd_workspace": (_Z, [_I, _I]),

@@ -10,6 +10,7 @@ in a fixed order - no float atomics, bit-reproducible (csrc/backward.hip).
     neighbor_maxpool(x, idx), gather_rows     model/kpconv/functional.py:53-66, 5-21
     im2col(x, H, W, ks, stride, pad)          unfolded operand of a convolution of the image branch (conv = im2col + linear)
     attention(q, k, v, nhead)                 model/transformer/linear_attention.py:56-79
+    group_norm_act(x, gamma, beta, groups, slope, res)   GroupNorm / InstanceNorm / train-mode BatchNorm over the rows + activation + residual
 """
 import math
 from typing import Optional
@@ -239,6 +240,46 @@ def conv2d(x, H: int, W: int, weight: torch.Tensor, stride: int = 1, pad: Option
     if ks == 1 and stride == 1:
         return linear(x, w2), Ho, Wo
     return linear(im2col(x, H, W, ks, stride, pad), w2), Ho, Wo
+
+
+# ------------------------------------------------------------------------------------------ normalisation over rows + activation
+class _GroupNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, groups, slope, eps, fixed_stats):
+        xd = x.detach().contiguous()
+        stats = ops.group_stats(xd, groups, eps, exact=True) if fixed_stats is None else fixed_stats
+        y = ops.group_norm_apply(xd, stats, None if gamma is None else gamma.detach().contiguous(), None if beta is None else beta.detach().contiguous(),
+                                 slope=slope, res=None if res is None else res.detach().contiguous())
+        ctx.save_for_backward(xd, y, stats, None if gamma is None else gamma.detach())
+        ctx.cfg = (groups, float(slope), fixed_stats is not None, res is not None)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        lib = _lib.load()
+        x, y, stats, gamma = ctx.saved_tensors
+        groups, slope, const_stats, has_res = ctx.cfg
+        M, C = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        dg = torch.empty((C,), dtype=torch.float32, device=x.device) if gamma is not None else None
+        db = torch.empty((C,), dtype=torch.float32, device=x.device) if gamma is not None else None
+        ws = torch.empty(lib.cofi_group_norm_bwd_workspace(M, C, groups), dtype=torch.uint8, device=x.device)
+        rc = lib.cofi_group_norm_bwd(_p(x), _ld(x), _p(y), _ld(y), _p(dy), _ld(dy), M, C, groups, _p(stats), _p(gamma), slope, int(const_stats),
+                                     _p(dx), _ld(dx), _p(dg), _p(db), _p(dres), 0 if dres is None else _ld(dres), _p(ws), ws.numel(), _stream())
+        _lib.check(rc, "cofi_group_norm_bwd")
+        return dx, dg, db, dres, None, None, None, None
+
+
+def group_norm_act(x, gamma=None, beta=None, groups: int = 32, slope: float = 1.0, res=None, eps: float = 1e-5, fixed_stats=None, return_stats: bool = False):
+    """y = leaky(gn(x) * gamma + beta + res, slope): nn.GroupNorm(groups, C) over ALL rows of (rows, C) (modules.py:45-49) fused with the
+    LeakyReLU / ReLU (slope 0.1 / 0) and the residual join behind it; groups == C, gamma = beta = None: the affine-less InstanceNorm of
+    imagenet.py / network.py:42-43; groups == C with an affine pair: BatchNorm on batch statistics (fixed_stats (C, 2) = {mean, rstd}:
+    on constant statistics).  HIP kernels forward (cofi_group_stats + cofi_group_norm_apply) and backward (cofi_group_norm_bwd)."""
+    y, stats = _GroupNormAct.apply(x, gamma, beta, res, groups, slope, eps, fixed_stats)
+    return (y, stats) if return_stats else y
 
 
 # ------------------------------------------------------------------------------------------ attention

@@ -410,6 +410,95 @@ __global__ void col_sum_final_kernel(const float *part, int RB, int C, float *ou
     out[c] = s;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Backward of  y = leaky( gn(x; mean_G, rstd_G) * gamma + beta + res, slope )  - nn.GroupNorm over all rows (modules.py:45-49), with
+// groups == C the affine-less InstanceNorm of imagenet.py / network.py:42-43 and the train-mode BatchNorm of imagenet.py:381-394 - in three
+// fixed-order stages.  With g = dy * (y > 0 ? 1 : slope), xh = (x - mean) rstd, n = rows * channels per group:
+//   dbeta_c = sum_rows g,  dgamma_c = sum_rows g xh,  S1_G = sum_{c in G} gamma_c dbeta_c,  S2_G = sum_{c in G} gamma_c dgamma_c,
+//   dx = rstd_G (g gamma_c - S1_G / n - xh S2_G / n)          (constant statistics - eval-mode BatchNorm: dx = rstd g gamma),   dres = g.
+struct NormBwdArgs {
+    const float *x, *y, *dy, *stats, *gamma;
+    float *part, *dgamma, *dbeta, *coef, *dx, *dres;
+    int ldx, ldy, lddy, lddx, lddr, M, C, cpg, rows_per_block, RB, const_stats;
+    float slope;
+};
+
+__global__ __launch_bounds__(256) void norm_bwd_partial_kernel(NormBwdArgs a) {   // grid (C / 64 chunks, RB row blocks)
+    __shared__ float red[4][64][2];
+    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * a.rows_per_block, r1 = min(a.M, r0 + a.rows_per_block);
+    float sa = 0.f, sb = 0.f;
+    if (c < a.C) {
+        const float mean = a.stats[2 * (c / a.cpg)], rstd = a.stats[2 * (c / a.cpg) + 1];
+        for (int m = r0 + ph; m < r1; m += 4) {
+            float g = a.dy[(size_t)m * a.lddy + c];
+            if (a.slope != 1.0f && !(a.y[(size_t)m * a.ldy + c] > 0.f)) g *= a.slope;
+            sa += g;
+            sb = fmaf(g, (a.x[(size_t)m * a.ldx + c] - mean) * rstd, sb);
+        }
+    }
+    red[ph][cl][0] = sa;
+    red[ph][cl][1] = sb;
+    __syncthreads();
+    if (ph == 0 && c < a.C) {
+        float *o = a.part + ((size_t)blockIdx.y * a.C + c) * 2;
+        o[0] = (red[0][cl][0] + red[1][cl][0]) + (red[2][cl][0] + red[3][cl][0]);
+        o[1] = (red[0][cl][1] + red[1][cl][1]) + (red[2][cl][1] + red[3][cl][1]);
+    }
+}
+
+__global__ void norm_bwd_finalize_kernel(NormBwdArgs a) {   // one thread per column; cpg (power of two <= 64) adjacent lanes = one group
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    double sa = 0.0, sb = 0.0;
+    if (c < a.C)
+        for (int b = 0; b < a.RB; ++b) {
+            sa += a.part[((size_t)b * a.C + c) * 2];
+            sb += a.part[((size_t)b * a.C + c) * 2 + 1];
+        }
+    if (c < a.C) {
+        if (a.dbeta) a.dbeta[c] = (float)sa;
+        if (a.dgamma) a.dgamma[c] = (float)sb;
+    }
+    const double gm = (c < a.C && a.gamma) ? (double)a.gamma[c] : 1.0;
+    double s1 = c < a.C ? gm * sa : 0.0, s2 = c < a.C ? gm * sb : 0.0;
+    for (int o = 1; o < a.cpg; o <<= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    if (c < a.C && (c & (a.cpg - 1)) == 0) {
+        const double n = (double)a.M * a.cpg;
+        a.coef[2 * (c / a.cpg)] = (float)(s1 / n);
+        a.coef[2 * (c / a.cpg) + 1] = (float)(s2 / n);
+    }
+}
+
+__global__ void norm_bwd_apply_kernel(NormBwdArgs a) {   // one thread per (row, 4 channels)
+    const int C4 = a.C >> 2;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)a.M * C4) return;
+    const int m = (int)(t / C4), c0 = 4 * (int)(t - (size_t)m * C4);
+    f32x4 g = *reinterpret_cast<const f32x4 *>(a.dy + (size_t)m * a.lddy + c0);
+    if (a.slope != 1.0f) {
+        const f32x4 yv = *reinterpret_cast<const f32x4 *>(a.y + (size_t)m * a.ldy + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (!(yv[e] > 0.f)) g[e] *= a.slope;
+    }
+    if (a.dres) *reinterpret_cast<f32x4 *>(a.dres + (size_t)m * a.lddr + c0) = g;
+    const f32x4 xv = *reinterpret_cast<const f32x4 *>(a.x + (size_t)m * a.ldx + c0);
+    f32x4 out;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = c0 + e, G = c / a.cpg;
+        const float mean = a.stats[2 * G], rstd = a.stats[2 * G + 1];
+        const float gg = g[e] * (a.gamma ? a.gamma[c] : 1.0f);
+        out[e] = a.const_stats ? rstd * gg : rstd * (gg - a.coef[2 * G] - (xv[e] - mean) * rstd * a.coef[2 * G + 1]);
+    }
+    *reinterpret_cast<f32x4 *>(a.dx + (size_t)m * a.lddx + c0) = out;
+}
+
 inline bool bad_mat(const void *p, int ld, int cols) { return !p || ld < cols || (ld & 3) || ((uintptr_t)p & 15); }
 
 }  // namespace
@@ -473,6 +562,36 @@ extern "C" int cofi_col2im_nhwc(const float *dcol, int ldc, int H, int W, int C,
     if (Ho <= 0 || Wo <= 0) return COFI_EINVAL;
     const long n = (long)H * W * (C / 4);
     hipLaunchKernelGGL(col2im_nhwc_kernel, dim3(cofi_cdiv(n, 256)), dim3(256), 0, cofi_s(stream), dcol, ldc, H, W, C, ks, stride, pad, Ho, Wo, dx, ldx);
+    return cofi_launch_status();
+}
+
+
+static int norm_bwd_blocks(int M) { return M <= 256 ? 1 : (M / 128 > 256 ? 256 : M / 128); }
+
+extern "C" size_t cofi_group_norm_bwd_workspace(int M, int C, int groups) {
+    if (M <= 0 || C <= 0 || groups <= 0) return 0;
+    return ((size_t)norm_bwd_blocks(M) * C * 2 + (size_t)groups * 2) * sizeof(float);
+}
+
+extern "C" int cofi_group_norm_bwd(const float *x, int ldx, const float *y, int ldy, const float *dy, int lddy, int M, int C, int groups,
+                                   const float *stats, const float *gamma, float slope, int const_stats, float *dx, int lddx, float *dgamma,
+                                   float *dbeta, float *dres, int lddr, void *ws, size_t ws_bytes, cofi_stream_t stream) {
+    if (M <= 0 || C <= 0 || groups <= 0 || (C % groups) || (C & 3) || !stats || bad_mat(x, ldx, C) || bad_mat(dy, lddy, C) || bad_mat(dx, lddx, C) ||
+        (slope != 1.0f && bad_mat(y, ldy, C)) || (dres && bad_mat(dres, lddr, C)) || !(slope >= 0.f && slope <= 1.f))
+        return COFI_EINVAL;
+    const int cpg = C / groups;
+    if (cpg > 64 || (cpg & (cpg - 1))) return COFI_EUNSUPPORTED;   // a group = a power of two <= 64 of adjacent columns (the network: 1 ... 64)
+    if (!ws || ws_bytes < cofi_group_norm_bwd_workspace(M, C, groups)) return COFI_EWORKSPACE;
+    NormBwdArgs a{};
+    a.x = x; a.y = y; a.dy = dy; a.stats = stats; a.gamma = gamma; a.dx = dx; a.dres = dres; a.dgamma = dgamma; a.dbeta = dbeta;
+    a.ldx = ldx; a.ldy = ldy; a.lddy = lddy; a.lddx = lddx; a.lddr = lddr; a.M = M; a.C = C; a.cpg = cpg; a.slope = slope; a.const_stats = const_stats;
+    a.RB = norm_bwd_blocks(M);
+    a.rows_per_block = cofi_cdiv(M, a.RB);
+    a.part = (float *)ws;
+    a.coef = a.part + (size_t)a.RB * C * 2;
+    hipLaunchKernelGGL(norm_bwd_partial_kernel, dim3(cofi_cdiv(C, 64), a.RB), dim3(256), 0, cofi_s(stream), a);
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(cofi_cdiv(C, 256)), dim3(256), 0, cofi_s(stream), a);
+    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(cofi_cdiv((long)M * (C / 4), 256)), dim3(256), 0, cofi_s(stream), a);
     return cofi_launch_status();
 }
 

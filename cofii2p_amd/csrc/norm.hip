@@ -13,6 +13,10 @@ namespace {
 // the partials in fp64 in a fixed order -> {mean, rstd}.  No atomics: bit-reproducible.
 constexpr int GS_ROWS = 64;
 
+// ACC = float: the serving path (a thread's <= 16 * cpg values in fp32, everything above in fp64).  ACC = double (cofi_group_stats_exact, the
+// training path): the sums are exact to fp64, so the variance does not lose the digits E[x^2] - mean^2 cancels when |mean| >> std - the
+// backward of a normalisation removes a large component along the normalised input and amplifies a relative error of rstd by its size.
+template <typename ACC>
 __global__ __launch_bounds__(256) void group_stats_partial_kernel(const float *x, int ldx, int M, int C, int groups, double *part) {
     // grid: x = row slab of GS_ROWS rows, y = 64-column tile (cpg < 64) or group (cpg >= 64), z = frame (M = rows per frame)
     const int cpg = C / groups;
@@ -24,10 +28,10 @@ __global__ __launch_bounds__(256) void group_stats_partial_kernel(const float *x
     if (cpg < 64) {
         // lanes own columns of this tile; a group is cpg adjacent lanes (cpg is a power of two)
         const int c = blockIdx.y * 64 + lane;
-        float s = 0.f, q = 0.f;
+        ACC s = 0, q = 0;
         if (c < C)
             for (int r = r0 + wv; r < r1; r += 4) {
-                const float v = x[(size_t)r * ldx + c];
+                const ACC v = x[(size_t)r * ldx + c];
                 s += v;
                 q += v * v;
             }
@@ -46,10 +50,10 @@ __global__ __launch_bounds__(256) void group_stats_partial_kernel(const float *x
         }
     } else {
         const int g = blockIdx.y;
-        float s = 0.f, q = 0.f;
+        ACC s = 0, q = 0;
         for (int r = r0 + wv; r < r1; r += 4)
             for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
-                const float v = x[(size_t)r * ldx + c];
+                const ACC v = x[(size_t)r * ldx + c];
                 s += v;
                 q += v * v;
             }
@@ -496,19 +500,32 @@ extern "C" size_t cofi_group_stats_workspace(int M, int C, int groups, int frame
     return (size_t)cofi_cdiv(M / frames, GS_ROWS) * frames * groups * 2 * sizeof(double);
 }
 
-extern "C" int cofi_group_stats(const float *x, int ldx, int M, int C, int groups, float eps, float *stats, void *ws,
-                                size_t ws_bytes, int frames, cofi_stream_t stream) {
+static int group_stats_entry(const float *x, int ldx, int M, int C, int groups, float eps, float *stats, void *ws, size_t ws_bytes, int frames,
+                             bool exact, cofi_stream_t stream) {
     if (!x || !stats || M <= 0 || C <= 0 || groups <= 0 || (C % groups) || ldx < C || frames <= 0 || (M % frames)) return COFI_EINVAL;
     const int cpg = C / groups;
     if (cpg < 64 && (cpg & (cpg - 1))) return COFI_EUNSUPPORTED;  // power-of-two group width below one wave
     if (!ws || ws_bytes < cofi_group_stats_workspace(M, C, groups, frames)) return COFI_EWORKSPACE;
     const int Mf = M / frames, nblk = cofi_cdiv(Mf, GS_ROWS);
     hipStream_t s = cofi_s(stream);
-    hipLaunchKernelGGL(group_stats_partial_kernel, dim3(nblk, cpg < 64 ? cofi_cdiv(C, 64) : groups, frames), dim3(256), 0, s, x, ldx, Mf, C,
-                       groups, (double *)ws);
+    const dim3 grid(nblk, cpg < 64 ? cofi_cdiv(C, 64) : groups, frames);
+    if (exact)
+        hipLaunchKernelGGL(group_stats_partial_kernel<double>, grid, dim3(256), 0, s, x, ldx, Mf, C, groups, (double *)ws);
+    else
+        hipLaunchKernelGGL(group_stats_partial_kernel<float>, grid, dim3(256), 0, s, x, ldx, Mf, C, groups, (double *)ws);
     hipLaunchKernelGGL(group_stats_final_kernel, dim3(cofi_cdiv(groups, 4), frames), dim3(256), 0, s, (const double *)ws, nblk, groups,
                        (double)Mf * cpg, eps, stats);
     return cofi_launch_status();
+}
+
+extern "C" int cofi_group_stats(const float *x, int ldx, int M, int C, int groups, float eps, float *stats, void *ws,
+                                size_t ws_bytes, int frames, cofi_stream_t stream) {
+    return group_stats_entry(x, ldx, M, C, groups, eps, stats, ws, ws_bytes, frames, false, stream);
+}
+
+extern "C" int cofi_group_stats_exact(const float *x, int ldx, int M, int C, int groups, float eps, float *stats, void *ws,
+                                      size_t ws_bytes, int frames, cofi_stream_t stream) {
+    return group_stats_entry(x, ldx, M, C, groups, eps, stats, ws, ws_bytes, frames, true, stream);
 }
 
 extern "C" int cofi_group_norm_apply(const float *x, int ldx, int M, int C, int groups, const float *stats, const float *gamma,

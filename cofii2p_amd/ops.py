@@ -517,14 +517,16 @@ def gather_rows(x, idx, out=None, frames: int = 1):
 
 
 # ------------------------------------------------------------------------------------------ norms
-def group_stats(x, groups: int, eps: float = 1e-5, frames: int = 1):
-    """-> stats (groups,2), or (frames, groups, 2) in stack mode (x = frames blocks of M/frames rows)."""
+def group_stats(x, groups: int, eps: float = 1e-5, frames: int = 1, exact: bool = False):
+    """-> stats (groups,2), or (frames, groups, 2) in stack mode (x = frames blocks of M/frames rows).  exact: every sum in fp64
+    (cofi_group_stats_exact, the training path)."""
     lib = _lib.load()
     _mat(x, "x")
     M, C = x.shape
     stats = torch.empty((groups, 2) if frames == 1 else (frames, groups, 2), dtype=torch.float32, device=x.device)
     ws = _WS_STATS.get(lib.cofi_group_stats_workspace(M, C, groups, frames), x.device)
-    _lib.check(lib.cofi_group_stats(_p(x), _ld(x), M, C, groups, eps, _p(stats), _p(ws), ws.numel(), frames, _stream()), "cofi_group_stats")
+    fn = lib.cofi_group_stats_exact if exact else lib.cofi_group_stats
+    _lib.check(fn(_p(x), _ld(x), M, C, groups, eps, _p(stats), _p(ws), ws.numel(), frames, _stream()), "cofi_group_stats")
     return stats
 
 

@@ -4,9 +4,10 @@ The same network as `network.CoFiI2P._run_device`, expressed as a torch.autograd
 train.py:224-288 (forward -> losses -> loss.backward() -> optimizer.step()) runs on this module.  Everything that carries weight or
 moves data between rows - every nn.Linear / nn.Conv2d / KPConv contraction, the KPConv neighbour aggregation, attention, the
 neighbour max-pool and up-sample gathers - is a `cofii2p_amd.autograd` Function whose forward AND backward are hand-written gfx950
-kernels.  The row-local glue between them (normalisations, activations, the bilinear x2, the 3x3 max-pool of the ResNet stem) is
-written with torch's differentiable tensor ops on the same device buffers: the "torch fallback" SURVEY.md row f3 allows for the parts
-that carry no weight.  Activations are pixel-major / point-major (rows, C) matrices as in the inference path.
+kernels - as are the normalisations over the rows of a map with the activation and residual join behind them (GroupNorm, InstanceNorm,
+train-mode BatchNorm: ag.group_norm_act).  What is left to torch's differentiable tensor ops on the same device buffers - the "torch
+fallback" SURVEY.md row f3 allows - is row-local and weight-free: LayerNorm, F.normalize, sigmoid, concatenations, the bilinear x2 and
+the 3x3 max-pool of the ResNet stem.  Activations are pixel-major / point-major (rows, C) matrices as in the inference path.
 
 Differences from the inference path, all the reference's own train()-mode semantics:
   * BatchNorm2d of the two ImageUpSample stages uses BATCH statistics and updates running_mean / running_var / num_batches_tracked
@@ -26,24 +27,36 @@ from .spec import D_MODEL, DECODERS, ENCODER, GN_GROUPS, LAYER_KINDS, N_HEAD, RE
 LRELU = 0.1
 
 
-# ------------------------------------------------------------------------------------------ row-local glue
-def group_norm_rows(x, w, b, groups: int = GN_GROUPS, eps: float = 1e-5):
-    """modules.py:45-49: nn.GroupNorm over (1, C, N) - statistics over all rows and the channels of a group."""
-    return F.group_norm(x.t().unsqueeze(0), groups, w, b, eps).squeeze(0).t()
+# ------------------------------------------------------------------------------------------ normalisations over the rows of a map
+def group_norm_rows(x, w, b, slope: float = 1.0, res=None, groups: int = GN_GROUPS):
+    """modules.py:45-49: nn.GroupNorm over (1, C, N) - statistics over all rows and the channels of a group - with the LeakyReLU and the
+    residual join that follow it in the reference's blocks (HIP forward and backward: ag.group_norm_act)."""
+    return ag.group_norm_act(x, w, b, groups, slope, res)
 
 
-def instance_norm_rows(x, eps: float = 1e-5):
-    """affine-less nn.InstanceNorm over the positions of one map = per-column normalisation of a (positions, C) matrix."""
-    var, mean = torch.var_mean(x, dim=0, unbiased=False, keepdim=True)
-    return (x - mean) * torch.rsqrt(var + eps)
+def instance_norm_rows(x, slope: float = 1.0, res=None):
+    """affine-less nn.InstanceNorm over the positions of one map = per-column normalisation of a (positions, C) matrix (+ ReLU / residual)"""
+    return ag.group_norm_act(x, None, None, x.shape[1], slope, res)
 
 
-def batch_norm_rows(x, P, B, p: str, training: bool):
-    """nn.BatchNorm2d on a (1, C, H, W) map = BatchNorm over the rows of (H W, C); train mode: batch statistics + running update."""
-    nbt = B.get(p + "num_batches_tracked")
-    if training and nbt is not None:
-        nbt.add_(1)
-    return F.batch_norm(x, B[p + "running_mean"], B[p + "running_var"], P[p + "weight"], P[p + "bias"], training, 0.1, 1e-5)
+def batch_norm_rows(x, P, B, p: str, training: bool, slope: float = 1.0, res=None, eps: float = 1e-5, momentum: float = 0.1):
+    """nn.BatchNorm2d on a (1, C, H, W) map = BatchNorm over the rows of (H W, C) (+ ReLU / residual).  train mode: batch statistics, and the
+    running buffers move as nn.BatchNorm2d moves them (momentum 0.1, unbiased variance); eval mode: the running statistics, as constants."""
+    C = x.shape[1]
+    rm, rv = B[p + "running_mean"], B[p + "running_var"]
+    if not training:
+        fixed = torch.stack([rm, torch.rsqrt(rv + eps)], 1).contiguous()
+        return ag.group_norm_act(x, P[p + "weight"], P[p + "bias"], C, slope, res, eps, fixed_stats=fixed)
+    y, stats = ag.group_norm_act(x, P[p + "weight"], P[p + "bias"], C, slope, res, eps, return_stats=True)
+    with torch.no_grad():
+        n = x.shape[0]
+        var_b = (1.0 / (stats[:, 1] * stats[:, 1]) - eps).clamp_min(0.0)
+        rm.mul_(1.0 - momentum).add_(stats[:, 0], alpha=momentum)
+        rv.mul_(1.0 - momentum).add_(var_b * (n / max(n - 1, 1)), alpha=momentum)
+        nbt = B.get(p + "num_batches_tracked")
+        if nbt is not None:
+            nbt.add_(1)
+    return y
 
 
 def pos_sine_table(coords: torch.Tensor) -> torch.Tensor:
@@ -53,10 +66,11 @@ def pos_sine_table(coords: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------ point encoder (kp_backbone.py:79-128)
-def _unary(P, p, x, relu: bool = True, norm: bool = True):
+def _unary(P, p, x, relu: bool = True, norm: bool = True, res=None):
+    """UnaryBlock (modules.py:63-94): Linear -> GroupNorm -> LeakyReLU; `res` joins before the activation (the residual tail, :236-240)"""
     y = ag.linear(x, P[p + "mlp.weight"], P[p + "mlp.bias"])
     if norm:
-        y = group_norm_rows(y, P[p + "norm.norm.weight"], P[p + "norm.norm.bias"])
+        return group_norm_rows(y, P[p + "norm.norm.weight"], P[p + "norm.norm.bias"], LRELU if relu else 1.0, res)
     return F.leaky_relu(y, LRELU) if relu else y
 
 
@@ -72,15 +86,14 @@ def _block(P, B, blk, feats, q_pts, s_pts, idx, tables):
     p = "pc_encoder.%s." % blk.name
     if blk.kind == "conv":   # modules.py:155-159
         y = _kpconv(P, B, p, feats, q_pts, s_pts, idx, blk.sigma, tables)
-        return F.leaky_relu(group_norm_rows(y, P[p + "norm.norm.weight"], P[p + "norm.norm.bias"]), LRELU)
+        return group_norm_rows(y, P[p + "norm.norm.weight"], P[p + "norm.norm.bias"], LRELU)
     x = _unary(P, p + "unary1.", feats) if blk.cin != blk.mid else feats   # modules.py:222-240
     x = _kpconv(P, B, p, x, q_pts, s_pts, idx, blk.sigma, tables)
-    x = F.leaky_relu(group_norm_rows(x, P[p + "norm_conv.norm.weight"], P[p + "norm_conv.norm.bias"]), LRELU)
-    x = _unary(P, p + "unary2.", x, relu=False)
+    x = group_norm_rows(x, P[p + "norm_conv.norm.weight"], P[p + "norm_conv.norm.bias"], LRELU)
     sc = ag.neighbor_maxpool(feats, idx, tables) if blk.strided else feats
     if blk.has_shortcut_unary:
         sc = _unary(P, p + "unary_shortcut.", sc, relu=False)
-    return F.leaky_relu(x + sc, LRELU)
+    return _unary(P, p + "unary2.", x, relu=True, res=sc)   # leaky(GroupNorm(unary2) + shortcut)
 
 
 def kpconv_fpn(P, B, points, neighbors, subsampling, upsampling, feats, tables) -> List[torch.Tensor]:
@@ -118,7 +131,7 @@ def resnet34_s8(P, img: torch.Tensor):
     col, H, W = ops.im2col_stem(img.contiguous())                  # (Ho Wo, 160): 7 x 7 x 3 = 147 columns, zero padded
     w = P[p + "conv1.weight"]
     w2 = F.pad(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1), (0, col.shape[1] - 147))
-    x = F.relu(instance_norm_rows(ag.linear(col, w2)))
+    x = instance_norm_rows(ag.linear(col, w2), 0.0)
     outs = [(x, H, W)]
     x4 = F.max_pool2d(_nchw(x, H, W), 3, 2, 1)
     H, W = x4.shape[2:]
@@ -128,14 +141,13 @@ def resnet34_s8(P, img: torch.Tensor):
             q = "%slayer%d.%d." % (p, li, b)
             st = stride if b == 0 else 1
             y, Ho, Wo = ag.conv2d(x, H, W, P[q + "conv1.weight"], st)
-            y = F.relu(instance_norm_rows(y))
+            y = instance_norm_rows(y, 0.0)
             y, _, _ = ag.conv2d(y, Ho, Wo, P[q + "conv2.weight"], 1)
-            y = instance_norm_rows(y)
             if (q + "downsample.0.weight") in P:
                 d, _, _ = ag.conv2d(x, H, W, P[q + "downsample.0.weight"], st, pad=0)
-                x = F.relu(y + instance_norm_rows(d))
+                x = instance_norm_rows(y, 0.0, res=instance_norm_rows(d))
             else:
-                x = F.relu(y + x)
+                x = instance_norm_rows(y, 0.0, res=x.contiguous())
             H, W = Ho, Wo
         outs.append((x, H, W))
     return outs
@@ -144,9 +156,8 @@ def resnet34_s8(P, img: torch.Tensor):
 def _residual_conv(P, B, p, x, H, W, training):
     """imagenet.py:377-411."""
     identity = batch_norm_rows(ag.conv2d(x, H, W, P[p + "conv_skip.0.weight"])[0], P, B, p + "conv_skip.1.", training)
-    out = F.relu(batch_norm_rows(ag.conv2d(x, H, W, P[p + "conv1.weight"])[0], P, B, p + "bn1.", training))
-    out = batch_norm_rows(ag.conv2d(out, H, W, P[p + "conv2.weight"])[0], P, B, p + "bn2.", training)
-    return F.relu(out + identity)
+    out = batch_norm_rows(ag.conv2d(x, H, W, P[p + "conv1.weight"])[0], P, B, p + "bn1.", training, 0.0)
+    return batch_norm_rows(ag.conv2d(out, H, W, P[p + "conv2.weight"])[0], P, B, p + "bn2.", training, 0.0, res=identity)
 
 
 def image_upsample(P, B, name, low, h, w, skip, training):
@@ -185,8 +196,8 @@ def transformer(P, tok_img, tok_pc):
 def score_head(P, head, tokens):
     """network.py:42-43 on token-major data."""
     w0, w3, w6 = (P["%s.%d.weight" % (head, i)] for i in (0, 3, 6))
-    y = F.relu(instance_norm_rows(ag.linear(tokens, w0.reshape(w0.shape[0], -1))))
-    y = F.relu(instance_norm_rows(ag.linear(y, w3.reshape(w3.shape[0], -1))))
+    y = instance_norm_rows(ag.linear(tokens, w0.reshape(w0.shape[0], -1)), 0.0)
+    y = instance_norm_rows(ag.linear(y, w3.reshape(w3.shape[0], -1)), 0.0)
     return torch.sigmoid(ag.linear(y, w6.reshape(w6.shape[0], -1)))   # (T, 1)
 
 

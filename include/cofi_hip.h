@@ -247,6 +247,10 @@ int cofi_col_inv_norm_from_colpart(const float *colpart, int nslab, int M /* row
 size_t cofi_group_stats_workspace(int M, int C, int groups, int frames);
 int cofi_group_stats(const float *x, int ldx, int M, int C, int groups, float eps, float *stats /* (frames, groups, 2) */, void *ws,
                      size_t ws_bytes, int frames /* stack mode: M = frames * rows-per-frame, statistics per frame */, cofi_stream_t stream);
+/* cofi_group_stats with every sum carried in fp64 (the training path: the backward of a normalisation amplifies a relative error of rstd
+ * by the size of the component it removes; E[x^2] - mean^2 must not lose digits when |mean| >> std).  Same arguments, same workspace. */
+int cofi_group_stats_exact(const float *x, int ldx, int M, int C, int groups, float eps, float *stats, void *ws, size_t ws_bytes, int frames,
+                           cofi_stream_t stream);
 int cofi_group_norm_apply(const float *x, int ldx, int M, int C, int groups, const float *stats, const float *gamma,
                           const float *beta, const float *res, int ldr, const float *res_stats, const float *res_gamma,
                           const float *res_beta, float slope, float *y, int ldy,
@@ -439,6 +443,15 @@ int cofi_gather_rows_bwd(const float *dy, int ldy, int C, const int32_t *pairs, 
                          cofi_stream_t stream);
 int cofi_im2col_nhwc(const float *x, int ldx, int H, int W, int C, int ks, int stride, int pad, float *col, int ldc, cofi_stream_t stream);
 int cofi_col2im_nhwc(const float *dcol, int ldc, int H, int W, int C, int ks, int stride, int pad, float *dx, int ldx, cofi_stream_t stream);
+/* Backward of y = leaky(gn(x; stats) * gamma + beta + res, slope) (cofi_group_stats + cofi_group_norm_apply: GroupNorm over all rows,
+ * InstanceNorm with groups == C, train-mode BatchNorm): dx, dgamma, dbeta (either may be NULL), dres (NULL without a residual) from
+ * x, y (the forward's output: its sign selects the activation slope; unused for slope == 1), dy and the forward's stats (groups, 2).
+ * const_stats != 0: the statistics were constants (eval-mode BatchNorm on running statistics).  Channels per group: a power of two <= 64.
+ * Three fixed-order stages; ws of cofi_group_norm_bwd_workspace(M, C, groups) bytes. */
+size_t cofi_group_norm_bwd_workspace(int M, int C, int groups);
+int cofi_group_norm_bwd(const float *x, int ldx, const float *y, int ldy, const float *dy, int lddy, int M, int C, int groups, const float *stats,
+                        const float *gamma, float slope, int const_stats, float *dx, int lddx, float *dgamma, float *dbeta, float *dres, int lddr,
+                        void *ws, size_t ws_bytes, cofi_stream_t stream);
 size_t cofi_col_sum_workspace(int M, int C);   /* out[c] = sum_m x[m, c] (bias gradients), two fixed-order stages */
 int cofi_col_sum(const float *x, int ldx, int M, int C, float *out, void *ws, size_t ws_bytes, cofi_stream_t stream);
 size_t cofi_attention_bwd_workspace(int L, int H);

@@ -190,6 +190,48 @@ def test_attention_function(L, S):
         assert rel_err(x.grad, y.grad) < 2e-5, n
 
 
+@pytest.mark.parametrize("M,C,groups,affine,slope,res,fixed", [
+    (2048, 64, 32, True, 0.1, False, False),     # UnaryBlock / ConvBlock: GroupNorm + LeakyReLU
+    (1000, 256, 32, True, 0.1, True, False),     # residual tail: leaky(GroupNorm(unary2) + shortcut), ragged row count
+    (333, 2048, 32, True, 1.0, False, False),    # shortcut branch: no activation, 64 channels per group
+    (5120, 64, 64, False, 0.0, True, False),     # BasicBlock end: relu(InstanceNorm(conv2) + identity)
+    (1280, 128, 128, False, 0.0, False, False),  # score head: InstanceNorm + ReLU
+    (10240, 128, 128, True, 0.0, True, False),   # ResidualConv end, train(): relu(BatchNorm(batch statistics) + identity)
+    (640, 64, 64, True, 0.0, False, True),       # BatchNorm on constant (running) statistics
+    (256, 128, 32, True, 0.1, False, False), (128, 512, 32, True, 0.1, True, False), (256, 512, 32, True, 0.1, True, False),   # deep stages of the tiny frame
+    (64, 32, 32, True, 0.1, False, False),
+])
+def test_group_norm_act_function(M, C, groups, affine, slope, res, fixed):
+    from cofii2p_amd import autograd as ag
+
+    g = torch.Generator(device=DEV).manual_seed(M + C)
+    x = torch.randn((M, C), device=DEV, generator=g) * 1.7 + 0.3
+    ga = (1 + 0.2 * torch.randn((C,), device=DEV, generator=g)) if affine else None
+    be = (0.3 * torch.randn((C,), device=DEV, generator=g)) if affine else None
+    r = torch.randn((M, C), device=DEV, generator=g) if res else None
+    dy = torch.randn((M, C), device=DEV, generator=g)
+    fs = None
+    if fixed:
+        rm, rv = torch.randn((C,), device=DEV, generator=g) * 0.2, torch.rand((C,), device=DEV, generator=g) + 0.5
+        fs = torch.stack([rm, torch.rsqrt(rv + 1e-5)], 1).contiguous()
+    ins = [t.clone().requires_grad_() if t is not None else None for t in (x, ga, be, r)]
+    y = ag.group_norm_act(ins[0], ins[1], ins[2], groups, slope, ins[3], fixed_stats=fs)
+    y.backward(dy)
+    ref = [t.double().clone().requires_grad_() if t is not None else None for t in (x, ga, be, r)]
+    if fixed:
+        z = (ref[0] - rm.double()) * torch.rsqrt(rv.double() + 1e-5) * ref[1] + ref[2]
+    else:
+        z = F.group_norm(ref[0].t().unsqueeze(0), groups, ref[1], ref[2], 1e-5).squeeze(0).t()
+    if res:
+        z = z + ref[3]
+    yr = F.leaky_relu(z, slope) if slope != 1.0 else z
+    yr.backward(dy.double())
+    assert rel_err(y, yr) < 1e-5
+    for a, b, n in zip(ins, ref, ("x", "gamma", "beta", "res")):
+        if a is not None:
+            assert rel_err(a.grad, b.grad) < 2e-5, n
+
+
 # ------------------------------------------------------------------------------------------ (b) one step of train.py vs the reference
 class Opt:
     img_H, img_W, img_fine_resolution_scale, norm = 160, 512, 32, "gn"
@@ -267,7 +309,7 @@ def test_train_step_matches_reference(gold, arith, tol, monkeypatch):
         allow = max(tol, 2.5 * float(gold["g_err32"][i]))   # same rounding noise, another summation order: within 2.5x of the reference's own deviation
         beyond += e_samp > tol
         worst = max(worst, (max(e_samp, e_norm), name))
-        assert e_samp < allow and e_norm < max(tol, GRAD_TOL), "%s: sampled entries off by %.3g (allowed %.3g), norm by %.3g (relative)" % (name, e_samp, allow, e_norm)
+        assert e_samp < allow and e_norm < allow, "%s: sampled entries off by %.3g (allowed %.3g), norm by %.3g (relative)" % (name, e_samp, allow, e_norm)
     print("worst parameter gradient error %.3g (%s); %d parameters beyond %.0e, all of them where the reference's own fp32 gradient is" % (worst + (beyond, tol)))
     bufs = dict(m.named_buffers())
     for k in gold.files:
