@@ -120,6 +120,7 @@ class _KPConvAggregate(torch.autograd.Function):
         ctx.save_for_backward(q_pts, s_pts, kernel_points)
         ctx.table, ctx.sigma, ctx.shape = table, float(sigma), f.shape
         ctx.mark_non_differentiable(cnt)
+        ctx.set_materialize_grads(False)
         return agg, cnt
 
     @staticmethod
@@ -253,6 +254,7 @@ class _GroupNormAct(torch.autograd.Function):
         ctx.save_for_backward(xd, y, stats, None if gamma is None else gamma.detach())
         ctx.cfg = (groups, float(slope), fixed_stats is not None, res is not None)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)
         return y, stats
 
     @staticmethod
