@@ -451,6 +451,27 @@ class Pipeline:
         return self.run(max(warmup, 2 * self.NSLOT, math.lcm(self.NSLOT, len(self.frames))), 0)
 
 
+class optional_leg:
+    """Everything after the headline measurement is additional information: a leg that fails (a worker pool that cannot spawn, a missing
+    fixture, ...) is recorded in the line as `<name>_error` instead of costing the line."""
+
+    def __init__(self, result, name):
+        self.result, self.name = result, name
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is not None and issubclass(et, Exception):
+            self.result[self.name + "_error"] = "%s: %s" % (et.__name__, ev)
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            return True
+        return False
+
+
 def timed_repeats(run_steps, barrier, steps, repeats):
     """`repeats` timed regions of EXACTLY `steps` steps each, every one bracketed by barrier + synchronize on both sides -> seconds per region"""
     out = []
@@ -646,241 +667,248 @@ def main():
     }
 
     if rank == 0 and world == 1 and Bsz == 1 and pipe is not None and args.gemm == "bf16x3" and not args.no_f32:
-        # the same pipelined loop in the two fp32-grade arithmetics, on record next to `value`: every dense contraction on the exact fp32
-        # MFMA (bit-equal to an fmaf chain), and on the 6-term bf16 split (three planes per operand: the same error against fp64 as the
-        # fp32 kernel, tools/x6_probe.py)
-        for key, mode, note in (("value_f32", "f32", "identical loop, COFI_GEMM=f32: every GEMM / convolution on v_mfma_f32_32x32x2_f32 (bit-equal to an fmaf chain)"),
-                                ("value_bf16x6", "bf16x6", "identical loop, COFI_GEMM=bf16x6: hi/mid/lo bf16 planes of both operands, six products on "
-                                                           "v_mfma_f32_32x32x16_bf16, fp32 accumulation - fp32-grade results (the reference-named shim's default)")):
-            cofi_ops.GEMM_MODE = mode
-            try:
-                pipe.warm(args.warmup)
-                dts32 = timed_repeats(pipe.run, barrier, args.steps, repeats)
-            finally:
-                cofi_ops.GEMM_MODE = args.gemm
-            d32 = float(np.median(dts32))
-            result[key] = {"frames_per_s": args.steps / d32, "ms_per_frame": 1e3 * d32 / args.steps, "repeats": repeats, "note": note}
+        with optional_leg(result, "value_f32"):
+            # the same pipelined loop in the two fp32-grade arithmetics, on record next to `value`: every dense contraction on the exact fp32
+            # MFMA (bit-equal to an fmaf chain), and on the 6-term bf16 split (three planes per operand: the same error against fp64 as the
+            # fp32 kernel, tools/x6_probe.py)
+            for key, mode, note in (("value_f32", "f32", "identical loop, COFI_GEMM=f32: every GEMM / convolution on v_mfma_f32_32x32x2_f32 (bit-equal to an fmaf chain)"),
+                                    ("value_bf16x6", "bf16x6", "identical loop, COFI_GEMM=bf16x6: hi/mid/lo bf16 planes of both operands, six products on "
+                                                               "v_mfma_f32_32x32x16_bf16, fp32 accumulation - fp32-grade results (the reference-named shim's default)")):
+                cofi_ops.GEMM_MODE = mode
+                try:
+                    pipe.warm(args.warmup)
+                    dts32 = timed_repeats(pipe.run, barrier, args.steps, repeats)
+                finally:
+                    cofi_ops.GEMM_MODE = args.gemm
+                d32 = float(np.median(dts32))
+                result[key] = {"frames_per_s": args.steps / d32, "ms_per_frame": 1e3 * d32 / args.steps, "repeats": repeats, "note": note}
     if rank == 0 and world == 1 and Bsz == 1 and not args.eager and not args.no_batch_sweep:
-        # the reference-surface call pattern (evaluation/eval_all.py:94-96): model(...) per frame, one host synchronisation per
-        # frame, nothing in flight behind it - what a caller gets without forward_async / finish
-        n_sync = max(20, min(100, args.steps))
-        for i in range(4):
-            one_step(model, frames[i % len(frames)])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(n_sync):
-            one_step(model, frames[i % len(frames)])
-        torch.cuda.synchronize()
-        dts = time.perf_counter() - t0
-        result["forward_sync"] = {"frames_per_s": n_sync / dts, "ms_per_frame": 1e3 * dts / n_sync, "frames": n_sync,
-                                  "note": "model(pc_data_dict, img, ..., 'test') per frame as eval_all.py:94-96 calls it (hipGraph replay, one host "
-                                          "sync per frame, no frames in flight); `value` is the pipelined forward_async / finish rate"}
-    if rank == 0 and not args.no_kernel_timing:
-        model.enable_graphs(False)
-        if Bsz == 1:
-            result.update(kernel_rooflines(model, dev, args, 1, frame=frames[0]))
-        else:
-            result.update(kernel_rooflines(model, dev, args, Bsz, batch=batches[0]))
-        rf = result.get("roofline", {})
-        if rf.get("bound") == "mfma" and "algorithmic_gflop_per_frame" in rf:
-            # `frac` prices one launch at a time (isolated replay); with frames in flight the kernels share the chip, so the family's
-            # share of the chip over the whole timed region is its work per frame x frames/s (per GPU) over the same peak
-            rf["chip_level_frac"] = rf["algorithmic_gflop_per_frame"] * 1e9 * (result["value"] / world) / (rf["peak"] * 1e12)
-    if rank == 0 and world == 1 and Bsz == 1 and not args.eager and not args.no_batch_sweep:
-        # additional information (BASELINE configs[2]): the same frames in stack-mode batches through the same kernels
-        model.enable_graphs(True)
-        sweep = {}
-        for bsz in (4, 16):
-            grp = [frames[i % len(frames)] for i in range(bsz)]
-            pyr_b, img_b = CoFiI2P.stack_frames([g[0] for g in grp], [g[1] for g in grp])
-            st = make_streams(dev, S)
-            pend = [None] * S
-            nst = max(2 * S, args.steps // bsz)
-            for phase in range(2):  # 0 = warm-up (captures the graphs), 1 = timed
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for i in range(nst):
-                    sl = i % S
-                    if pend[sl] is not None:
-                        model.finish(pend[sl])
-                    with torch.cuda.stream(st[sl]):
-                        pend[sl] = model.forward_async(10 + sl, pyr_b, img_b)
-                for sl in range(S):
-                    if pend[sl] is not None:
-                        model.finish(pend[sl])
-                        pend[sl] = None
-                torch.cuda.synchronize()
-                dtb = time.perf_counter() - t0
-            sweep["batch_%d" % bsz] = {"frames_per_s": nst * bsz / dtb, "ms_per_frame": 1e3 * dtb / (nst * bsz), "submissions_in_flight": S}
-            if bsz == 16 and not args.no_kernel_timing:   # BASELINE configs[2]: the same roofline rows for the stacked batch
-                model.enable_graphs(False)
-                sweep["batch_16"].update(kernel_rooflines(model, dev, args, bsz, batch=(pyr_b, img_b)))
-                model.enable_graphs(True)
-            del pyr_b, img_b
-        result["stack_mode_batches"] = sweep
-    if rank == 0 and world == 1 and Bsz == 1 and not args.no_batch_sweep:
-        # additional information, outside `value` (the reference's DataLoader builds the pyramid, preprocess_data.py:36-107): the 13
-        # KNN-128 searches of one frame's pyramid on this GPU, cell-grid search vs the brute-force kernel (identical tables)
-        from cofii2p_amd import ops as _ops
-        from cofii2p_amd.preprocess import build_pyramid
-        from cofii2p_amd.synth import subsample_indices
-
-        p0 = frames[0][0]["points"][0]
-        sub = [torch.from_numpy(s_).to(dev) for s_ in subsample_indices(args.points, 5, seed=1000)]
-
-        def pyramid_ms(n=20):
-            for _ in range(3):
-                build_pyramid(p0, sub)
+        with optional_leg(result, "forward_sync"):
+            # the reference-surface call pattern (evaluation/eval_all.py:94-96): model(...) per frame, one host synchronisation per
+            # frame, nothing in flight behind it - what a caller gets without forward_async / finish
+            n_sync = max(20, min(100, args.steps))
+            for i in range(4):
+                one_step(model, frames[i % len(frames)])
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(n):
-                build_pyramid(p0, sub)
+            for i in range(n_sync):
+                one_step(model, frames[i % len(frames)])
             torch.cuda.synchronize()
-            return 1e3 * (time.perf_counter() - t0) / n
-
-        saved = _ops.KNN_GRID_MIN_SUPPORT
-        grid_ms = pyramid_ms()
-        _ops.KNN_GRID_MIN_SUPPORT = 1 << 30
-        brute_ms = pyramid_ms()
-        _ops.KNN_GRID_MIN_SUPPORT = saved
-        result["knn_pyramid"] = {"ms_per_frame": grid_ms, "brute_force_ms_per_frame": brute_ms,
-                                 "note": "build_pyramid (5 stages, 13 searches, k = 128) as called from Python, one stream; not part of `value`"}
-        if S > 1 and not args.eager:
-            # ... and the whole chain on this GPU: every frame's pyramid is built on its frame stream right before its forward - the ~40
-            # launches of a pyramid as ONE hipGraph per slot (preprocess.PyramidGraph), its tables read in place by the forward's graph
-            from cofii2p_amd.preprocess import PyramidGraph
-
+            dts = time.perf_counter() - t0
+            result["forward_sync"] = {"frames_per_s": n_sync / dts, "ms_per_frame": 1e3 * dts / n_sync, "frames": n_sync,
+                                      "note": "model(pc_data_dict, img, ..., 'test') per frame as eval_all.py:94-96 calls it (hipGraph replay, one host "
+                                              "sync per frame, no frames in flight); `value` is the pipelined forward_async / finish rate"}
+    if rank == 0 and not args.no_kernel_timing:
+        with optional_leg(result, "roofline"):
+            model.enable_graphs(False)
+            if Bsz == 1:
+                result.update(kernel_rooflines(model, dev, args, 1, frame=frames[0]))
+            else:
+                result.update(kernel_rooflines(model, dev, args, Bsz, batch=batches[0]))
+            rf = result.get("roofline", {})
+            if rf.get("bound") == "mfma" and "algorithmic_gflop_per_frame" in rf:
+                # `frac` prices one launch at a time (isolated replay); with frames in flight the kernels share the chip, so the family's
+                # share of the chip over the whole timed region is its work per frame x frames/s (per GPU) over the same peak
+                rf["chip_level_frac"] = rf["algorithmic_gflop_per_frame"] * 1e9 * (result["value"] / world) / (rf["peak"] * 1e12)
+    if rank == 0 and world == 1 and Bsz == 1 and not args.eager and not args.no_batch_sweep:
+        with optional_leg(result, "stack_mode_batches"):
+            # additional information (BASELINE configs[2]): the same frames in stack-mode batches through the same kernels
             model.enable_graphs(True)
-            st = make_streams(dev, S)
-            NSL = S * max(1, args.slots_per_stream)
-            pend = [None] * NSL
-            feats0 = frames[0][0]["feats"]
-            sub_sizes = [int(t.shape[0]) for t in sub]
-            rates = {}
-            for upk in (None, 1):   # the reference's (N, 128) up-sampling tables / their first column only (all the forward reads), derived without a search
-                pgs = [PyramidGraph(args.points, sub_sizes, dev, capture_stream=st[0], upsample_k=upk) for _ in range(NSL)]
-                imgs = [frames[0][1].clone() for _ in range(NSL)]   # static per slot, like the tables
-                for phase in range(2):   # 0 = warm-up (captures the graphs of these slots), 1 = timed
-                    nfr = max(args.steps, 3 * NSL)
+            sweep = {}
+            for bsz in (4, 16):
+                grp = [frames[i % len(frames)] for i in range(bsz)]
+                pyr_b, img_b = CoFiI2P.stack_frames([g[0] for g in grp], [g[1] for g in grp])
+                st = make_streams(dev, S)
+                pend = [None] * S
+                nst = max(2 * S, args.steps // bsz)
+                for phase in range(2):  # 0 = warm-up (captures the graphs), 1 = timed
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    for i in range(nfr):
-                        sl = i % NSL
+                    for i in range(nst):
+                        sl = i % S
                         if pend[sl] is not None:
                             model.finish(pend[sl])
-                        with torch.cuda.stream(st[i % S]):
-                            pyr = dict(pgs[sl].run(p0, sub))
-                            pyr["feats"] = feats0
-                            pend[sl] = model.forward_async((30 if upk is None else 45) + sl, pyr, imgs[sl], inputs_stable=True)
-                    for sl in range(NSL):
+                        with torch.cuda.stream(st[sl]):
+                            pend[sl] = model.forward_async(10 + sl, pyr_b, img_b)
+                    for sl in range(S):
                         if pend[sl] is not None:
                             model.finish(pend[sl])
                             pend[sl] = None
                     torch.cuda.synchronize()
-                    dte = time.perf_counter() - t0
-                rates[upk] = (nfr / dte, 1e3 * dte / nfr)
-                del pgs
-            result["with_pyramid_build"] = {"frames_per_s": rates[None][0], "ms_per_frame": rates[None][1],
-                                            "nearest_only_upsampling": {"frames_per_s": rates[1][0], "ms_per_frame": rates[1][1],
-                                                                        "note": "build_pyramid(upsample_k=1): the four up-sampling tables hold their first column only - "
-                                                                                "all the forward reads (functional.py:20) - derived from neighbors[i] without a search; "
-                                                                                "outputs bit-identical"},
-                                            "note": "pyramid construction (5 cell grids + 9 KNN-128 searches + 4 row gathers, one hipGraph) + forward + fine matching per "
-                                                    "frame on the same GPU; not the headline"}
+                    dtb = time.perf_counter() - t0
+                sweep["batch_%d" % bsz] = {"frames_per_s": nst * bsz / dtb, "ms_per_frame": 1e3 * dtb / (nst * bsz), "submissions_in_flight": S}
+                if bsz == 16 and not args.no_kernel_timing:   # BASELINE configs[2]: the same roofline rows for the stacked batch
+                    model.enable_graphs(False)
+                    sweep["batch_16"].update(kernel_rooflines(model, dev, args, bsz, batch=(pyr_b, img_b)))
+                    model.enable_graphs(True)
+                del pyr_b, img_b
+            result["stack_mode_batches"] = sweep
+    if rank == 0 and world == 1 and Bsz == 1 and not args.no_batch_sweep:
+        with optional_leg(result, "knn_pyramid"):
+            # additional information, outside `value` (the reference's DataLoader builds the pyramid, preprocess_data.py:36-107): the 13
+            # KNN-128 searches of one frame's pyramid on this GPU, cell-grid search vs the brute-force kernel (identical tables)
+            from cofii2p_amd import ops as _ops
+            from cofii2p_amd.preprocess import build_pyramid
+            from cofii2p_amd.synth import subsample_indices
+
+            p0 = frames[0][0]["points"][0]
+            sub = [torch.from_numpy(s_).to(dev) for s_ in subsample_indices(args.points, 5, seed=1000)]
+
+            def pyramid_ms(n=20):
+                for _ in range(3):
+                    build_pyramid(p0, sub)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    build_pyramid(p0, sub)
+                torch.cuda.synchronize()
+                return 1e3 * (time.perf_counter() - t0) / n
+
+            saved = _ops.KNN_GRID_MIN_SUPPORT
+            grid_ms = pyramid_ms()
+            _ops.KNN_GRID_MIN_SUPPORT = 1 << 30
+            brute_ms = pyramid_ms()
+            _ops.KNN_GRID_MIN_SUPPORT = saved
+            result["knn_pyramid"] = {"ms_per_frame": grid_ms, "brute_force_ms_per_frame": brute_ms,
+                                     "note": "build_pyramid (5 stages, 13 searches, k = 128) as called from Python, one stream; not part of `value`"}
+            if S > 1 and not args.eager:
+                # ... and the whole chain on this GPU: every frame's pyramid is built on its frame stream right before its forward - the ~40
+                # launches of a pyramid as ONE hipGraph per slot (preprocess.PyramidGraph), its tables read in place by the forward's graph
+                from cofii2p_amd.preprocess import PyramidGraph
+
+                model.enable_graphs(True)
+                st = make_streams(dev, S)
+                NSL = S * max(1, args.slots_per_stream)
+                pend = [None] * NSL
+                feats0 = frames[0][0]["feats"]
+                sub_sizes = [int(t.shape[0]) for t in sub]
+                rates = {}
+                for upk in (None, 1):   # the reference's (N, 128) up-sampling tables / their first column only (all the forward reads), derived without a search
+                    pgs = [PyramidGraph(args.points, sub_sizes, dev, capture_stream=st[0], upsample_k=upk) for _ in range(NSL)]
+                    imgs = [frames[0][1].clone() for _ in range(NSL)]   # static per slot, like the tables
+                    for phase in range(2):   # 0 = warm-up (captures the graphs of these slots), 1 = timed
+                        nfr = max(args.steps, 3 * NSL)
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for i in range(nfr):
+                            sl = i % NSL
+                            if pend[sl] is not None:
+                                model.finish(pend[sl])
+                            with torch.cuda.stream(st[i % S]):
+                                pyr = dict(pgs[sl].run(p0, sub))
+                                pyr["feats"] = feats0
+                                pend[sl] = model.forward_async((30 if upk is None else 45) + sl, pyr, imgs[sl], inputs_stable=True)
+                        for sl in range(NSL):
+                            if pend[sl] is not None:
+                                model.finish(pend[sl])
+                                pend[sl] = None
+                        torch.cuda.synchronize()
+                        dte = time.perf_counter() - t0
+                    rates[upk] = (nfr / dte, 1e3 * dte / nfr)
+                    del pgs
+                result["with_pyramid_build"] = {"frames_per_s": rates[None][0], "ms_per_frame": rates[None][1],
+                                                "nearest_only_upsampling": {"frames_per_s": rates[1][0], "ms_per_frame": rates[1][1],
+                                                                            "note": "build_pyramid(upsample_k=1): the four up-sampling tables hold their first column only - "
+                                                                                    "all the forward reads (functional.py:20) - derived from neighbors[i] without a search; "
+                                                                                    "outputs bit-identical"},
+                                                "note": "pyramid construction (5 cell grids + 9 KNN-128 searches + 4 row gathers, one hipGraph) + forward + fine matching per "
+                                                        "frame on the same GPU; not the headline"}
     if rank == 0 and world == 1 and Bsz == 1 and not args.no_batch_sweep and not args.eager:
-        # row f2: the whole data side of a frame on this GPU (data/kitti.py:259-393: calibration transform, 0.1 m voxel grid, resample to
-        # num_pc, random SE(3), KNN pyramid, image resize / crop, labels) from a raw 120 000-point scan + 376 x 1241 image already in
-        # HBM, alone and in front of the forward
-        from cofii2p_amd import dataside, synth as _synth
+        with optional_leg(result, "with_dataside"):
+            # row f2: the whole data side of a frame on this GPU (data/kitti.py:259-393: calibration transform, 0.1 m voxel grid, resample to
+            # num_pc, random SE(3), KNN pyramid, image resize / crop, labels) from a raw 120 000-point scan + 376 x 1241 image already in
+            # HBM, alone and in front of the forward
+            from cofii2p_amd import dataside, synth as _synth
 
-        raw, rimg, rK = _synth.make_raw_scan(0)
-        cal = dataside.calib_matrices(_synth.KITTI_CALIB_LINES)
-        P_Tr = np.dot(cal["P2"], cal["Tr"])
-        raw_d, img_d = torch.from_numpy(raw).to(dev), torch.from_numpy(rimg).to(dev)
-        opt_ds = Opt()
-        for k_, v_ in dict(num_pc=args.points, num_kpt=64, P_tx_amplitude=10, P_ty_amplitude=0, P_tz_amplitude=10, P_Rx_amplitude=0.0, P_Ry_amplitude=2.0 * np.pi, P_Rz_amplitude=0.0).items():
-            setattr(opt_ds, k_, v_)
-        st = make_streams(dev, max(S, 1))
-        prep0 = dataside.FramePreparer(opt_ds, dev)
-        for i in range(3):
-            prep0.prepare(raw_d, img_d, rK, P_Tr, i)
-        torch.cuda.synchronize()
-        nl = 20
-        t0 = time.perf_counter()
-        for i in range(nl):
-            prep0.prepare(raw_d, img_d, rK, P_Tr, i)
-        torch.cuda.synchronize()
-        loader_ms = 1e3 * (time.perf_counter() - t0) / nl
-        voxels = prep0.last["voxels"]
-        del prep0
-        # the pipelined loader (cofii2p_amd/loader.py): voxel grid enqueued LOOK frames ahead, draws in worker processes, resample +
-        # pyramid + image as one hipGraph per slot, tables read in place by the forward's graph; INFL forwards in flight
-        from cofii2p_amd.loader import FrameLoader
+            raw, rimg, rK = _synth.make_raw_scan(0)
+            cal = dataside.calib_matrices(_synth.KITTI_CALIB_LINES)
+            P_Tr = np.dot(cal["P2"], cal["Tr"])
+            raw_d, img_d = torch.from_numpy(raw).to(dev), torch.from_numpy(rimg).to(dev)
+            opt_ds = Opt()
+            for k_, v_ in dict(num_pc=args.points, num_kpt=64, P_tx_amplitude=10, P_ty_amplitude=0, P_tz_amplitude=10, P_Rx_amplitude=0.0, P_Ry_amplitude=2.0 * np.pi, P_Rz_amplitude=0.0).items():
+                setattr(opt_ds, k_, v_)
+            st = make_streams(dev, max(S, 1))
+            prep0 = dataside.FramePreparer(opt_ds, dev)
+            for i in range(3):
+                prep0.prepare(raw_d, img_d, rK, P_Tr, i)
+            torch.cuda.synchronize()
+            nl = 20
+            t0 = time.perf_counter()
+            for i in range(nl):
+                prep0.prepare(raw_d, img_d, rK, P_Tr, i)
+            torch.cuda.synchronize()
+            loader_ms = 1e3 * (time.perf_counter() - t0) / nl
+            voxels = prep0.last["voxels"]
+            del prep0
+            # the pipelined loader (cofii2p_amd/loader.py): voxel grid enqueued LOOK frames ahead, draws in worker processes, resample +
+            # pyramid + image as one hipGraph per slot, tables read in place by the forward's graph; INFL forwards in flight
+            from cofii2p_amd.loader import FrameLoader
 
-        model.enable_graphs(True)
-        LOOK, INFL = len(st), len(st) * max(1, args.slots_per_stream)
-        NSL = INFL + LOOK
-        ds_rates = {}
-        for upk in (None, 1):   # the reference's (N, 128) up-sampling tables / nearest-only tables derived without a search (outputs bit-identical)
-            loader = FrameLoader(opt_ds, dev, slots=NSL, workers=4, capture_stream=st[0], upsample_k=upk)
-            pend = [None] * NSL
+            model.enable_graphs(True)
+            LOOK, INFL = len(st), len(st) * max(1, args.slots_per_stream)
+            NSL = INFL + LOOK
+            ds_rates = {}
+            for upk in (None, 1):   # the reference's (N, 128) up-sampling tables / nearest-only tables derived without a search (outputs bit-identical)
+                loader = FrameLoader(opt_ds, dev, slots=NSL, workers=4, capture_stream=st[0], upsample_k=upk)
+                pend = [None] * NSL
 
-            host = {"begin": 0.0, "complete": 0.0, "forward": 0.0, "collect": 0.0}   # host seconds inside each call (timed phase)
+                host = {"begin": 0.0, "complete": 0.0, "forward": 0.0, "collect": 0.0}   # host seconds inside each call (timed phase)
 
-            def timed(name, fn, *a, **k):
-                t_ = time.perf_counter()
-                r = fn(*a, **k)
-                host[name] += time.perf_counter() - t_
-                return r
+                def timed(name, fn, *a, **k):
+                    t_ = time.perf_counter()
+                    r = fn(*a, **k)
+                    host[name] += time.perf_counter() - t_
+                    return r
 
-            def collect(sl):
-                h, smp = pend[sl]
-                model.finish(h)
-                smp["finish_labels"]()
-                loader.release(sl)
-                pend[sl] = None
+                def collect(sl):
+                    h, smp = pend[sl]
+                    model.finish(h)
+                    smp["finish_labels"]()
+                    loader.release(sl)
+                    pend[sl] = None
 
-            try:
-                for phase in range(2):
-                    nfr = max(args.steps, 3 * NSL)
-                    for k_ in host:
-                        host[k_] = 0.0
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    for j in range(min(LOOK, nfr)):
-                        with torch.cuda.stream(st[j % len(st)]):
-                            loader.begin(j % NSL, raw_d, img_d, rK, P_Tr, j)
-                    for i in range(nfr):
-                        sl, nxt = i % NSL, i + LOOK
-                        with torch.cuda.stream(st[i % len(st)]):
-                            if nxt < nfr:   # the voxel grid of frame i + LOOK goes onto this stream AHEAD of frame i's own work
-                                if pend[nxt % NSL] is not None:
-                                    timed("collect", collect, nxt % NSL)
-                                timed("begin", loader.begin, nxt % NSL, raw_d, img_d, rK, P_Tr, nxt)
+                try:
+                    for phase in range(2):
+                        nfr = max(args.steps, 3 * NSL)
+                        for k_ in host:
+                            host[k_] = 0.0
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for j in range(min(LOOK, nfr)):
+                            with torch.cuda.stream(st[j % len(st)]):
+                                loader.begin(j % NSL, raw_d, img_d, rK, P_Tr, j)
+                        for i in range(nfr):
+                            sl, nxt = i % NSL, i + LOOK
+                            with torch.cuda.stream(st[i % len(st)]):
+                                if nxt < nfr:   # the voxel grid of frame i + LOOK goes onto this stream AHEAD of frame i's own work
+                                    if pend[nxt % NSL] is not None:
+                                        timed("collect", collect, nxt % NSL)
+                                    timed("begin", loader.begin, nxt % NSL, raw_d, img_d, rK, P_Tr, nxt)
+                                loader.poll()
+                                smp = timed("complete", loader.complete, sl)
+                                pend[sl] = (timed("forward", model.forward_async, (60 if upk is None else 80) + sl, smp["pc_data_dict"], smp["img"][None], inputs_stable=True), smp)
                             loader.poll()
-                            smp = timed("complete", loader.complete, sl)
-                            pend[sl] = (timed("forward", model.forward_async, (60 if upk is None else 80) + sl, smp["pc_data_dict"], smp["img"][None], inputs_stable=True), smp)
-                        loader.poll()
-                    for k in range(NSL):
-                        if pend[(nfr + k) % NSL] is not None:
-                            timed("collect", collect, (nfr + k) % NSL)
-                    torch.cuda.synchronize()
-                    dtl = time.perf_counter() - t0
-            finally:
-                loader.close()
-            ds_rates[upk] = (nfr / dtl, dict(host))
-        dtl, host = nfr / ds_rates[None][0], ds_rates[None][1]
-        result["with_dataside"] = {"loader_ms_per_frame": loader_ms, "loader_frames_per_s": 1e3 / loader_ms, "frames_per_s": nfr / dtl,
-                                   "ms_per_frame": 1e3 * dtl / nfr, "voxels": voxels, "raw_points": int(raw.shape[1]),
-                                   "frames_in_flight": INFL, "voxel_grids_ahead": LOOK, "draw_workers": 4,
-                                   "nearest_only_upsampling_frames_per_s": ds_rates[1][0],
-                                   "host_ms_per_frame_in": {k_: round(1e3 * v_ / nfr, 4) for k_, v_ in host.items()},
-                                   "note": "kitti.py:259-393 on the device (voxel grid + resample + SE(3) + KNN pyramid + image + labels) in front of the "
-                                           "forward + fine matching, pipelined (cofii2p_amd/loader.py): raw scan and image resident in HBM, voxel count "
-                                           "read asynchronously, Mersenne-Twister draws in worker processes, labels finished when the frame's forward is "
-                                           "collected; loader_ms_per_frame = the synchronous FramePreparer.prepare() alone; not the headline"}
+                        for k in range(NSL):
+                            if pend[(nfr + k) % NSL] is not None:
+                                timed("collect", collect, (nfr + k) % NSL)
+                        torch.cuda.synchronize()
+                        dtl = time.perf_counter() - t0
+                finally:
+                    loader.close()
+                ds_rates[upk] = (nfr / dtl, dict(host))
+            dtl, host = nfr / ds_rates[None][0], ds_rates[None][1]
+            result["with_dataside"] = {"loader_ms_per_frame": loader_ms, "loader_frames_per_s": 1e3 / loader_ms, "frames_per_s": nfr / dtl,
+                                       "ms_per_frame": 1e3 * dtl / nfr, "voxels": voxels, "raw_points": int(raw.shape[1]),
+                                       "frames_in_flight": INFL, "voxel_grids_ahead": LOOK, "draw_workers": 4,
+                                       "nearest_only_upsampling_frames_per_s": ds_rates[1][0],
+                                       "host_ms_per_frame_in": {k_: round(1e3 * v_ / nfr, 4) for k_, v_ in host.items()},
+                                       "note": "kitti.py:259-393 on the device (voxel grid + resample + SE(3) + KNN pyramid + image + labels) in front of the "
+                                               "forward + fine matching, pipelined (cofii2p_amd/loader.py): raw scan and image resident in HBM, voxel count "
+                                               "read asynchronously, Mersenne-Twister draws in worker processes, labels finished when the frame's forward is "
+                                               "collected; loader_ms_per_frame = the synchronous FramePreparer.prepare() alone; not the headline"}
     if rank == 0 and world == 1 and Bsz == 1 and not args.eager and not args.no_batch_sweep and not args.stress:
-        result["stress_config"] = stress_summary(dev, args)
+        with optional_leg(result, "stress_config"):
+            result["stress_config"] = stress_summary(dev, args)
     if rank == 0 and world == 1 and Bsz == 1 and not args.no_batch_sweep and not args.stress:
         # row f3, outside `value`: one optimisation step of train.py:186-286 on the same frame (forward(mode='train') -> the three losses ->
         # backward -> Adam), fp32-grade contractions (bf16x6); a separate module instance so the served one keeps its weights
@@ -889,7 +917,8 @@ def main():
         except Exception as e:   # additional information only: never costs the line
             result["train_step"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(frames[0])
+        with optional_leg(result, "cpu_baseline"):
+            result["cpu_baseline"] = cpu_baseline(frames[0])
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
