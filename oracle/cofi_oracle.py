@@ -237,7 +237,17 @@ def resnet34_in(sd, img: Tensor) -> List[Tensor]:
     return outs
 
 
+BN_TRAIN = False   # set by forward(..., train_bn=True): the module under model.train() (train.py:188)
+
+
 def _bn_eval(sd, p: str, x: Tensor) -> Tensor:
+    """nn.BatchNorm2d: running statistics (eval), or - forward(train_bn=True) - batch statistics with the running buffers of `sd` updated in
+    place (momentum 0.1, unbiased variance), as imagenet.py:381-394 behaves under model.train()."""
+    if BN_TRAIN:
+        nbt = sd.get(p + "num_batches_tracked")
+        if nbt is not None:
+            nbt.add_(1)
+        return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"], True, 0.1, 1e-5)
     return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"], False, 0.0, 1e-5)
 
 
@@ -405,8 +415,20 @@ def get_P_diff(P_pred: np.ndarray, P_gt: np.ndarray) -> Tuple[float, float]:
 
 
 def forward(sd, data: Dict, img: Tensor, fine_center_kpt_coors: Optional[Tensor], fine_pc_inline_index: Optional[Tensor],
-            mode: str, taps: Optional[dict] = None):
-    """Returns the reference's 8-tuple.  ``img`` is (1,3,H,W)."""
+            mode: str, taps: Optional[dict] = None, train_bn: bool = False):
+    """Returns the reference's 8-tuple.  ``img`` is (1,3,H,W).  train_bn: the up-sampler's BatchNorm on batch statistics (the module in
+    train() mode); every function here is written with differentiable torch ops, so torch.autograd through this forward is the
+    oracle of the backward (row f3)."""
+    global BN_TRAIN
+    saved, BN_TRAIN = BN_TRAIN, bool(train_bn)
+    try:
+        return _forward(sd, data, img, fine_center_kpt_coors, fine_pc_inline_index, mode, taps)
+    finally:
+        BN_TRAIN = saved
+
+
+def _forward(sd, data: Dict, img: Tensor, fine_center_kpt_coors: Optional[Tensor], fine_pc_inline_index: Optional[Tensor],
+             mode: str, taps: Optional[dict] = None):
     pc_set = kpconv_fpn(sd, data, taps=taps)
     img_set = resnet34_in(sd, img)
     fine_pc = F.normalize(pc_set[0], dim=1)  # (N1,64)

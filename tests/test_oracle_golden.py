@@ -208,3 +208,88 @@ def test_get_p_diff():
     P_gt = np.eye(4); P_gt[:3, :3] = R; P_gt[:3, 3] = [0.3, -0.4, 1.2]
     rte, rre = O.get_P_diff(np.eye(4), P_gt)
     assert abs(rte - 1.3) < 1e-9 and abs(rre - 15.0) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ row f3: losses and the backward
+@pytest.mark.parametrize("tag", ["kitti", "nuscenes", "odd"])
+def test_loss_oracle_against_reference_losses(tag):
+    """oracle/loss_oracle.py against the reference's model/loss.py: values, the `dists` matrix and - through torch.autograd on both
+    sides - the gradients w.r.t. descriptors, scores and patches (tests/golden/loss_ref.npz, tests/tools/make_golden_loss.py)."""
+    import loss_oracle as LO
+
+    g = load_golden("loss_ref.npz")
+    img, pc = T(g[tag + "_img"]).requires_grad_(), T(g[tag + "_pc"]).requires_grad_()
+    loss, dists = LO.desc_loss(img, pc, T(g[tag + "_mask"]), pos_margin=0.2, neg_margin=1.8)
+    loss.backward()
+    close(loss.detach(), g[tag + "_desc_loss"])
+    close(dists.detach(), g[tag + "_dists"])
+    close(img.grad, g[tag + "_desc_gimg"])
+    close(pc.grad, g[tag + "_desc_gpc"])
+    s_in, s_out = T(g[tag + "_sin"]).requires_grad_(), T(g[tag + "_sout"]).requires_grad_()
+    lo = LO.overlap_loss(s_in, s_out)
+    lo.backward()
+    close(lo.detach(), g[tag + "_overlap_loss"])
+    close(s_in.grad, g[tag + "_overlap_gin"])
+    close(s_out.grad, g[tag + "_overlap_gout"])
+    pt, pf = T(g[tag + "_patches"]).requires_grad_(), T(g[tag + "_fpc"]).requires_grad_()
+    lf = LO.fine_circle_loss(pt, pf, T(g[tag + "_rel"]))
+    lf.backward()
+    close(lf.detach(), g[tag + "_fine_loss"])
+    close(pt.grad, g[tag + "_fine_gpatches"])
+    close(pf.grad, g[tag + "_fine_gpc"])
+
+
+def test_oracle_train_step_against_reference_train_step():
+    """One optimisation step of train.py:186-285 through the ORACLE - forward(mode='train', train_bn=True), the caller-side gathers and mask,
+    the loss oracle, torch.autograd - against the step recorded from the reference's module in train() mode (tests/golden/train_ref.npz):
+    outputs, losses, BatchNorm buffers, which parameters get a gradient, and every gradient's fingerprint (judged as in
+    tests/test_train_gpu.py: against the float64 values, within the reference's own fp32 deviation where that exceeds 1e-3)."""
+    import math
+
+    import loss_oracle as LO
+
+    gold = load_golden("train_ref.npz")
+    fr, data = frame_inputs(int(gold["frame_id"]), int(gold["num_points"]), int(gold["pyr_seed"]))
+    lab = {k[4:]: T(gold[k]) for k in gold.files if k.startswith("lab_")}
+    sd = {k: v.clone() for k, v in synth_sd().items()}
+    names = [str(n) for n in gold["g_names"]]
+    for n in names:
+        sd[n] = sd[n].clone().requires_grad_()
+    img = T(fr.img)[None]
+    outs = O.forward(sd, data, img, lab["fine_center_kpt_coors"].float(), lab["fine_pc_inline_index"], "train", train_bn=True)
+    img_f, pc_f, _img_s, pc_s, patches, fine_pc = outs[:6]
+    for n_, t in zip(("img_desc", "pc_desc", "img_score", "pc_score", "patches", "fine_pc"), outs[:6]):
+        assert float((t.detach() - T(gold["train_" + n_]).reshape(t.shape)).abs().max()) < 2e-5, n_
+    K = int(gold["num_kpt"])
+    kp, ko, ci = lab["pc_kpt_idx"], lab["pc_outline_idx"], lab["coarse_img_kpt_idx"]
+    H8, W8 = img_f.shape[2:]
+    xy = torch.stack([(ci % W8).float(), (ci // W8).float()])                                    # train.py:219-222,245
+    xyz = data["points"][-1].t()[:, kp]
+    proj = lab["K_4"] @ (lab["P"][:3, :3] @ xyz + lab["P"][:3, 3:])                              # train.py:248
+    mask = ((xy.unsqueeze(-1) - (proj[:2] / proj[2:]).unsqueeze(-2)).square().sum(0).sqrt() <= float(gold["dist_thres"])).float()
+    assert np.array_equal(mask.numpy(), gold["mask"])
+    l_desc, _ = LO.desc_loss(img_f.reshape(img_f.shape[1], -1)[:, ci], pc_f[:, kp], mask, float(gold["pos_margin"]), float(gold["neg_margin"]))
+    l_coarse = LO.overlap_loss(pc_s[0, 0, kp], pc_s[0, 0, ko])
+    rel = lab["fine_xy"] - lab["fine_center_kpt_coors"] + 2
+    l_fine = LO.fine_circle_loss(patches, fine_pc, rel[1] * 4 + rel[0])
+    for name, val in (("loss_desc", l_desc), ("loss_coarse", l_coarse), ("loss_fine", l_fine)):
+        assert abs(float(val.detach()) - float(gold[name])) < 2e-5 * max(1.0, abs(float(gold[name]))), name
+    (l_desc + l_coarse + l_fine).backward()
+    total = float(np.sqrt((gold["g_norm64"] ** 2).sum()))
+    for i, name in enumerate(names):
+        g_ = sd[name].grad
+        if not int(gold["g_has"][i]):
+            assert g_ is None, name
+            continue
+        flat = g_.double().reshape(-1)
+        norm_ref = float(gold["g_norm64"][i])
+        if norm_ref < 1e-6 * total:
+            assert float(flat.norm()) < 1e-5 * total, name
+            continue
+        got, ref = flat[T(gold["g_pos"][i])].numpy(), gold["g_val64"][i]
+        scale = max(np.linalg.norm(ref), norm_ref * math.sqrt(len(ref) / flat.numel()))
+        allow = max(1e-3, 2.5 * float(gold["g_err32"][i]))
+        assert float(np.linalg.norm(got - ref) / scale) < allow and abs(float(flat.norm()) - norm_ref) / norm_ref < allow, name
+    for k in gold.files:
+        if k.startswith("buf/"):
+            assert torch.allclose(sd[k[4:]].double(), T(np.asarray(gold[k])).double(), rtol=1e-4, atol=1e-5), k
