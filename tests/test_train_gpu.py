@@ -319,9 +319,10 @@ def test_train_step_matches_reference(gold, arith, tol, monkeypatch):
             assert torch.allclose(b.double(), ref.double(), rtol=1e-4, atol=1e-5), k
 
 
-def test_backward_matches_the_cpu_oracle_autograd():
-    """Independent of the reference fixture: the differentiable forward in eval() mode (BatchNorm on running statistics - the oracle's
-    semantics) against torch.autograd through the CPU oracle (oracle/cofi_oracle.py, the validated restatement of the reference forward),
+@pytest.mark.parametrize("train_bn", [False, True])
+def test_backward_matches_the_cpu_oracle_autograd(train_bn):
+    """Independent of the reference fixture: the differentiable forward - eval() mode (BatchNorm on running statistics) and train() mode
+    (batch statistics) - against torch.autograd through the CPU oracle (oracle/cofi_oracle.py, the validated restatement of the reference forward),
     a linear probe of all six outputs as the loss, EVERY parameter's gradient.  Both sides are fp32 with different summation orders and the
     probe (a ramp over unit-norm descriptors) cancels heavily, so they agree to the fp32 noise level only: observed <= 3.2e-3 outside the
     image branch (DESIGN.md section 3a explains the conditioning; the reference fixture above is judged in float64 instead)."""
@@ -343,9 +344,11 @@ def test_backward_matches_the_cpu_oracle_autograd():
     probe = lambda outs: sum((o * torch.linspace(-1, 1, o.numel(), device=o.device).reshape(o.shape)).sum() for o in outs[:6])
     sd = {k: torch.from_numpy(v) for k, v in synth_state_dict().items()}
     leaves = {k: v.clone().requires_grad_() for k, v in sd.items() if v.is_floating_point() and not k.endswith(("running_mean", "running_var", "kernel_points"))}
+    sd = {k: v.clone() for k, v in sd.items()}   # train_bn updates the running buffers in place
     sd.update(leaves)
-    probe(O.forward(sd, data, img, kpt, inl, "val")).backward()
-    m = CoFiI2P(Opt(), arithmetic="f32").to(DEV).eval()
+    probe(O.forward(sd, data, img, kpt, inl, "val", train_bn=train_bn)).backward()
+    m = CoFiI2P(Opt(), arithmetic="f32").to(DEV)
+    m.train(train_bn)
     dd = {k: [t.to(DEV) for t in v] for k, v in data.items() if k in ("points", "neighbors", "subsampling", "upsampling")}
     dd["feats"] = data["feats"].to(DEV)
     probe(train_forward.forward_train(m, dd, img.to(DEV), kpt.to(DEV), inl.to(DEV))).backward()
