@@ -319,12 +319,12 @@ def test_train_step_matches_reference(gold, arith, tol, monkeypatch):
             assert torch.allclose(b.double(), ref.double(), rtol=1e-4, atol=1e-5), k
 
 
-@pytest.mark.parametrize("train_bn", [False, True])
-def test_backward_matches_the_cpu_oracle_autograd(train_bn):
+@pytest.mark.parametrize("train_bn,num_points,img_hw", [(False, 2048, (160, 512)), (True, 2048, (160, 512)), (True, 4096, (128, 320))])
+def test_backward_matches_the_cpu_oracle_autograd(train_bn, num_points, img_hw):
     """Independent of the reference fixture: the differentiable forward - eval() mode (BatchNorm on running statistics) and train() mode
     (batch statistics) - against torch.autograd through the CPU oracle (oracle/cofi_oracle.py, the validated restatement of the reference forward),
     a linear probe of all six outputs as the loss, EVERY parameter's gradient.  Both sides are fp32 with different summation orders and the
-    probe (a ramp over unit-norm descriptors) cancels heavily, so they agree to the fp32 noise level only: observed <= 3.2e-3 outside the
+    probe (a ramp over unit-norm descriptors) cancels heavily, so they agree to the fp32 noise level only: observed <= 6.1e-3 outside the
     image branch (DESIGN.md section 3a explains the conditioning; the reference fixture above is judged in float64 instead)."""
     import cofi_oracle as O
     import knn_c
@@ -333,21 +333,25 @@ def test_backward_matches_the_cpu_oracle_autograd(train_bn):
     from cofii2p_amd.spec import synth_state_dict
     from cofii2p_amd.synth import make_frame
 
-    fr = make_frame(2, num_points=2048)
+    fr = make_frame(2, num_points=num_points, img_hw=img_hw)
     pyr = O.build_pyramid(np.ascontiguousarray(fr.points.T), 5, np.random.RandomState(4), knn=knn_c.knn_torch_compatible)
     data = dict(pyr)
     data["feats"] = torch.from_numpy(fr.feats)
     img = torch.from_numpy(fr.img)[None]
     g = np.random.default_rng(0)
-    kpt = torch.from_numpy(np.stack([g.integers(2, 254, 8), g.integers(2, 78, 8)]).astype(np.float32))
-    inl = torch.from_numpy(g.integers(0, 1024, 8))
+    kpt = torch.from_numpy(np.stack([g.integers(2, img_hw[1] // 2 - 2, 8), g.integers(2, img_hw[0] // 2 - 2, 8)]).astype(np.float32))
+    inl = torch.from_numpy(g.integers(0, num_points // 2, 8))
+
+    class OptHW(Opt):
+        img_H, img_W = img_hw
+
     probe = lambda outs: sum((o * torch.linspace(-1, 1, o.numel(), device=o.device).reshape(o.shape)).sum() for o in outs[:6])
     sd = {k: torch.from_numpy(v) for k, v in synth_state_dict().items()}
     leaves = {k: v.clone().requires_grad_() for k, v in sd.items() if v.is_floating_point() and not k.endswith(("running_mean", "running_var", "kernel_points"))}
     sd = {k: v.clone() for k, v in sd.items()}   # train_bn updates the running buffers in place
     sd.update(leaves)
     probe(O.forward(sd, data, img, kpt, inl, "val", train_bn=train_bn)).backward()
-    m = CoFiI2P(Opt(), arithmetic="f32").to(DEV)
+    m = CoFiI2P(OptHW(), arithmetic="f32").to(DEV)
     m.train(train_bn)
     dd = {k: [t.to(DEV) for t in v] for k, v in data.items() if k in ("points", "neighbors", "subsampling", "upsampling")}
     dd["feats"] = data["feats"].to(DEV)
@@ -372,7 +376,7 @@ def test_backward_matches_the_cpu_oracle_autograd(train_bn):
           % (worst + (loose, len(errs), ", ".join("%s %.1e" % (n.replace("pc_encoder.", "pc.").replace("img_encoder.backbone.", "rn."), e) for e, n in errs[:12]))))
     for e, name in errs:
         ill = name.startswith("img_encoder.") or name.startswith("img_upsample")   # behind InstanceNorm / BatchNorm over a whole map
-        assert e < (2e-2 if ill else 5e-3), (name, e)   # a wrong adjoint shows up as O(1); what is left here is fp32 summation-order noise
+        assert e < (2e-2 if ill else 1e-2), (name, e)   # a wrong adjoint shows up as O(1); what is left here is fp32 summation-order noise
 
 
 def test_training_changes_the_served_weights(gold):
