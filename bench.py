@@ -695,7 +695,24 @@ def main():
                 one_step(model, frames[i % len(frames)])
             torch.cuda.synchronize()
             dts = time.perf_counter() - t0
+            # ... and what a caller that only swaps the import gets: the reference-named class with ITS defaults (fp32-grade bf16x6
+            # arithmetic, hipGraph replay unasked with results the caller owns)
+            from model.network import CoFiI2P as ShimCoFiI2P
+
+            shim = ShimCoFiI2P(Opt()).to(dev)
+            with torch.no_grad():
+                for i in range(4):
+                    one_step(shim, frames[i % len(frames)])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(n_sync):
+                    one_step(shim, frames[i % len(frames)])
+                torch.cuda.synchronize()
+            dshim = time.perf_counter() - t0
+            del shim
             result["forward_sync"] = {"frames_per_s": n_sync / dts, "ms_per_frame": 1e3 * dts / n_sync, "frames": n_sync,
+                                      "reference_named_class_defaults": {"frames_per_s": n_sync / dshim, "arithmetic": "bf16x6",
+                                                                         "note": "`from model.network import CoFiI2P`, nothing else changed"},
                                       "note": "model(pc_data_dict, img, ..., 'test') per frame as eval_all.py:94-96 calls it (hipGraph replay, one host "
                                               "sync per frame, no frames in flight); `value` is the pipelined forward_async / finish rate"}
     if rank == 0 and not args.no_kernel_timing:

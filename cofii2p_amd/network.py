@@ -75,7 +75,12 @@ class CoFiI2P(nn.Module):
     # the stress configuration ≈ 20 GB): a loader should recycle
     # a RING of input buffers - one graph per (slot, ring entry) - not allocate fresh inputs per frame; past the limit forward_async raises
     MAX_STABLE_GRAPHS = 64
-    DEFAULT_ARITHMETIC = None   # None: follow ops.GEMM_MODE (COFI_GEMM); the model.network shim sets "f32"
+    DEFAULT_ARITHMETIC = None   # None: follow ops.GEMM_MODE (COFI_GEMM); the model.network shim sets "bf16x6"
+    # True: forward() replays a hipGraph per input signature WITHOUT being asked (enable_graphs) and hands out CLONES of the graph's static
+    # outputs, so nothing about the call changes for an unchanged caller (the model.network shim: 242 vs 173 frames/s for an eval_all.py-shaped
+    # loop); enable_graphs(False) switches it off, enable_graphs(True) keeps the zero-copy views
+    DEFAULT_GRAPHS = False
+    MAX_COPY_GRAPHS = 8         # input signatures (sizes) whose staged-input graphs are kept; the oldest is dropped beyond that
 
     def __init__(self, opt, init: str = "synthetic", arithmetic: Optional[str] = None):
         super().__init__()
@@ -100,6 +105,7 @@ class CoFiI2P(nn.Module):
         self._trained = False   # set by the first differentiable forward: from then on _pack() watches the parameters' version counters
         self.compute_unused_image_maps = True  # layer3/layer4/avg-pool of the ResNet (network.py:87-89)
         self._use_graphs = False
+        self._auto_graphs = bool(self.DEFAULT_GRAPHS)
         self._graphs = {}
         self._multicopy = {}
         self._grid_cache = {}
@@ -307,6 +313,7 @@ class CoFiI2P(nn.Module):
         forward overwrites (clone them to keep them)."""
         self._use_graphs = bool(flag)
         if not flag:
+            self._auto_graphs = False
             self._graphs = {}
             self._multicopy = {}
         return self
@@ -339,6 +346,10 @@ class CoFiI2P(nn.Module):
                                              "inputs_stable=False" % self.MAX_STABLE_GRAPHS)
                     static = list(tensors)   # the entry keeps the tensors alive for as long as the graph exists
                 else:
+                    copies = [k_ for k_ in self._graphs if k_[0] == "copy"]
+                    if len(copies) >= self.MAX_COPY_GRAPHS:   # a caller whose frames keep changing size: bounded memory, oldest signature first
+                        del self._graphs[copies[0]]
+                        self._multicopy.pop(copies[0], None)
                     static = [None if t is None else torch.empty_like(t) for t in tensors]
                     for s_, t in zip(static, tensors):
                         if t is not None:
@@ -515,16 +526,22 @@ class CoFiI2P(nn.Module):
         upsampling = [self._as_idx32(t) for t in pc_data_dict["upsampling"]]
         feats = pc_data_dict["feats"].contiguous()
         order = pc_data_dict.get("order")  # optional: spatially sorted processing order per stage (preprocess.morton_order)
-        if getattr(self, "_use_graphs", False) and taps is None:
+        auto = self._auto_graphs and not self._use_graphs and taps is None
+        if (self._use_graphs or auto) and taps is None:
             o = self._graph_forward(P, points, neighbors, subsampling, upsampling, feats, img.contiguous(), mode, fine_center_kpt_coors,
                                     fine_pc_inline_index, order=order)[0]
         else:
             o = self._run_device(P, points, neighbors, subsampling, upsampling, feats, img, mode, fine_center_kpt_coors,
                                  fine_pc_inline_index, taps=taps, order=order)[0]
+        own = (lambda t: t.clone() if torch.is_tensor(t) else t) if auto else (lambda t: t)   # unasked graphs: results the caller owns
         if mode in ("train", "val"):
-            return o["img_desc"], o["pc_desc"], o["img_score"], o["pc_score"], o["patches"], o["fine_pc"], None, None
+            return tuple(own(t) for t in (o["img_desc"], o["pc_desc"], o["img_score"], o["pc_score"], o["patches"], o["fine_pc"])) + (None, None)
         n, thr_i = (int(v) for v in o["count"].cpu())  # the only device->host synchronisation of forward
-        return self._slice_result(o, n, thr_i)
+        res = self._slice_result(o, n, thr_i)
+        if auto:
+            self.last_match = {k_: own(v_) for k_, v_ in self.last_match.items()}
+            res = tuple(own(t) for t in res)
+        return res
 
 
 def fine_matching(fine_img_feature_patch, fine_pc_inline_feature, fine_center_xy):

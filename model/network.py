@@ -5,7 +5,8 @@ dense contractions are fp32-GRADE - "bf16x6": three bf16 planes per operand, six
 fp64 as an exact-fp32 contraction (tools/x6_probe.py, tests/test_forward_gpu.py::test_kitti_frame_bf16x6_is_fp32_grade) - so
 `evaluation/eval_all.py` / `train.py` callers that only swap the import get fp32-level results, not the faster but coarser 3-term
 split `cofii2p_amd.network.CoFiI2P` defaults to.  `opt.arithmetic = "f32"` selects the exact fp32 MFMA (products bit-equal
-to an fmaf chain) at about half the frame rate.  INTEGRATION.md "Arithmetic"."""
+to an fmaf chain) at about half the frame rate.  INTEGRATION.md "Arithmetic".  It also replays a hipGraph per input signature without being
+asked (results are clones the caller owns): 242 instead of 173 frames/s for an eval_all.py-shaped loop; `enable_graphs(False)` = eager launches."""
 from cofii2p_amd import network as _net
 from cofii2p_amd.network import (CoFiI2P_wrapper as _Wrapper, extract_patch, fine_matching, fine_process, point2node,  # noqa: F401
                                  score_thresholds, square_distance)
@@ -13,6 +14,7 @@ from cofii2p_amd.network import (CoFiI2P_wrapper as _Wrapper, extract_patch, fin
 
 class CoFiI2P(_net.CoFiI2P):
     DEFAULT_ARITHMETIC = "bf16x6"
+    DEFAULT_GRAPHS = True   # an unchanged caller gets hipGraph replay (inputs staged, results cloned): same call, same ownership, 1.4x the rate
 
 
 class CoFiI2P_wrapper(_Wrapper):

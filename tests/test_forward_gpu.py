@@ -163,6 +163,44 @@ def test_nearest_only_upsampling_tables_are_exact(model):
         assert torch.equal(a, b)
 
 
+def test_shim_replays_graphs_unasked_and_results_are_owned(monkeypatch):
+    """`from model.network import CoFiI2P` (the unchanged caller's class): hipGraph replay without enable_graphs - the first frame's
+    results are the caller's own tensors (the second forward does not touch them), equal to the eager launches bit for bit; the set of
+    kept input signatures is bounded."""
+    from model.network import CoFiI2P as Shim
+
+    from cofii2p_amd.preprocess import build_pyramid
+    from cofii2p_amd.synth import make_frame, subsample_indices
+
+    def inputs(fid, n):
+        fr = make_frame(fid, n)
+        sub = [torch.from_numpy(s_).to(DEV) for s_ in subsample_indices(n, 5, seed=fid)]
+        pyr = build_pyramid(torch.from_numpy(fr.points).to(DEV), sub, int64=True)
+        pyr["feats"] = torch.from_numpy(fr.feats).to(DEV)
+        return pyr, torch.from_numpy(fr.img)[None].to(DEV)
+
+    m = Shim(Opt()).to(DEV)
+    a_in, b_in = inputs(21, 4096), inputs(22, 4096)
+    with torch.no_grad():
+        a = m(a_in[0], a_in[1], None, None, None, "test")
+        keep = [t.clone() for t in a]
+        lm = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in m.last_match.items()}
+        m(b_in[0], b_in[1], None, None, None, "test")            # same signature: the same graph replays over the same static buffers
+        assert len(m._graphs) == 1
+        for x, y in zip(a, keep):
+            assert torch.equal(x, y)
+        m.enable_graphs(False)
+        e = m(a_in[0], a_in[1], None, None, None, "test")
+        for x, y in zip(e, keep):
+            assert torch.equal(x, y)
+        assert torch.equal(m.last_match["fine_xy"], lm["fine_xy"])
+        m2 = Shim(Opt()).to(DEV)
+        for i, n in enumerate(range(2048, 2048 + 64 * (m2.MAX_COPY_GRAPHS + 3), 64)):   # a caller whose clouds keep changing size
+            p_, i_ = inputs(30 + i, n)
+            m2(p_, i_, None, None, None, "test")
+        assert len(m2._graphs) == m2.MAX_COPY_GRAPHS
+
+
 def test_product_refuses_cpu_tensors(model):
     from cofii2p_amd._lib import CofiError
 

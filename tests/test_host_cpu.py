@@ -147,7 +147,7 @@ def test_model_import_path_shim_and_training_guard():
 
     # the shim's class IS the implementation, specialised only in its default arithmetic (exact fp32: test_arithmetic_is_an_explicit_option...)
     assert issubclass(shim.CoFiI2P, network.CoFiI2P) and shim.point2node is network.point2node and issubclass(shim.CoFiI2P_wrapper, network.CoFiI2P_wrapper)
-    assert set(vars(shim.CoFiI2P)) - {'__module__', '__doc__', '__qualname__'} == {'DEFAULT_ARITHMETIC'}
+    assert set(vars(shim.CoFiI2P)) - {'__module__', '__doc__', '__qualname__'} == {'DEFAULT_ARITHMETIC', 'DEFAULT_GRAPHS'}
     assert precompute_point_cloud_stack_mode is preprocess.precompute_point_cloud_stack_mode is precompute_point_cloud_cuda
 
     class Opt:
