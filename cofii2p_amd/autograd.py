@@ -155,7 +155,7 @@ class _NeighborMaxpool(torch.autograd.Function):
         N, C = xd.shape
         M, H = idx.shape
         out = torch.empty((M, C), dtype=torch.float32, device=x.device)
-        arg = torch.empty((M, C), dtype=torch.int32, device=x.device)
+        arg = torch.empty((M, C), dtype=torch.uint8, device=x.device)
         _lib.check(lib.cofi_neighbor_maxpool_arg(_p(xd), _ld(xd), N, C, _p(idx), M, H, _p(out), _ld(out), _p(arg), _stream()), "cofi_neighbor_maxpool_arg")
         ctx.save_for_backward(arg)
         ctx.table, ctx.shape = table, (N, C)

@@ -28,7 +28,12 @@ struct KpBwdArgs {
 };
 
 __global__ __launch_bounds__(256) void kpconv_aggregate_bwd_kernel(KpBwdArgs a) {
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    // wave-private LDS: the influence weights of the 64 pairs of a round, [pair][16], and per pair its query row and the bit mask of its
+    // non-zero weights.  A wave reads only what it wrote itself (LDS executes one wave's instructions in order): no workgroup barrier.
+    __shared__ float s_w[4][64][16];
+    __shared__ int s_m[4][64], s_mask[4][64];
+    const int wslot = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int CW = a.C >= 64 ? 64 : a.C;          // channels a wave covers per pass (C < 64: 64 / CW pairs side by side)
     const int chunks = (a.C + CW - 1) / CW;
     const int j = wave / chunks, ch = wave - j * chunks;
@@ -38,15 +43,13 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_bwd_kernel(KpBwdArgs a) 
     const float sx = a.s_pts[3 * j], sy = a.s_pts[3 * j + 1], sz = a.s_pts[3 * j + 2];
     const int p0 = a.offsets[j], p1 = a.offsets[j + 1];
     float acc = 0.f;
-    // 64 pairs per round, lane = pair: one coalesced read of the pair ids, one gather of the query positions, all 15 influence
-    // weights of the pair in this lane's registers.  The accumulation loop then takes pair i's row id and weights from lane i
-    // (wave-uniform values) - its only memory traffic is the dagg rows with a non-zero weight, addresses known up front.
+    // 64 pairs per round, lane = pair: one coalesced read of the pair ids, one gather of the query positions, the 15 influence weights of
+    // the pair computed in this lane and parked in LDS with the mask of the non-zero ones (typically 1-3 of 15).  The accumulation loop
+    // then walks the pairs: per pair one broadcast read of (row, mask) and, per set bit, one broadcast weight read + one coalesced
+    // 256-byte load of the dagg row segment - nothing is spent on the kernel points a neighbour does not reach.
     for (int base = p0; base < p1; base += 64) {
         const int cnt = min(64, p1 - base);
-        int m = 0;
-        float w[15];
-#pragma unroll
-        for (int k = 0; k < 15; ++k) w[k] = 0.f;
+        int m = 0, mask = 0;
         if (lane < cnt) {
             m = a.pairs[base + lane] / a.H;
             const float ox = sx - a.q_pts[3 * m], oy = sy - a.q_pts[3 * m + 1], oz = sz - a.q_pts[3 * m + 2];
@@ -54,19 +57,26 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_bwd_kernel(KpBwdArgs a) 
             for (int k = 0; k < 15; ++k) {
                 const float dx = ox - a.kp[3 * k], dy = oy - a.kp[3 * k + 1], dz = oz - a.kp[3 * k + 2];
                 const float sq = (dx * dx + dy * dy) + dz * dz;
-                w[k] = fmaxf(1.0f - __builtin_amdgcn_sqrtf(sq) * a.inv_sigma, 0.0f);
+                const float w = fmaxf(1.0f - __builtin_amdgcn_sqrtf(sq) * a.inv_sigma, 0.0f);
+                s_w[wslot][lane][k] = w;
+                mask |= (w > 0.f) ? (1 << k) : 0;
             }
         }
-        for (int i = 0; i < cnt; i += NS) {
-            const int src = i + sub;                      // the pair this lane group works on (uniform when NS == 1)
-            const int mi = __shfl(m, src, 64);
-            const float *d = a.dagg + (size_t)mi * a.ldd + c;
-#pragma unroll
-            for (int k = 0; k < 15; ++k) {
-                const float wk = __shfl(w[k], src, 64);   // lanes past cnt hold w = 0
-                if (wk > 0.f && c_ok) acc = fmaf(wk, d[(size_t)k * a.C], acc);
+        s_m[wslot][lane] = m;
+        s_mask[wslot][lane] = mask;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = sub; i < cnt; i += NS) {      // NS == 1: i is wave-uniform; NS > 1: the lane groups take alternate pairs
+            int bits = s_mask[wslot][i];
+            const float *d = a.dagg + (size_t)s_m[wslot][i] * a.ldd + c;
+            while (bits) {
+                const int k = __builtin_ctz(bits);
+                bits &= bits - 1;
+                if (c_ok) acc = fmaf(s_w[wslot][i][k], d[(size_t)k * a.C], acc);
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     // fold the NS side-by-side partial sums (lanes with equal channel) in a fixed order
     for (int o = 32; o >= CW; o >>= 1) acc += __shfl_xor(acc, o, 64);
@@ -75,36 +85,69 @@ __global__ __launch_bounds__(256) void kpconv_aggregate_bwd_kernel(KpBwdArgs a) 
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Neighbour max-pool with the arg-max (functional.py:53-66: x padded with a zero row, max over the H neighbours; the first
-// neighbour attaining the maximum receives the gradient).  One thread per (query, channel).
-__global__ void neighbor_maxpool_arg_kernel(const float *x, int ldx, int N, int C, const int32_t *idx, int M, int H, float *out, int ldo,
-                                            int32_t *arg) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)M * C) return;
-    const int m = (int)(t / C), c = (int)(t - (size_t)m * C);
-    float best = -INFINITY;
-    int bh = 0;
-    for (int h = 0; h < H; ++h) {
+// neighbour attaining the maximum receives the gradient).  One wave per (query, 32-channel chunk), as the serving kernel: lane
+// (g = l >> 3, c4 = l & 7) reads float4 number c4 of the chunk for neighbours h = 8 i + g - one load instruction fetches 8 neighbour
+// rows x 128 contiguous bytes - and keeps (max, first h) per channel; the 8 lane groups are folded with xor-shuffles (larger value,
+// then lower h).  arg: (M, C) bytes (H <= 256).
+__global__ __launch_bounds__(256) void neighbor_maxpool_arg_kernel(const float *x, int ldx, int N, int C, const int32_t *idx, int M, int H, float *out, int ldo,
+                                                                   uint8_t *arg) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int chunks = (C + 31) / 32;
+    const int m = wave % M, ch = wave / M;     // chunks are the slow axis: a chunk's source slice stays in L2 while its queries run
+    if (ch >= chunks) return;
+    const int g = lane >> 3, c0 = ch * 32 + 4 * (lane & 7);
+    const bool c_ok = c0 < C;                   // C % 4 == 0 (host-checked)
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bh[4] = {0, 0, 0, 0};
+    for (int h = g; h < H; h += 8) {
         const int id = idx[(size_t)m * H + h];
-        const float v = (id >= 0 && id < N) ? x[(size_t)id * ldx + c] : 0.f;
-        if (v > best) { best = v; bh = h; }
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (id >= 0 && id < N && c_ok) v = *reinterpret_cast<const f32x4 *>(x + (size_t)id * ldx + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (v[e] > best[e]) { best[e] = v[e]; bh[e] = h; }
     }
-    out[(size_t)m * ldo + c] = best;
-    arg[(size_t)m * C + c] = bh;
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ov = __shfl_xor(best[e], o, 64);
+            const int oh = __shfl_xor(bh[e], o, 64);
+            if (ov > best[e] || (ov == best[e] && oh < bh[e])) { best[e] = ov; bh[e] = oh; }
+        }
+    if (g == 0 && c_ok) {
+        *reinterpret_cast<f32x4 *>(out + (size_t)m * ldo + c0) = f32x4{best[0], best[1], best[2], best[3]};
+        *reinterpret_cast<uchar4 *>(arg + (size_t)m * C + c0) = make_uchar4((unsigned char)bh[0], (unsigned char)bh[1], (unsigned char)bh[2], (unsigned char)bh[3]);
+    }
 }
 
-// dx[j, c] = sum over the pairs (m, h) of row j with arg[m, c] == h of dy[m, c]; one wave per (j, 64-channel chunk)
-__global__ __launch_bounds__(256) void neighbor_maxpool_bwd_kernel(const float *dy, int ldy, const int32_t *arg, int C, int H, const int32_t *pairs,
+// dx[j, c] = sum over the pairs (m, h) of row j with arg[m, c] == h of dy[m, c]; one wave per (j, 64-channel chunk).  The pair list is
+// staged 64 at a time by lane = pair (one coalesced read) into wave-private LDS, so the walk's loads (arg byte, dy) are independent.
+__global__ __launch_bounds__(256) void neighbor_maxpool_bwd_kernel(const float *dy, int ldy, const uint8_t *arg, int C, int H, const int32_t *pairs,
                                                                    const int32_t *offsets, int N, float *dx, int ldx) {
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    __shared__ int s_pair[4][64];
+    const int wslot = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int chunks = (C + 63) / 64;
     const int j = wave / chunks, c = (wave - j * chunks) * 64 + lane;
-    if (j >= N || c >= C) return;
+    if (j >= N) return;
+    const bool c_ok = c < C;
+    const int p0 = offsets[j], p1 = offsets[j + 1];
     float acc = 0.f;
-    for (int p = offsets[j]; p < offsets[j + 1]; ++p) {
-        const int pair = pairs[p], m = pair / H, h = pair - m * H;
-        if (arg[(size_t)m * C + c] == h) acc += dy[(size_t)m * ldy + c];
+    for (int base = p0; base < p1; base += 64) {
+        const int cnt = min(64, p1 - base);
+        s_pair[wslot][lane] = lane < cnt ? pairs[base + lane] : 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (c_ok)
+            for (int i = 0; i < cnt; ++i) {
+                const int pair = s_pair[wslot][i], m = pair / H, h = pair - m * H;
+                if (arg[(size_t)m * C + c] == h) acc += dy[(size_t)m * ldy + c];
+            }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
-    dx[(size_t)j * ldx + c] = acc;
+    if (c_ok) dx[(size_t)j * ldx + c] = acc;
 }
 
 // adjoint of out[m] = x[idx[m * stride]] (functional.py:5-21 nearest_upsample; any row gather): dx[j] = sum over the rows m of
@@ -402,12 +445,16 @@ __global__ __launch_bounds__(256) void col_sum_partial_kernel(const float *x, in
     if (ph == 0 && c < C) part[(size_t)blockIdx.y * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
-__global__ void col_sum_final_kernel(const float *part, int RB, int C, float *out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void col_sum_final_kernel(const float *part, int RB, int C, float *out) {   // 64 columns x 4 phases per workgroup
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int b = 0; b < RB; ++b) s += part[(size_t)b * C + c];
-    out[c] = s;
+    if (c < C)
+        for (int b = ph; b < RB; b += 4) s += part[(size_t)b * C + c];
+    red[ph][cl] = s;
+    __syncthreads();
+    if (ph == 0 && c < C) out[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
 
@@ -432,9 +479,26 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_kernel(NormBwdArgs a) { 
     float sa = 0.f, sb = 0.f;
     if (c < a.C) {
         const float mean = a.stats[2 * (c / a.cpg)], rstd = a.stats[2 * (c / a.cpg) + 1];
-        for (int m = r0 + ph; m < r1; m += 4) {
+        const bool act = a.slope != 1.0f;
+        int m = r0 + ph;
+        for (; m + 12 < r1; m += 16) {   // four rows in flight per thread (the loop is a chain of L2 round trips otherwise)
+            float g[4], xv[4], yv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g[u] = a.dy[(size_t)(m + 4 * u) * a.lddy + c];
+                xv[u] = a.x[(size_t)(m + 4 * u) * a.ldx + c];
+                yv[u] = act ? a.y[(size_t)(m + 4 * u) * a.ldy + c] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {   // same order as the scalar tail: row by row
+                if (act && !(yv[u] > 0.f)) g[u] *= a.slope;
+                sa += g[u];
+                sb = fmaf(g[u], (xv[u] - mean) * rstd, sb);
+            }
+        }
+        for (; m < r1; m += 4) {
             float g = a.dy[(size_t)m * a.lddy + c];
-            if (a.slope != 1.0f && !(a.y[(size_t)m * a.ldy + c] > 0.f)) g *= a.slope;
+            if (act && !(a.y[(size_t)m * a.ldy + c] > 0.f)) g *= a.slope;
             sa += g;
             sb = fmaf(g, (a.x[(size_t)m * a.ldx + c] - mean) * rstd, sb);
         }
@@ -449,14 +513,24 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_kernel(NormBwdArgs a) { 
     }
 }
 
-__global__ void norm_bwd_finalize_kernel(NormBwdArgs a) {   // one thread per column; cpg (power of two <= 64) adjacent lanes = one group
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// 64 columns per workgroup, 4 waves: wave w folds the row-block partials w, w + 4, ... of its column (fp64), the four are joined through
+// LDS in wave order; cpg (power of two <= 64) adjacent lanes of wave 0 = one group
+__global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(NormBwdArgs a) {
+    __shared__ double red[4][64][2];
+    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     double sa = 0.0, sb = 0.0;
     if (c < a.C)
-        for (int b = 0; b < a.RB; ++b) {
+        for (int b = ph; b < a.RB; b += 4) {
             sa += a.part[((size_t)b * a.C + c) * 2];
             sb += a.part[((size_t)b * a.C + c) * 2 + 1];
         }
+    red[ph][cl][0] = sa;
+    red[ph][cl][1] = sb;
+    __syncthreads();
+    if (ph != 0) return;
+    sa = (red[0][cl][0] + red[1][cl][0]) + (red[2][cl][0] + red[3][cl][0]);
+    sb = (red[0][cl][1] + red[1][cl][1]) + (red[2][cl][1] + red[3][cl][1]);
     if (c < a.C) {
         if (a.dbeta) a.dbeta[c] = (float)sa;
         if (a.dgamma) a.dgamma[c] = (float)sb;
@@ -517,16 +591,16 @@ extern "C" int cofi_kpconv_aggregate_bwd(const float *dagg, int ldd, const float
     return cofi_launch_status();
 }
 
-extern "C" int cofi_neighbor_maxpool_arg(const float *x, int ldx, int N, int C, const int32_t *idx, int M, int H, float *out, int ldo, int32_t *arg,
+extern "C" int cofi_neighbor_maxpool_arg(const float *x, int ldx, int N, int C, const int32_t *idx, int M, int H, float *out, int ldo, uint8_t *arg,
                                          cofi_stream_t stream) {
-    if (!x || !idx || !out || !arg || N <= 0 || C <= 0 || M < 0 || H <= 0 || ldx < C || ldo < C) return COFI_EINVAL;
+    if (!idx || !arg || N <= 0 || C <= 0 || (C & 3) || M < 0 || H <= 0 || H > 256 || bad_mat(x, ldx, C) || bad_mat(out, ldo, C)) return COFI_EINVAL;
     if (M == 0) return 0;
-    hipLaunchKernelGGL(neighbor_maxpool_arg_kernel, dim3(cofi_cdiv((long)M * C, 256)), dim3(256), 0, cofi_s(stream), x, ldx, N, C, idx, M, H, out, ldo,
-                       arg);
+    const long waves = (long)M * ((C + 31) / 32);
+    hipLaunchKernelGGL(neighbor_maxpool_arg_kernel, dim3(cofi_cdiv(waves, 4)), dim3(256), 0, cofi_s(stream), x, ldx, N, C, idx, M, H, out, ldo, arg);
     return cofi_launch_status();
 }
 
-extern "C" int cofi_neighbor_maxpool_bwd(const float *dy, int ldy, const int32_t *arg, int C, int H, const int32_t *pairs, const int32_t *offsets,
+extern "C" int cofi_neighbor_maxpool_bwd(const float *dy, int ldy, const uint8_t *arg, int C, int H, const int32_t *pairs, const int32_t *offsets,
                                          int N, float *dx, int ldx, cofi_stream_t stream) {
     if (!dy || !arg || !pairs || !offsets || !dx || N <= 0 || C <= 0 || H <= 0 || ldy < C || ldx < C) return COFI_EINVAL;
     const long waves = (long)N * ((C + 63) / 64);
@@ -590,7 +664,7 @@ extern "C" int cofi_group_norm_bwd(const float *x, int ldx, const float *y, int 
     a.part = (float *)ws;
     a.coef = a.part + (size_t)a.RB * C * 2;
     hipLaunchKernelGGL(norm_bwd_partial_kernel, dim3(cofi_cdiv(C, 64), a.RB), dim3(256), 0, cofi_s(stream), a);
-    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(cofi_cdiv(C, 256)), dim3(256), 0, cofi_s(stream), a);
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(cofi_cdiv(C, 64)), dim3(256), 0, cofi_s(stream), a);
     hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(cofi_cdiv((long)M * (C / 4), 256)), dim3(256), 0, cofi_s(stream), a);
     return cofi_launch_status();
 }
@@ -604,7 +678,7 @@ extern "C" int cofi_col_sum(const float *x, int ldx, int M, int C, float *out, v
     const int RB = col_sum_blocks(M);
     if (!ws || ws_bytes < cofi_col_sum_workspace(M, C)) return COFI_EWORKSPACE;
     hipLaunchKernelGGL(col_sum_partial_kernel, dim3(cofi_cdiv(C, 64), RB), dim3(256), 0, cofi_s(stream), x, ldx, M, C, cofi_cdiv(M, RB), (float *)ws);
-    hipLaunchKernelGGL(col_sum_final_kernel, dim3(cofi_cdiv(C, 256)), dim3(256), 0, cofi_s(stream), (const float *)ws, RB, C, out);
+    hipLaunchKernelGGL(col_sum_final_kernel, dim3(cofi_cdiv(C, 64)), dim3(256), 0, cofi_s(stream), (const float *)ws, RB, C, out);
     return cofi_launch_status();
 }
 

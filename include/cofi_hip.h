@@ -427,7 +427,7 @@ int cofi_overlap_loss(const float *inline_score, int n_in, const float *outline_
  * sorted by (j, id), `offsets` (N + 1) - and a wave per row j sums its list in that order: no float atomics, bit-reproducible.
  * cofi_kpconv_aggregate_bwd  model/kpconv/kpconv.py:91-105: dfeats[j, c] = sum_{(m,h)} sum_k w(m, h, k) dagg[m, k C + c] with the kernel-point
  *                            influences w recomputed from q_pts (M, 3), s_pts (N, 3), kernel_points (15, 3), sigma.  C >= 64 or a power of 2.
- * cofi_neighbor_maxpool_arg  functional.py:53-66 with the index h of the first neighbour attaining the maximum (arg (M, C) int32);
+ * cofi_neighbor_maxpool_arg  functional.py:53-66 with the index h of the first neighbour attaining the maximum (arg (M, C) uint8);
  * cofi_neighbor_maxpool_bwd  its adjoint.   cofi_gather_rows_bwd: adjoint of cofi_gather_rows (functional.py:5-21).
  * cofi_im2col_nhwc / cofi_col2im_nhwc: a convolution of the image branch in training = im2col + GEMM (the weight gradient needs the
  *                            unfolded input): col (Ho Wo, ks ks C) with column (dy ks + dx) C + c; col2im is the adjoint (gather form).
@@ -435,9 +435,9 @@ int cofi_overlap_loss(const float *inline_score, int n_in, const float *outline_
  *                            matrix instruction; D == 32; ws of cofi_attention_bwd_workspace(L, H) bytes. */
 int cofi_kpconv_aggregate_bwd(const float *dagg, int ldd, const float *q_pts, const float *s_pts, const int32_t *pairs, const int32_t *offsets,
                               int N, int C, int H, const float *kernel_points, float sigma, float *dfeats, int ldf, cofi_stream_t stream);
-int cofi_neighbor_maxpool_arg(const float *x, int ldx, int N, int C, const int32_t *idx, int M, int H, float *out, int ldo, int32_t *arg,
-                              cofi_stream_t stream);
-int cofi_neighbor_maxpool_bwd(const float *dy, int ldy, const int32_t *arg, int C, int H, const int32_t *pairs, const int32_t *offsets, int N,
+int cofi_neighbor_maxpool_arg(const float *x, int ldx, int N, int C, const int32_t *idx, int M, int H, float *out, int ldo,
+                              uint8_t *arg /* (M, C) bytes; H <= 256, C % 4 == 0 */, cofi_stream_t stream);
+int cofi_neighbor_maxpool_bwd(const float *dy, int ldy, const uint8_t *arg, int C, int H, const int32_t *pairs, const int32_t *offsets, int N,
                               float *dx, int ldx, cofi_stream_t stream);
 int cofi_gather_rows_bwd(const float *dy, int ldy, int C, const int32_t *pairs, const int32_t *offsets, int N, float *dx, int ldx,
                          cofi_stream_t stream);
