@@ -430,6 +430,31 @@ __global__ __launch_bounds__(256) void col_mean_kernel(const float *x, int ldx, 
     if (ph == 0 && c < C) out[(size_t)blockIdx.y * C + c] = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)M;
 }
 
+// 64 x 64 tiles, 16-byte accesses on both sides (M, C, ldx, ldy multiples of 4, 16-byte aligned bases: the backward's activation
+// transposes - up to 39 MB - ran at 1.1 TB/s through the scalar kernel below)
+__global__ __launch_bounds__(256) void transpose_vec_kernel(const float *x, int ldx, int M, int C, float *y, int ldy) {
+    __shared__ float tile[64][65];
+    const int m0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int q = threadIdx.x & 15, r = threadIdx.x >> 4;   // 16 float4 per tile row, 16 rows per pass
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + r + 16 * i, c = c0 + 4 * q;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < M && c < C) v = *reinterpret_cast<const f32x4 *>(x + (size_t)m * ldx + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[r + 16 * i][4 * q + e] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + r + 16 * i, m = m0 + 4 * q;
+        if (c < C && m < M) {
+            const f32x4 v = {tile[4 * q][r + 16 * i], tile[4 * q + 1][r + 16 * i], tile[4 * q + 2][r + 16 * i], tile[4 * q + 3][r + 16 * i]};
+            *reinterpret_cast<f32x4 *>(y + (size_t)c * ldy + m) = v;
+        }
+    }
+}
+
 __global__ void transpose_kernel(const float *x, int ldx, int M, int C, float *y, int ldy) {
     __shared__ float tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
@@ -618,7 +643,10 @@ extern "C" int cofi_col_mean(const float *x, int ldx, int M, int C, float *out, 
 
 extern "C" int cofi_transpose(const float *x, int ldx, int M, int C, float *y, int ldy, cofi_stream_t stream) {
     if (!x || !y || M <= 0 || C <= 0 || ldx < C || ldy < M) return COFI_EINVAL;
-    hipLaunchKernelGGL(transpose_kernel, dim3(cofi_cdiv(C, 32), cofi_cdiv(M, 32)), dim3(256), 0, cofi_s(stream), x, ldx, M, C, y, ldy);
+    if (!((M | C | ldx | ldy) & 3) && !(((uintptr_t)x | (uintptr_t)y) & 15) && (long)M * C >= 64 * 64)
+        hipLaunchKernelGGL(transpose_vec_kernel, dim3(cofi_cdiv(C, 64), cofi_cdiv(M, 64)), dim3(256), 0, cofi_s(stream), x, ldx, M, C, y, ldy);
+    else
+        hipLaunchKernelGGL(transpose_kernel, dim3(cofi_cdiv(C, 32), cofi_cdiv(M, 32)), dim3(256), 0, cofi_s(stream), x, ldx, M, C, y, ldy);
     return cofi_launch_status();
 }
 

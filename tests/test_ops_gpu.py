@@ -621,6 +621,15 @@ def test_gemm_bf16x3_split(ops, M, N, K, monkeypatch):
         close(ln, torch.nn.functional.layer_norm(ref.float(), (N,)), 2e-4)
 
 
+@pytest.mark.parametrize("M,C", [(64, 64), (20480, 480), (1280, 128), (130, 68), (77, 33), (4096, 4), (8, 2048), (1000, 260)])
+def test_transpose_shapes(ops, M, C):
+    """cofi_transpose: the 16-byte tile kernel (everything a multiple of 4) and the scalar one, incl. a strided source view"""
+    x = torch.arange(M * (C + 4), dtype=torch.float32).reshape(M, C + 4)
+    xg = G(x)
+    assert torch.equal(ops.transpose(xg[:, :C]).cpu(), x[:, :C].t())
+    assert torch.equal(ops.transpose(xg.contiguous()[:, :C].contiguous()).cpu(), x[:, :C].t())
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 128), (1280, 512, 7680), (77, 33, 60), (2560, 1024, 3072), (20480, 32, 480), (100, 64, 1000), (64, 480, 20480),
                                    (4700, 512, 64), (1350, 1024, 256)])
 def test_gemm_bf16x6_is_fp32_grade(ops, M, N, K, monkeypatch):
