@@ -155,8 +155,12 @@ def resnet34_s8(P, img: torch.Tensor):
 
 def _residual_conv(P, B, p, x, H, W, training):
     """imagenet.py:377-411."""
-    identity = batch_norm_rows(ag.conv2d(x, H, W, P[p + "conv_skip.0.weight"])[0], P, B, p + "conv_skip.1.", training)
-    out = batch_norm_rows(ag.conv2d(x, H, W, P[p + "conv1.weight"])[0], P, B, p + "bn1.", training, 0.0)
+    # conv_skip and conv1 read the same input (imagenet.py:399-402): one unfolded operand, one contraction with the stacked filters
+    ws, w1 = P[p + "conv_skip.0.weight"], P[p + "conv1.weight"]
+    Cout = ws.shape[0]
+    both = ag.linear(ag.im2col(x.contiguous(), H, W, 3, 1, 1), torch.cat([ws, w1], 0).permute(0, 2, 3, 1).reshape(2 * Cout, -1))
+    identity = batch_norm_rows(both[:, :Cout], P, B, p + "conv_skip.1.", training)
+    out = batch_norm_rows(both[:, Cout:], P, B, p + "bn1.", training, 0.0)
     return batch_norm_rows(ag.conv2d(out, H, W, P[p + "conv2.weight"])[0], P, B, p + "bn2.", training, 0.0, res=identity)
 
 
@@ -170,12 +174,16 @@ def image_upsample(P, B, name, low, h, w, skip, training):
 
 # ------------------------------------------------------------------------------------------ transformer (transformer.py:43-104)
 def loftr_layer(P, p, x, src, nhead: int = N_HEAD):
-    q = ag.linear(x, P[p + "q_proj.weight"])
-    k = ag.linear(src, P[p + "k_proj.weight"])
-    v = ag.linear(src, P[p + "v_proj.weight"])
+    C = x.shape[1]
+    if src is x:   # self layer: the three projections read the same tokens - one contraction with the stacked weights [Wq; Wk; Wv]
+        qkv = ag.linear(x, torch.cat([P[p + "q_proj.weight"], P[p + "k_proj.weight"], P[p + "v_proj.weight"]], 0))
+        q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    else:
+        q = ag.linear(x, P[p + "q_proj.weight"])
+        kv = ag.linear(src, torch.cat([P[p + "k_proj.weight"], P[p + "v_proj.weight"]], 0))
+        k, v = kv[:, :C], kv[:, C:]
     q = F.normalize(q, dim=0)   # transformer.py:53: F.normalize's default dim=1 on (1, L, H, D) = over the L tokens
     msg = ag.attention(q, k, v, nhead)
-    C = x.shape[1]
     msg = F.layer_norm(ag.linear(msg, P[p + "merge.weight"]), (C,), P[p + "norm1.weight"], P[p + "norm1.bias"])
     h = ag.linear(F.relu(ag.linear(torch.cat([x, msg], 1), P[p + "mlp.0.weight"])), P[p + "mlp.2.weight"])
     return x + F.layer_norm(h, (C,), P[p + "norm2.weight"], P[p + "norm2.bias"])
