@@ -284,7 +284,7 @@ class CoFiI2P(nn.Module):
             if mode in ("train", "val"):
                 K = fine_center_kpt_coors.shape[1]
                 cnt = torch.zeros((2,), dtype=torch.int32, device=dev)
-                cnt[0] = K
+                cnt[:1].fill_(K)   # a fill kernel, not a host-to-device copy: capturable in a hipGraph
                 ctr = fine_center_kpt_coors.to(torch.float32).contiguous()
                 pat = ops.extract_patches_nhwc(up2_f, H2, W2, ctr, cnt, K, 1.0)
                 o["patches"] = pat.reshape(K, C2, 4, 4)

@@ -196,6 +196,15 @@ def test_shim_replays_graphs_unasked_and_results_are_owned(monkeypatch):
         for x, y in zip(e, keep):
             assert torch.equal(x, y)
         assert torch.equal(m.last_match["fine_xy"], lm["fine_xy"])
+        # mode='val' (train.py's validation pass: int64 label tensors on the device) through the unasked graph == eager launches
+        kpt = torch.tensor([[8, 40, 100, 250], [4, 30, 60, 70]], dtype=torch.int64, device=DEV)
+        inl = torch.tensor([0, 5, 77, 2000], dtype=torch.int64, device=DEV)
+        mv = Shim(Opt()).to(DEV)
+        gv = mv(a_in[0], a_in[1], kpt, None, inl, "val")
+        assert len(mv._graphs) == 1
+        mv.enable_graphs(False)
+        for x, y in zip(gv[:6], mv(a_in[0], a_in[1], kpt, None, inl, "val")[:6]):
+            assert torch.equal(x, y)
         m2 = Shim(Opt()).to(DEV)
         for i, n in enumerate(range(2048, 2048 + 64 * (m2.MAX_COPY_GRAPHS + 3), 64)):   # a caller whose clouds keep changing size
             p_, i_ = inputs(30 + i, n)
