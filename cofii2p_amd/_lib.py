@@ -104,6 +104,7 @@ SIGNATURES = {
     "cofi_fine_match": (_I, [_P, _P, _I, _I, _P, _I, _F, _P, _I, _P, _P, _P]),
     "cofi_kpconv_fused_slab_rows": (_I, [_I, _I, _I]),
     "cofi_kpconv_fused": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _F, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P, _P]),
+    "cofi_color_jitter_chw": (_I, [_P, _I, _I, _P, _F, _F, _F, _F, _P, _Z, _P]),
     "cofi_pack_transform_scan": (_I, [_P, _I, _P, _P, _P]),
     "cofi_voxel_downsample_workspace": (_Z, [_I]),
     "cofi_voxel_downsample": (_I, [_P, _I, ctypes.c_double, _P, _I, _P, _P, _Z, _P]),

@@ -414,6 +414,81 @@ __global__ void radius_mask_kernel(const int32_t *idx, const float *dist, int M,
     }
     if (lane == 0) atomicMax(max_count, cnt);
 }
+
+// ---- train-mode image augmentation: torchvision ColorJitter on the PIL image (kitti.py:193-201) -----------------------------------------
+// The four operations of torchvision's transforms/_functional_pil.py on the cropped uint8 image, which lives here as the (3, H, W) float
+// image of cofi_resize_crop_image (every value k / 255): PIL.ImageEnhance.Brightness / Contrast / Color = Image.blend(degenerate, img,
+// factor) in float32 with truncation, and the hue shift through PIL's RGB <-> HSV conversion (float ratios, double literals: the
+// operation order of libImaging/Convert.c).  Bit-equal to oracle/dataside_oracle.py::color_jitter, which is pinned to PIL itself.
+__device__ __forceinline__ int cj_u8(float x) { return (int)(x * 255.0f + 0.5f); }
+__device__ __forceinline__ int cj_gray(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
+__device__ __forceinline__ int cj_blend(int deg, int v, float a, bool inside) {
+    float t = (float)deg + a * ((float)v - (float)deg);
+    if (!inside) t = fminf(fmaxf(t, 0.f), 255.f);
+    return (int)t;
+}
+
+__global__ void cj_gray_sum_kernel(const float *img, int P, unsigned long long *sum) {
+    unsigned long long s = 0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x)
+        s += (unsigned long long)cj_gray(cj_u8(img[p]), cj_u8(img[P + p]), cj_u8(img[2 * P + p]));
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sum, s);   // integer sum: order-free
+}
+
+__global__ void cj_op_kernel(float *img, int P, int op, float factor, int shift, const unsigned long long *gray_sum) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    int r = cj_u8(img[p]), g = cj_u8(img[P + p]), b = cj_u8(img[2 * P + p]);
+    const bool inside = factor >= 0.f && factor <= 1.f;
+    if (op == 0) {                       // brightness: blend with black
+        r = cj_blend(0, r, factor, inside); g = cj_blend(0, g, factor, inside); b = cj_blend(0, b, factor, inside);
+    } else if (op == 1) {                // contrast: blend with the rounded mean of the grey image
+        const int mean = (int)((double)*gray_sum / (double)P + 0.5);
+        r = cj_blend(mean, r, factor, inside); g = cj_blend(mean, g, factor, inside); b = cj_blend(mean, b, factor, inside);
+    } else if (op == 2) {                // saturation: blend with the grey image
+        const int l = cj_gray(r, g, b);
+        r = cj_blend(l, r, factor, inside); g = cj_blend(l, g, factor, inside); b = cj_blend(l, b, factor, inside);
+    } else {                             // hue: RGB -> HSV, H += shift (mod 256), HSV -> RGB
+        const int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
+        int uh = 0, us = 0;
+        if (minc != maxc) {
+            const float cr = (float)(maxc - minc);
+            const float sat = cr / (float)maxc;
+            const float rc = (float)(maxc - r) / cr, gc = (float)(maxc - g) / cr, bc = (float)(maxc - b) / cr;
+            float h;
+            if (r == maxc) h = bc - gc;
+            else if (g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
+            else h = (float)(4.0 + (double)gc - (double)rc);
+            h = (float)fmod((double)h / 6.0 + 1.0, 1.0);
+            uh = min(max((int)((double)h * 255.0), 0), 255);
+            us = min(max((int)((double)sat * 255.0), 0), 255);
+        }
+        const int h8 = (uh + shift) & 255, v8 = maxc;
+        if (us == 0) {
+            r = g = b = v8;
+        } else {
+            const double hf = (double)h8 * 6.0 / 255.0;
+            const int i = (int)floor(hf);
+            const double f = (double)(float)(hf - (double)i), fs = (double)(float)((double)us / 255.0), vf = (double)v8;
+            const int pp = min(max((int)floor(vf * (1.0 - fs) + 0.5), 0), 255);
+            const int qq = min(max((int)floor(vf * (1.0 - fs * f) + 0.5), 0), 255);
+            const int tt = min(max((int)floor(vf * (1.0 - fs * (1.0 - f)) + 0.5), 0), 255);
+            switch (i % 6) {
+                case 0: r = v8; g = tt; b = pp; break;
+                case 1: r = qq; g = v8; b = pp; break;
+                case 2: r = pp; g = v8; b = tt; break;
+                case 3: r = pp; g = qq; b = v8; break;
+                case 4: r = tt; g = pp; b = v8; break;
+                default: r = v8; g = pp; b = qq; break;
+            }
+        }
+    }
+    img[p] = (float)r / 255.f;
+    img[P + p] = (float)g / 255.f;
+    img[2 * P + p] = (float)b / 255.f;
+}
+
 }  // namespace
 
 static inline size_t vox_align(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -525,5 +600,29 @@ extern "C" int cofi_resize_crop_image(const uint8_t *src_hwc, int src_h, int src
     if (crop_y < 0 || crop_x < 0 || crop_y + H > dst_h || crop_x + W > dst_w) return COFI_EINVAL;
     hipLaunchKernelGGL(resize_crop_kernel, dim3(cofi_cdiv(3 * H * W, 256)), dim3(256), 0, cofi_s(stream), src_hwc, src_h, src_w, dst_h, dst_w, crop_y, crop_x,
                        H, W, out_chw);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_color_jitter_chw(float *img, int H, int W, const int *order4, float brightness, float contrast, float saturation, float hue,
+                                     void *ws, size_t ws_bytes, cofi_stream_t stream) {
+    if (!img || !order4 || H <= 0 || W <= 0 || !ws || ws_bytes < 8 || ((uintptr_t)ws & 7)) return COFI_EINVAL;
+    int seen = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (order4[i] < 0 || order4[i] > 3) return COFI_EINVAL;
+        seen |= 1 << order4[i];
+    }
+    if (seen != 15 || !(brightness >= 0.f) || !(contrast >= 0.f) || !(saturation >= 0.f) || !(hue >= -0.5f && hue <= 0.5f)) return COFI_EINVAL;
+    const int P = H * W;
+    hipStream_t s = cofi_s(stream);
+    const float fac[4] = {brightness, contrast, saturation, 0.f};
+    const int shift = (int)(unsigned char)(int)((double)hue * 255.0);   // np.uint8 cast of hue_factor * 255: truncation, modulo 256
+    for (int i = 0; i < 4; ++i) {
+        const int op = order4[i];
+        if (op == 1) {
+            if (hipError_t e = hipMemsetAsync(ws, 0, 8, s); e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(cj_gray_sum_kernel, dim3(cofi_cdiv(P, 1024) > 256 ? 256 : cofi_cdiv(P, 1024)), dim3(256), 0, s, img, P, (unsigned long long *)ws);
+        }
+        hipLaunchKernelGGL(cj_op_kernel, dim3(cofi_cdiv(P, 256)), dim3(256), 0, s, img, P, op, fac[op], shift, (const unsigned long long *)ws);
+    }
     return cofi_launch_status();
 }

@@ -3,7 +3,7 @@
 (csrc/dataside.hip, csrc/knn_grid.hip):
 
     raw scan (7, N)  --calibration transform-->  0.1 m voxel grid  --resample to num_pc-->  random SE(3)  -->  KNN pyramid
-    raw image (H, W, 3) uint8  --x0.5 bilinear resize, crop, / 255, CHW-->  model image
+    raw image (H, W, 3) uint8  --x0.5 bilinear resize, crop (train mode: random), [train mode: colour jitter], / 255, CHW-->  model image
     coarsest-stage points  --project with K/8 and K/2-->  coarse / fine labels                     (host numpy, 1280 points)
 
 The reference seeds the GLOBAL numpy and `random` generators per frame index and draws from them in a fixed order
@@ -13,11 +13,16 @@ gets the reference's choice INDICES, SE(3) and label permutations.  Caveat: the 
 voxel-index order here, in open3d's hash-map order in the reference - the same index therefore names a different voxel and the
 resampled cloud equals the reference's in distribution, not point for point (exactly equal whenever the voxel table is, e.g. the
 nuScenes path, which has no voxel grid).  The draws are host-side by nature (Mersenne Twister streams); they are handed to the
-kernels as plain index arrays / a 4x4 matrix.  `prepare()` syncs once per frame on the voxel count (the resampling draw depends on
+kernels as plain index arrays / a 4x4 matrix.  mode='train' (kitti.py:312-314, 329-330): the crop offsets come from the same `random`
+stream as in the reference; torchvision's ColorJitter (brightness / contrast / saturation in (0.8, 1.2), hue in (-0.1, 0.1), random
+order) runs as a kernel that is bit-equal to the PIL operations torchvision applies - its order and factors are drawn from the frame
+seed (torchvision uses the unseeded torch generator), so a training frame is reproducible.  `prepare()` syncs once per frame on the voxel count (the resampling draw depends on
 it); cofii2p_amd/loader.py pipelines frames so that nothing waits.
 """
 import random
 from typing import Dict, Optional
+
+import ctypes
 
 import numpy as np
 import torch
@@ -134,9 +139,6 @@ class FramePreparer:
         if dataset not in ("kitti", "nuscenes"):
             raise ValueError("dataset name invalid, only support KITTI Odometry and Nuscenes now!")   # train.py:130
         self.dataset = dataset
-        if mode == "train":
-            # kitti.py:329-330 augments the image with torchvision ColorJitter in train mode: not built (training is out of scope)
-            raise NotImplementedError("train-mode image augmentation (ColorJitter, kitti.py:193-201) is not implemented")
         self.opt, self.device, self.mode = opt, torch.device(device), mode
         self._ws = ops.Workspace()
         self._rows = self._vox = None
@@ -197,6 +199,16 @@ class FramePreparer:
                                               self.opt.img_H, self.opt.img_W, _p(out), _stream()), "cofi_resize_crop_image")
         return out
 
+    def color_jitter(self, image: torch.Tensor, order, brightness: float, contrast: float, saturation: float, hue: float):
+        """train mode (kitti.py:193-201, 329-330): torchvision ColorJitter on the cropped image, in place on the (3, H, W) float image
+        (bit-equal to the PIL operations torchvision applies: cofi_color_jitter_chw)."""
+        lib = _lib.load()
+        ws = torch.empty((1,), dtype=torch.int64, device=image.device)
+        arr = (ctypes.c_int * 4)(*[int(v) for v in order])
+        _lib.check(lib.cofi_color_jitter_chw(_p(image), image.shape[1], image.shape[2], arr, float(brightness), float(contrast), float(saturation),
+                                             float(hue), _p(ws), 8, _stream()), "cofi_color_jitter_chw")
+        return image
+
     def begin(self, data, img, K: np.ndarray, P_Tr: np.ndarray, index: int):
         """First half of `prepare`: uploads (if needed) and enqueues everything that does not depend on a random draw - calibration
         transform + voxel grid - WITHOUT waiting for the voxel count.  A loader that keeps several frames in flight calls begin() for a
@@ -255,6 +267,8 @@ class FramePreparer:
         pyr["feats"] = feats
         K_2, K_4, crop, rhw = intrinsics_and_crop(K, img.shape[:2], opt, s, self.mode)
         image = self.image(img, rhw, crop)
+        if self.mode == "train":
+            self.color_jitter(image, *s.color_jitter_params())
         self.last = {"voxels": nvox, "choice": choice, "P_random": P, "subsample": sub, "crop": crop}
         out = {"img": image, "pc_data_dict": pyr,
                "K": torch.from_numpy(K_2.astype(np.float32)).to(dev, non_blocking=True), "K_4": torch.from_numpy(K_4.astype(np.float32)).to(dev, non_blocking=True),

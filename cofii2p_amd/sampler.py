@@ -68,6 +68,15 @@ class FrameSampler:
     def permutation(self, n: int) -> np.ndarray:
         return self.rs.permutation(n)
 
+    def color_jitter_params(self):
+        """train mode (kitti.py:193-201): order of the four ColorJitter operations (0 brightness, 1 contrast, 2 saturation, 3 hue) and their
+        factors, U(0.8, 1.2) x 3 and U(-0.1, 0.1).  torchvision draws them from the unseeded torch generator; here they come from the frame
+        seed (a generator of their own: the reference's numpy / random streams are not disturbed), so a frame is reproducible."""
+        rs = np.random.RandomState((int(self.seed) + 0x9E3779B9) % (1 << 32))
+        order = [int(v) for v in rs.permutation(4)]
+        fb, fc, fs = (float(v) for v in rs.uniform(0.8, 1.2, 3))
+        return order, fb, fc, fs, float(rs.uniform(-0.1, 0.1))
+
 
 def draw_frame(index: int, nvox: int, num_pc: int, amplitudes, dataset: str = "kitti", num_stages: int = NUM_STAGES):
     """Everything `FramePreparer.complete` draws before the KNN pyramid, for a worker process: -> dict with

@@ -492,6 +492,12 @@ int cofi_pnp_ransac(const float *obj, const float *img, const int32_t *count_dev
  *   cofi_resize_crop_image    cv2.resize(INTER_LINEAR) of the uint8 HWC image to (dst_h, dst_w) in OpenCV's 11-bit fixed point, crop
  *       [crop_y, crop_y + H) x [crop_x, crop_x + W), / 255, HWC -> CHW (kitti.py:306-322, 375).  cv2 is absent from this image:
  *       parity with it is unpinned. */
+/*   cofi_color_jitter_chw     train mode (kitti.py:193-201,329-330): torchvision ColorJitter on the cropped image = the four operations of its
+ *       PIL path in the order `order4` (host array: 0 brightness, 1 contrast, 2 saturation, 3 hue) with the given factors, applied in
+ *       place to the (3, H, W) float image cofi_resize_crop_image wrote (values k / 255).  Bit-equal to PIL.ImageEnhance / PIL's HSV
+ *       conversions (torchvision itself is absent: its published algorithm; PIL is present and pins the restatement).  ws: 8 bytes. */
+int cofi_color_jitter_chw(float *img, int H, int W, const int *order4, float brightness, float contrast, float saturation, float hue, void *ws,
+                          size_t ws_bytes, cofi_stream_t stream);
 int cofi_pack_transform_scan(const float *data7n, int N, const float *P44_dev, float *rows8, cofi_stream_t stream);
 size_t cofi_voxel_downsample_workspace(int N);
 int cofi_voxel_downsample(const float *rows8, int N, double voxel, float *out_rows8, int cap, int32_t *count_dev, void *ws, size_t ws_bytes,

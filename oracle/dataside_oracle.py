@@ -168,6 +168,90 @@ def resize_linear_u8(img, dw, dh):
     return np.clip(v, 0, 255).astype(np.uint8)
 
 
+# --------------------------------------------------------------------------------------
+# train-mode image augmentation: torchvision ColorJitter on a PIL image (kitti.py:193-201, nuscenes.py:109-117)
+# --------------------------------------------------------------------------------------
+# torchvision (absent from this image; the reference pins no version) applies, in a random order, adjust_brightness / _contrast /
+# _saturation / _hue of transforms/_functional_pil.py: PIL.ImageEnhance.Brightness / Contrast / Color = Image.blend(degenerate, img,
+# factor), and a uint8 shift of the H plane of img.convert("HSV").  PIL itself IS in the image: tests/test_dataside_cpu.py holds the
+# restatement below to PIL's own results bit for bit.  (torchvision draws order and factors from the unseeded torch generator; the
+# device-side loader draws them from the frame seed instead - jitter_params - so that a frame is reproducible.)
+
+
+def jitter_params(seed: int):
+    """order of the four operations (0 brightness, 1 contrast, 2 saturation, 3 hue) and their factors: ColorJitter((0.8, 1.2), (0.8, 1.2),
+    (0.8, 1.2), (-0.1, 0.1)) (kitti.py:194-199), drawn from the frame seed."""
+    rs = np.random.RandomState((int(seed) + 0x9E3779B9) % (1 << 32))
+    order = [int(v) for v in rs.permutation(4)]
+    fb, fc, fs = (float(v) for v in rs.uniform(0.8, 1.2, 3))
+    fh = float(rs.uniform(-0.1, 0.1))
+    return order, fb, fc, fs, fh
+
+
+def _gray_u8(img):
+    """PIL convert("L") (ITU-R 601-2 luma, Convert.c L24): (19595 R + 38470 G + 7471 B + 0x8000) >> 16"""
+    r, g, b = (img[..., i].astype(np.int64) for i in range(3))
+    return ((r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16).astype(np.uint8)
+
+
+def _blend_u8(deg, img, alpha):
+    """PIL Image.blend(degenerate, img, alpha) (Blend.c): float32 deg + alpha (img - deg), truncated; clipped first when alpha is outside [0, 1]"""
+    t = deg.astype(np.float32) + np.float32(alpha) * (img.astype(np.float32) - deg.astype(np.float32))
+    if not 0.0 <= alpha <= 1.0:
+        t = np.clip(t, 0, 255)
+    return t.astype(np.int64).astype(np.uint8)
+
+
+def _rgb2hsv_u8(img):
+    """PIL convert("HSV") (Convert.c rgb2hsv_row): float ratios, the hue sum and h / 6 + 1 in double (C literals), (int)(x * 255.0)"""
+    r, g, b = (img[..., i].astype(np.int64) for i in range(3))
+    maxc, minc = np.maximum(r, np.maximum(g, b)), np.minimum(r, np.minimum(g, b))
+    cr = (maxc - minc).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s = cr / maxc.astype(np.float32)
+        rc, gc, bc = ((maxc - c).astype(np.float32) / cr for c in (r, g, b))
+        rc64, gc64, bc64 = rc.astype(np.float64), gc.astype(np.float64), bc.astype(np.float64)
+        h = np.where(r == maxc, (bc - gc).astype(np.float64), np.where(g == maxc, 2.0 + rc64 - bc64, 4.0 + gc64 - rc64)).astype(np.float32)
+        h = np.fmod(h.astype(np.float64) / 6.0 + 1.0, 1.0).astype(np.float32)
+        uh = np.clip((h.astype(np.float64) * 255.0).astype(np.int64), 0, 255)
+        us = np.clip((s.astype(np.float64) * 255.0).astype(np.int64), 0, 255)
+    flat = minc == maxc
+    return np.where(flat, 0, uh).astype(np.uint8), np.where(flat, 0, us).astype(np.uint8), maxc.astype(np.uint8)
+
+
+def _hsv2rgb_u8(h, s, v):
+    """PIL HSV -> RGB (Convert.c hsv2rgb): i = floor(h 6 / 255), f the remainder (float), p / q / t = round(v (1 - s' ...)) in double"""
+    hf = h.astype(np.float64) * 6.0 / 255.0
+    i = np.floor(hf).astype(np.int64)
+    f = (hf - i.astype(np.float64)).astype(np.float32).astype(np.float64)
+    fs = (s.astype(np.float64) / 255.0).astype(np.float32).astype(np.float64)
+    vf = v.astype(np.float64)
+    rnd = lambda x: np.clip(np.floor(x + 0.5).astype(np.int64), 0, 255)   # C round() of a non-negative value
+    p, q, t = rnd(vf * (1.0 - fs)), rnd(vf * (1.0 - fs * f)), rnd(vf * (1.0 - fs * (1.0 - f)))
+    vv, sel = v.astype(np.int64), i % 6
+    r, g, b = np.choose(sel, [vv, q, p, p, t, vv]), np.choose(sel, [t, vv, vv, q, p, p]), np.choose(sel, [p, p, t, vv, vv, q])
+    z = s == 0
+    return np.stack([np.where(z, vv, r), np.where(z, vv, g), np.where(z, vv, b)], -1).astype(np.uint8)
+
+
+def color_jitter(img, order, fb, fc, fs, fh):
+    """(H, W, 3) uint8 -> (H, W, 3) uint8: the four ColorJitter operations in `order` (0 brightness, 1 contrast, 2 saturation, 3 hue)."""
+    for op in order:
+        if op == 0:
+            img = _blend_u8(np.zeros_like(img), img, fb)
+        elif op == 1:
+            gm = _gray_u8(img)
+            mean = int(gm.astype(np.float64).sum() / gm.size + 0.5)        # int(ImageStat.Stat(gray).mean[0] + 0.5)
+            img = _blend_u8(np.full_like(img, mean), img, fc)
+        elif op == 2:
+            img = _blend_u8(np.repeat(_gray_u8(img)[..., None], 3, -1), img, fs)
+        else:
+            h, s_, v = _rgb2hsv_u8(img)
+            shift = int(fh * 255) & 255                                     # np.uint8 cast of hue_factor * 255: truncation, modulo 256
+            img = _hsv2rgb_u8((h.astype(np.int64) + shift).astype(np.uint8), s_, v)
+    return img
+
+
 def project_labels(coarse_points, P, K_2, K_4, img_H, img_W, num_kpt, rs, nuscenes=False):
     """kitti.py:334-372 (nuscenes.py:254-296 with nuscenes=True: too few in-picture points -> zero indices and valid_kpt False instead of
     a short draw; no assertion on the fine pixels): coarse (1/8) and fine (1/2) correspondences of the coarsest-stage points.
@@ -228,7 +312,7 @@ def point2node(nodes, points):
 
 
 def prepare_frame(data, img, K, P_Tr, index, opt, mode="val"):
-    """The whole of kitti.py:259-393 (val mode) minus the disk reads and the KNN tables (oracle/cofi_oracle.build_pyramid covers
+    """The whole of kitti.py:259-393 (val mode; mode='train': random crop + colour jitter) minus the disk reads and the KNN tables (oracle/cofi_oracle.build_pyramid covers
     those).  `opt` carries img_H, img_W, num_pc, num_kpt and the six P_*_amplitude values.  Returns the reference's dict plus the
     intermediates the tests compare stage by stage."""
     seed = frame_seed(index)
@@ -265,6 +349,8 @@ def prepare_frame(data, img, K, P_Tr, index, opt, mode="val"):
     K = camera_matrix_cropping(K, dx=dx, dy=dy)
     K_2 = camera_matrix_scaling(K, 0.5)
     K_4 = camera_matrix_scaling(K, 0.125)
+    if mode == "train":
+        crop = color_jitter(crop, *jitter_params(seed))                     # kitti.py:329-330
     coarse_points = np.array(points[-1], dtype=np.float32).T
     out = project_labels(coarse_points, P, K_2, K_4, opt.img_H, opt.img_W, opt.num_kpt, rs)
     out["fine_pc_inline_index"] = point2node(points[1], points[-1][out["pc_kpt_idx"]])

@@ -190,3 +190,52 @@ def test_oracle_matches_reference_nuscenes_getitem(index):
     assert lab["valid_kpt"] == bool(gold[tag + "valid_kpt"])
     for k in INT_KEYS[:-1]:
         assert np.array_equal(lab[k], gold[tag + k]), k
+
+
+def test_color_jitter_oracle_equals_pil():
+    """train-mode augmentation (kitti.py:193-201): the oracle's restatement of the four ColorJitter operations against PIL itself - what
+    torchvision's PIL path calls (ImageEnhance.Brightness / Contrast / Color, the HSV round trip with a uint8 hue shift) - bit for bit,
+    incl. grey pixels (hue undefined) and every operation order the frame seeds draw; the product's sampler draws the same parameters."""
+    Image = pytest.importorskip("PIL.Image")
+    from PIL import ImageEnhance
+
+    from cofii2p_amd.sampler import FrameSampler
+
+    def pil_jitter(img, order, fb, fc, fs, fh):
+        im = Image.fromarray(img)
+        for op in order:   # torchvision/transforms/_functional_pil.py: adjust_brightness / _contrast / _saturation / _hue
+            if op == 0:
+                im = ImageEnhance.Brightness(im).enhance(fb)
+            elif op == 1:
+                im = ImageEnhance.Contrast(im).enhance(fc)
+            elif op == 2:
+                im = ImageEnhance.Color(im).enhance(fs)
+            else:
+                h, s_, v = im.convert("HSV").split()
+                np_h = np.array(h, dtype=np.uint8)
+                with np.errstate(over="ignore"):
+                    np_h += np.array(fh * 255).astype(np.uint8)
+                im = Image.merge("HSV", (Image.fromarray(np_h, "L"), s_, v)).convert("RGB")
+        return np.array(im)
+
+    g = np.random.default_rng(1)
+    orders = set()
+    for t in range(48):
+        img = g.integers(0, 256, (40, 56, 3), dtype=np.uint8)
+        if t % 4 == 0:
+            img[:6] = img[:6, :, :1]
+        order, fb, fc, fs, fh = D.jitter_params(t)
+        orders.add(tuple(order))
+        assert (order, fb, fc, fs, fh) == FrameSampler.__new__(FrameSampler).__class__.color_jitter_params(type("S", (), {"seed": t})())
+        assert 0.8 <= min(fb, fc, fs) and max(fb, fc, fs) <= 1.2 and -0.1 <= fh <= 0.1
+        assert np.array_equal(pil_jitter(img, order, fb, fc, fs, fh), D.color_jitter(img, order, fb, fc, fs, fh)), t
+        for op in range(4):
+            assert np.array_equal(pil_jitter(img, [op], fb, fc, fs, fh), D.color_jitter(img, [op], fb, fc, fs, fh)), (t, op)
+    assert len(orders) > 10
+    # extremes of the blend (factor outside [0, 1]: clipped) and of the hue wrap
+    img = g.integers(0, 256, (32, 32, 3), dtype=np.uint8)
+    for f in (0.0, 0.5, 1.0, 1.7, 2.5):
+        for op in (0, 1, 2):
+            assert np.array_equal(pil_jitter(img, [op], f, f, f, 0.0), D.color_jitter(img, [op], f, f, f, 0.0)), (op, f)
+    for fh in (-0.5, -0.1, -0.004, 0.0, 0.003, 0.25, 0.5):
+        assert np.array_equal(pil_jitter(img, [3], 1, 1, 1, fh), D.color_jitter(img, [3], 1, 1, 1, fh)), fh

@@ -179,6 +179,50 @@ def test_prepared_frame_against_reference_golden(ds, index):
         assert dd["neighbors"][i].dtype == torch.int64
 
 
+def test_color_jitter_kernel_against_oracle(ds):
+    """cofi_color_jitter_chw (train mode, kitti.py:193-201) == oracle/dataside_oracle.py::color_jitter, which tests/test_dataside_cpu.py
+    holds to PIL itself: every single operation, drawn orders / factors, clipped blends, the hue wrap, grey pixels - bit for bit."""
+    g = np.random.default_rng(2)
+    prep = ds.FramePreparer(kitti_opt(), DEV, mode="train")
+
+    def run(img, order, fb, fc, fs, fh):
+        x = G(np.ascontiguousarray((img.astype(np.float32) / 255.0).transpose(2, 0, 1)))
+        return np.rint(prep.color_jitter(x, order, fb, fc, fs, fh).cpu().numpy().transpose(1, 2, 0) * 255).astype(np.uint8)
+
+    for t in range(24):
+        img = g.integers(0, 256, (48, 72, 3), dtype=np.uint8)
+        if t % 3 == 0:
+            img[:8] = img[:8, :, :1]
+        order, fb, fc, fs, fh = D.jitter_params(100 + t)
+        assert np.array_equal(run(img, order, fb, fc, fs, fh), D.color_jitter(img, order, fb, fc, fs, fh)), t
+        for op in range(4):
+            rest = [o for o in range(4) if o != op]
+            assert np.array_equal(run(img, [op] + rest, fb, fc, fs, fh), D.color_jitter(img, [op] + rest, fb, fc, fs, fh)), (t, op)
+    img = g.integers(0, 256, (160, 512, 3), dtype=np.uint8)
+    for f, fh in ((0.0, -0.5), (0.5, -0.004), (1.0, 0.0), (1.7, 0.25), (2.5, 0.5)):
+        assert np.array_equal(run(img, [2, 0, 3, 1], f, f, f, fh), D.color_jitter(img, [2, 0, 3, 1], f, f, f, fh)), (f, fh)
+
+
+def test_prepared_train_frame_against_oracle(ds):
+    """FramePreparer(mode='train'): the frame's random crop (kitti.py:312-314, the reference's own `random` stream) and the colour jitter;
+    everything else as in val mode.  Against the oracle's prepare_frame(mode='train'), exactly."""
+    from cofii2p_amd import synth
+
+    opt = kitti_opt()
+    for index in (3, 12):
+        data, img, K = synth.make_raw_scan(index)
+        out = ds.FramePreparer(opt, DEV, mode="train").prepare(data, img, K, calib_P_Tr(), index)
+        want = D.prepare_frame(data, img, K, calib_P_Tr(), index, opt, mode="train")
+        val = D.prepare_frame(data, img, K, calib_P_Tr(), index, opt, mode="val")
+        assert want["crop"] != val["crop"] and not np.array_equal(want["img"], val["img"])
+        assert np.array_equal(out["img"].cpu().numpy(), want["img"])
+        for k in ("K", "K_4", "P"):
+            assert np.array_equal(out[k].cpu().numpy(), want[k]), k
+        for k in INT_KEYS:
+            assert np.array_equal(out[k].cpu().numpy(), want[k]), k
+        assert np.array_equal(out["pc_data_dict"]["points"][4].cpu().numpy(), want["points"][4])
+
+
 def test_prepared_frame_feeds_the_model(ds):
     """Loader output -> CoFiI2P forward, as evaluation/eval_all.py:64-83 consumes a sample (batch of one)."""
     from cofii2p_amd import synth
