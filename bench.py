@@ -100,9 +100,32 @@ def train_step_summary(dev, frame, steps=8, warmup=3, arith="bf16x6"):
             for j in range(3):
                 t[j] += ev[j].elapsed_time(ev[j + 1])
     peak = torch.cuda.max_memory_allocated() - base
-    del model, optim
+    del optim, _o, _m, ls, loss     # the recording below must not find last step's autograd graph alive (its AccumulateGrad nodes sit on this stream)
+    # the same step as one hipGraph (cofii2p_amd.train_step.GraphedTrainStep): the eager step is bound by the Python thread issuing ~3 800 launches
+    from cofii2p_amd.train_step import GraphedTrainStep
+
+    graphed = None
+    try:
+        gopt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-3, capturable=True)
+        gstep = GraphedTrainStep(model, gopt, StepOpt, validate=False)
+        for _ in range(2 + warmup):
+            gstep(pyr, img, batch)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            gl = gstep(pyr, img, batch)
+        e1.record()
+        torch.cuda.synchronize()
+        graphed = {"ms_per_step": e0.elapsed_time(e1) / steps, "steps_per_s": 1e3 * steps / e0.elapsed_time(e1), "loss_after": round(float(gl.sum()), 4),
+                   "note": "GraphedTrainStep: forward + losses + backward + Adam recorded once, replayed per frame (static inputs restaged every call)"}
+        del gstep, gopt
+    except Exception as e:  # noqa: BLE001 - an optional leg: the eager figure stands on its own
+        graphed = {"error": "%s: %s" % (type(e).__name__, e)}
+    del model
     torch.cuda.empty_cache()
     return {"ms_per_step": sum(t) / steps, "forward_ms": t[0] / steps, "backward_ms": t[1] / steps, "optimizer_ms": t[2] / steps, "steps": steps,
+            "graphed": graphed,
             "arithmetic": arith, "num_kpt": 64, "peak_mem_GB": peak / 2 ** 30, "loss": losses,
             "note": "train.py:186-286 on the bench frame: model.train(); forward(mode='train'); desc / overlap / fine-circle losses; backward; Adam. "
                     "HIP kernels in both directions for every weight contraction, KPConv aggregation, attention and neighbour gather "

@@ -10,6 +10,7 @@ in a fixed order - no float atomics, bit-reproducible (csrc/backward.hip).
     neighbor_maxpool(x, idx), gather_rows     model/kpconv/functional.py:53-66, 5-21
     im2col(x, H, W, ks, stride, pad)          unfolded operand of a convolution of the image branch (conv = im2col + linear)
     attention(q, k, v, nhead)                 model/transformer/linear_attention.py:56-79
+    normalize_cols(x)                         F.normalize(x, dim=0): transformer.py:53 normalises Q over the tokens
     group_norm_act(x, gamma, beta, groups, slope, res)   GroupNorm / InstanceNorm / train-mode BatchNorm over the rows + activation + residual
 """
 import math
@@ -308,6 +309,32 @@ class _Attention(torch.autograd.Function):
                                     _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv), _p(ws), ws.numel(), _stream())
         _lib.check(rc, "cofi_attention_bwd")
         return dq, dk, dv, None
+
+
+class _NormalizeCols(torch.autograd.Function):
+    """y[:, c] = x[:, c] / max(||x[:, c]||_2, eps): F.normalize(x, dim=0), the token-axis normalisation of transformer.py:53.  The two
+    column reductions (forward: sum of squares, backward: <dy, x>) run `cofi_col_sum` (fixed summation order); torch's own reduction over
+    the long axis splits a column over several workgroups behind a semaphore and did not survive hipGraph replays of the training step."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        xd = x.detach()
+        norm = col_sum(xd * xd).sqrt_()
+        live = norm >= eps
+        inv = 1.0 / norm.clamp_min(eps)
+        ctx.save_for_backward(xd, inv, live)
+        return xd * inv
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, inv, live = ctx.saved_tensors
+        t = col_sum((dy * x).contiguous()) * live          # a clamped norm is a constant
+        return dy * inv - x * (t * inv * inv * inv), None
+
+
+def normalize_cols(x: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    """F.normalize(x, p=2, dim=0) for a (rows, C) matrix."""
+    return _NormalizeCols.apply(x, eps)
 
 
 def attention(q, k, v, nhead: int = 4):

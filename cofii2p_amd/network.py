@@ -102,6 +102,7 @@ class CoFiI2P(nn.Module):
             self.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(norm=self.pc_norm_kind).items()}, strict=True)
         self._packed: Optional[Dict[str, torch.Tensor]] = None
         self._packed_key = None
+        self._replayed_steps = 0   # optimisation steps replayed from a hipGraph (train_step.GraphedTrainStep): they do not bump version counters
         self._trained = False   # set by the first differentiable forward: from then on _pack() watches the parameters' version counters
         self.compute_unused_image_maps = True  # layer3/layer4/avg-pool of the ResNet (network.py:87-89)
         self._use_graphs = False
@@ -133,7 +134,7 @@ class CoFiI2P(nn.Module):
         # the packed (folded, pre-split) weights are a function of the parameters: an optimizer step (in-place update, train.py:286)
         # bumps the tensors' version counters, and the next inference forward (train.py's validation pass) packs again
         # (checked only once the training path has run: the serving loop does not pay for 430 version reads per frame)
-        stamp = (device, self._param_versions() if self._trained else 0)
+        stamp = (device, self._param_versions() + self._replayed_steps if self._trained else 0)
         if self._packed is not None and self._packed_key == stamp:
             return self._packed
         if self._packed is not None:

@@ -182,7 +182,7 @@ def loftr_layer(P, p, x, src, nhead: int = N_HEAD):
         q = ag.linear(x, P[p + "q_proj.weight"])
         kv = ag.linear(src, torch.cat([P[p + "k_proj.weight"], P[p + "v_proj.weight"]], 0))
         k, v = kv[:, :C], kv[:, C:]
-    q = F.normalize(q, dim=0)   # transformer.py:53: F.normalize's default dim=1 on (1, L, H, D) = over the L tokens
+    q = ag.normalize_cols(q)    # transformer.py:53: F.normalize's default dim=1 on (1, L, H, D) = over the L tokens
     msg = ag.attention(q, k, v, nhead)
     msg = F.layer_norm(ag.linear(msg, P[p + "merge.weight"]), (C,), P[p + "norm1.weight"], P[p + "norm1.bias"])
     h = ag.linear(F.relu(ag.linear(torch.cat([x, msg], 1), P[p + "mlp.0.weight"])), P[p + "mlp.2.weight"])
@@ -258,7 +258,8 @@ def forward_train(model, pc_data_dict: Dict, img: torch.Tensor, fine_center_kpt_
     lt = torch.floor(ctr.to(torch.float32) - 2.0).to(torch.int64)             # network.py:213: left/top = floor(centre - size / 2)
     ar = torch.arange(4, device=img.device)
     rows, cols = lt[1][:, None] + ar[None], lt[0][:, None] + ar[None]         # (K, 4)
-    if bool(((rows < 0) | (rows >= H2)).any()) or bool(((cols < 0) | (cols >= W2)).any()):
+    # (a host read: not possible while a hipGraph records - GraphedTrainStep checks the frame before it launches the recording)
+    if not torch.cuda.is_current_stream_capturing() and (bool(((rows < 0) | (rows >= H2)).any()) or bool(((cols < 0) | (cols >= W2)).any())):
         raise AssertionError("patch leaves the feature map (network.py:222)")
     pix = (rows[:, :, None] * W2 + cols[:, None, :]).reshape(-1)             # (K 16,)
     patches = ag.gather_rows(up2, pix.to(torch.int32), tables).reshape(ctr.shape[1], 4, 4, -1).permute(0, 3, 1, 2)
