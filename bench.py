@@ -106,7 +106,7 @@ def train_step_summary(dev, frame, steps=8, warmup=3, arith="bf16x6"):
 
     graphed = None
     try:
-        gopt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-3, capturable=True)
+        gopt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-3, capturable=True, fused=True)
         gstep = GraphedTrainStep(model, gopt, StepOpt, validate=False)
         for _ in range(2 + warmup):
             gstep(pyr, img, batch)

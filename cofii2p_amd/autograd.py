@@ -63,6 +63,14 @@ def _pad4_cols(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """A row-major view the kernels can read in place (unit column stride, 16-byte aligned rows - e.g. one part of a split (M, 3 C)
+    projection, a column block of a concatenation's gradient), else a contiguous copy."""
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.stride(0) >= t.shape[1] and t.data_ptr() % 16 == 0:
+        return t
+    return t.contiguous()
+
+
 def _gemm_nt(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """a (M, K) . w (N, K)^T with operands padded to the GEMM's alignment rules."""
     return ops.gemm(_pad4_cols(a), _pad4_cols(w))
@@ -93,7 +101,7 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w, rowdiv = ctx.saved_tensors
-        dy = dy.contiguous()
+        dy = _rows(dy)
         dx = dw = db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = col_sum(dy)                                                             # the bias is added after the division
@@ -101,9 +109,9 @@ class _Linear(torch.autograd.Function):
             dy = dy / rowdiv[:, None]
         with ops.arithmetic(ctx.arith):
             if ctx.needs_input_grad[0]:
-                dx = _gemm_nt(dy, ops.transpose(w.contiguous()))[:, :x.shape[1]]         # dY W
+                dx = _gemm_nt(dy, ops.transpose(_rows(w)))[:, :x.shape[1]]         # dY W
             if ctx.needs_input_grad[1]:
-                dw = _gemm_nt(ops.transpose(dy), ops.transpose(x.contiguous()))          # dY^T X
+                dw = _gemm_nt(ops.transpose(dy), ops.transpose(_rows(x)))          # dY^T X
         return dx, dw, db, None
 
 
@@ -132,7 +140,7 @@ class _KPConvAggregate(torch.autograd.Function):
         q_pts, s_pts, kp = ctx.saved_tensors
         N, C = ctx.shape
         t = ctx.table
-        dagg = dagg.contiguous()
+        dagg = _rows(dagg)
         df = torch.empty((N, C), dtype=torch.float32, device=dagg.device)
         rc = lib.cofi_kpconv_aggregate_bwd(_p(dagg), _ld(dagg), _p(q_pts), _p(s_pts), _p(t.pairs), _p(t.offsets), N, C, t.H, _p(kp), ctx.sigma,
                                            _p(df), _ld(df), _stream())
@@ -168,7 +176,7 @@ class _NeighborMaxpool(torch.autograd.Function):
         (arg,) = ctx.saved_tensors
         N, C = ctx.shape
         t = ctx.table
-        dy = dy.contiguous()
+        dy = _rows(dy)
         dx = torch.empty((N, C), dtype=torch.float32, device=dy.device)
         _lib.check(lib.cofi_neighbor_maxpool_bwd(_p(dy), _ld(dy), _p(arg), C, t.H, _p(t.pairs), _p(t.offsets), N, _p(dx), _ld(dx), _stream()),
                    "cofi_neighbor_maxpool_bwd")
@@ -192,7 +200,7 @@ class _GatherRows(torch.autograd.Function):
         lib = _lib.load()
         N, C = ctx.shape
         t = ctx.table
-        dy = dy.contiguous()
+        dy = _rows(dy)
         dx = torch.empty((N, C), dtype=torch.float32, device=dy.device)
         _lib.check(lib.cofi_gather_rows_bwd(_p(dy), _ld(dy), C, _p(t.pairs), _p(t.offsets), N, _p(dx), _ld(dx), _stream()), "cofi_gather_rows_bwd")
         return dx, None, None
@@ -220,7 +228,7 @@ class _Im2col(torch.autograd.Function):
     def backward(ctx, dcol):
         lib = _lib.load()
         H, W, C, ks, stride, pad = ctx.geom
-        dcol = dcol.contiguous()
+        dcol = _rows(dcol)
         dx = torch.empty((H * W, C), dtype=torch.float32, device=dcol.device)
         _lib.check(lib.cofi_col2im_nhwc(_p(dcol), _ld(dcol), H, W, C, ks, stride, pad, _p(dx), _ld(dx), _stream()), "cofi_col2im_nhwc")
         return dx, None, None, None, None, None
@@ -264,7 +272,7 @@ class _GroupNormAct(torch.autograd.Function):
         x, y, stats, gamma = ctx.saved_tensors
         groups, slope, const_stats, has_res = ctx.cfg
         M, C = x.shape
-        dy = dy.contiguous()
+        dy = _rows(dy)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
         dg = torch.empty((C,), dtype=torch.float32, device=x.device) if gamma is not None else None
@@ -289,7 +297,7 @@ def group_norm_act(x, gamma=None, beta=None, groups: int = 32, slope: float = 1.
 class _Attention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, nhead):
-        qd, kd, vd = q.detach().contiguous(), k.detach().contiguous(), v.detach().contiguous()
+        qd, kd, vd = _rows(q.detach()), _rows(k.detach()), _rows(v.detach())
         o = ops.attention(qd, kd, vd, nhead=nhead)
         ctx.save_for_backward(qd, kd, vd, o)
         ctx.nhead = nhead
@@ -302,7 +310,7 @@ class _Attention(torch.autograd.Function):
         H = ctx.nhead
         L, HD = q.shape
         S, D = k.shape[0], HD // H
-        do = do.contiguous()
+        do = _rows(do)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         ws = torch.empty(lib.cofi_attention_bwd_workspace(L, H), dtype=torch.uint8, device=q.device)
         rc = lib.cofi_attention_bwd(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o), _p(do), _ld(do), L, S, H, D, 1.0 / math.sqrt(D),
@@ -312,24 +320,35 @@ class _Attention(torch.autograd.Function):
 
 
 class _NormalizeCols(torch.autograd.Function):
-    """y[:, c] = x[:, c] / max(||x[:, c]||_2, eps): F.normalize(x, dim=0), the token-axis normalisation of transformer.py:53.  The two
-    column reductions (forward: sum of squares, backward: <dy, x>) run `cofi_col_sum` (fixed summation order); torch's own reduction over
-    the long axis splits a column over several workgroups behind a semaphore and did not survive hipGraph replays of the training step."""
+    """y[:, c] = x[:, c] / max(||x[:, c]||_2, eps): F.normalize(x, dim=0), the token-axis normalisation of transformer.py:53, as
+    `cofi_col_normalize` in both directions (column partials in a fixed order + apply).  torch's own reduction over the long axis splits
+    a column over several workgroups behind a semaphore and did not survive hipGraph replays of the training step."""
+
+    @staticmethod
+    def _run(x, dy, stats, eps, bwd):
+        lib = _lib.load()
+        M, C = x.shape
+        out = torch.empty((M, C), dtype=torch.float32, device=x.device)
+        ws = torch.empty(lib.cofi_col_normalize_workspace(M, C), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.cofi_col_normalize(_p(x), _ld(x), _p(dy), 0 if dy is None else _ld(dy), M, C, eps, bwd, _p(stats), _p(out), C, _p(ws), ws.numel(),
+                                          _stream()), "cofi_col_normalize")
+        return out
 
     @staticmethod
     def forward(ctx, x, eps):
         xd = x.detach()
-        norm = col_sum(xd * xd).sqrt_()
-        live = norm >= eps
-        inv = 1.0 / norm.clamp_min(eps)
-        ctx.save_for_backward(xd, inv, live)
-        return xd * inv
+        _mat(xd, "x")
+        stats = torch.empty((2, xd.shape[1]), dtype=torch.float32, device=xd.device)
+        y = _NormalizeCols._run(xd, None, stats, eps, 0)
+        ctx.save_for_backward(xd, stats)
+        ctx.eps = eps
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, inv, live = ctx.saved_tensors
-        t = col_sum((dy * x).contiguous()) * live          # a clamped norm is a constant
-        return dy * inv - x * (t * inv * inv * inv), None
+        x, stats = ctx.saved_tensors
+        dy = _rows(dy)
+        return _NormalizeCols._run(x, dy, stats, ctx.eps, 1), None
 
 
 def normalize_cols(x: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:

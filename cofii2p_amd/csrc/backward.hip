@@ -459,6 +459,59 @@ __global__ __launch_bounds__(256) void col_sum_final_kernel(const float *part, i
 
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// F.normalize(x, dim=0) of a (M, C) matrix - transformer.py:53 normalises Q over the tokens - forward and backward, two launches each:
+// column partials of a * b over row blocks (a = b = x: sum of squares; a = dy, b = x: <dy, x>), then an apply kernel whose workgroups
+// first fold the partials of their 64 columns in a fixed order.  With n_c = ||x[:, c]||, inv_c = 1 / max(n_c, eps):
+//   y = x inv_c;   dx = dy inv_c - x (n_c >= eps ? <dy, x>_c inv_c^3 : 0)      (a clamped norm is a constant)
+__global__ __launch_bounds__(256) void col_dot_partial_kernel(const float *a, int lda, const float *b, int ldb, int M, int C, int rows_per_block,
+                                                              float *part) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    if (c < C)
+        for (int m = r0 + ph; m < r1; m += 4) s = fmaf(a[(size_t)m * lda + c], b[(size_t)m * ldb + c], s);
+    red[ph][cl] = s;
+    __syncthreads();
+    if (ph == 0 && c < C) part[(size_t)blockIdx.y * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
+__device__ inline float fold_col_partials(const float *part, int RB, int C, int c, int cl, int ph, float (*red)[64]) {
+    float s = 0.f;
+    if (c < C)
+        for (int b = ph; b < RB; b += 4) s += part[(size_t)b * C + c];
+    red[ph][cl] = s;
+    __syncthreads();
+    return (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
+// stats (2, C): inv | live.  BWD: part holds <dy, x>; stats are read, dx written.
+template <bool BWD>
+__global__ __launch_bounds__(256) void col_normalize_apply_kernel(const float *x, int ldx, const float *dy, int lddy, const float *part, int RB, int M,
+                                                                  int C, float eps, int rows_per_block, float *stats, float *out, int ldo) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const float t = fold_col_partials(part, RB, C, c, cl, ph, red);
+    if (c >= C) return;
+    float inv, coef = 0.f;
+    if (!BWD) {
+        const float n = sqrtf(t);
+        inv = 1.0f / fmaxf(n, eps);
+        if (blockIdx.y == 0 && ph == 0) { stats[c] = inv; stats[C + c] = n >= eps ? 1.0f : 0.0f; }
+    } else {
+        inv = stats[c];
+        coef = stats[C + c] != 0.0f ? t * inv * inv * inv : 0.0f;
+    }
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int m = r0 + ph; m < r1; m += 4) {
+        const float xv = x[(size_t)m * ldx + c];
+        out[(size_t)m * ldo + c] = BWD ? dy[(size_t)m * lddy + c] * inv - xv * coef : xv * inv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // Backward of  y = leaky( gn(x; mean_G, rstd_G) * gamma + beta + res, slope )  - nn.GroupNorm over all rows (modules.py:45-49), with
 // groups == C the affine-less InstanceNorm of imagenet.py / network.py:42-43 and the train-mode BatchNorm of imagenet.py:381-394 - in three
 // fixed-order stages.  With g = dy * (y > 0 ? 1 : slope), xh = (x - mean) rstd, n = rows * channels per group:
@@ -679,6 +732,27 @@ extern "C" int cofi_col_sum(const float *x, int ldx, int M, int C, float *out, v
     if (!ws || ws_bytes < cofi_col_sum_workspace(M, C)) return COFI_EWORKSPACE;
     hipLaunchKernelGGL(col_sum_partial_kernel, dim3(cofi_cdiv(C, 64), RB), dim3(256), 0, cofi_s(stream), x, ldx, M, C, cofi_cdiv(M, RB), (float *)ws);
     hipLaunchKernelGGL(col_sum_final_kernel, dim3(cofi_cdiv(C, 64)), dim3(256), 0, cofi_s(stream), (const float *)ws, RB, C, out);
+    return cofi_launch_status();
+}
+
+extern "C" size_t cofi_col_normalize_workspace(int M, int C) { return cofi_col_sum_workspace(M, C); }
+
+// bwd == 0: y = F.normalize(x, dim=0), stats (2, C) written.  bwd != 0: out = dx for the upstream gradient dy, stats read.
+extern "C" int cofi_col_normalize(const float *x, int ldx, const float *dy, int lddy, int M, int C, float eps, int bwd, float *stats, float *out, int ldo,
+                                  void *ws, size_t ws_bytes, cofi_stream_t stream) {
+    if (!x || !stats || !out || M <= 0 || C <= 0 || ldx < C || ldo < C || (bwd && (!dy || lddy < C))) return COFI_EINVAL;
+    const int RB = col_sum_blocks(M);
+    if (!ws || ws_bytes < cofi_col_normalize_workspace(M, C)) return COFI_EWORKSPACE;
+    const float *a = bwd ? dy : x;
+    hipLaunchKernelGGL(col_dot_partial_kernel, dim3(cofi_cdiv(C, 64), RB), dim3(256), 0, cofi_s(stream), a, bwd ? lddy : ldx, x, ldx, M, C, cofi_cdiv(M, RB),
+                       (float *)ws);
+    const int AB = cofi_cdiv(M, 32) > 128 ? 128 : cofi_cdiv(M, 32);
+    if (bwd)
+        hipLaunchKernelGGL(col_normalize_apply_kernel<true>, dim3(cofi_cdiv(C, 64), AB), dim3(256), 0, cofi_s(stream), x, ldx, dy, lddy, (const float *)ws, RB,
+                           M, C, eps, cofi_cdiv(M, AB), stats, out, ldo);
+    else
+        hipLaunchKernelGGL(col_normalize_apply_kernel<false>, dim3(cofi_cdiv(C, 64), AB), dim3(256), 0, cofi_s(stream), x, ldx, dy, lddy, (const float *)ws, RB,
+                           M, C, eps, cofi_cdiv(M, AB), stats, out, ldo);
     return cofi_launch_status();
 }
 

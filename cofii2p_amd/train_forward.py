@@ -177,11 +177,11 @@ def loftr_layer(P, p, x, src, nhead: int = N_HEAD):
     C = x.shape[1]
     if src is x:   # self layer: the three projections read the same tokens - one contraction with the stacked weights [Wq; Wk; Wv]
         qkv = ag.linear(x, torch.cat([P[p + "q_proj.weight"], P[p + "k_proj.weight"], P[p + "v_proj.weight"]], 0))
-        q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+        q, k, v = qkv.split(C, 1)   # (split, not three slices: its backward is one concatenation)
     else:
         q = ag.linear(x, P[p + "q_proj.weight"])
         kv = ag.linear(src, torch.cat([P[p + "k_proj.weight"], P[p + "v_proj.weight"]], 0))
-        k, v = kv[:, :C], kv[:, C:]
+        k, v = kv.split(C, 1)
     q = ag.normalize_cols(q)    # transformer.py:53: F.normalize's default dim=1 on (1, L, H, D) = over the L tokens
     msg = ag.attention(q, k, v, nhead)
     msg = F.layer_norm(ag.linear(msg, P[p + "merge.weight"]), (C,), P[p + "norm1.weight"], P[p + "norm1.bias"])
@@ -217,6 +217,17 @@ def pc_feature_mlp(P, x):
     return ag.linear(x, P[p + "6.weight"])
 
 
+OVERLAP_BRANCHES = True   # image branch on a side stream while a hipGraph records (forward_train)
+_SIDE = {}
+
+
+def _side_stream(dev) -> torch.cuda.Stream:
+    key = str(dev)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
+
 # ------------------------------------------------------------------------------------------ network.py:74-164, train / val branch
 def forward_train(model, pc_data_dict: Dict, img: torch.Tensor, fine_center_kpt_coors: torch.Tensor, fine_pc_inline_index: torch.Tensor):
     """-> the reference's 8-tuple (fine_center_xy = coarse_pc_points = None) with a graph behind every tensor."""
@@ -238,30 +249,50 @@ def forward_train(model, pc_data_dict: Dict, img: torch.Tensor, fine_center_kpt_
     feats = pc_data_dict["feats"].contiguous()
     tables = ag.TableCache()
 
+    # While a hipGraph records (train_step.GraphedTrainStep) the image branch - ResNet, both up-samplers, the patches - is issued on a side
+    # stream: forked here, joined where its results meet the point branch.  The recording then holds two independent chains (autograd
+    # runs every backward node on the stream of its forward), and the replay overlaps their many small kernels.  Eager execution is bound
+    # by the issuing thread and stays on one stream.
+    dev = img.device
+    main = torch.cuda.current_stream(dev)
+    fork = torch.cuda.is_current_stream_capturing() and OVERLAP_BRANCHES
+    side = _side_stream(dev) if fork else main
+    if fork:
+        side.wait_stream(main)
+    with torch.cuda.stream(side):
+        (s2, H2, W2), (s4, H4, W4), (s8, H8, W8) = resnet34_s8(P, img)
+        s8n = F.normalize(s8, dim=1)                                              # network.py:90
+        tok_img = s8n + pos_sine_table(model._pixel_grid(H8, W8, 1, dev))         # network.py:104-110
+        tokens_ready = torch.cuda.Event()
+        tokens_ready.record(side)
+        up4 = image_upsample(P, B, "img_upsample_1", s8n, H8, W8, s4, training)
+        up2 = F.normalize(image_upsample(P, B, "img_upsample_2", up4, H4, W4, s2, training), dim=1)   # (H2 W2, 64)
+        # network.py:137-141: 4 x 4 patches around the labelled pixels
+        ctr = fine_center_kpt_coors.to(device=dev)
+        lt = torch.floor(ctr.to(torch.float32) - 2.0).to(torch.int64)             # network.py:213: left/top = floor(centre - size / 2)
+        ar = torch.arange(4, device=dev)
+        rows, cols = lt[1][:, None] + ar[None], lt[0][:, None] + ar[None]         # (K, 4)
+        # (a host read: not possible while a hipGraph records - GraphedTrainStep checks the frame before it launches the recording)
+        if not torch.cuda.is_current_stream_capturing() and (bool(((rows < 0) | (rows >= H2)).any()) or bool(((cols < 0) | (cols >= W2)).any())):
+            raise AssertionError("patch leaves the feature map (network.py:222)")
+        pix = (rows[:, :, None] * W2 + cols[:, None, :]).reshape(-1)             # (K 16,)
+        patches = ag.gather_rows(up2, pix.to(torch.int32), tables).reshape(ctr.shape[1], 4, 4, -1).permute(0, 3, 1, 2)
+
     pc_set = kpconv_fpn(P, B, points, neighbors, subsampling, upsampling, feats, tables)
-    (s2, H2, W2), (s4, H4, W4), (s8, H8, W8) = resnet34_s8(P, img)
     fine_pc = F.normalize(pc_set[0], dim=1)                                   # network.py:83
     pc_mid = F.normalize(pc_feature_mlp(P, pc_set[-1]), dim=1)                # network.py:84
-    s8n = F.normalize(s8, dim=1)                                              # network.py:90
-    tok_img = s8n + pos_sine_table(model._pixel_grid(H8, W8, 1, img.device))  # network.py:104-110
     tok_pc = pc_mid + pos_sine_table(points[-1])                              # network.py:107,111
+    fine_feat = ag.gather_rows(fine_pc, as32(fine_pc_inline_index.reshape(-1)), tables)   # network.py:137: descriptors of the labelled points
+    if fork:
+        main.wait_event(tokens_ready)
+        tok_img.record_stream(main)
     tok_img, tok_pc = transformer(P, tok_img, tok_pc)
     pc_score = score_head(P, "pc_score_layer", tok_pc)
     img_score = score_head(P, "img_score_layer", tok_img)
     pc_desc = F.normalize(tok_pc, dim=1).t()                                  # (C, N4)  network.py:125
     img_desc = F.normalize(tok_img, dim=1).t().reshape(1, D_MODEL, H8, W8)    # network.py:126
-    up4 = image_upsample(P, B, "img_upsample_1", s8n, H8, W8, s4, training)
-    up2 = F.normalize(image_upsample(P, B, "img_upsample_2", up4, H4, W4, s2, training), dim=1)   # (H2 W2, 64)
-    # network.py:137-141: fine point descriptors of the labelled points, 4 x 4 patches around the labelled pixels
-    fine_feat = ag.gather_rows(fine_pc, as32(fine_pc_inline_index.reshape(-1)), tables)
-    ctr = fine_center_kpt_coors.to(device=img.device)
-    lt = torch.floor(ctr.to(torch.float32) - 2.0).to(torch.int64)             # network.py:213: left/top = floor(centre - size / 2)
-    ar = torch.arange(4, device=img.device)
-    rows, cols = lt[1][:, None] + ar[None], lt[0][:, None] + ar[None]         # (K, 4)
-    # (a host read: not possible while a hipGraph records - GraphedTrainStep checks the frame before it launches the recording)
-    if not torch.cuda.is_current_stream_capturing() and (bool(((rows < 0) | (rows >= H2)).any()) or bool(((cols < 0) | (cols >= W2)).any())):
-        raise AssertionError("patch leaves the feature map (network.py:222)")
-    pix = (rows[:, :, None] * W2 + cols[:, None, :]).reshape(-1)             # (K 16,)
-    patches = ag.gather_rows(up2, pix.to(torch.int32), tables).reshape(ctr.shape[1], 4, 4, -1).permute(0, 3, 1, 2)
+    if fork:
+        main.wait_stream(side)
+        patches.record_stream(main)
     N4 = points[-1].shape[0]
     return (img_desc, pc_desc, img_score.reshape(1, 1, H8, W8), pc_score.reshape(1, 1, N4), patches, fine_feat, None, None)

@@ -454,6 +454,13 @@ int cofi_group_norm_bwd(const float *x, int ldx, const float *y, int ldy, const 
                         void *ws, size_t ws_bytes, cofi_stream_t stream);
 size_t cofi_col_sum_workspace(int M, int C);   /* out[c] = sum_m x[m, c] (bias gradients), two fixed-order stages */
 int cofi_col_sum(const float *x, int ldx, int M, int C, float *out, void *ws, size_t ws_bytes, cofi_stream_t stream);
+
+/* F.normalize(x, dim=0) of a (M, C) matrix (model/transformer/transformer.py:53: Q is normalised over the tokens), forward and backward.
+ * bwd == 0: out = y, stats (2, C) = 1 / max(norm, eps) | (norm >= eps) written.  bwd != 0: out = dx for the upstream gradient dy, stats read.
+ * Two launches per call, every sum in a fixed order. */
+size_t cofi_col_normalize_workspace(int M, int C);
+int cofi_col_normalize(const float *x, int ldx, const float *dy, int lddy, int M, int C, float eps, int bwd, float *stats, float *out, int ldo,
+                       void *ws, size_t ws_bytes, cofi_stream_t stream);
 size_t cofi_attention_bwd_workspace(int L, int H);
 int cofi_attention_bwd(const float *q, int ldq, const float *k, int ldk, const float *v, int ldv, const float *o, int ldo, const float *d_o,
                        int lddo, int L, int S, int H, int D, float scale, float *dq, int lddq, float *dk, int lddk, float *dv, int lddv, void *ws,

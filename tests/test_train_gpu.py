@@ -206,7 +206,7 @@ def test_normalize_cols_function(L, C, view):
     y = ag.normalize_cols(x[:, :C])
     y.backward(G(dy))
     assert rel_err(y, yr) < 2e-6 and rel_err(x.grad, xr.grad) < 5e-6
-    assert float(y[:, 5].abs().max()) == 0.0
+    assert float(y.detach()[:, 5].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("M,C,groups,affine,slope,res,fixed", [
@@ -427,7 +427,8 @@ def test_training_changes_the_served_weights(gold):
         assert float((a - b.detach()).abs().max()) < 2e-4, n_
 
 
-def test_graphed_train_step_equals_eager(gold):
+@pytest.mark.parametrize("fused", [False, True])
+def test_graphed_train_step_equals_eager(gold, fused):
     """train_step.GraphedTrainStep (forward + losses + backward + Adam as ONE hipGraph, replayed per frame) against the eager step with
     the same capturable optimizer: two alternating frames of one signature (the static inputs are restaged every call), a learning-rate
     change the way train.py:326-330 makes it, then the validation forward on the updated weights.  The step's own kernels are
@@ -449,7 +450,7 @@ def test_graphed_train_step_equals_eager(gold):
         m = CoFiI2P(Opt(), arithmetic="bf16x6").to(DEV)
         m.load_state_dict(sd0)
         # (the learning rate as a device scalar on both sides: Adam divides by float32(lr) then, not by the double - one ulp apart)
-        opt = torch.optim.Adam(filter(lambda p: p.requires_grad, m.parameters()), lr=torch.full((), 1e-3, device=DEV), capturable=True)
+        opt = torch.optim.Adam(filter(lambda p: p.requires_grad, m.parameters()), lr=torch.full((), 1e-3, device=DEV), capturable=True, fused=fused)
         step = GraphedTrainStep(m, opt, sopt) if graphed else None
         losses = []
         for it in range(7):
