@@ -11,6 +11,8 @@
                     tensors, int32 tables, which `CoFiI2P.forward_async(slot, ..., inputs_stable=True)` reads in place
     labels          the coarsest-stage points come back through a pinned buffer written by the same graph; the numpy label
                     projection runs when the caller asks for it (`sample["finish_labels"]()`), typically when the forward is collected
+    mode='train'    kitti.py:312-314, 329-330: the frame's random crop (drawn on the main process from the generators the worker left behind)
+                    and colour jitter; the image is then produced behind the replay (its crop is a kernel argument), a fresh tensor per frame
 
 No extra HIP stream is created: HIP serves a process's streams from 4 hardware queues, and a fifth queue user costs the forward pipeline
 more than the loader gains (DESIGN.md section 3 "Concurrency").  Stage A of a later frame is enqueued on its stream BEFORE the
@@ -37,15 +39,15 @@ class _Slot:
 
 class FrameLoader:
     def __init__(self, opt, device="cuda", slots: int = 8, workers: int = 4, dataset: str = "kitti", capture_stream: Optional[torch.cuda.Stream] = None,
-                 upsample_k: Optional[int] = None):
+                 upsample_k: Optional[int] = None, mode: str = "val"):
         """slots: frames that can be in preparation / flight at once (a slot is reusable once the forward that read its tensors has been
         collected).  capture_stream: the stream hipGraphs are captured on (pass the model's: `model.frame_streams(n)[0]`); capture
         needs a non-default stream and every extra stream costs a hardware queue."""
-        self.opt, self.device, self.dataset = opt, torch.device(device), dataset
+        self.opt, self.device, self.dataset, self.mode = opt, torch.device(device), dataset, mode
         # upsample_k=1: the up-sampling tables hold their first column only (all the forward reads), derived without a search
         # (preprocess.build_pyramid); None: the reference's (N, 128) tables
         self.upsample_k = upsample_k
-        self.preps = [dataside.FramePreparer(opt, device, dataset=dataset) for _ in range(slots)]
+        self.preps = [dataside.FramePreparer(opt, device, dataset=dataset, mode=mode) for _ in range(slots)]
         self.slots = [_Slot() for _ in range(slots)]
         self.pool = ProcessPoolExecutor(max_workers=max(1, workers), mp_context=mp.get_context("spawn"), initializer=worker_init)
         self._amp = tuple(getattr(opt, k) for k in ("P_tx_amplitude", "P_ty_amplitude", "P_tz_amplitude", "P_Rx_amplitude", "P_Ry_amplitude", "P_Rz_amplitude"))
@@ -99,7 +101,9 @@ class FrameLoader:
         points, feats = prep.resample_transform_dev(st.h["vox"], buf[0], buf[-1])
         pyr = build_pyramid(points, buf[1:-1], int64=False, upsample_k=self.upsample_k)
         pyr["feats"] = feats
-        image = prep.image(img_dev, rhw, crop)
+        # train mode: the crop is drawn per frame (a kernel argument) and the colour jitter's order / factors with it - the image is then
+        # produced by complete() behind the replay, not recorded
+        image = prep.image(img_dev, rhw, crop) if self.mode != "train" else None
         st.stage["coarse_host"].copy_(pyr["points"][-1], non_blocking=True)
         return pyr, image
 
@@ -121,9 +125,10 @@ class FrameLoader:
         for hb, db, src in zip(buf["host"], buf["dev"], [d["choice"]] + d["sub"] + [d["P"]]):
             hb.copy_(torch.from_numpy(src))
             db.copy_(hb, non_blocking=True)
-        K_2, K_4, crop, rhw = dataside.intrinsics_and_crop(K, img.shape[:2], opt, None, "val")
+        s = sampler_from_state(d)   # the generators as the worker's draws left them: crop (train mode), then the label permutations
+        K_2, K_4, crop, rhw = dataside.intrinsics_and_crop(K, img.shape[:2], opt, s, self.mode)
         # static image input of the graph: one buffer per image size
-        key = (tuple(img.shape), rhw, crop, h["vox"].data_ptr())
+        key = (tuple(img.shape), rhw, crop if self.mode != "train" else None, h["vox"].data_ptr())
         ent = st.graphs.get(key)
         if ent is None:
             if len(st.graphs) >= 4:
@@ -145,6 +150,9 @@ class FrameLoader:
         g, (pyr, image), img_static = ent
         img_static.copy_(img, non_blocking=True)
         g.replay()
+        if self.mode == "train":     # kitti.py:312-314, 329-330: this frame's crop, this frame's jitter
+            image = prep.image(img_static, rhw, crop)
+            prep.color_jitter(image, *s.color_jitter_params())
         ready = torch.cuda.Event()
         ready.record()
         P = d["P"]
@@ -155,7 +163,6 @@ class FrameLoader:
 
         def finish_labels():
             ready.synchronize()
-            s = sampler_from_state(d)
             lab = dataside.project_labels(coarse_host.numpy(), P, K_2, K_4, opt, s, dataset=self.dataset)
             kpt = torch.from_numpy(lab["pc_kpt_idx"]).to(dev)
             out["fine_pc_inline_index"] = ops.nearest_node(pyr["points"][1], pyr["points"][-1][kpt].contiguous()).to(torch.int64)   # point2node, kitti.py:374

@@ -365,7 +365,7 @@ def prepare_frame(data, img, K, P_Tr, index, opt, mode="val"):
 
 
 def prepare_frame_nuscenes(pc4, img, K, index, opt, mode="val"):
-    """nuscenes.py:177-320 (val mode) minus the disk reads and the KNN tables: seed = index, the stored (4, N) cloud [xyz | intensity]
+    """nuscenes.py:177-320 (val mode; mode='train': random crop + colour jitter, nuscenes.py:232-234, 249-250) minus the disk reads and the KNN tables: seed = index, the stored (4, N) cloud [xyz | intensity]
     is already in the camera frame and is resampled directly (the voxel grid is commented out there), features = [intensity | point]."""
     seed = int(index)
     rs = np.random.RandomState(seed)
@@ -396,6 +396,8 @@ def prepare_frame_nuscenes(pc4, img, K, index, opt, mode="val"):
     K = camera_matrix_cropping(K, dx=dx, dy=dy)
     K_2 = camera_matrix_scaling(K, 0.5)
     K_4 = camera_matrix_scaling(K, 0.125)
+    if mode == "train":
+        crop = color_jitter(crop, *jitter_params(seed))                     # nuscenes.py:249-250
     coarse_points = np.array(points[-1], dtype=np.float32).T
     out = project_labels(coarse_points, P, K_2, K_4, opt.img_H, opt.img_W, opt.num_kpt, rs, nuscenes=True)
     out["fine_pc_inline_index"] = point2node(points[1], points[-1][out["pc_kpt_idx"]])

@@ -271,6 +271,29 @@ def test_prepared_nuscenes_frame_against_reference_golden(ds, index):
     assert np.array_equal(out["img"].cpu().numpy(), want["img"]) and tuple(out["img"].shape) == (3, 160, 320)
 
 
+def test_prepared_nuscenes_train_frame_against_oracle(ds):
+    """FramePreparer(dataset='nuscenes', mode='train') (nuscenes.py:232-234 random crop, :249-250 colour jitter) against the oracle, exactly."""
+    from cofii2p_amd import synth
+    from test_dataside_cpu import nuscenes_opt
+
+    gold = load_golden("dataside_nuscenes_ref.npz")
+    fid, n = gold["i1_frame_points"]
+    pc4, img, K = synth.make_raw_nuscenes(int(fid), int(n))
+    opt = nuscenes_opt()
+    for index in (1, 7):
+        out = ds.FramePreparer(opt, DEV, dataset="nuscenes", mode="train").prepare(pc4, img, K, None, index)
+        want = D.prepare_frame_nuscenes(pc4, img, K, index, opt, mode="train")
+        val = D.prepare_frame_nuscenes(pc4, img, K, index, opt)
+        assert want["crop"] != val["crop"] and not np.array_equal(want["img"], val["img"])
+        assert out["valid_kpt"] and want["valid_kpt"]
+        assert np.array_equal(out["img"].cpu().numpy(), want["img"])
+        for k in ("K", "K_4", "P"):
+            assert np.array_equal(out[k].cpu().numpy(), want[k]), k
+        for k in INT_KEYS:
+            assert np.array_equal(out[k].cpu().numpy(), want[k]), k
+        assert np.array_equal(out["pc_data_dict"]["points"][4].cpu().numpy(), want["points"][4])
+
+
 def test_begin_complete_pipeline_equals_prepare(ds):
     """FramePreparer.begin / complete (the voxel grid enqueued ahead, no wait on its count) == prepare, also with two frames interleaved
     on two preparers and the labels deferred."""

@@ -14,16 +14,18 @@ from test_dataside_gpu import calib_P_Tr  # noqa: E402
 DEV = "cuda:0"
 
 
-def test_pipelined_loader_equals_prepare():
+@pytest.mark.parametrize("mode", ["val", "train"])
+def test_pipelined_loader_equals_prepare(mode):
+    """mode='train': the frame's random crop and colour jitter (kitti.py:312-314, 329-330) behind the slot's recorded pyramid"""
     from cofii2p_amd import dataside, synth
     from cofii2p_amd.loader import FrameLoader
 
     opt, P_Tr = kitti_opt(), calib_P_Tr()
     frames = [synth.make_raw_scan(i) for i in (0, 1)]
     ids = [10, 11, 12, 13, 14, 15, 16]                      # 7 frames through 3 slots: every slot is reused, two raw scans alternate
-    want = [dataside.FramePreparer(opt, DEV).prepare(*frames[k % 2], P_Tr, ids[k]) for k in range(len(ids))]
+    want = [dataside.FramePreparer(opt, DEV, mode=mode).prepare(*frames[k % 2], P_Tr, ids[k]) for k in range(len(ids))]
     cap = torch.cuda.Stream(device=DEV)
-    loader = FrameLoader(opt, DEV, slots=3, workers=2, capture_stream=cap)
+    loader = FrameLoader(opt, DEV, slots=3, workers=2, capture_stream=cap, mode=mode)
     try:
         got = [None] * len(ids)
         LOOK = 2
