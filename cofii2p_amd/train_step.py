@@ -61,6 +61,22 @@ def train_step(model, optimizer, pc_data_dict, img, batch, opt):
 
 
 _PYRAMID_LISTS = ("points", "neighbors", "subsampling", "upsampling")
+_BATCH_KEYS = (("K_4", "K_4"), ("P", "P"), ("pc_kpt_idx", "pc_kpt_idx"), ("pc_outline_idx", "pc_outline_idx"), ("coarse_img_kpt_idx", "coarse_img_kpt_idx"),
+               ("fine_center_kpt_coors", "fine_center_kpt_coors"), ("fine_xy", "fine_xy_coors"), ("fine_pc_inline_index", "fine_pc_inline_index"))
+
+
+def batch_from_sample(sample: Dict, device=None) -> Tuple[Dict, torch.Tensor, Dict[str, torch.Tensor]]:
+    """train.py:192-217: what one optimisation step reads out of a data-side sample - `FramePreparer.prepare`, `FrameLoader.complete`
+    (after `finish_labels()`), or a batch of 1 of the reference's DataLoader - as (pc_data_dict, img (1, 3, H, W), batch) for
+    `step_losses` / `train_step` / `GraphedTrainStep`.  Leading batch dimensions of 1 are squeezed the way train.py does it."""
+    dev = torch.device(device) if device is not None else sample["img"].device
+    sq = lambda t: torch.squeeze(t.to(dev), 0) if t.dim() and t.shape[0] == 1 else t.to(dev)
+    pc = sample["pc_data_dict"]
+    pc_data_dict = {k: [sq(t) for t in pc[k]] for k in _PYRAMID_LISTS}
+    pc_data_dict["feats"] = sq(pc["feats"])
+    img = sample["img"].to(dev)
+    img = img[None] if img.dim() == 3 else img
+    return pc_data_dict, img, {k: sq(sample[src]) for k, src in _BATCH_KEYS}
 
 
 class GraphedTrainStep:

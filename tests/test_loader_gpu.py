@@ -61,6 +61,43 @@ def test_pipelined_loader_equals_prepare(mode):
             assert torch.equal(w[key], g[key]), key
 
 
+def test_train_loader_feeds_the_graphed_train_step():
+    """data/kitti.py (train mode) -> train.py:186-286 entirely on the device: FrameLoader(mode='train') samples -> batch_from_sample ->
+    GraphedTrainStep (first call eager, second recorded, then replays fed from the loader's int32 tables)."""
+    from cofii2p_amd import synth
+    from cofii2p_amd.loader import FrameLoader
+    from cofii2p_amd.network import CoFiI2P
+    from cofii2p_amd.train_step import GraphedTrainStep, batch_from_sample
+    import bench
+
+    opt, P_Tr = kitti_opt(), calib_P_Tr()
+    frames = [synth.make_raw_scan(i) for i in (0, 1)]
+    model = CoFiI2P(bench.Opt()).to(DEV)
+    optim = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-3, capturable=True, fused=True)
+    step = GraphedTrainStep(model, optim, bench.StepOpt)
+    loader = FrameLoader(opt, DEV, slots=2, workers=1, capture_stream=torch.cuda.Stream(device=DEV), mode="train")
+    losses = []
+    try:
+        loader.begin(0, *frames[0], P_Tr, 20)
+        for k in range(5):
+            loader.poll()
+            smp = loader.complete(k % 2)
+            if k + 1 < 5:
+                loader.begin((k + 1) % 2, *frames[(k + 1) % 2], P_Tr, 21 + k)
+            smp["finish_labels"]()
+            losses.append(step(*batch_from_sample(smp)).cpu())
+            loader.release(k % 2)
+    finally:
+        loader.close()
+    assert step.replays == 4
+    L = torch.stack(losses)
+    assert torch.isfinite(L).all() and float(L[-1].sum()) < float(L[0].sum())
+    model.eval()
+    with torch.no_grad():   # the served weights follow the replayed steps
+        out = model(*batch_from_sample(smp)[:2], smp["fine_center_kpt_coors"], None, smp["fine_pc_inline_index"], "val")
+    assert all(torch.isfinite(t).all() for t in out[:6])
+
+
 def test_loader_feeds_the_model_in_place():
     """a loader sample goes straight into forward_async(inputs_stable=True) - the graph reads the slot's tensors where they lie - and gives
     what the synchronous path gives"""
