@@ -208,5 +208,7 @@ class GraphedTrainStep:
             self._record()
         self._graph.replay()
         self.replays += 1
-        self.model._replayed_steps += 1     # parameters changed behind their version counters: _pack() looks at this
+        for m in self.model.modules():      # parameters changed behind their version counters: CoFiI2P._pack() looks at this count
+            if hasattr(m, "_replayed_steps"):
+                m._replayed_steps += 1
         return self._losses.clone()
