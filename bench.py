@@ -68,7 +68,7 @@ class StepOpt:
     dist_thres, pos_margin, neg_margin = 1.0, 0.2, 1.8   # data/options.py:39,42-43
 
 
-def train_step_summary(dev, frame, steps=8, warmup=3, arith="bf16x6"):
+def train_step_summary(dev, frame, steps=8, warmup=3, arith="bf16x6", eager=True):
     """ms per optimisation step (device events around forward / backward / optimizer), peak memory, loss trajectory."""
     from cofii2p_amd.network import CoFiI2P
     from cofii2p_amd.train_step import step_losses
@@ -84,7 +84,7 @@ def train_step_summary(dev, frame, steps=8, warmup=3, arith="bf16x6"):
     torch.cuda.synchronize()
     base = torch.cuda.memory_allocated()
     torch.cuda.reset_peak_memory_stats()
-    for it in range(warmup + steps):
+    for it in range(warmup + steps if eager else 0):
         optim.zero_grad()
         ev[0].record()
         _o, _m, ls = step_losses(model, pyr, img, batch, StepOpt)
@@ -100,7 +100,9 @@ def train_step_summary(dev, frame, steps=8, warmup=3, arith="bf16x6"):
             for j in range(3):
                 t[j] += ev[j].elapsed_time(ev[j + 1])
     peak = torch.cuda.max_memory_allocated() - base
-    del optim, _o, _m, ls, loss     # the recording below must not find last step's autograd graph alive (its AccumulateGrad nodes sit on this stream)
+    if eager:
+        del _o, _m, ls, loss
+    del optim     # the recording below must not find last step's autograd graph alive (its AccumulateGrad nodes sit on this stream)
     # the same step as one hipGraph (cofii2p_amd.train_step.GraphedTrainStep): the eager step is bound by the Python thread issuing ~3 800 launches
     from cofii2p_amd.train_step import GraphedTrainStep
 

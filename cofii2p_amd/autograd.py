@@ -11,6 +11,7 @@ in a fixed order - no float atomics, bit-reproducible (csrc/backward.hip).
     im2col(x, H, W, ks, stride, pad)          unfolded operand of a convolution of the image branch (conv = im2col + linear)
     attention(q, k, v, nhead)                 model/transformer/linear_attention.py:56-79
     normalize_cols(x)                         F.normalize(x, dim=0): transformer.py:53 normalises Q over the tokens
+    upsample2x_cat(low, skip, h, w)           imagenet.py:433-434: bilinear x2 + concatenation with the skip map
     group_norm_act(x, gamma, beta, groups, slope, res)   GroupNorm / InstanceNorm / train-mode BatchNorm over the rows + activation + residual
 """
 import math
@@ -29,9 +30,9 @@ class TransposedTable:
     kpconv.py:89) and anything out of range are dropped.  Built once per table and frame with a stable device sort."""
 
     def __init__(self, idx: torch.Tensor, N: int):
-        flat = idx.reshape(-1).to(torch.int64)
+        flat = idx.reshape(-1).to(torch.int32)     # 32-bit keys: half the radix passes of an int64 sort (13 tables per step)
         key, perm = torch.sort(flat, stable=True)
-        bounds = torch.searchsorted(key, torch.arange(N + 1, device=idx.device, dtype=torch.int64))
+        bounds = torch.searchsorted(key, torch.arange(N + 1, device=idx.device, dtype=torch.int32))
         self.pairs = perm.to(torch.int32).contiguous()
         self.offsets = bounds.to(torch.int32).contiguous()   # rows j >= N lie behind offsets[N]: never visited
         self.N, self.M, self.H = N, idx.shape[0], (idx.shape[1] if idx.dim() == 2 else 1)
@@ -111,7 +112,7 @@ class _Linear(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dx = _gemm_nt(dy, ops.transpose(_rows(w)))[:, :x.shape[1]]         # dY W
             if ctx.needs_input_grad[1]:
-                dw = _gemm_nt(ops.transpose(dy), ops.transpose(_rows(x)))          # dY^T X
+                dw = _gemm_nt(*ops.transpose_pair(dy, _rows(x)))                         # dY^T X
         return dx, dw, db, None
 
 
@@ -317,6 +318,29 @@ class _Attention(torch.autograd.Function):
                                     _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv), _p(ws), ws.numel(), _stream())
         _lib.check(rc, "cofi_attention_bwd")
         return dq, dk, dv, None
+
+
+class _Upsample2xCat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, low, skip, h, w):
+        ctx.geom = (h, w, low.shape[1])
+        return ops.upsample2x_cat_nhwc(_rows(low.detach()), h, w, _rows(skip.detach()))
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        h, w, C1 = ctx.geom
+        dout = _rows(dout)
+        dlow = None
+        if ctx.needs_input_grad[0]:
+            dlow = torch.empty((h * w, C1), dtype=torch.float32, device=dout.device)
+            _lib.check(lib.cofi_upsample2x_bwd_nhwc(_p(dout), _ld(dout), C1, h, w, _p(dlow), _ld(dlow), _stream()), "cofi_upsample2x_bwd_nhwc")
+        return dlow, (dout[:, C1:] if ctx.needs_input_grad[1] else None), None, None
+
+
+def upsample2x_cat(low: torch.Tensor, skip: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """imagenet.py:433-434: bilinear x2 (align_corners=False) of the pixel-major (h w, C1) map, concatenated with the (2h 2w, C2) skip map."""
+    return _Upsample2xCat.apply(low, skip, h, w)
 
 
 class _NormalizeCols(torch.autograd.Function):

@@ -459,6 +459,41 @@ __global__ __launch_bounds__(256) void col_sum_final_kernel(const float *part, i
 
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// Adjoint of the bilinear x2 up-sampling (align_corners = False, imagenet.py:433) of a pixel-major (h w, C1) map: the gradient of the
+// (2h 2w, C1 [+ C2]) output's first C1 columns gathered per INPUT pixel - no atomics, fixed order.  Along one axis the output sample Y reads
+// in[k-1], in[k] with 0.25 / 0.75 (Y = 2k, k >= 1; Y = 0 reads in[0] alone) and in[k], in[min(k+1, n-1)] with 0.75 / 0.25 (Y = 2k + 1), hence
+// input i receives from Y = 2i-1 (0.25), 2i (0.75; 1 at i = 0), 2i+1 (0.75; 1 at i = n-1), 2i+2 (0.25).
+__device__ inline int up2_taps(int i, int n, int *Y, float *wgt) {
+    int t = 0;
+    if (i >= 1) { Y[t] = 2 * i - 1; wgt[t++] = 0.25f; }
+    Y[t] = 2 * i; wgt[t++] = i == 0 ? 1.0f : 0.75f;
+    Y[t] = 2 * i + 1; wgt[t++] = i == n - 1 ? 1.0f : 0.75f;
+    if (i + 1 <= n - 1) { Y[t] = 2 * i + 2; wgt[t++] = 0.25f; }
+    return t;
+}
+
+__global__ __launch_bounds__(256) void upsample2x_bwd_nhwc_kernel(const float *dout, int lddo, int C1, int h, int w, float *dlow, int lddl) {
+    const int ct = C1 >> 2, W = 2 * w;
+    const size_t total = (size_t)h * w * ct;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % ct) * 4, p = (int)(e / ct), i = p / w, j = p - i * w;
+        int Ys[4], Xs[4];
+        float wy[4], wx[4];
+        const int ny = up2_taps(i, h, Ys, wy), nx = up2_taps(j, w, Xs, wx);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < ny; ++a) {
+            f32x4 row = {0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < nx; ++b) {
+                const f32x4 g = *reinterpret_cast<const f32x4 *>(dout + ((size_t)Ys[a] * W + Xs[b]) * lddo + c);
+                for (int k = 0; k < 4; ++k) row[k] = fmaf(wx[b], g[k], row[k]);
+            }
+            for (int k = 0; k < 4; ++k) acc[k] = fmaf(wy[a], row[k], acc[k]);
+        }
+        *reinterpret_cast<f32x4 *>(dlow + (size_t)p * lddl + c) = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // F.normalize(x, dim=0) of a (M, C) matrix - transformer.py:53 normalises Q over the tokens - forward and backward, two launches each:
 // column partials of a * b over row blocks (a = b = x: sum of squares; a = dy, b = x: <dy, x>), then an apply kernel whose workgroups
 // first fold the partials of their 64 columns in a fixed order.  With n_c = ||x[:, c]||, inv_c = 1 / max(n_c, eps):
@@ -732,6 +767,16 @@ extern "C" int cofi_col_sum(const float *x, int ldx, int M, int C, float *out, v
     if (!ws || ws_bytes < cofi_col_sum_workspace(M, C)) return COFI_EWORKSPACE;
     hipLaunchKernelGGL(col_sum_partial_kernel, dim3(cofi_cdiv(C, 64), RB), dim3(256), 0, cofi_s(stream), x, ldx, M, C, cofi_cdiv(M, RB), (float *)ws);
     hipLaunchKernelGGL(col_sum_final_kernel, dim3(cofi_cdiv(C, 64)), dim3(256), 0, cofi_s(stream), (const float *)ws, RB, C, out);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_upsample2x_bwd_nhwc(const float *dout, int lddo, int C1, int h, int w, float *dlow, int lddl, cofi_stream_t stream) {
+    if (!dout || !dlow || C1 <= 0 || (C1 & 3) || h <= 0 || w <= 0 || lddo < C1 || lddl < C1 || (lddo & 3) || (lddl & 3)) return COFI_EINVAL;
+    if ((((uintptr_t)dout) | ((uintptr_t)dlow)) & 15) return COFI_EINVAL;
+    const size_t total = (size_t)h * w * (C1 >> 2);
+    int nb = (int)((total + 255) / 256);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(upsample2x_bwd_nhwc_kernel, dim3(nb), dim3(256), 0, cofi_s(stream), dout, lddo, C1, h, w, dlow, lddl);
     return cofi_launch_status();
 }
 

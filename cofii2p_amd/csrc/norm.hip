@@ -455,6 +455,54 @@ __global__ __launch_bounds__(256) void transpose_vec_kernel(const float *x, int 
     }
 }
 
+// Two matrices with the same row count in ONE launch (the backward of a linear layer transposes dY and X for dW = dY^T X): column blocks
+// [0, nb1) belong to the first matrix, the rest to the second; a matrix that does not meet the 16-byte rules takes the scalar path.
+struct TransposePairArgs {
+    const float *x[2];
+    float *y[2];
+    int ldx[2], ldy[2], C[2], vec[2], M, nb1;
+};
+
+__global__ __launch_bounds__(256) void transpose_pair_kernel(TransposePairArgs a) {
+    __shared__ float tile[64][65];
+    const int w = blockIdx.x >= a.nb1 ? 1 : 0;
+    const float *x = a.x[w];
+    float *y = a.y[w];
+    const int ldx = a.ldx[w], ldy = a.ldy[w], C = a.C[w], M = a.M;
+    const int m0 = blockIdx.y * 64, c0 = (blockIdx.x - (w ? a.nb1 : 0)) * 64;
+    if (a.vec[w]) {
+        const int q = threadIdx.x & 15, r = threadIdx.x >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + r + 16 * i, c = c0 + 4 * q;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < M && c < C) v = *reinterpret_cast<const f32x4 *>(x + (size_t)m * ldx + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[r + 16 * i][4 * q + e] = v[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + r + 16 * i, m = m0 + 4 * q;
+            if (c < C && m < M) {
+                const f32x4 v = {tile[4 * q][r + 16 * i], tile[4 * q + 1][r + 16 * i], tile[4 * q + 2][r + 16 * i], tile[4 * q + 3][r + 16 * i]};
+                *reinterpret_cast<f32x4 *>(y + (size_t)c * ldy + m) = v;
+            }
+        }
+    } else {
+        const int cl = threadIdx.x & 63, rr = threadIdx.x >> 6;
+        for (int i = rr; i < 64; i += 4) {
+            const int m = m0 + i, c = c0 + cl;
+            tile[i][cl] = (m < M && c < C) ? x[(size_t)m * ldx + c] : 0.f;
+        }
+        __syncthreads();
+        for (int i = rr; i < 64; i += 4) {
+            const int c = c0 + i, m = m0 + cl;
+            if (c < C && m < M) y[(size_t)c * ldy + m] = tile[cl][i];
+        }
+    }
+}
+
 __global__ void transpose_kernel(const float *x, int ldx, int M, int C, float *y, int ldy) {
     __shared__ float tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
@@ -647,6 +695,19 @@ extern "C" int cofi_transpose(const float *x, int ldx, int M, int C, float *y, i
         hipLaunchKernelGGL(transpose_vec_kernel, dim3(cofi_cdiv(C, 64), cofi_cdiv(M, 64)), dim3(256), 0, cofi_s(stream), x, ldx, M, C, y, ldy);
     else
         hipLaunchKernelGGL(transpose_kernel, dim3(cofi_cdiv(C, 32), cofi_cdiv(M, 32)), dim3(256), 0, cofi_s(stream), x, ldx, M, C, y, ldy);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_transpose_pair(const float *x1, int ldx1, int C1, float *y1, int ldy1, const float *x2, int ldx2, int C2, float *y2, int ldy2, int M,
+                                   cofi_stream_t stream) {
+    if (!x1 || !y1 || !x2 || !y2 || M <= 0 || C1 <= 0 || C2 <= 0 || ldx1 < C1 || ldx2 < C2 || ldy1 < M || ldy2 < M) return COFI_EINVAL;
+    TransposePairArgs a;
+    a.x[0] = x1; a.x[1] = x2; a.y[0] = y1; a.y[1] = y2;
+    a.ldx[0] = ldx1; a.ldx[1] = ldx2; a.ldy[0] = ldy1; a.ldy[1] = ldy2; a.C[0] = C1; a.C[1] = C2; a.M = M;
+    a.vec[0] = !((M | C1 | ldx1 | ldy1) & 3) && !(((uintptr_t)x1 | (uintptr_t)y1) & 15);
+    a.vec[1] = !((M | C2 | ldx2 | ldy2) & 3) && !(((uintptr_t)x2 | (uintptr_t)y2) & 15);
+    a.nb1 = cofi_cdiv(C1, 64);
+    hipLaunchKernelGGL(transpose_pair_kernel, dim3(a.nb1 + cofi_cdiv(C2, 64), cofi_cdiv(M, 64)), dim3(256), 0, cofi_s(stream), a);
     return cofi_launch_status();
 }
 

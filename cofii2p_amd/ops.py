@@ -636,6 +636,20 @@ def transpose(x, out=None):
     return out
 
 
+def transpose_pair(a, b):
+    """(a^T, b^T) of two matrices with the same number of rows, one launch."""
+    lib = _lib.load()
+    _mat(a, "a"), _mat(b, "b")
+    M = a.shape[0]
+    if b.shape[0] != M:
+        raise _lib.CofiError("transpose_pair: both matrices must have the same number of rows")
+    at = torch.empty((a.shape[1], M), dtype=torch.float32, device=a.device)
+    bt = torch.empty((b.shape[1], M), dtype=torch.float32, device=a.device)
+    _lib.check(lib.cofi_transpose_pair(_p(a), _ld(a), a.shape[1], _p(at), _ld(at), _p(b), _ld(b), b.shape[1], _p(bt), _ld(bt), M, _stream()),
+               "cofi_transpose_pair")
+    return at, bt
+
+
 def sine_frequencies(n_dim: int, d_model: int = 128, temperature: float = 10000.0) -> np.ndarray:
     """position_encoding.py:39-40 evaluated with the same fp32 torch ops (host constant table)."""
     f = d_model // n_dim // 2 * 2

@@ -5,9 +5,9 @@ train.py:224-288 (forward -> losses -> loss.backward() -> optimizer.step()) runs
 moves data between rows - every nn.Linear / nn.Conv2d / KPConv contraction, the KPConv neighbour aggregation, attention, the
 neighbour max-pool and up-sample gathers - is a `cofii2p_amd.autograd` Function whose forward AND backward are hand-written gfx950
 kernels - as are the normalisations over the rows of a map with the activation and residual join behind them (GroupNorm, InstanceNorm,
-train-mode BatchNorm: ag.group_norm_act).  What is left to torch's differentiable tensor ops on the same device buffers - the "torch
-fallback" SURVEY.md row f3 allows - is row-local and weight-free: LayerNorm, F.normalize, sigmoid, concatenations, the bilinear x2 and
-the 3x3 max-pool of the ResNet stem.  Activations are pixel-major / point-major (rows, C) matrices as in the inference path.
+train-mode BatchNorm: ag.group_norm_act), the token-axis normalisation of Q and the bilinear x2 of the up-samplers.  What is left to
+torch's differentiable tensor ops on the same device buffers - the "torch fallback" SURVEY.md row f3 allows - is row-local and
+weight-free: LayerNorm, F.normalize over a row, sigmoid, concatenations and the 3x3 max-pool of the ResNet stem.  Activations are pixel-major / point-major (rows, C) matrices as in the inference path.
 
 Differences from the inference path, all the reference's own train()-mode semantics:
   * BatchNorm2d of the two ImageUpSample stages uses BATCH statistics and updates running_mean / running_var / num_batches_tracked
@@ -166,8 +166,7 @@ def _residual_conv(P, B, p, x, H, W, training):
 
 def image_upsample(P, B, name, low, h, w, skip, training):
     """imagenet.py:431-444: bilinear x2 (align_corners=False), concat with the skip map, two ResidualConv."""
-    up = F.interpolate(_nchw(low, h, w), scale_factor=2, mode="bilinear", align_corners=False)
-    x = torch.cat([_rows(up), skip], 1)
+    x = ag.upsample2x_cat(low, skip, h, w)
     x = _residual_conv(P, B, name + ".conv.0.", x, 2 * h, 2 * w, training)
     return _residual_conv(P, B, name + ".conv.1.", x, 2 * h, 2 * w, training)
 

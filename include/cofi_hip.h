@@ -458,6 +458,12 @@ int cofi_col_sum(const float *x, int ldx, int M, int C, float *out, void *ws, si
 /* F.normalize(x, dim=0) of a (M, C) matrix (model/transformer/transformer.py:53: Q is normalised over the tokens), forward and backward.
  * bwd == 0: out = y, stats (2, C) = 1 / max(norm, eps) | (norm >= eps) written.  bwd != 0: out = dx for the upstream gradient dy, stats read.
  * Two launches per call, every sum in a fixed order. */
+/* adjoint of the bilinear x2 up-sampling of cofi_upsample2x_cat_nhwc (imagenet.py:433): dout = the gradient of the (2h 2w, C1 + C2) map, of which the
+ * first C1 columns are read; dlow (h w, C1).  Gather form per input pixel: no atomics, fixed order. */
+int cofi_upsample2x_bwd_nhwc(const float *dout, int lddo, int C1, int h, int w, float *dlow, int lddl, cofi_stream_t stream);
+/* y1 = x1^T, y2 = x2^T for two matrices of M rows (x1 (M, C1), x2 (M, C2)) in one launch - dW = dY^T X of a linear layer needs both */
+int cofi_transpose_pair(const float *x1, int ldx1, int C1, float *y1, int ldy1, const float *x2, int ldx2, int C2, float *y2, int ldy2, int M,
+                        cofi_stream_t stream);
 size_t cofi_col_normalize_workspace(int M, int C);
 int cofi_col_normalize(const float *x, int ldx, const float *dy, int lddy, int M, int C, float eps, int bwd, float *stats, float *out, int ldo,
                        void *ws, size_t ws_bytes, cofi_stream_t stream);

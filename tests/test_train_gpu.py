@@ -190,6 +190,33 @@ def test_attention_function(L, S):
         assert rel_err(x.grad, y.grad) < 2e-5, n
 
 
+@pytest.mark.parametrize("h,w,C1,C2", [(20, 64, 128, 128), (5, 7, 8, 4), (1, 3, 4, 8), (8, 1, 4, 4)])
+def test_upsample2x_cat_function(h, w, C1, C2):
+    """imagenet.py:433-434: bilinear x2 (align_corners=False) + concatenation, forward and both gradients (the adjoint gathers per input pixel)."""
+    from cofii2p_amd import autograd as ag
+
+    g = torch.Generator().manual_seed(h * 100 + w)
+    low, skip, dy = torch.randn((h * w, C1), generator=g), torch.randn((4 * h * w, C2), generator=g), torch.randn((4 * h * w, C1 + C2), generator=g)
+    lr, sr = low.clone().double().requires_grad_(), skip.clone().double().requires_grad_()
+    up = F.interpolate(lr.t().reshape(1, C1, h, w), scale_factor=2, mode="bilinear", align_corners=False)
+    yr = torch.cat([up.reshape(C1, 4 * h * w).t(), sr], 1)
+    yr.backward(dy.double())
+    l, s_ = G(low, grad=True), G(skip, grad=True)
+    y = ag.upsample2x_cat(l, s_, h, w)
+    y.backward(G(dy))
+    assert rel_err(y, yr) < 1e-6 and rel_err(l.grad, lr.grad) < 1e-6 and torch.equal(s_.grad.cpu(), dy[:, C1:])
+
+
+@pytest.mark.parametrize("M,C1,C2", [(20480, 64, 576), (130, 6, 33), (64, 64, 64), (1, 8, 4)])
+def test_transpose_pair(M, C1, C2):
+    from cofii2p_amd import ops
+
+    g = torch.Generator().manual_seed(M)
+    a, b = G(torch.randn((M, C1 + 4), generator=g))[:, :C1], G(torch.randn((M, C2), generator=g))
+    at, bt = ops.transpose_pair(a, b)
+    assert torch.equal(at, a.t().contiguous()) and torch.equal(bt, b.t().contiguous())
+
+
 @pytest.mark.parametrize("L,C,view", [(1280, 128, True), (96, 128, False), (8, 128, False), (333, 64, True)])
 def test_normalize_cols_function(L, C, view):
     """F.normalize(x, dim=0) (transformer.py:53 normalises Q over the tokens), forward and backward, incl. a dead (all-zero) column."""

@@ -20,13 +20,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=20480)
     ap.add_argument("--arith", default="bf16x6")
+    ap.add_argument("--graph-only", action="store_true", help="skip the eager steps (a clean kernel trace of the recorded step)")
     ap.add_argument("--stress", action="store_true", help="BASELINE configs[4] shape: 896 x 1600 image, 40 960 points")
     args = ap.parse_args()
     if args.stress:
         bench.Opt.img_H, bench.Opt.img_W, args.points = 896, 1600, 40960
     dev = torch.device("cuda", 0)
     frame, = bench.make_inputs(dev, [0], args.points)
-    out = bench.train_step_summary(dev, frame, steps=args.steps, warmup=args.warmup, arith=args.arith)
+    out = bench.train_step_summary(dev, frame, steps=args.steps, warmup=args.warmup, arith=args.arith, eager=not args.graph_only)
     out.update(metric="train_step_ms", points=args.points)
     print(json.dumps(out))
 
