@@ -98,6 +98,7 @@ SIGNATURES = {
     "cofi_group_norm_bwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _P, _P, _I, _P, _Z, _P]),
     "cofi_col_sum_workspace": (_Z, [_I, _I]),
     "cofi_col_sum": (_I, [_P, _I, _I, _I, _P, _P, _Z, _P]),
+    "cofi_l2norm_rows_bwd": (_I, [_P, _I, _P, _I, _I, _I, _F, _P, _I, _P]),
     "cofi_upsample2x_bwd_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
     "cofi_transpose_pair": (_I, [_P, _I, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P]),
     "cofi_col_normalize_workspace": (_Z, [_I, _I]),

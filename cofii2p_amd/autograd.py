@@ -10,6 +10,7 @@ in a fixed order - no float atomics, bit-reproducible (csrc/backward.hip).
     neighbor_maxpool(x, idx), gather_rows     model/kpconv/functional.py:53-66, 5-21
     im2col(x, H, W, ks, stride, pad)          unfolded operand of a convolution of the image branch (conv = im2col + linear)
     attention(q, k, v, nhead)                 model/transformer/linear_attention.py:56-79
+    normalize_rows(x)                         F.normalize(x, dim=1): network.py:83-84, 90, 125-126
     normalize_cols(x)                         F.normalize(x, dim=0): transformer.py:53 normalises Q over the tokens
     upsample2x_cat(low, skip, h, w)           imagenet.py:433-434: bilinear x2 + concatenation with the skip map
     group_norm_act(x, gamma, beta, groups, slope, res)   GroupNorm / InstanceNorm / train-mode BatchNorm over the rows + activation + residual
@@ -341,6 +342,29 @@ class _Upsample2xCat(torch.autograd.Function):
 def upsample2x_cat(low: torch.Tensor, skip: torch.Tensor, h: int, w: int) -> torch.Tensor:
     """imagenet.py:433-434: bilinear x2 (align_corners=False) of the pixel-major (h w, C1) map, concatenated with the (2h 2w, C2) skip map."""
     return _Upsample2xCat.apply(low, skip, h, w)
+
+
+class _NormalizeRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xd = _rows(x.detach())
+        ctx.save_for_backward(xd)
+        return ops.l2norm_rows(xd)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        dy = _rows(dy)
+        M, C = x.shape
+        dx = torch.empty((M, C), dtype=torch.float32, device=x.device)
+        _lib.check(lib.cofi_l2norm_rows_bwd(_p(x), _ld(x), _p(dy), _ld(dy), M, C, 1e-12, _p(dx), C, _stream()), "cofi_l2norm_rows_bwd")
+        return dx
+
+
+def normalize_rows(x: torch.Tensor) -> torch.Tensor:
+    """F.normalize(x, p=2, dim=1) of a (rows, C) matrix (network.py:83-84, 90, 125-126: descriptors are unit rows)."""
+    return _NormalizeRows.apply(x)
 
 
 class _NormalizeCols(torch.autograd.Function):

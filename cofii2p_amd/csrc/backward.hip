@@ -459,6 +459,27 @@ __global__ __launch_bounds__(256) void col_sum_final_kernel(const float *part, i
 
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// Backward of F.normalize(x, dim=1) (network.py:83-84, 90, 125-126: descriptors are unit rows), a wave per row:
+//   n = ||x_m||;  dx = dy / n - x <dy, x> / n^3   (n >= eps),   dx = dy / eps   (the clamped norm is a constant)
+__global__ __launch_bounds__(256) void l2norm_rows_bwd_kernel(const float *x, int ldx, const float *dy, int lddy, int M, int C, float eps, float *dx,
+                                                             int lddx) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int lane = threadIdx.x & 63;
+    float q = 0.f, t = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float v = x[(size_t)m * ldx + c];
+        q = fmaf(v, v, q);
+        t = fmaf(dy[(size_t)m * lddy + c], v, t);
+    }
+    const float n = sqrtf(wave_sum(q));
+    t = wave_sum(t);
+    const float inv = 1.0f / fmaxf(n, eps);
+    const float coef = n >= eps ? t * inv * inv * inv : 0.f;
+    for (int c = lane; c < C; c += 64) dx[(size_t)m * lddx + c] = dy[(size_t)m * lddy + c] * inv - x[(size_t)m * ldx + c] * coef;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // Adjoint of the bilinear x2 up-sampling (align_corners = False, imagenet.py:433) of a pixel-major (h w, C1) map: the gradient of the
 // (2h 2w, C1 [+ C2]) output's first C1 columns gathered per INPUT pixel - no atomics, fixed order.  Along one axis the output sample Y reads
 // in[k-1], in[k] with 0.25 / 0.75 (Y = 2k, k >= 1; Y = 0 reads in[0] alone) and in[k], in[min(k+1, n-1)] with 0.75 / 0.25 (Y = 2k + 1), hence
@@ -767,6 +788,12 @@ extern "C" int cofi_col_sum(const float *x, int ldx, int M, int C, float *out, v
     if (!ws || ws_bytes < cofi_col_sum_workspace(M, C)) return COFI_EWORKSPACE;
     hipLaunchKernelGGL(col_sum_partial_kernel, dim3(cofi_cdiv(C, 64), RB), dim3(256), 0, cofi_s(stream), x, ldx, M, C, cofi_cdiv(M, RB), (float *)ws);
     hipLaunchKernelGGL(col_sum_final_kernel, dim3(cofi_cdiv(C, 64)), dim3(256), 0, cofi_s(stream), (const float *)ws, RB, C, out);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_l2norm_rows_bwd(const float *x, int ldx, const float *dy, int lddy, int M, int C, float eps, float *dx, int lddx, cofi_stream_t stream) {
+    if (!x || !dy || !dx || M <= 0 || C <= 0 || ldx < C || lddy < C || lddx < C) return COFI_EINVAL;
+    hipLaunchKernelGGL(l2norm_rows_bwd_kernel, dim3(cofi_cdiv(M, 4)), dim3(256), 0, cofi_s(stream), x, ldx, dy, lddy, M, C, eps, dx, lddx);
     return cofi_launch_status();
 }
 

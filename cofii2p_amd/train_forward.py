@@ -5,9 +5,9 @@ train.py:224-288 (forward -> losses -> loss.backward() -> optimizer.step()) runs
 moves data between rows - every nn.Linear / nn.Conv2d / KPConv contraction, the KPConv neighbour aggregation, attention, the
 neighbour max-pool and up-sample gathers - is a `cofii2p_amd.autograd` Function whose forward AND backward are hand-written gfx950
 kernels - as are the normalisations over the rows of a map with the activation and residual join behind them (GroupNorm, InstanceNorm,
-train-mode BatchNorm: ag.group_norm_act), the token-axis normalisation of Q and the bilinear x2 of the up-samplers.  What is left to
+train-mode BatchNorm: ag.group_norm_act), the L2 normalisations (descriptor rows; Q over the tokens) and the bilinear x2 of the up-samplers.  What is left to
 torch's differentiable tensor ops on the same device buffers - the "torch fallback" SURVEY.md row f3 allows - is row-local and
-weight-free: LayerNorm, F.normalize over a row, sigmoid, concatenations and the 3x3 max-pool of the ResNet stem.  Activations are pixel-major / point-major (rows, C) matrices as in the inference path.
+weight-free: LayerNorm, sigmoid, ReLU, concatenations and the 3x3 max-pool of the ResNet stem.  Activations are pixel-major / point-major (rows, C) matrices as in the inference path.
 
 Differences from the inference path, all the reference's own train()-mode semantics:
   * BatchNorm2d of the two ImageUpSample stages uses BATCH statistics and updates running_mean / running_var / num_batches_tracked
@@ -260,12 +260,12 @@ def forward_train(model, pc_data_dict: Dict, img: torch.Tensor, fine_center_kpt_
         side.wait_stream(main)
     with torch.cuda.stream(side):
         (s2, H2, W2), (s4, H4, W4), (s8, H8, W8) = resnet34_s8(P, img)
-        s8n = F.normalize(s8, dim=1)                                              # network.py:90
+        s8n = ag.normalize_rows(s8)                                              # network.py:90
         tok_img = s8n + pos_sine_table(model._pixel_grid(H8, W8, 1, dev))         # network.py:104-110
         tokens_ready = torch.cuda.Event()
         tokens_ready.record(side)
         up4 = image_upsample(P, B, "img_upsample_1", s8n, H8, W8, s4, training)
-        up2 = F.normalize(image_upsample(P, B, "img_upsample_2", up4, H4, W4, s2, training), dim=1)   # (H2 W2, 64)
+        up2 = ag.normalize_rows(image_upsample(P, B, "img_upsample_2", up4, H4, W4, s2, training))   # (H2 W2, 64)
         # network.py:137-141: 4 x 4 patches around the labelled pixels
         ctr = fine_center_kpt_coors.to(device=dev)
         lt = torch.floor(ctr.to(torch.float32) - 2.0).to(torch.int64)             # network.py:213: left/top = floor(centre - size / 2)
@@ -278,8 +278,8 @@ def forward_train(model, pc_data_dict: Dict, img: torch.Tensor, fine_center_kpt_
         patches = ag.gather_rows(up2, pix.to(torch.int32), tables).reshape(ctr.shape[1], 4, 4, -1).permute(0, 3, 1, 2)
 
     pc_set = kpconv_fpn(P, B, points, neighbors, subsampling, upsampling, feats, tables)
-    fine_pc = F.normalize(pc_set[0], dim=1)                                   # network.py:83
-    pc_mid = F.normalize(pc_feature_mlp(P, pc_set[-1]), dim=1)                # network.py:84
+    fine_pc = ag.normalize_rows(pc_set[0])                                   # network.py:83
+    pc_mid = ag.normalize_rows(pc_feature_mlp(P, pc_set[-1]))                # network.py:84
     tok_pc = pc_mid + pos_sine_table(points[-1])                              # network.py:107,111
     fine_feat = ag.gather_rows(fine_pc, as32(fine_pc_inline_index.reshape(-1)), tables)   # network.py:137: descriptors of the labelled points
     if fork:
@@ -288,8 +288,8 @@ def forward_train(model, pc_data_dict: Dict, img: torch.Tensor, fine_center_kpt_
     tok_img, tok_pc = transformer(P, tok_img, tok_pc)
     pc_score = score_head(P, "pc_score_layer", tok_pc)
     img_score = score_head(P, "img_score_layer", tok_img)
-    pc_desc = F.normalize(tok_pc, dim=1).t()                                  # (C, N4)  network.py:125
-    img_desc = F.normalize(tok_img, dim=1).t().reshape(1, D_MODEL, H8, W8)    # network.py:126
+    pc_desc = ag.normalize_rows(tok_pc).t()                                  # (C, N4)  network.py:125
+    img_desc = ag.normalize_rows(tok_img).t().reshape(1, D_MODEL, H8, W8)    # network.py:126
     if fork:
         main.wait_stream(side)
         patches.record_stream(main)

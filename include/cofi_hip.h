@@ -458,6 +458,8 @@ int cofi_col_sum(const float *x, int ldx, int M, int C, float *out, void *ws, si
 /* F.normalize(x, dim=0) of a (M, C) matrix (model/transformer/transformer.py:53: Q is normalised over the tokens), forward and backward.
  * bwd == 0: out = y, stats (2, C) = 1 / max(norm, eps) | (norm >= eps) written.  bwd != 0: out = dx for the upstream gradient dy, stats read.
  * Two launches per call, every sum in a fixed order. */
+/* backward of cofi_l2norm_rows (F.normalize(x, dim=1), network.py:83-84, 90, 125-126): dx for the upstream gradient dy, eps = 1e-12 */
+int cofi_l2norm_rows_bwd(const float *x, int ldx, const float *dy, int lddy, int M, int C, float eps, float *dx, int lddx, cofi_stream_t stream);
 /* adjoint of the bilinear x2 up-sampling of cofi_upsample2x_cat_nhwc (imagenet.py:433): dout = the gradient of the (2h 2w, C1 + C2) map, of which the
  * first C1 columns are read; dlow (h w, C1).  Gather form per input pixel: no atomics, fixed order. */
 int cofi_upsample2x_bwd_nhwc(const float *dout, int lddo, int C1, int h, int w, float *dlow, int lddl, cofi_stream_t stream);

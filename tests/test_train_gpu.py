@@ -190,6 +190,24 @@ def test_attention_function(L, S):
         assert rel_err(x.grad, y.grad) < 2e-5, n
 
 
+@pytest.mark.parametrize("M,C", [(20480, 64), (1280, 128), (7, 128), (33, 20)])
+def test_normalize_rows_function(M, C):
+    """F.normalize(x, dim=1), forward and backward, incl. an all-zero row (clamped norm: gradient dy / eps = 0 for dy = 0 there)."""
+    from cofii2p_amd import autograd as ag
+
+    g = torch.Generator().manual_seed(M + C)
+    base, dy = torch.randn((M, C), generator=g), torch.randn((M, C), generator=g)
+    base[3] = 0.0
+    dy[3] = 0.0
+    xr = base.clone().double().requires_grad_()
+    yr = F.normalize(xr, dim=1)
+    yr.backward(dy.double())
+    x = G(base, grad=True)
+    y = ag.normalize_rows(x)
+    y.backward(G(dy))
+    assert rel_err(y, yr) < 1e-6 and rel_err(x.grad, xr.grad) < 2e-6
+
+
 @pytest.mark.parametrize("h,w,C1,C2", [(20, 64, 128, 128), (5, 7, 8, 4), (1, 3, 4, 8), (8, 1, 4, 4)])
 def test_upsample2x_cat_function(h, w, C1, C2):
     """imagenet.py:433-434: bilinear x2 (align_corners=False) + concatenation, forward and both gradients (the adjoint gathers per input pixel)."""
