@@ -53,6 +53,9 @@ def score_thresholds(n: int = 64) -> np.ndarray:
 ALTERNATE_ORDER = True   # odd forward_async slots run the point encoder first (measured 515-518 vs 510 frames/s)
 
 
+_EXTRA_FRAME_STREAMS = {}   # device -> streams handed out by CoFiI2P.frame_streams beyond the capture and the default stream
+
+
 class CoFiI2P(nn.Module):
     """See module docstring.  ``opt`` needs ``img_H, img_W, img_fine_resolution_scale, norm``
     (data/options.py:17-19,51).  ``norm``: 'gn' (the shipped configuration, the fast path), 'bn' (inference: running statistics, folded
@@ -415,7 +418,13 @@ class CoFiI2P(nn.Module):
         if getattr(self, "_capture_stream", None) is None or self._capture_stream.device != dev:
             self._capture_stream = torch.cuda.Stream(device=dev)
         pool = [self._capture_stream, torch.cuda.default_stream(dev)]
-        return (pool + [torch.cuda.Stream(device=dev) for _ in range(max(0, n - len(pool)))])[:n]
+        # the extra streams are created once per device and process: HIP binds a stream to the least-loaded hardware queue when it is
+        # created, so fresh streams per call would land on different queues from one call to the next (a pipeline with the KNN pyramid in
+        # the chain measured 355 or 478 frames/s depending on that)
+        extra = _EXTRA_FRAME_STREAMS.setdefault(str(dev), [])
+        while len(extra) < n - len(pool):
+            extra.append(torch.cuda.Stream(device=dev))
+        return (pool + extra)[:n]
 
     @torch.no_grad()
     def forward_async(self, slot: int, pc_data_dict, img, mode: str = "test", inputs_stable: bool = False):
