@@ -415,6 +415,8 @@ class CoFiI2P(nn.Module):
         configuration this is a convenience, not a requirement: four FRESH streams, or a fifth stream that a loader / RCCL uses next to
         the four, run at the same rate (profiles/r03_fifth_stream.md; the round-2 pipeline lost 45 % there)."""
         dev = torch.device(device) if device is not None else next(self.parameters()).device
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())   # 'cuda' and 'cuda:0' are one pool
         if getattr(self, "_capture_stream", None) is None or self._capture_stream.device != dev:
             self._capture_stream = torch.cuda.Stream(device=dev)
         pool = [self._capture_stream, torch.cuda.default_stream(dev)]

@@ -259,3 +259,59 @@ def test_pyramid_shim_refuses_forked_dataloader_workers():
     msg = q.get(timeout=60)
     p.join(30)
     assert "forked DataLoader worker" in msg and "FramePreparer" in msg
+
+
+def test_transposed_table_is_the_csr_transpose_in_pair_order():
+    """autograd.TransposedTable (the backward's scatter-free adjoints walk it): for every support row j the ids m * H + h with
+    idx[m, h] == j, ascending - the fixed summation order that makes gradients bit-reproducible; shadow entries (== N) are dropped."""
+    import torch
+    from cofii2p_amd.autograd import TableCache, TransposedTable
+
+    g = torch.Generator().manual_seed(3)
+    M, H, N = 37, 5, 11
+    idx = torch.randint(0, N + 1, (M, H), generator=g, dtype=torch.int32)
+    t = TransposedTable(idx, N)
+    flat = idx.reshape(-1)
+    assert t.offsets.shape == (N + 1,) and int(t.offsets[0]) == 0 and t.pairs.dtype == torch.int32
+    for j in range(N):
+        want = torch.nonzero(flat == j).reshape(-1).to(torch.int32)
+        got = t.pairs[int(t.offsets[j]):int(t.offsets[j + 1])]
+        assert torch.equal(got, want), j
+    assert int(t.offsets[N]) == int((flat < N).sum())
+    cache = TableCache()
+    assert cache.get(idx, N) is cache.get(idx, N) and cache.get(idx, N, first_column=True).H == 1
+
+
+def test_batch_from_sample_maps_a_loader_sample_the_way_train_py_does():
+    """train_step.batch_from_sample = train.py:192-217: squeeze the DataLoader's batch dimension of 1, rename fine_xy_coors -> fine_xy."""
+    import torch
+    from cofii2p_amd.train_step import batch_from_sample
+
+    K = 6
+    sample = {"img": torch.zeros(1, 3, 8, 16), "K_4": torch.eye(3)[None], "P": torch.eye(4)[None],
+              "pc_data_dict": {"points": [torch.zeros(1, 32, 3), torch.zeros(1, 16, 3)], "neighbors": [torch.zeros(1, 32, 4, dtype=torch.int64)],
+                               "subsampling": [torch.zeros(1, 16, 4, dtype=torch.int64)], "upsampling": [torch.zeros(1, 32, 4, dtype=torch.int64)],
+                               "feats": torch.zeros(1, 32, 4)}}
+    for k in ("pc_kpt_idx", "pc_outline_idx", "coarse_img_kpt_idx", "fine_pc_inline_index"):
+        sample[k] = torch.arange(K)[None]
+    sample["fine_center_kpt_coors"] = torch.ones(1, 2, K, dtype=torch.int64)
+    sample["fine_xy_coors"] = 2 * torch.ones(1, 2, K, dtype=torch.int64)
+    pc, img, batch = batch_from_sample(sample, device="cpu")
+    assert img.shape == (1, 3, 8, 16) and pc["points"][0].shape == (32, 3) and pc["neighbors"][0].shape == (32, 4) and pc["feats"].shape == (32, 4)
+    assert batch["K_4"].shape == (3, 3) and batch["P"].shape == (4, 4) and batch["pc_kpt_idx"].shape == (K,)
+    assert batch["fine_xy"].shape == (2, K) and int(batch["fine_xy"][0, 0]) == 2 and set(batch) == {
+        "K_4", "P", "pc_kpt_idx", "pc_outline_idx", "coarse_img_kpt_idx", "fine_center_kpt_coors", "fine_xy", "fine_pc_inline_index"}
+    unbatched = {k: (v[0] if torch.is_tensor(v) else v) for k, v in sample.items() if k != "pc_data_dict"}
+    unbatched["pc_data_dict"] = {k: ([t[0] for t in v] if isinstance(v, list) else v[0]) for k, v in sample["pc_data_dict"].items()}
+    pc2, img2, batch2 = batch_from_sample(unbatched, device="cpu")     # FramePreparer / FrameLoader samples carry no batch dimension
+    assert img2.shape == (1, 3, 8, 16) and pc2["points"][1].shape == (16, 3) and batch2["fine_center_kpt_coors"].shape == (2, K)
+
+
+def test_graphed_train_step_refuses_a_host_side_step_counter():
+    import pytest
+    import torch
+    from cofii2p_amd.train_step import GraphedTrainStep
+
+    p = torch.nn.Parameter(torch.zeros(3))
+    with pytest.raises(ValueError):
+        GraphedTrainStep(torch.nn.Linear(1, 1), torch.optim.Adam([p], lr=1e-3), None)
