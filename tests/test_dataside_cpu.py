@@ -69,6 +69,30 @@ def test_oracle_labels_match_reference_getitem(gold, oracle_frames, index):
         assert hashlib.sha256(np.ascontiguousarray(q).tobytes()).hexdigest() == str(gold[tag + "img_sha256"])
 
 
+@pytest.mark.parametrize("index", (0, 3))
+def test_oracle_train_mode_matches_reference_getitem(index):
+    """mode='train' against the REFERENCE's own __getitem__ in train mode (tests/tools/make_golden_dataside_train.py): the random crop from
+    `random` after the SE(3) draws (kitti.py:312-314), the intrinsics of the cropped image, the jittered image (the ColorJitter stand-in of
+    the recording is the oracle's, pinned to PIL below) and every label drawn afterwards."""
+    gold = load_golden("dataside_train_ref.npz")
+    tag = "i%d_" % index
+    seq_i, cam = gold[tag + "frame_cam"]
+    data, img, K = synth.make_raw_scan(int(seq_i))
+    if cam == 3:
+        img = img[:, ::-1].copy()
+    r = D.prepare_frame(data, img, K, gold[tag + "P_Tr"], index, kitti_opt(), mode="train")
+    v = D.prepare_frame(data, img, K, gold[tag + "P_Tr"], index, kitti_opt())
+    assert r["crop"] != v["crop"]
+    for k in INT_KEYS:
+        assert np.array_equal(np.asarray(r[k]), gold[tag + k]), k
+    assert np.array_equal(r["coarse_img_mask"], gold[tag + "coarse_img_mask"])
+    for k in ("K", "K_4", "P"):
+        np.testing.assert_array_equal(r[k], gold[tag + k])
+    np.testing.assert_allclose(r["points"][4], gold[tag + "points4"], rtol=0, atol=2e-5)
+    q = np.rint(r["img"] * 255.0).astype(np.uint8)
+    assert hashlib.sha256(np.ascontiguousarray(q).tobytes()).hexdigest() == str(gold[tag + "img_sha256"])
+
+
 def test_oracle_points_and_feats_match_reference(gold, oracle_frames):
     r = oracle_frames[0]
     np.testing.assert_allclose(r["points"][0], gold["i0_points0"], rtol=0, atol=2e-5)
@@ -190,6 +214,26 @@ def test_oracle_matches_reference_nuscenes_getitem(index):
     assert lab["valid_kpt"] == bool(gold[tag + "valid_kpt"])
     for k in INT_KEYS[:-1]:
         assert np.array_equal(lab[k], gold[tag + k]), k
+
+
+@pytest.mark.parametrize("index", NUS_INDICES)
+def test_oracle_train_mode_matches_reference_nuscenes_getitem(index):
+    """nuscenes.py:232-234 (random crop: dx, then dy, from `random` after the SE(3) draws) and :249-250 (colour jitter) against the
+    reference's own __getitem__ in train mode (tests/tools/make_golden_dataside_nuscenes.py --train), incl. the valid_kpt False sample."""
+    gold = load_golden("dataside_nuscenes_train_ref.npz")
+    tag = "i%d_" % index
+    fid, n = gold[tag + "frame_points"]
+    pc4, img, K = synth.make_raw_nuscenes(int(fid), int(n))
+    r = D.prepare_frame_nuscenes(pc4, img, K, index, nuscenes_opt(), mode="train")
+    assert bool(r["valid_kpt"]) == bool(gold[tag + "valid_kpt"])
+    for k in INT_KEYS:
+        assert np.array_equal(np.asarray(r[k]), gold[tag + k]), k
+    assert np.array_equal(r["coarse_img_mask"], gold[tag + "coarse_img_mask"])
+    for k in ("K", "K_4", "P"):
+        np.testing.assert_array_equal(r[k], gold[tag + k])
+    np.testing.assert_allclose(r["points"][4], gold[tag + "points4"], rtol=0, atol=2e-5)
+    q = np.rint(r["img"] * 255.0).astype(np.uint8)
+    assert hashlib.sha256(np.ascontiguousarray(q).tobytes()).hexdigest() == str(gold[tag + "img_sha256"])
 
 
 def test_color_jitter_oracle_equals_pil():

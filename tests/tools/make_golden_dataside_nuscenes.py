@@ -4,7 +4,12 @@ only):   python tests/tools/make_golden_dataside_nuscenes.py
 A synthetic nuScenes-style tree (cofii2p_amd.synth.make_raw_nuscenes: test/{img,ext,int,pc}/<name>.npy) is written to a temporary
 directory and read back by the reference's own loader (/root/reference/data/nuscenes.py:177-320).  Stand-ins for calls the image lacks:
 cv2.resize -> oracle resize_linear_u8 (parity with cv2 unpinned), open3d.ml KNNSearch -> zeros (KNN is pinned by knn_ref.npz); torchvision
-is an empty stub (unused in 'val' mode).  Everything recorded is produced by the reference's own numpy / torch code."""
+is an empty stub (unused in 'val' mode).  Everything recorded is produced by the reference's own numpy / torch code.
+
+    python tests/tools/make_golden_dataside_nuscenes.py --train    ->  tests/golden/dataside_nuscenes_train_ref.npz
+
+runs the same loader in TRAIN mode (nuscenes.py:232-234 random crop, :249-250 colour jitter); torchvision's ColorJitter is then served by the
+oracle's colour jitter with the frame's drawn parameters (pinned to PIL by tests/test_dataside_cpu.py::test_color_jitter_oracle_equals_pil)."""
 import hashlib
 import os
 import sys
@@ -31,9 +36,23 @@ SAMPLES = ((0, 26000), (1, 15000), (2, 21000))
 
 
 def main():
+    train = "--train" in sys.argv
+    state = {}
     ref_shims.import_reference()
     tv = types.ModuleType("torchvision")
     tv.transforms = types.ModuleType("torchvision.transforms")
+    if train:
+        from PIL import Image
+
+        class ColorJitterStandIn:   # torchvision.transforms.ColorJitter(brightness, contrast, saturation, hue), nuscenes.py:109-117
+            def __init__(self, *ranges):
+                assert tuple(tuple(r) for r in ranges) == ((0.8, 1.2), (0.8, 1.2), (0.8, 1.2), (-0.1, 0.1))
+
+            def __call__(self, pil_img):
+                state["jitter_calls"] = state.get("jitter_calls", 0) + 1
+                return Image.fromarray(D.color_jitter(np.array(pil_img), *D.jitter_params(state["seed"])))
+
+        tv.transforms.ColorJitter = ColorJitterStandIn
     sys.modules["torchvision"], sys.modules["torchvision.transforms"] = tv, tv.transforms
     cv2 = types.ModuleType("cv2")
     cv2.INTER_LINEAR = 1
@@ -55,20 +74,23 @@ def main():
     opt = ref_shims.reference_options("nuscenes")
     out = {}
     with tempfile.TemporaryDirectory() as root:
+        folder = "train" if train else "test"
         for sub in ("img", "ext", "int", "pc"):
-            os.makedirs(os.path.join(root, "test", sub))
+            os.makedirs(os.path.join(root, folder, sub))
         for fid, n in SAMPLES:
             pc4, img, K = synth.make_raw_nuscenes(fid, n)
             name = "%06d.npy" % fid
-            np.save(os.path.join(root, "test", "pc", name), pc4)
-            np.save(os.path.join(root, "test", "img", name), img)
-            np.save(os.path.join(root, "test", "int", name), K)
-            np.save(os.path.join(root, "test", "ext", name), np.eye(4))
+            np.save(os.path.join(root, folder, "pc", name), pc4)
+            np.save(os.path.join(root, folder, "img", name), img)
+            np.save(os.path.join(root, folder, "int", name), K)
+            np.save(os.path.join(root, folder, "ext", name), np.eye(4))
         opt.data_path = root
-        ds = nus.nuscenes_pc_img_dataset(opt, "val")
+        ds = nus.nuscenes_pc_img_dataset(opt, "train" if train else "val")
         assert len(ds) == len(SAMPLES)
         for index, (fid, n) in enumerate(SAMPLES):
+            state["seed"], state["jitter_calls"] = index, 0     # nuscenes.py:179-181: seed = index
             r = ds[index]
+            assert state["jitter_calls"] == (1 if train else 0)
             tag = "i%d_" % index
             out[tag + "frame_points"] = np.array([fid, n])
             out[tag + "valid_kpt"] = np.array(bool(r["valid_kpt"]))
@@ -86,7 +108,7 @@ def main():
             out[tag + "feats_rows"] = dd["feats"].numpy()[::64]          # every 64th row of (num_pc, 4)
             out[tag + "points0_rows"] = dd["points"][0].numpy()[::64]
             print(index, "valid_kpt", bool(r["valid_kpt"]), "kpts", len(out[tag + "pc_kpt_idx"]), "mask", int(out[tag + "coarse_img_mask"].sum()))
-    path = os.path.join(GOLD, "dataside_nuscenes_ref.npz")
+    path = os.path.join(GOLD, "dataside_nuscenes_train_ref.npz" if train else "dataside_nuscenes_ref.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
