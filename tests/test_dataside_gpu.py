@@ -223,6 +223,30 @@ def test_prepared_train_frame_against_oracle(ds):
         assert np.array_equal(out["pc_data_dict"]["points"][4].cpu().numpy(), want["points"][4])
 
 
+@pytest.mark.parametrize("index", (0, 3))
+def test_prepared_train_frame_against_reference_golden(ds, index):
+    """FramePreparer(mode='train') against what the REFERENCE's __getitem__ returned in train mode for the same frame index
+    (tests/tools/make_golden_dataside_train.py: crop, intrinsics, labels exactly; the jittered image by its SHA-256)."""
+    import hashlib
+    from cofii2p_amd import synth
+
+    gold = load_golden("dataside_train_ref.npz")
+    tag = "i%d_" % index
+    seq_i, cam = gold[tag + "frame_cam"]
+    data, img, K = synth.make_raw_scan(int(seq_i))
+    if cam == 3:
+        img = img[:, ::-1].copy()
+    out = ds.FramePreparer(kitti_opt(), DEV, mode="train").prepare(data, img, K, gold[tag + "P_Tr"], index)
+    for k in INT_KEYS:
+        assert np.array_equal(out[k].cpu().numpy(), gold[tag + k]), k
+    assert np.array_equal(out["coarse_img_mask"].cpu().numpy(), gold[tag + "coarse_img_mask"])
+    for k in ("K", "K_4", "P"):
+        assert np.array_equal(out[k].cpu().numpy(), gold[tag + k]), k
+    np.testing.assert_allclose(out["pc_data_dict"]["points"][4].cpu().numpy(), gold[tag + "points4"], rtol=0, atol=2e-5)
+    q = np.rint(out["img"].cpu().numpy() * 255.0).astype(np.uint8)
+    assert hashlib.sha256(np.ascontiguousarray(q).tobytes()).hexdigest() == str(gold[tag + "img_sha256"])
+
+
 def test_prepared_frame_feeds_the_model(ds):
     """Loader output -> CoFiI2P forward, as evaluation/eval_all.py:64-83 consumes a sample (batch of one)."""
     from cofii2p_amd import synth
