@@ -318,6 +318,30 @@ def test_prepared_nuscenes_train_frame_against_oracle(ds):
         assert np.array_equal(out["pc_data_dict"]["points"][4].cpu().numpy(), want["points"][4])
 
 
+@pytest.mark.parametrize("index", (0, 1, 2))
+def test_prepared_nuscenes_train_frame_against_reference_golden(ds, index):
+    """FramePreparer(dataset='nuscenes', mode='train') against the reference's own train-mode __getitem__
+    (tests/tools/make_golden_dataside_nuscenes.py --train), incl. the valid_kpt False sample."""
+    import hashlib
+    from cofii2p_amd import synth
+    from test_dataside_cpu import nuscenes_opt
+
+    gold = load_golden("dataside_nuscenes_train_ref.npz")
+    tag = "i%d_" % index
+    fid, n = gold[tag + "frame_points"]
+    pc4, img, K = synth.make_raw_nuscenes(int(fid), int(n))
+    out = ds.FramePreparer(nuscenes_opt(), DEV, dataset="nuscenes", mode="train").prepare(pc4, img, K, None, index)
+    assert out["valid_kpt"] == bool(gold[tag + "valid_kpt"])
+    for k in INT_KEYS:
+        assert np.array_equal(out[k].cpu().numpy(), gold[tag + k]), k
+    assert np.array_equal(out["coarse_img_mask"].cpu().numpy(), gold[tag + "coarse_img_mask"])
+    for k in ("K", "K_4", "P"):
+        assert np.array_equal(out[k].cpu().numpy(), gold[tag + k]), k
+    np.testing.assert_allclose(out["pc_data_dict"]["points"][4].cpu().numpy(), gold[tag + "points4"], rtol=0, atol=2e-5)
+    q = np.rint(out["img"].cpu().numpy() * 255.0).astype(np.uint8)
+    assert hashlib.sha256(np.ascontiguousarray(q).tobytes()).hexdigest() == str(gold[tag + "img_sha256"])
+
+
 def test_begin_complete_pipeline_equals_prepare(ds):
     """FramePreparer.begin / complete (the voxel grid enqueued ahead, no wait on its count) == prepare, also with two frames interleaved
     on two preparers and the labels deferred."""
