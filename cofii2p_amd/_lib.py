@@ -24,6 +24,21 @@ class NormDesc(ctypes.Structure):
 
 _N = ctypes.POINTER(NormDesc)
 
+
+class TailDesc(ctypes.Structure):
+    """cofi_loftr_tail_desc_t (include/cofi_hip.h): one LoFTR layer tail with its optional fused successors."""
+    _fields_ = [("msg", c_void_p), ("ldm", c_int), ("rows", c_int),
+                ("parts", c_void_p), ("parts_bytes", c_size_t), ("L", c_int), ("S", c_int), ("H", c_int), ("frames", c_int),
+                ("x", c_void_p), ("ldx", c_int), ("planes", c_int),
+                ("wm", c_void_p), ("w0", c_void_p), ("w2", c_void_p),
+                ("n1_gamma", c_void_p), ("n1_beta", c_void_p), ("n2_gamma", c_void_p), ("n2_beta", c_void_p), ("eps", c_float),
+                ("out", c_void_p), ("ldo", c_int),
+                ("proj_n", c_int * 2), ("proj_w", c_void_p * 2), ("proj_y", c_void_p * 2), ("proj_ldy", c_int * 2), ("proj_part", c_void_p * 2),
+                ("out_l2", c_void_p), ("ld_l2", c_int), ("out_l2t", c_void_p), ("ld_l2t", c_int)]
+
+
+_T = ctypes.POINTER(TailDesc)
+
 # name -> (restype, argtypes); mirrors include/cofi_hip.h declaration by declaration
 SIGNATURES = {
     "cofi_abi_version": (_I, []),
@@ -61,6 +76,7 @@ SIGNATURES = {
     "cofi_layer_norm": (_I, [_P, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _I, _P]),
     "cofi_layer_norm_act": (_I, [_P, _I, _I, _I, _P, _P, _F, _F, _P, _I, _I, _P, _I, _P]),
     "cofi_loftr_tail_bf16x3": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
+    "cofi_loftr_tail": (_I, [_T, _P]),
     "cofi_loftr_tail_parts_bf16x3": (_I, [_P, _Z, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P]),
     "cofi_attention_workspace": (_Z, [_I, _I, _I, _I, _I]),
     "cofi_attention_parts": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _F, _I, _I, _I, _I, _F, _I, _P, _Z, _P]),

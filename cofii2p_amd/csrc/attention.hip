@@ -367,7 +367,11 @@ extern "C" int cofi_attention_parts(const float *Q, int ldq, const float *K, int
     if (q_colscale && q_colpart) return COFI_EINVAL;
     if (q_colpart) {
         // the partials' 64-row slabs must be whole per frame
-        if (q_nslab <= 0 || (q_nslab % frames) || q_ncols < H * D || q_nslab / frames != cofi_cdiv(L, 64) || (frames > 1 && (L % 64))) return COFI_EINVAL;
+        // (64-row slabs of the GEMM epilogues, or the 32-row slabs of cofi_loftr_tail's fused projections: the fold only sums them)
+        if (q_nslab <= 0 || (q_nslab % frames) || q_ncols < H * D) return COFI_EINVAL;
+        const bool s64 = q_nslab / frames == cofi_cdiv(L, 64) && (frames == 1 || L % 64 == 0);
+        const bool s32 = q_nslab / frames == cofi_cdiv(L, 32) && (frames == 1 || L % 32 == 0);
+        if (!s64 && !s32) return COFI_EINVAL;
     }
     if (!parts || ((uintptr_t)parts & 15) || parts_bytes < attn_layout(L, S, H, frames).bytes) return COFI_EWORKSPACE;
     AttnArgs a{Q, K, V, q_colscale, (float *)parts, ldq, ldk, ldv, L, S, H, scale * 1.4426950408889634f, q_colpart,

@@ -107,7 +107,7 @@ class CoFiI2P(nn.Module):
         self._packed_key = None
         self._replayed_steps = 0   # optimisation steps replayed from a hipGraph (train_step.GraphedTrainStep): they do not bump version counters
         self._trained = False   # set by the first differentiable forward: from then on _pack() watches the parameters' version counters
-        self.compute_unused_image_maps = True  # layer3/layer4/avg-pool of the ResNet (network.py:87-89)
+        self.compute_unused_image_maps = os.environ.get("COFI_DEAD_MAPS", "1") != "0"  # layer3/layer4/avg-pool of the ResNet (network.py:87-89): read by nothing
         self._use_graphs = False
         self._auto_graphs = bool(self.DEFAULT_GRAPHS)
         self._graphs = {}
@@ -266,13 +266,22 @@ class CoFiI2P(nn.Module):
             up2 = ops.l2norm_rows(up2_raw)  # (B*H2*W2, C2) pixel-major fine image descriptors
 
         # ---- transformer (network.py:113-115)
-        tok_img, tok_pc = transformer.run_transformer(self._layers, LAYER_KINDS, ts, N_HEAD, frames=B)
+        # the descriptors' L2 normalisation (network.py:125-126) and, for a single frame, their channel-major output layout are written
+        # by the last layer's tails when the fused chain runs (transformer._run_chain)
+        pc_desc_tok = torch.empty((B * N4, C), dtype=torch.float32, device=dev)   # token-major copies for the similarity GEMM
+        img_desc_tok = torch.empty((B * T_img, C), dtype=torch.float32, device=dev)
+        img_desc_t = torch.empty((C, T_img), dtype=torch.float32, device=dev) if B == 1 else None
+        pc_desc_t = torch.empty((C, N4), dtype=torch.float32, device=dev) if B == 1 else None
+        tok_img, tok_pc, l2_done = transformer.run_transformer(self._layers, LAYER_KINDS, ts, N_HEAD, frames=B,
+                                                               l2=(img_desc_tok, pc_desc_tok, img_desc_t, pc_desc_t))
 
         # ---- scores + coarse descriptors (network.py:123-126)
         pc_score = self._score_head(P, "pc_score_layer", tok_pc, B)  # (B*N4,1)
         img_score = self._score_head(P, "img_score_layer", tok_img, B)  # (B*T,1)
-        pc_desc_tok = ops.l2norm_rows(tok_pc)  # (B*N4,128) token-major copy for the similarity GEMM
-        img_desc_tok = ops.l2norm_rows(tok_img)
+        if not l2_done:
+            ops.l2norm_rows(tok_pc, out=pc_desc_tok)
+            ops.l2norm_rows(tok_img, out=img_desc_tok)
+            img_desc_t = pc_desc_t = None
         br_up.join(up2)
         if taps is not None:
             taps.update(up2=up2, fine_pc=fine_pc, tok_img_out=tok_img, tok_pc_out=tok_pc)
@@ -281,7 +290,8 @@ class CoFiI2P(nn.Module):
         outs = []
         for f in range(B):  # per-frame tail: output layouts + matching (small kernels)
             pdt, idt = pc_desc_tok[f * N4:(f + 1) * N4], img_desc_tok[f * T_img:(f + 1) * T_img]
-            o = {"img_desc": ops.transpose(idt).reshape(1, C, H8, W8), "pc_desc": ops.transpose(pdt),
+            o = {"img_desc": (ops.transpose(idt) if img_desc_t is None else img_desc_t).reshape(1, C, H8, W8),
+                 "pc_desc": ops.transpose(pdt) if pc_desc_t is None else pc_desc_t,
                  "img_score": img_score[f * T_img:(f + 1) * T_img].reshape(1, 1, H8, W8), "pc_score": pc_score[f * N4:(f + 1) * N4].reshape(1, 1, N4)}
             fpc = fine_pc[f * N1:(f + 1) * N1]
             up2_f = up2[f * P2:(f + 1) * P2]
@@ -337,7 +347,7 @@ class CoFiI2P(nn.Module):
         tensors = list(points) + list(neighbors) + list(subsampling) + list(upsampling) + order + [feats, img, kpt, inl]
         # everything a captured launch sequence depends on besides the tensor signature: arithmetic, optional branches
         key = ("stable" if inputs_stable else "copy", mode, str(img.device), slot, branch_mask, ops.GEMM_MODE, self.compute_unused_image_maps,
-               transformer.JOINT_SELF, kpfpn.FUSED_KPCONV, kpfpn.AGG_PLANES) + tuple(sig(t) for t in tensors)
+               transformer.JOINT_SELF, transformer.FUSED_CHAIN, kpfpn.FUSED_KPCONV, kpfpn.AGG_PLANES) + tuple(sig(t) for t in tensors)
         saved_mask, saved_slot = ops.BRANCH_MASK, ops.Workspace.slot
         ops.set_workspace_slot(slot)
         ops.BRANCH_MASK = branch_mask  # which intra-frame forks the capture records

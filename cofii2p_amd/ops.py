@@ -806,24 +806,66 @@ def split_bf16(w: torch.Tensor):
     return hi.contiguous().view(torch.int16), lo.contiguous().view(torch.int16)
 
 
-def loftr_tail(msg, x, w, out, eps: float = 1e-5):
-    """out = x + LN2(relu([x | LN1(msg Wm^T)] W0^T) W2^T) in one kernel; `w` holds the pre-split planes.  msg: the attention
-    output as a matrix or as AttnParts (merged by the kernel's loader)."""
+def split_planes(w: torch.Tensor, n: int) -> torch.Tensor:
+    """fp32 (N, K) -> (n, N, K) bf16 planes as int16: plane 0 = bf16(w) (RNE), every further plane = bf16 of what the planes before it
+    left over (n = 2: the hi / lo pair of the 3-term split, n = 3: hi / mid / lo = all 24 mantissa bits, the 6-term split)."""
+    r = w.to(torch.float32)
+    out = []
+    for _ in range(n):
+        p = r.to(torch.bfloat16)
+        out.append(p.view(torch.int16))
+        r = r - p.to(torch.float32)
+    return torch.stack(out).contiguous()
+
+
+def tail_planes() -> int:
+    """bf16 planes per operand of the fused layer tail for the current arithmetic; 0 = not served (exact fp32)."""
+    return {"bf16x3": 2, "bf16x6": 3}.get(GEMM_MODE, 0)
+
+
+def loftr_tail(msg, x, w, out, eps: float = 1e-5, proj=(), out_l2=None, out_l2t=None):
+    """out = x + LN2(relu([x | LN1(msg Wm^T)] W0^T) W2^T) in one kernel (cofi_loftr_tail); `w` holds the pre-split planes
+    ("merge.p2" / ".p3", ...).  msg: the attention output as a matrix or as AttnParts (merged by the kernel's loader).
+    proj: up to two (planes (p, N, 128) int16, y (rows, N) view, part (rows / 32, N, 2) or None) - projections of `out` computed in the
+    same launch (the next layers' q / k / v); out_l2 / out_l2t: F.normalize(out, dim=1) token-major / channel-major."""
     lib = _lib.load()
     _mat(x, "x"), _mat(out, "out")
+    npl = tail_planes()
+    if npl == 0:
+        raise _lib.CofiError("loftr_tail serves the bf16x3 / bf16x6 arithmetics")
+    sfx = ".p%d" % npl
+    d = _lib.TailDesc()
+    keep = []   # tensors whose addresses the descriptor holds (alive until the launch is enqueued)
     if isinstance(msg, AttnParts):
-        rc = lib.cofi_loftr_tail_parts_bf16x3(_p(msg.buf), msg.buf.numel(), msg.L, msg.S, msg.H, msg.frames, _p(x), _ld(x), _p(w["merge.hi"]),
-                                              _p(w["merge.lo"]), _p(w["norm1.weight"]), _p(w["norm1.bias"]), _p(w["mlp.0.hi"]), _p(w["mlp.0.lo"]),
-                                              _p(w["mlp.2.hi"]), _p(w["mlp.2.lo"]), _p(w["norm2.weight"]), _p(w["norm2.bias"]), eps, _p(out),
-                                              _ld(out), _stream())
-        _lib.check(rc, "cofi_loftr_tail_parts_bf16x3")
-        return out
-    _mat(msg, "msg")
-    L = msg.shape[0]
-    rc = lib.cofi_loftr_tail_bf16x3(_p(msg), _ld(msg), _p(x), _ld(x), _p(w["merge.hi"]), _p(w["merge.lo"]), _p(w["norm1.weight"]),
-                                    _p(w["norm1.bias"]), _p(w["mlp.0.hi"]), _p(w["mlp.0.lo"]), _p(w["mlp.2.hi"]), _p(w["mlp.2.lo"]),
-                                    _p(w["norm2.weight"]), _p(w["norm2.bias"]), eps, _p(out), _ld(out), L, _stream())
-    _lib.check(rc, "cofi_loftr_tail_bf16x3")
+        d.parts, d.parts_bytes, d.L, d.S, d.H, d.frames = msg.buf.data_ptr(), msg.buf.numel(), msg.L, msg.S, msg.H, msg.frames
+    else:
+        _mat(msg, "msg")
+        d.msg, d.ldm, d.rows, d.frames = msg.data_ptr(), _ld(msg), msg.shape[0], 1
+    d.x, d.ldx, d.planes = x.data_ptr(), _ld(x), npl
+    d.wm, d.w0, d.w2 = w["merge" + sfx].data_ptr(), w["mlp.0" + sfx].data_ptr(), w["mlp.2" + sfx].data_ptr()
+    d.n1_gamma, d.n1_beta, d.n2_gamma, d.n2_beta = (w[k].data_ptr() for k in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"))
+    d.eps, d.out, d.ldo = eps, out.data_ptr(), _ld(out)
+    if len(proj) > 2:
+        raise _lib.CofiError("loftr_tail: at most two projection segments")
+    for i, (pw, y, part) in enumerate(proj):
+        N = pw.shape[1]
+        if pw.dtype != torch.int16 or pw.shape[0] != npl or pw.shape[2] != 128 or not pw.is_contiguous():
+            raise _lib.CofiError("loftr_tail: projection weights must be (%d, N, 128) int16 planes" % npl)
+        _mat(y, "proj_y")
+        if y.shape[1] != N or y.shape[0] != out.shape[0]:
+            raise _lib.CofiError("loftr_tail: projection output must be (rows, %d)" % N)
+        if part is not None and (tuple(part.shape) != ((out.shape[0] + 31) // 32, N, 2) or not part.is_contiguous() or part.dtype != torch.float32):
+            raise _lib.CofiError("loftr_tail: projection partials must be a contiguous (rows / 32, N, 2) float32 tensor")
+        d.proj_n[i], d.proj_w[i], d.proj_y[i], d.proj_ldy[i] = N, pw.data_ptr(), y.data_ptr(), _ld(y)
+        d.proj_part[i] = None if part is None else part.data_ptr()
+        keep += [pw, y, part]
+    if out_l2 is not None:
+        _mat(out_l2, "out_l2")
+        d.out_l2, d.ld_l2 = out_l2.data_ptr(), _ld(out_l2)
+    if out_l2t is not None:
+        _mat(out_l2t, "out_l2t")
+        d.out_l2t, d.ld_l2t = out_l2t.data_ptr(), _ld(out_l2t)
+    _lib.check(lib.cofi_loftr_tail(ctypes.byref(d), _stream()), "cofi_loftr_tail")
     return out
 
 

@@ -17,12 +17,11 @@ JOINT_SELF = True   # the four self layers run ONCE over [image | point] tokens 
 
 def pack_layer(sd: Dict[str, torch.Tensor], p: str) -> Dict[str, torch.Tensor]:
     """Fused projection weights of one LoFTREncoderLayer: [Wq;Wk;Wv] (3C,C) for self layers,
-    [Wk;Wv] for cross layers; everything else is used in place (nn.Linear layout == GEMM layout)."""
+    [Wk;Wv] for cross layers; everything else is used in place (nn.Linear layout == GEMM layout).  The weights the fused layer tail
+    reads (merge, MLP, and the stacked projections a PREVIOUS layer's tail computes for this one) also as bf16 planes:
+    ".p2" = (2, N, K) hi / lo (3-term split), ".p3" = (3, N, K) hi / mid / lo (6-term split)."""
     wq, wk, wv = sd[p + "q_proj.weight"], sd[p + "k_proj.weight"], sd[p + "v_proj.weight"]
-    out = {}
-    for name in ("merge", "mlp.0", "mlp.2"):  # bf16 hi/lo planes for the fused layer tail
-        out[name + ".hi"], out[name + ".lo"] = ops.split_bf16(sd[p + name + ".weight"])
-    out.update({
+    out = {
         "q_proj.weight": wq.contiguous(),
         "kv.weight": torch.cat([wk, wv], 0).contiguous(),
         "qkv.weight": torch.cat([wq, wk, wv], 0).contiguous(),
@@ -31,7 +30,10 @@ def pack_layer(sd: Dict[str, torch.Tensor], p: str) -> Dict[str, torch.Tensor]:
         "mlp.2.weight": sd[p + "mlp.2.weight"].contiguous(),
         "norm1.weight": sd[p + "norm1.weight"].contiguous(), "norm1.bias": sd[p + "norm1.bias"].contiguous(),
         "norm2.weight": sd[p + "norm2.weight"].contiguous(), "norm2.bias": sd[p + "norm2.bias"].contiguous(),
-    })
+    }
+    for name in ("merge", "mlp.0", "mlp.2", "qkv", "kv"):
+        for n in (2, 3):
+            out["%s.p%d" % (name, n)] = ops.split_planes(out[name + ".weight"], n)
     return out
 
 
@@ -50,7 +52,7 @@ def _layer(w, xcat: torch.Tensor, src: torch.Tensor, out: torch.Tensor, self_att
         kv = ops.gemm(src, w["kv.weight"])
         k, v = kv[:, :C], kv[:, C:]
     # the attention kernel folds the partials into the per-frame token-axis norm of Q itself
-    fused_tail = ops.GEMM_MODE == "bf16x3" and C == 128
+    fused_tail = ops.tail_planes() > 0 and C == 128
     rows_q = x.shape[0] // frames
     if frames > 1 and rows_q % 64:   # the projection's 64-row statistics slabs straddle frames: explicit per-frame column norms
         qs = torch.stack([ops.col_inv_norm(q[f * rows_q:(f + 1) * rows_q]) for f in range(frames)])
@@ -102,10 +104,74 @@ class TokenStreams:
         return self.pc[self.cur_pc][:, : self.C]
 
 
-def run_transformer(layers, kinds, ts: TokenStreams, nhead: int = 4, frames: int = 1):
+FUSED_CHAIN = os.environ.get("COFI_TRANSFORMER_CHAIN", "1") != "0"
+
+
+def _chain_ok(ts: "TokenStreams", kinds, frames: int) -> bool:
+    """The fused chain (every tail also computes the projections of the layers that follow) serves the reference's configuration:
+    d_model 128, alternating self / cross layers starting with a self layer, equally many image and point tokens per frame in
+    multiples of 64 (the first projection's statistics slabs; the tails work on 32-row tiles - KITTI: 1280 / 1280), one of the bf16-split arithmetics."""
+    L = ts.img[0].shape[0] // frames
+    return (FUSED_CHAIN and JOINT_SELF and ts.C == 128 and ops.tail_planes() > 0 and ts.joint and L % 64 == 0 and len(kinds) >= 2
+            and all(k == ("self", "cross")[i & 1] for i, k in enumerate(kinds)))
+
+
+def _run_chain(layers, kinds, ts: "TokenStreams", nhead: int, frames: int, l2=None):
+    """transformer.py:85-104 as 1 + 3 launches per layer pair and direction less than the layer-by-layer form: ONE projection GEMM in
+    front of layer 0, then per self layer attention + tail, per cross layer (attention + tail) x 2 - every tail computes, from its
+    32-row tile of `out` still in LDS, the q / k / v the following attention calls read (and the column partials of q for the token-axis
+    norm).  l2 = (img_l2, pc_l2, img_l2t, pc_l2t): F.normalize(dim=1) of the last layer's outputs written by its tails (entries may be None)."""
+    C, sfx = ts.C, ".p%d" % ops.tail_planes()
+    T = ts.img[0].shape[0]            # rows per stream (frames * tokens)
+    dev = ts.both[0].device
+    qkv = [torch.empty((2 * T, 3 * C), dtype=torch.float32, device=dev) for _ in range(2)]
+    part = [torch.empty((2 * T // 32, 3 * C, 2), dtype=torch.float32, device=dev) for _ in range(2)]
+    kv2 = torch.empty((T, 2 * C), dtype=torch.float32, device=dev)
+    ns = T // 32                      # 32-row slabs per stream
+    cur = 0
+    # layer 0 (self): the only stand-alone projection
+    xb = ts.both[ts.cur_img]
+    _, part0 = ops.gemm_colstats(xb[:, :C], layers[0]["qkv.weight"], out=qkv[cur])
+    cur_part = part0                  # 64-row slabs from the GEMM epilogue; the tails write 32-row slabs into part[...]
+    nl = len(kinds)
+    for li, (w, kind) in enumerate(zip(layers, kinds)):
+        nxt = layers[li + 1] if li + 1 < nl else None
+        q_all = qkv[cur]
+        if kind == "self":
+            xb, ob = ts.both[ts.cur_img], ts.both[ts.cur_img ^ 1]
+            msg = ops.attention(q_all[:, :C], q_all[:, C:2 * C], q_all[:, 2 * C:], q_colpart=cur_part, nhead=nhead, frames=2 * frames, parts=True)
+            proj = [] if nxt is None else [(nxt["qkv" + sfx], qkv[cur ^ 1], part[cur ^ 1])]
+            ops.loftr_tail(msg, xb[:, :C], w, ob[:, :C], proj=proj)
+            cur, cur_part = cur ^ 1, part[cur ^ 1]
+        else:
+            xi, xp = ts.img[ts.cur_img], ts.pc[ts.cur_pc]
+            oi, op = ts.img[ts.cur_img ^ 1], ts.pc[ts.cur_pc ^ 1]
+            half = cur_part.shape[0] // 2
+            last = nxt is None
+            # image tokens attend to the point tokens (transformer.py:99): q of the image rows, k / v of the point rows
+            msg = ops.attention(q_all[:T, :C], q_all[T:, C:2 * C], q_all[T:, 2 * C:], q_colpart=cur_part[:half], nhead=nhead, frames=frames, parts=True)
+            proj = [(w["kv" + sfx], kv2, None)]
+            if not last:
+                proj.append((nxt["qkv" + sfx], qkv[cur ^ 1][:T], part[cur ^ 1][:ns]))
+            ops.loftr_tail(msg, xi[:, :C], w, oi[:, :C], proj=proj, out_l2=l2[0] if (last and l2) else None, out_l2t=l2[2] if (last and l2) else None)
+            # point tokens attend to the UPDATED image tokens (transformer.py:100): k / v from the image tail's projection
+            msg = ops.attention(q_all[T:, :C], kv2[:, :C], kv2[:, C:], q_colpart=cur_part[half:], nhead=nhead, frames=frames, parts=True)
+            proj = [] if last else [(nxt["qkv" + sfx], qkv[cur ^ 1][T:], part[cur ^ 1][ns:])]
+            ops.loftr_tail(msg, xp[:, :C], w, op[:, :C], proj=proj, out_l2=l2[1] if (last and l2) else None, out_l2t=l2[3] if (last and l2) else None)
+            cur, cur_part = cur ^ 1, part[cur ^ 1]
+        ts.cur_img ^= 1
+        ts.cur_pc ^= 1
+    return ts.img_tokens(), ts.pc_tokens()
+
+
+def run_transformer(layers, kinds, ts: TokenStreams, nhead: int = 4, frames: int = 1, l2=None):
     """transformer.py:85-104.  Self layers share weights between the streams; in a cross layer the
-    point stream attends to the ALREADY UPDATED image stream (:99-100)."""
+    point stream attends to the ALREADY UPDATED image stream (:99-100).  l2 (optional, the fused chain only - see _run_chain):
+    destinations for the L2-normalised outputs; returns (img tokens, pc tokens, l2 written?)."""
     C = ts.C
+    if _chain_ok(ts, kinds, frames):
+        ti, tp = _run_chain(layers, kinds, ts, nhead, frames, l2 if kinds[-1] == "cross" else None)
+        return ti, tp, (l2 is not None and kinds[-1] == "cross")
     for w, kind in zip(layers, kinds):
         xi, xp = ts.img[ts.cur_img], ts.pc[ts.cur_pc]
         oi, op = ts.img[ts.cur_img ^ 1], ts.pc[ts.cur_pc ^ 1]
@@ -123,4 +189,4 @@ def run_transformer(layers, kinds, ts: TokenStreams, nhead: int = 4, frames: int
             _layer(w, xp, oi[:, :C], op[:, :C], False, nhead, frames)
         ts.cur_img ^= 1
         ts.cur_pc ^= 1
-    return ts.img_tokens(), ts.pc_tokens()
+    return ts.img_tokens(), ts.pc_tokens(), False

@@ -291,7 +291,7 @@ int cofi_layer_norm(const float *x, int ldx, int M, int C, const float *gamma, c
  *   cofi_attention_parts      the attention kernel: fills `parts`.  Exactly one of q_colscale / q_colpart may be given;
  *                             q_colpart (q_nslab, q_ncols, 2) = the column partials of the projection that produced Q
  *                             (cofi_gemm_f32_colstats, Q = its first H*D columns; q_nslab = frames * ceil(L/64), L % 64 == 0
- *                             when frames > 1): the token-axis norm of Q is then folded inside the kernel
+ *                             when frames > 1 - or the 32-row slabs cofi_loftr_tail writes: frames * ceil(L/32), L % 32 == 0): the token-axis norm of Q is then folded inside the kernel
  *   cofi_attention_merge      combines the slots of every query row into O (fixed order)
  *   cofi_attention_fwd, cofi_attention_fwd_colpart   = parts + merge
  * cofi_loftr_tail_parts_bf16x3 (K7) consumes `parts` directly: no merge launch, O never exists in memory.
@@ -327,6 +327,36 @@ int cofi_loftr_tail_parts_bf16x3(const void *parts, size_t parts_bytes, int L, i
                                  const uint16_t *wm_hi, const uint16_t *wm_lo, const float *n1_gamma, const float *n1_beta,
                                  const uint16_t *w0_hi, const uint16_t *w0_lo, const uint16_t *w2_hi, const uint16_t *w2_lo,
                                  const float *n2_gamma, const float *n2_beta, float eps, float *out, int ldo, cofi_stream_t stream);
+
+/* The general form of K7 (both arithmetics, optional fused successors).  One launch computes the layer tail and, while the 32-row tile
+ * of `out` is still in LDS, what the NEXT layers read first:
+ *   proj s (s < 2, proj_n[s] in {0, 128, 256, 384}):  proj_y[s] (rows, proj_n[s]) = out @ proj_w[s]^T - stacked [Wq; Wk; Wv] blocks of
+ *       the following layer(s) (model/transformer/transformer.py:45-47), weights pre-split like wm / w0 / w2; proj_part[s] (optional,
+ *       (rows / 32, proj_n[s], 2)) = per 32-row slab and column {sum, sum of squares} of proj_y[s]: the table cofi_attention_parts
+ *       takes as q_colpart (token-axis norm of Q, transformer.py:53); rows per frame % 32 == 0 then.
+ *   out_l2 (rows, 128) ld_l2 and / or out_l2t (128, rows) ld_l2t (optional) = F.normalize(out, dim=1), token-major / channel-major
+ *       (model/network.py:125-126 after the last layer).
+ * planes = 2: COFI_GEMM_BF16X3 arithmetic, weights as (2, N, K) bf16 planes [hi | lo]; planes = 3: COFI_GEMM_BF16X6 (fp32-grade),
+ * (3, N, K) planes [hi | mid | lo], hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid).  wm (p,128,128), w0 (p,256,256),
+ * w2 (p,128,256), proj_w[s] (p, proj_n[s], 128).  Exactly one of msg (rows, 128) ldm / parts (cofi_attention_parts slot table over
+ * (L, S, H, frames): rows = L * frames) is given. */
+typedef struct cofi_loftr_tail_desc {
+    const float *msg; int ldm; int rows;
+    const void *parts; size_t parts_bytes; int L, S, H, frames;
+    const float *x; int ldx;
+    int planes;
+    const uint16_t *wm, *w0, *w2;
+    const float *n1_gamma, *n1_beta, *n2_gamma, *n2_beta;
+    float eps;
+    float *out; int ldo;
+    int proj_n[2];
+    const uint16_t *proj_w[2];
+    float *proj_y[2]; int proj_ldy[2];
+    float *proj_part[2];
+    float *out_l2; int ld_l2;
+    float *out_l2t; int ld_l2t;
+} cofi_loftr_tail_desc_t;
+int cofi_loftr_tail(const cofi_loftr_tail_desc_t *desc, cofi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K8 / glue.

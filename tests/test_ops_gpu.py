@@ -840,18 +840,97 @@ def test_statistics_slabs_must_not_straddle_frames(ops):
     close(st2[:, :, 0], ref.mean((1, 3)), 1e-4)
 
 
-def test_loftr_layer_fused_tail_bf16x3(ops, mg, monkeypatch):
-    """the one-kernel layer tail (merge+LN1+MLP+LN2+residual) against the reference layer output"""
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-4), ("bf16x6", 2e-5)])
+def test_loftr_layer_fused_tail(ops, mg, monkeypatch, mode, tol):
+    """the one-kernel layer tail (merge+LN1+MLP+LN2+residual, cofi_loftr_tail) against the reference layer output, in both bf16-split
+    arithmetics (2 / 3 planes per operand)"""
     from cofii2p_amd.transformer import loftr_layer
 
-    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x3")
+    monkeypatch.setattr(ops, "GEMM_MODE", mode)
     w = {k[len("lay_w_"):]: G(mg[k]) for k in mg.files if k.startswith("lay_w_")}
     out = loftr_layer(w, G(mg["lay_x"]), G(mg["lay_src"]))  # L = 48: exercises the row tail of the 32-row tiles
-    close(out, mg["lay_out"], 1e-4)
+    close(out, mg["lay_out"], tol)
     g = torch.Generator().manual_seed(8)
     x, src = torch.randn(1280, 128, generator=g), torch.randn(300, 128, generator=g)
     sd = {k: v.cpu() for k, v in w.items()}
-    close(loftr_layer(w, G(x), G(src)), O.loftr_layer({"l." + k: v for k, v in sd.items()}, "l.", x, src), 1e-4)
+    close(loftr_layer(w, G(x), G(src)), O.loftr_layer({"l." + k: v for k, v in sd.items()}, "l.", x, src), tol)
+
+
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 2e-4), ("bf16x6", 2e-5)])
+def test_loftr_tail_fused_successors(ops, monkeypatch, mode, tol):
+    """cofi_loftr_tail with its optional successors: two projection segments of `out` (+ the 32-row column partials the attention
+    kernel folds into the token-axis Q norm) and F.normalize(out, dim=1) token- and channel-major, against the same launch without
+    them + fp64 torch; rows = 200: a partial last tile"""
+    from cofii2p_amd.transformer import pack_layer
+
+    monkeypatch.setattr(ops, "GEMM_MODE", mode)
+    g = torch.Generator().manual_seed(21)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    sd = {"q_proj.weight": rn(128, 128) / 11, "k_proj.weight": rn(128, 128) / 11, "v_proj.weight": rn(128, 128) / 11, "merge.weight": rn(128, 128) / 11,
+          "mlp.0.weight": rn(256, 256) / 16, "mlp.2.weight": rn(128, 256) / 16, "norm1.weight": 1 + 0.1 * rn(128), "norm1.bias": 0.1 * rn(128),
+          "norm2.weight": 1 + 0.1 * rn(128), "norm2.bias": 0.1 * rn(128)}
+    w = pack_layer({k: G(v) for k, v in sd.items()}, "")
+    for rows in (200, 256):
+        msg, x = G(rn(rows, 128)), G(rn(rows, 128))
+        base = ops.loftr_tail(msg, x, w, torch.empty_like(x))
+        sfx = ".p%d" % ops.tail_planes()
+        y0, y1 = torch.empty((rows, 256), device=DEV), torch.empty((rows, 400), device=DEV)[:, 8:392]   # a strided destination
+        part = torch.empty(((rows + 31) // 32, 384, 2), device=DEV) if rows % 32 == 0 else None
+        l2, l2t = torch.empty((rows, 128), device=DEV), torch.empty((128, rows), device=DEV)
+        out = ops.loftr_tail(msg, x, w, torch.empty_like(x), proj=[(w["kv" + sfx], y0, None), (w["qkv" + sfx], y1, part)], out_l2=l2, out_l2t=l2t)
+        assert torch.equal(out, base)
+        o64 = out.double().cpu()
+        close(y0, (o64 @ torch.cat([sd["k_proj.weight"], sd["v_proj.weight"]]).double().t()).float(), tol)
+        ref1 = o64 @ torch.cat([sd["q_proj.weight"], sd["k_proj.weight"], sd["v_proj.weight"]]).double().t()
+        close(y1, ref1.float(), tol)
+        assert torch.equal(l2, ops.l2norm_rows(out)) and torch.equal(l2t, l2.t())
+        if part is not None:
+            yb = y1.double().cpu().reshape(rows // 32, 32, 384)
+            close(part[:, :, 0], yb.sum(1).float(), 1e-4)
+            close(part[:, :, 1], (yb * yb).sum(1).float(), 1e-4)
+
+
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 3e-4), ("bf16x6", 3e-5)])
+@pytest.mark.parametrize("frames,L", [(1, 128), (2, 192)])
+def test_transformer_fused_chain(ops, monkeypatch, mode, tol, frames, L):
+    """the whole I2P transformer (transformer.py:85-104) as the fused chain - every tail computes the q / k / v of the layers that
+    follow, the last tails the normalised descriptors - against the CPU oracle and against the layer-by-layer form"""
+    from cofii2p_amd import transformer as T
+    from cofii2p_amd.spec import LAYER_KINDS, N_LAYERS
+
+    monkeypatch.setattr(ops, "GEMM_MODE", mode)
+    g = torch.Generator().manual_seed(5 + L)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    sd = {}
+    for l in range(N_LAYERS):
+        p = "transformer.layers.%d." % l
+        for n in ("q_proj", "k_proj", "v_proj", "merge"):
+            sd[p + n + ".weight"] = rn(128, 128) / 11
+        sd[p + "mlp.0.weight"], sd[p + "mlp.2.weight"] = rn(256, 256) / 16, rn(128, 256) / 16
+        for n in ("norm1", "norm2"):
+            sd[p + n + ".weight"], sd[p + n + ".bias"] = 1 + 0.1 * rn(128), 0.1 * rn(128)
+    layers = [T.pack_layer({k: G(v) for k, v in sd.items()}, "transformer.layers.%d." % l) for l in range(N_LAYERS)]
+    xi, xp = rn(frames * L, 128), rn(frames * L, 128)
+
+    def run(chain):
+        monkeypatch.setattr(T, "FUSED_CHAIN", chain)
+        ts = T.TokenStreams(frames * L, frames * L, 128, torch.device(DEV))
+        ts.img[0][:, :128].copy_(G(xi)), ts.pc[0][:, :128].copy_(G(xp))
+        l2 = (torch.empty((frames * L, 128), device=DEV), torch.empty((frames * L, 128), device=DEV),
+              torch.empty((128, L), device=DEV) if frames == 1 else None, torch.empty((128, L), device=DEV) if frames == 1 else None)
+        ti, tp, done = T.run_transformer(layers, LAYER_KINDS, ts, 4, frames=frames, l2=l2)
+        assert done == chain
+        return ti.clone(), tp.clone(), l2
+
+    ci, cp, l2 = run(True)
+    pi, pp, _ = run(False)
+    close(ci, pi, tol), close(cp, pp, tol)
+    for f in range(frames):
+        ri, rp = O.transformer(sd, xi[f * L:(f + 1) * L], xp[f * L:(f + 1) * L])
+        close(ci[f * L:(f + 1) * L], ri, tol), close(cp[f * L:(f + 1) * L], rp, tol)
+    assert torch.equal(l2[0], ops.l2norm_rows(ci)) and torch.equal(l2[1], ops.l2norm_rows(cp))
+    if frames == 1:
+        assert torch.equal(l2[2], l2[0].t()) and torch.equal(l2[3], l2[1].t())
 
 
 def test_workspace_growth_keeps_captured_addresses(ops):
