@@ -86,6 +86,7 @@ SIGNATURES = {
     "cofi_col_inv_norm": (_I, [_P, _I, _I, _I, _F, _P, _P]),
     "cofi_pos_sine": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _P, _I, _P]),
     "cofi_l2norm_rows": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
+    "cofi_l2norm_rows2": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P]),
     "cofi_transpose": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "cofi_col_mean": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "cofi_conv2d_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _Z, _I, _P]),
@@ -122,6 +123,7 @@ SIGNATURES = {
     "cofi_attention_bwd_workspace": (_Z, [_I, _I]),
     "cofi_attention_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _I, _P, _I, _P, _I, _P, _Z, _P]),
     "cofi_pnp_ransac": (_I, [_P, _P, _P, _I, _F, _F, _F, _F, _I, _F, ctypes.c_uint, _I, _P, _Z, _P, _P, _P, _P]),
+    "cofi_match_finish": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P, _I, _F, _P, _I, _P, _P, _P, _I, _P, _P, _P]),
     "cofi_fine_match": (_I, [_P, _P, _I, _I, _P, _I, _F, _P, _I, _P, _P, _P]),
     "cofi_kpconv_fused_slab_rows": (_I, [_I, _I, _I]),
     "cofi_kpconv_fused": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _F, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P, _P]),

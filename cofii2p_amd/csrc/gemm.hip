@@ -51,6 +51,7 @@ struct GemmArgs {
     int cv_Pout;  // output pixels per frame (stack mode: GEMM row m is frame m / cv_Pout, pixel m % cv_Pout)
     int xcd;      // 0: hardware tile order; 1 + log2(gridDim.x): XCD-contiguous tile order (gemm_block_id)
     unsigned xcd_rcp_gy;
+    int l2n;          // COFI_GEMM_L2NORM: rows are L2-normalised after bias / residual / activation (a tile spans the whole row, N <= 128)
     int act_col0;     // the activation applies to output columns >= act_col0 only (two layers sharing one A operand: [skip | conv1])
     int stat_shift;   // colpart holds one entry per 2^stat_shift adjacent columns: (nslab, N >> stat_shift, 2)
     // pending normalisation of the A operand (stat_fold.h): the loader applies  a -> leaky(a * sc[c] + sh[c])  to every element
@@ -230,6 +231,16 @@ __device__ __forceinline__ void rowwise_epilogue(const GemmArgs &g, const float 
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[p][e] = apply_act(v[p][e] + rs[p][e], col + e >= g.act_col0 ? g.act : COFI_ACT_NONE);  // residual before the activation
+            if (g.l2n) {   // F.normalize(row, dim = 1): x / max(|x|, 1e-12); the TPR threads of a row are adjacent lanes
+                float q = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q += (col + e < g.N) ? v[p][e] * v[p][e] : 0.f;
+#pragma unroll
+                for (int o = 1; o < TPR; o <<= 1) q += __shfl_xor(q, o, 64);
+                const float inv = 1.0f / fmaxf(sqrtf(q), 1e-12f);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[p][e] *= inv;
+            }
         }
         if (rin) {
             if (g.colpart) {
@@ -386,6 +397,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     if constexpr (BM == 128) {
         // two 64-row halves: the statistics slabs are 64 rows for every tile shape (see the bf16x3 kernel)
         for (int half = 0; half < 2; ++half) {
+            if (m0 + 64 * half >= g.M) break;   // uniform: no second slab behind the last valid row
             if (wm == half) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -840,6 +852,7 @@ __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
         // epilogue in two 64-row halves (statistics slabs of 64 rows): half the LDS tile, so the operand buffer - not the epilogue -
         // sizes the workgroup's LDS and a third workgroup fits on the CU
         for (int half = 0; half < 2; ++half) {
+            if (m0 + 64 * half >= g.M) break;   // uniform: a last tile with <= 64 valid rows has no second slab (its table entry does not exist)
             if (wm == half) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -914,6 +927,8 @@ constexpr int kNumPlanesCfg = sizeof(kPlanesCfg) / sizeof(kPlanesCfg[0]);
 // {M, N, K, bm, bn, ksplit}.  Anything not listed falls through to the heuristic below.
 struct TunedPlan { int M, N, K, bm, bn, ks; };
 #include "gemm_plans.inc"
+// ... and for the bf16x6 kernel (twice the MFMAs and 1.5x the LDS traffic per K-tile move the best split): tools/tune_gemm.py --gemm bf16x6
+#include "gemm_plans_x6.inc"
 
 // tuning hook (tools/tune_gemm.py only): forces the next plans; not used by the product path
 int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;
@@ -933,7 +948,7 @@ Plan finish_plan(int K, int bm, int bn, int ks) {
 
 // Heuristic: largest tile that still gives >= ~1 workgroup per CU, then split K until the chip
 // (256 CUs) is covered about twice, keeping >= 2 k-tiles (64 values) per split.
-Plan make_plan(int M, int N, int K, bool fused_ln) {
+Plan make_plan(int M, int N, int K, bool fused_ln, int arith = 1) {   // arith: GemmArgs::bf16x3 (2 = bf16x6: its own table first)
     Plan p;
     p.pcfg = -1;
     if (g_force_bm) {
@@ -941,6 +956,13 @@ Plan make_plan(int M, int N, int K, bool fused_ln) {
         if (fused_ln && p.ksplit == 1 && p.bn < N) { p.bm = 64; p.bn = 128; }
         return p;
     }
+    if (arith == 2)
+        for (const TunedPlan &t : kTunedPlansX6)
+            if (t.M == M && t.N == N && t.K == K) {
+                p = finish_plan(K, t.bm, t.bn, t.ks);
+                if (fused_ln && p.ksplit == 1 && p.bn < N) { p.bm = 64; p.bn = 128; }
+                return p;
+            }
     for (const TunedPlan &t : kTunedPlans)
         if (t.M == M && t.N == N && t.K == K) {
             p = finish_plan(K, t.bm, t.bn, t.ks);
@@ -1104,7 +1126,7 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
     else
         hipLaunchKernelGGL((gemm_kernel<64, 64, 1, 1>), grid, dim3(256), 0, s, g);
     if (p.ksplit > 1) {
-        if (g.ln_gamma)
+        if (g.ln_gamma || g.l2n)
             hipLaunchKernelGGL(splitk_epilogue_ln_kernel, dim3(1, cofi_cdiv(g.M, SKLN_ROWS)), dim3(256), 0, s, g);
         else if (g.colpart && g.stat_shift > 5)
             hipLaunchKernelGGL(splitk_epilogue_kernel<64>, dim3(cofi_cdiv(g.N, 64), cofi_cdiv(g.M, SK_ROWS)), dim3(256), 0, s, g);
@@ -1151,18 +1173,21 @@ int gemm_entry(const float *A, int lda, const cofi_norm_desc_t *a_norm, const fl
     const int bf16x3 = (act & COFI_GEMM_BF16X6) ? 2 : ((act & COFI_GEMM_BF16X3) ? 1 : 0);
     const int wsplit = (act & COFI_GEMM_W_SPLIT) ? 1 : 0;
     const int asplit = (act & COFI_GEMM_A_SPLIT) ? 1 : 0;
-    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT | COFI_GEMM_A_SPLIT);
+    const int l2n = (act & COFI_GEMM_L2NORM) ? 1 : 0;
+    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT | COFI_GEMM_A_SPLIT | COFI_GEMM_L2NORM);
+    if (l2n && (N > 128 || asplit)) return COFI_EUNSUPPORTED;
     if (act < 0 || act > 3 || (wsplit && (bf16x3 != 1 || (ldw & 7))) || frames <= 0) return COFI_EINVAL;
     if (asplit && (!wsplit || a_norm || (lda & 7) || (K & 7))) return COFI_EINVAL;
     const int sshift = colpart ? stat_shift_of(stat_width, N) : 0;
     if (sshift < 0) return COFI_EINVAL;
-    Plan p = (asplit && g_force_pcfg != -2) ? make_planes_plan(M, N, K) : make_plan(M, N, K, false);
+    Plan p = (asplit && g_force_pcfg != -2) ? make_planes_plan(M, N, K) : make_plan(M, N, K, l2n != 0, bf16x3);
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
     GemmArgs g{};
     g.A = A; g.W = W; g.C = C; g.bias = bias; g.rowdiv = rowdiv; g.ws = (float *)ws; g.colpart = colpart;
     g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.act = act; g.ksplit = 1;
     g.bf16x3 = bf16x3; g.wsplit = wsplit; g.w_lo_off = (long)N * ldw; g.cv_Pout = 1; g.stat_shift = sshift;
     g.asplit = asplit; g.a_lo_off = (long)M * lda;
+    g.l2n = l2n;
     if (int rc = set_a_norm(g, a_norm, K, M / frames, frames, p)) return rc;
     return launch(g, p, cofi_s(stream));
 }
@@ -1177,12 +1202,14 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
     const int M = Ho * Wo * frames, K = ks * ks * Cin;
     const int bf16x3 = (act & COFI_GEMM_BF16X6) ? 2 : ((act & COFI_GEMM_BF16X3) ? 1 : 0);
     const int wsplit = (act & COFI_GEMM_W_SPLIT) ? 1 : 0;
-    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT);
+    const int l2n = (act & COFI_GEMM_L2NORM) ? 1 : 0;
+    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT | COFI_GEMM_L2NORM);
     if (act < 0 || act > 3 || (wsplit && bf16x3 != 1) || act_col0 < 0 || act_col0 > Cout) return COFI_EINVAL;
+    if (l2n && Cout > 128) return COFI_EUNSUPPORTED;
     const int sshift = colpart ? stat_shift_of(stat_width, Cout) : 0;
     if (sshift < 0) return COFI_EINVAL;
     const int ldw = wsplit ? (K + 7) / 8 * 8 : K;   // pre-split planes: rows padded to 8 values
-    Plan p = make_plan(M, Cout, K, false);
+    Plan p = make_plan(M, Cout, K, l2n != 0, bf16x3);
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * Cout * sizeof(float))) return COFI_EWORKSPACE;
     GemmArgs g{};
     g.A = x; g.W = Wt; g.C = y; g.bias = bias; g.ws = (float *)ws; g.colpart = colpart; g.res = res;
@@ -1191,6 +1218,7 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
     g.cv_ks = ks; g.cv_H = H; g.cv_W = W; g.cv_Cin = Cin; g.cv_Wo = Wo; g.cv_stride = stride; g.cv_pad = pad; g.cv_Pout = Ho * Wo;
     g.stat_shift = sshift;
     g.act_col0 = act_col0;
+    g.l2n = l2n;
     if (int rc = set_a_norm(g, x_norm, Cin, H * W, frames, p)) return rc;   // statistics of the INPUT map: H * W rows per frame
     return launch(g, p, cofi_s(stream));
 }
@@ -1199,8 +1227,8 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
 
 extern "C" size_t cofi_gemm_f32_workspace(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const Plan p = make_plan(M, N, K, false), q = make_planes_plan(M, N, K);   // whichever kernel the operands select
-    const int ks = p.ksplit > q.ksplit ? p.ksplit : q.ksplit;
+    const Plan p = make_plan(M, N, K, false), q = make_planes_plan(M, N, K), r = make_plan(M, N, K, false, 2);   // whichever kernel the operands select
+    const int ks = std::max(p.ksplit, std::max(q.ksplit, r.ksplit));
     return ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
 }
 
@@ -1232,9 +1260,9 @@ extern "C" int cofi_gemm_f32_layernorm(const float *A, int lda, const float *W, 
     if (int rc = check_common(A, lda, W, ldw, C, ldc, M, N, K)) return rc;
     if (!gamma || !beta || N > 128 || (res && ldr < N)) return COFI_EINVAL;
     if (M == 0) return 0;
-    Plan p = make_plan(M, N, K, true);
-    if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
     const int bf16x3 = (relu & COFI_GEMM_BF16X6) ? 2 : ((relu & COFI_GEMM_BF16X3) ? 1 : 0);
+    Plan p = make_plan(M, N, K, true, bf16x3);
+    if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
     const int wsplit = (relu & COFI_GEMM_W_SPLIT) ? 1 : 0;
     relu &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT);
     if (wsplit && (bf16x3 != 1 || (ldw & 7))) return COFI_EINVAL;

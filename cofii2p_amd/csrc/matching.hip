@@ -4,6 +4,7 @@
 // The match count stays on the device (count_dev); downstream kernels are launched at capacity and
 // read it, so the only host synchronisation of a test-mode forward is the final read of the count.
 #include "common.h"
+#include "knn_common.h"
 
 namespace {
 
@@ -166,7 +167,119 @@ __global__ __launch_bounds__(64) void fine_match_kernel(const float *patches, co
     }
 }
 
+// Everything of a test-mode forward that follows the match selection (network.py:153-161 + eval_all.py:99-105), one workgroup per
+// accepted match i (count read on the device): the coarse point, its nearest stage-1 node (point2node, network.py:250-264: canonical
+// distance, lowest index on ties - the (distance, index) key of nearest_kernel), that node's fine descriptor, the 4 x 4 patch of the
+// fine image map under the coarse pixel and the fine matching of the two.  Same per-element arithmetic, in the same order, as the five
+// stand-alone kernels above / in knn.hip: bit-identical outputs, four launches fewer on a frame's chain.
+struct FinishArgs {
+    const float *pts4, *pts1, *fmap, *xy, *fpc;
+    const int32_t *sel, *count;
+    float *coarse_pts, *patches, *fine_pc, *fine_xy;
+    int32_t *best;
+    int N1, cap, ldf, C, H2, W2, ldxy, ldfpc, ldo;
+    float cscale;
+};
+constexpr int FIN_MAXC = 128;
+
+__global__ __launch_bounds__(256) void match_finish_kernel(FinishArgs a) {
+    __shared__ u64 s_key[4];
+    __shared__ float s_f[FIN_MAXC], s_p[FIN_MAXC * 16];
+    const int i = blockIdx.x;
+    if (i >= min(*a.count, a.cap)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t n = (size_t)a.sel[i];
+    const float qx = a.pts4[3 * n], qy = a.pts4[3 * n + 1], qz = a.pts4[3 * n + 2];
+    if (tid < 3) a.coarse_pts[3 * (size_t)i + tid] = a.pts4[3 * n + tid];
+    // nearest stage-1 node
+    const float qq = canon_sqnorm(qx, qy, qz);
+    u64 bestk = KEY_INF;
+    for (int c0 = tid; c0 < a.N1; c0 += 1024) {
+        float px[4], py[4], pz[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = min(c0 + 256 * u, a.N1 - 1);
+            px[u] = a.pts1[3 * (size_t)c];
+            py[u] = a.pts1[3 * (size_t)c + 1];
+            pz[u] = a.pts1[3 * (size_t)c + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + 256 * u;
+            const float d = canon_dist(qx, qy, qz, qq, px[u], py[u], pz[u], canon_sqnorm(px[u], py[u], pz[u]));
+            if (c < a.N1) bestk = umin64(bestk, ((u64)__float_as_uint(d) << 32) | (unsigned)c);
+        }
+    }
+    bestk = umin64(bestk, lane_xor64<32>(bestk, lane));
+    bestk = umin64(bestk, lane_xor64<16>(bestk, lane));
+    bestk = umin64(bestk, lane_xor64<8>(bestk, lane));
+    bestk = umin64(bestk, lane_xor64<4>(bestk, lane));
+    bestk = umin64(bestk, lane_xor64<2>(bestk, lane));
+    bestk = umin64(bestk, lane_xor64<1>(bestk, lane));
+    if (lane == 0) s_key[wave] = bestk;
+    // the patch does not depend on the node: gathered while the keys settle
+    const float cx = a.xy[i], cy = a.xy[a.ldxy + i];
+    const int left = (int)floorf(cx * a.cscale - 2.0f), top = (int)floorf(cy * a.cscale - 2.0f);
+    for (int e = tid; e < a.C * 16; e += 256) {
+        const int c = e % a.C, t = e / a.C, r = t >> 2, w = t & 3;  // lanes sweep channels: contiguous reads
+        const int yy = top + r, xx = left + w;
+        float v = 0.f;
+        if (yy >= 0 && yy < a.H2 && xx >= 0 && xx < a.W2) v = a.fmap[((size_t)yy * a.W2 + xx) * a.ldf + c];
+        a.patches[((size_t)i * a.C + c) * 16 + t] = v;
+        s_p[c * 16 + t] = v;
+    }
+    __syncthreads();
+    const size_t node = (size_t)(unsigned)(umin64(umin64(s_key[0], s_key[1]), umin64(s_key[2], s_key[3])) & 0xffffffffu);
+    for (int c = tid; c < a.C; c += 256) {
+        const float v = a.fpc[node * a.ldfpc + c];
+        a.fine_pc[(size_t)i * a.ldo + c] = v;
+        s_f[c] = v;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // fine matching (fine_match_kernel): 16 cosine similarities, 4 lane groups split the channels of one pixel
+    const int pxl = lane & 15, part = lane >> 4;
+    float dot = 0.f, nn = 0.f, pp = 0.f;
+    for (int c = part; c < a.C; c += 4) {
+        const float pv = s_p[c * 16 + pxl];
+        const float fv = s_f[c];
+        dot += pv * fv;
+        nn += pv * pv;
+        pp += fv * fv;
+    }
+    dot += __shfl_xor(dot, 16, 64); dot += __shfl_xor(dot, 32, 64);
+    nn += __shfl_xor(nn, 16, 64); nn += __shfl_xor(nn, 32, 64);
+    pp += __shfl_xor(pp, 16, 64); pp += __shfl_xor(pp, 32, 64);
+    float sim = dot / (fmaxf(sqrtf(nn), 1e-8f) * fmaxf(sqrtf(pp), 1e-8f));
+    int bi = pxl;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        const float os = __shfl_xor(sim, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (os > sim || (os == sim && oi < bi)) { sim = os; bi = oi; }
+    }
+    if (lane == 0) {
+        a.best[i] = bi;
+        a.fine_xy[i] = (cx * a.cscale - 2.0f) + (float)(bi / 4);         // eval_all.py:103-105: x receives idx // 4, y idx % 4
+        a.fine_xy[a.cap + i] = (cy * a.cscale - 2.0f) + (float)(bi % 4);
+    }
+}
+
 }  // namespace
+
+extern "C" int cofi_match_finish(const float *pts4, const float *pts1, int N1, const int32_t *sel, const int32_t *count_dev, int cap,
+                                 const float *fmap, int ldf, int C, int H2, int W2, const float *coarse_xy, int ldxy, float center_scale,
+                                 const float *fine_pc_all, int ldfpc, float *coarse_pts, float *patches, float *fine_pc, int ldo,
+                                 float *fine_xy, int32_t *best, cofi_stream_t stream) {
+    if (!pts4 || !pts1 || !sel || !count_dev || !fmap || !coarse_xy || !fine_pc_all || !coarse_pts || !patches || !fine_pc || !fine_xy || !best)
+        return COFI_EINVAL;
+    if (N1 <= 0 || cap <= 0 || C <= 0 || H2 <= 0 || W2 <= 0 || ldf < C || ldfpc < C || ldo < C) return COFI_EINVAL;
+    if (C > FIN_MAXC) return COFI_EUNSUPPORTED;
+    FinishArgs a{pts4, pts1, fmap, coarse_xy, fine_pc_all, sel, count_dev, coarse_pts, patches, fine_pc, fine_xy, best,
+                 N1, cap, ldf, C, H2, W2, ldxy, ldfpc, ldo, center_scale};
+    hipLaunchKernelGGL(match_finish_kernel, dim3(cap), dim3(256), 0, cofi_s(stream), a);
+    return cofi_launch_status();
+}
 
 extern "C" int cofi_row_argmin_1m(const float *sim, int lds, int N, int P, int32_t *pix, cofi_stream_t stream) {
     if (!sim || !pix || N <= 0 || P <= 0 || lds < P) return COFI_EINVAL;

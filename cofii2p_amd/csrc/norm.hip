@@ -396,6 +396,23 @@ __global__ __launch_bounds__(256) void col_inv_norm_kernel(const float *x, int l
 }
 
 // ---------------------------------------------------------------------------- L2 norm of rows
+__global__ __launch_bounds__(256) void l2norm_rows2_kernel(const float *x, int ldx, int M, int C, float *y, int ldy, float *y2, int ldy2) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int lane = threadIdx.x & 63;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float v = x[(size_t)m * ldx + c];
+        q += v * v;
+    }
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+    for (int c = lane; c < C; c += 64) {
+        const float v = x[(size_t)m * ldx + c] * inv;
+        y[(size_t)m * ldy + c] = v;
+        y2[(size_t)m * ldy2 + c] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float *x, int ldx, int M, int C, float *y, int ldy, int transpose) {
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
@@ -680,6 +697,12 @@ extern "C" int cofi_col_inv_norm(const float *x, int ldx, int M, int C, float ep
 extern "C" int cofi_l2norm_rows(const float *x, int ldx, int M, int C, float *y, int ldy, int transpose, cofi_stream_t stream) {
     if (!x || !y || M <= 0 || C <= 0 || ldx < C || (transpose ? ldy < M : ldy < C)) return COFI_EINVAL;
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cofi_cdiv(M, 4)), dim3(256), 0, cofi_s(stream), x, ldx, M, C, y, ldy, transpose);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_l2norm_rows2(const float *x, int ldx, int M, int C, float *y, int ldy, float *y2, int ldy2, cofi_stream_t stream) {
+    if (!x || !y || !y2 || M <= 0 || C <= 0 || ldx < C || ldy < C || ldy2 < C) return COFI_EINVAL;
+    hipLaunchKernelGGL(l2norm_rows2_kernel, dim3(cofi_cdiv(M, 4)), dim3(256), 0, cofi_s(stream), x, ldx, M, C, y, ldy, y2, ldy2);
     return cofi_launch_status();
 }
 

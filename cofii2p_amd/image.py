@@ -119,18 +119,20 @@ def resnet34_nhwc(P, img: torch.Tensor, full: bool = True, tail_branch=None):
     return outs, dims
 
 
-def _residual_conv_nhwc(P, p: str, x, H, W, frames: int = 1):
+def _residual_conv_nhwc(P, p: str, x, H, W, frames: int = 1, l2norm: bool = False):
     """imagenet.py:397-411: the skip convolution and conv1 share their input and run as ONE implicit GEMM (filters stacked
     [skip | conv1], ReLU on the conv1 half only), conv2 reads that half as a strided view; folded-BN bias, ReLU and the skip add
     live in the epilogues."""
     C = P[p + "conv2.b"].shape[0]
     z, _, _ = ops.conv2d_nhwc(x, H, W, P[p + "skip_conv1.w.nhwc"], 3, 1, 1, bias=P[p + "skip_conv1.b"], act=ops.ACT_RELU, act_col0=C, frames=frames)
-    out, _, _ = ops.conv2d_nhwc(z[:, C:], H, W, P[p + "conv2.w.nhwc"], 3, 1, 1, bias=P[p + "conv2.b"], res=z[:, :C], act=ops.ACT_RELU, frames=frames)
-    return out
+    out, _, _ = ops.conv2d_nhwc(z[:, C:], H, W, P[p + "conv2.w.nhwc"], 3, 1, 1, bias=P[p + "conv2.b"], res=z[:, :C], act=ops.ACT_RELU, frames=frames,
+                                l2norm=l2norm and C <= 128)
+    return out if (not l2norm or C <= 128) else ops.l2norm_rows(out)
 
 
-def upsample_stage_nhwc(P, name: str, low, h, w, skip, frames: int = 1):
-    """imagenet.py:431-444 on NHWC maps: low (h*w, C1), skip (4hw, C2) -> (4hw, Cout)."""
+def upsample_stage_nhwc(P, name: str, low, h, w, skip, frames: int = 1, l2norm: bool = False):
+    """imagenet.py:431-444 on NHWC maps: low (h*w, C1), skip (4hw, C2) -> (4hw, Cout).  l2norm: the pixels of the result are
+    L2-normalised (network.py:130) by the last convolution's epilogue."""
     x = ops.upsample2x_cat_nhwc(low, h, w, skip, frames)
     x = _residual_conv_nhwc(P, name + ".conv.0.", x, 2 * h, 2 * w, frames)
-    return _residual_conv_nhwc(P, name + ".conv.1.", x, 2 * h, 2 * w, frames)
+    return _residual_conv_nhwc(P, name + ".conv.1.", x, 2 * h, 2 * w, frames, l2norm=l2norm)

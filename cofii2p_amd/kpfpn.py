@@ -184,7 +184,7 @@ def run_block_plain(P, kind: str, blk: KPBlock, feats, q_pts, s_pts, idx, out=No
     return _unary_plain(P, kind, p + "unary2.", x, LRELU, res=sc, out=out)
 
 
-def run_fpn(P, points: List[torch.Tensor], neighbors, subsampling, upsampling, feats, taps=None, frames: int = 1, order=None):
+def run_fpn(P, points: List[torch.Tensor], neighbors, subsampling, upsampling, feats, taps=None, frames: int = 1, order=None, l2norm_fine: bool = False):
     """`order` (optional): per stage, the frame-local processing order of the stage's points (spatially sorted)."""
     """Returns [latent_s2 (N1,64), latent_s3 (N2,512), latent_s4 (N3,1024), feats_s5 (N4,2048)].
     The last block of stages 1..3 writes directly into the right part of the decoder's concat
@@ -226,7 +226,8 @@ def run_fpn(P, points: List[torch.Tensor], neighbors, subsampling, upsampling, f
     ops.gather_rows(l4, upsampling[2], out=cat[2][:, :1024], frames=frames)
     l3 = dec("pc_encoder.decoder3.", cat[2])
     ops.gather_rows(l3, upsampling[1], out=cat[1][:, :512], frames=frames)
-    l2 = ops.gemm(cat[1], P["pc_encoder.decoder2.mlp.weight"], bias=P["pc_encoder.decoder2.mlp.bias"])
+    # l2norm_fine: the stage-2 latent leaves L2-normalised (network.py:83, its only reader) from this GEMM's epilogue
+    l2 = ops.gemm(cat[1], P["pc_encoder.decoder2.mlp.weight"], bias=P["pc_encoder.decoder2.mlp.bias"], l2norm=l2norm_fine)
     if taps is not None:
         taps.update(decoder4=l4, decoder3=l3, decoder2=l2)
     return [l2, l3, l4, s5]

@@ -116,7 +116,7 @@ class CoFiI2P(nn.Module):
 
         # intra-frame fork/join slots captured by forward_async (bit 0 image branch, 1 residual shortcuts, 2 attention streams,
         # 3 the ResNet tail nothing reads)
-        self.async_branch_mask = 0
+        self.async_branch_mask = int(os.environ.get("COFI_ASYNC_BRANCH_MASK", "0"))
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
         self.eval()
 
@@ -199,12 +199,12 @@ class CoFiI2P(nn.Module):
         y, part = ops.gemm_colstats(in_relu(y, part), P[head + ".3.weight"], frames=frames)
         return ops.gemm(in_relu(y, part), P[head + ".6.weight"], act=ops.ACT_SIGMOID, frames=frames)  # (T,1)
 
-    def _pc_feature_mlp(self, P, x: torch.Tensor) -> torch.Tensor:
-        """network.py:29."""
+    def _pc_feature_mlp(self, P, x: torch.Tensor, out=None, l2norm: bool = False) -> torch.Tensor:
+        """network.py:29; l2norm: followed by F.normalize(dim=1) (network.py:84) in the last GEMM's epilogue."""
         p = "pc_feature_layer."
         y = ops.layer_norm(ops.gemm(x, P[p + "0.weight"]), P[p + "1.weight"], P[p + "1.bias"], relu=True)
         y = ops.layer_norm(ops.gemm(y, P[p + "3.weight"]), P[p + "4.weight"], P[p + "4.bias"], relu=True)
-        return ops.gemm(y, P[p + "6.weight"])
+        return ops.gemm(y, P[p + "6.weight"], out=out, l2norm=l2norm)
 
     # ------------------------------------------------------------------ device-side forward (no host sync)
     def _run_device(self, P, points, neighbors, subsampling, upsampling, feats, img, mode, fine_center_kpt_coors,
@@ -233,15 +233,17 @@ class CoFiI2P(nn.Module):
                 grid = self._pixel_grid(H8, W8, B, dev)   # (y, x) of every token of the 1/8 map: a constant, built once
                 img_set, dims = image.resnet34_nhwc(P, img, full=self.compute_unused_image_maps, tail_branch=br_dead)
                 s2_, s4_, s8_ = img_set[0], img_set[1], img_set[2]  # (B*H*W, C) pixel-major
-                s8n_ = ops.l2norm_rows(s8_)  # the normalised s8 map also feeds the up-sampler (network.py:90,129)
-                ops.l2norm_rows(s8_, out=ts.img[0][:, :D_MODEL])
+                # the normalised s8 map feeds the transformer AND the up-sampler (network.py:90,129): one launch, two destinations
+                s8n_ = torch.empty_like(s8_)
+                ops.l2norm_rows2(s8_, s8n_, ts.img[0][:, :D_MODEL])
                 ops.pos_sine(grid, ts.img[0], accumulate=True)
             return br, s2_, s4_, s8n_
 
         def point_branch():   # network.py:76,83-84,107,111
-            pc_set_ = kpfpn.run_fpn(P, points, neighbors, subsampling, upsampling, feats, taps=taps, frames=B, order=order)
-            fine_pc_ = ops.l2norm_rows(pc_set_[0])  # (B*N1,64)
-            ops.l2norm_rows(self._pc_feature_mlp(P, pc_set_[-1]), out=ts.pc[0][:, :D_MODEL])
+            # F.normalize of the fine point descriptors (network.py:83) rides in decoder2's GEMM epilogue (taps: the raw decoder output is wanted)
+            pc_set_ = kpfpn.run_fpn(P, points, neighbors, subsampling, upsampling, feats, taps=taps, frames=B, order=order, l2norm_fine=taps is None)
+            fine_pc_ = pc_set_[0] if taps is None else ops.l2norm_rows(pc_set_[0])  # (B*N1,64)
+            self._pc_feature_mlp(P, pc_set_[-1], out=ts.pc[0][:, :D_MODEL], l2norm=True)   # ... and of the coarse tokens (network.py:84) in the MLP's last GEMM
             ops.pos_sine(points[-1], ts.pc[0], accumulate=True)
             return pc_set_, fine_pc_
 
@@ -261,9 +263,8 @@ class CoFiI2P(nn.Module):
         # ---- fine image descriptors (network.py:129-130): only image data -> side stream, under the transformer
         with ops.Branch(dev, 0) as br_up:
             up4 = image.upsample_stage_nhwc(P, "img_upsample_1", s8n, H8, W8, s4, frames=B)
-            up2_raw = image.upsample_stage_nhwc(P, "img_upsample_2", up4, 2 * H8, 2 * W8, s2, frames=B)
-            H2, W2, C2 = 4 * H8, 4 * W8, up2_raw.shape[1]
-            up2 = ops.l2norm_rows(up2_raw)  # (B*H2*W2, C2) pixel-major fine image descriptors
+            up2 = image.upsample_stage_nhwc(P, "img_upsample_2", up4, 2 * H8, 2 * W8, s2, frames=B, l2norm=True)  # (B*H2*W2, C2) pixel-major fine image descriptors
+            H2, W2, C2 = 4 * H8, 4 * W8, up2.shape[1]
 
         # ---- transformer (network.py:113-115)
         # the descriptors' L2 normalisation (network.py:125-126) and, for a single frame, their channel-major output layout are written
@@ -309,11 +310,14 @@ class CoFiI2P(nn.Module):
                 sim = ops.gemm(pdt, idt)  # (N4, T): <pc, pixel>
                 pix = ops.row_argmin_1m(sim)
                 sel, xy, cnt = ops.select_matches(o["pc_score"].reshape(-1), pix, W8, H8, score_thresholds(), 4)
-                o["coarse_pts"] = ops.gather_points_sel(pts4, sel, cnt)
-                node = ops.nearest_node_sel(pts1, pts4, sel, cnt)
-                o["patches"] = ops.extract_patches_nhwc(up2_f, H2, W2, xy, cnt, N4, 4.0)
-                o["fine_pc"] = ops.gather_rows_sel(fpc, node, cnt, N4)
-                o["fine_xy"], o["fine_best"] = ops.fine_match(o["patches"], o["fine_pc"], xy, cnt, 4.0)  # eval_all.py:99-105
+                if C2 <= 128:   # coarse point, point2node, patch, fine descriptor and the caller's fine matching (eval_all.py:99-105): one launch
+                    o["coarse_pts"], o["patches"], o["fine_pc"], o["fine_xy"], o["fine_best"] = ops.match_finish(pts4, pts1, sel, cnt, up2_f, H2, W2, xy, fpc, 4.0)
+                else:
+                    o["coarse_pts"] = ops.gather_points_sel(pts4, sel, cnt)
+                    node = ops.nearest_node_sel(pts1, pts4, sel, cnt)
+                    o["patches"] = ops.extract_patches_nhwc(up2_f, H2, W2, xy, cnt, N4, 4.0)
+                    o["fine_pc"] = ops.gather_rows_sel(fpc, node, cnt, N4)
+                    o["fine_xy"], o["fine_best"] = ops.fine_match(o["patches"], o["fine_pc"], xy, cnt, 4.0)  # eval_all.py:99-105
                 o.update(sel=sel, coarse_xy=xy, count=cnt)
             outs.append(o)
         br_dead.join()

@@ -18,6 +18,7 @@ import os
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_LEAKY01 = 0, 1, 2, 3
 GEMM_BF16X3 = 0x100
 GEMM_BF16X6 = 0x800
+GEMM_L2NORM = 0x1000   # rows L2-normalised in the epilogue (N <= 128)
 # arithmetic of the dense contractions: "bf16x3" (default) = 3-term bf16 split (hi*hi + hi*lo + lo*hi) on the bf16 matrix cores
 # with fp32 accumulation, ~2^-16 relative error per product; "f32" = exact fp32 MFMA (COFI_GEMM=f32)
 GEMM_MODE = os.environ.get("COFI_GEMM", "bf16x3")
@@ -306,7 +307,7 @@ class SplitA:
         self.shape, self.device, self.dtype = (planes.shape[1], K), planes.device, torch.float32
 
 
-def _gemm_impl(a, w, out, bias, rowdiv, act, stat_width, frames):
+def _gemm_impl(a, w, out, bias, rowdiv, act, stat_width, frames, l2norm=False):
     lib = _lib.load()
     if isinstance(a, Normed) and not isinstance(w, SplitW) and a.fusable():
         w = SplitW(w)   # the normalising loader lives in the pre-split-weight kernels
@@ -339,16 +340,19 @@ def _gemm_impl(a, w, out, bias, rowdiv, act, stat_width, frames):
         return out, colpart
     ws = _WS_GEMM.get(lib.cofi_gemm_f32_workspace(M, N, K), a.device)
     wp, wld, wflag = _wargs(w)
+    if l2norm and N > 128:
+        raise _lib.CofiError("gemm: the L2-normalising epilogue serves N <= 128")
     rc = lib.cofi_gemm_f32_fused(a_ptr, a_ld, None if nd is None else ctypes.byref(nd), wp, wld, _p(out), _ld(out), M, N, K, _p(bias),
-                                 _p(rowdiv), act | _gemm_flag() | wflag | aflag, _p(colpart), max(stat_width, 1), _p(ws), 0 if ws is None else ws.numel(),
+                                 _p(rowdiv), act | _gemm_flag() | wflag | aflag | (GEMM_L2NORM if l2norm else 0), _p(colpart), max(stat_width, 1), _p(ws), 0 if ws is None else ws.numel(),
                                  frames, _stream())
     _lib.check(rc, "cofi_gemm_f32_fused")
     return out, colpart
 
 
-def gemm(a, w, out: Optional[torch.Tensor] = None, bias=None, rowdiv=None, act: int = ACT_NONE, frames: int = 1):
-    """out[m,n] = act( (a @ w.T)[m,n] / rowdiv[m] + bias[n] );  a (M,K) [or a Normed: normalised on the fly], w (N,K)."""
-    return _gemm_impl(a, w, out, bias, rowdiv, act, 0, frames)[0]
+def gemm(a, w, out: Optional[torch.Tensor] = None, bias=None, rowdiv=None, act: int = ACT_NONE, frames: int = 1, l2norm: bool = False):
+    """out[m,n] = act( (a @ w.T)[m,n] / rowdiv[m] + bias[n] );  a (M,K) [or a Normed: normalised on the fly], w (N,K).
+    l2norm (N <= 128): the rows of the result are L2-normalised in the epilogue (F.normalize(dim=1))."""
+    return _gemm_impl(a, w, out, bias, rowdiv, act, 0, frames, l2norm)[0]
 
 
 def gemm_colstats(a, w, out=None, bias=None, rowdiv=None, act: int = ACT_NONE, stat_width: int = 1, frames: int = 1):
@@ -617,6 +621,17 @@ def l2norm_rows(x, out=None, transpose: bool = False):
     return out
 
 
+def l2norm_rows2(x, out, out2):
+    """F.normalize(x, dim=1) written to two row-major destinations in one launch."""
+    lib = _lib.load()
+    _mat(x, "x"), _mat(out, "out"), _mat(out2, "out2")
+    M, C = x.shape
+    if M == 0:
+        return out, out2
+    _lib.check(lib.cofi_l2norm_rows2(_p(x), _ld(x), M, C, _p(out), _ld(out), _p(out2), _ld(out2), _stream()), "cofi_l2norm_rows2")
+    return out, out2
+
+
 def col_mean(x, frames: int = 1):
     """(frames * rows, C) -> (frames, C) column means per frame (AdaptiveAvgPool2d(1) of an NHWC map)."""
     lib = _lib.load()
@@ -672,7 +687,7 @@ def pos_sine(coords, out, accumulate: bool, d_model: int = 128):
 
 # ------------------------------------------------------------------------------------------ image branch, NHWC
 def conv2d_nhwc(x, H: int, W: int, w, ks: int, stride: int = 1, pad: int = 1, bias=None, res=None, act: int = ACT_NONE,
-                colstats: bool = False, out=None, frames: int = 1, stat_width: int = 1, act_col0: int = 0):
+                colstats: bool = False, out=None, frames: int = 1, stat_width: int = 1, act_col0: int = 0, l2norm: bool = False):
     """Implicit-GEMM convolution on an NHWC map x (H*W, Cin) [row-major view, any leading dimension; or a Normed: the pending
     InstanceNorm + ReLU of the previous convolution is applied by the operand loader]; w (Cout, ks*ks*Cin).
     act applies to output columns >= act_col0 (stacked filters of two convolutions of the same input).
@@ -700,7 +715,7 @@ def conv2d_nhwc(x, H: int, W: int, w, ks: int, stride: int = 1, pad: int = 1, bi
     ws = _WS_GEMM.get(lib.cofi_gemm_f32_workspace(M, Cout, K), x.device)
     wp, _wld, wflag = _wargs(w)   # convolution weights are dense (Cout, K) / planes (2, Cout, roundup8(K))
     rc = lib.cofi_conv2d_nhwc_fused(_p(x), _ld(x), None if nd is None else ctypes.byref(nd), H, W, Cin, wp, Cout, ks, stride, pad, _p(bias),
-                                    _p(res), 0 if res is None else _ld(res), act | _gemm_flag() | wflag, act_col0, _p(out), _ld(out), _p(part), stat_width,
+                                    _p(res), 0 if res is None else _ld(res), act | _gemm_flag() | wflag | (GEMM_L2NORM if l2norm else 0), act_col0, _p(out), _ld(out), _p(part), stat_width,
                                     _p(ws), 0 if ws is None else ws.numel(), frames, _stream())
     _lib.check(rc, "cofi_conv2d_nhwc_fused")
     return (out, part, Ho, Wo) if colstats else (out, Ho, Wo)
@@ -1068,3 +1083,22 @@ def fine_match(patches, pc_feats, xy, cnt, center_scale: float):
                              _p(fine_xy), _p(best), _stream())
     _lib.check(rc, "cofi_fine_match")
     return fine_xy, best
+
+
+def match_finish(pts4, pts1, sel, cnt, fmap, H2: int, W2: int, xy, fine_pc_all, center_scale: float):
+    """The tail of a test-mode forward in one launch (cofi_match_finish): -> coarse_pts (cap,3), patches (cap,C,16), fine_pc (cap,C),
+    fine_xy (2,cap), best (cap,) - bit-identical to gather_points_sel + nearest_node_sel + gather_rows_sel + extract_patches_nhwc +
+    fine_match."""
+    lib = _lib.load()
+    _mat(fmap, "fmap"), _mat(fine_pc_all, "fine_pc_all")
+    cap, C, dev = sel.numel(), fmap.shape[1], fmap.device
+    coarse_pts = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+    patches = torch.empty((cap, C, 16), dtype=torch.float32, device=dev)
+    fine_pc = torch.empty((cap, C), dtype=torch.float32, device=dev)
+    fine_xy = torch.empty((2, cap), dtype=torch.float32, device=dev)
+    best = torch.empty((cap,), dtype=torch.int32, device=dev)
+    rc = lib.cofi_match_finish(_p(pts4.contiguous()), _p(pts1.contiguous()), pts1.shape[0], _p(sel), _p(cnt), cap, _p(fmap), _ld(fmap), C, H2, W2,
+                               _p(xy), xy.stride(0), float(center_scale), _p(fine_pc_all), _ld(fine_pc_all), _p(coarse_pts), _p(patches), _p(fine_pc),
+                               C, _p(fine_xy), _p(best), _stream())
+    _lib.check(rc, "cofi_match_finish")
+    return coarse_pts, patches, fine_pc, fine_xy, best

@@ -92,6 +92,10 @@ typedef struct cofi_norm_desc {
  * against fp64 as the fp32 MFMA kernel) at 16/6 = 2.7x its matrix rate.  Plain fp32 operands only (no COFI_GEMM_W_SPLIT / A_SPLIT, no
  * normalising loader).  Accepted by cofi_gemm_f32*, cofi_conv2d_nhwc*. */
 #define COFI_GEMM_BF16X6 0x800
+/* OR-ed into `act` of cofi_gemm_f32_fused / cofi_conv2d_nhwc_fused (N <= 128): every output row is L2-normalised after bias, residual
+ * and activation - y = v / max(|v|, 1e-12), F.normalize(dim=1) of model/network.py:83-84, 90 - in the epilogue (a tile, or the split-K
+ * reduction, spans the whole row): the stand-alone cofi_l2norm_rows pass over the output disappears. */
+#define COFI_GEMM_L2NORM 0x1000
 
 int cofi_abi_version(void);
 /* name of the code object's target, "gfx950" */
@@ -370,6 +374,9 @@ int cofi_loftr_tail(const cofi_loftr_tail_desc_t *desc, cofi_stream_t stream);
 int cofi_pos_sine(const void *coords, int coords_are_int, int T, int n_dim, const float *dim_t_host, int F, int d_model,
                   int accumulate, float *out, int ldo, cofi_stream_t stream);
 int cofi_l2norm_rows(const float *x, int ldx, int M, int C, float *y, int ldy, int transpose, cofi_stream_t stream);
+/* the same rows into two destinations (y2 row-major, ldy2): the normalised 1/8 image map is both the transformer's input and the
+ * up-sampler's (model/network.py:90,110,129) */
+int cofi_l2norm_rows2(const float *x, int ldx, int M, int C, float *y, int ldy, float *y2, int ldy2, cofi_stream_t stream);
 int cofi_transpose(const float *x, int ldx, int M, int C, float *y, int ldy, cofi_stream_t stream);
 /* out (frames, C) = column means over the M / frames rows of each frame: nn.AdaptiveAvgPool2d(1) on an NHWC map
  * (model/imagenet.py:145,215). */
@@ -429,6 +436,16 @@ int cofi_gather_rows_sel(const float *x, int ldx, int C, const int32_t *row_idx,
                          int ldo, cofi_stream_t stream);
 int cofi_fine_match(const float *patches, const float *pc_feats, int ldp, int C, const float *coarse_xy, int ldxy,
                     float center_scale, const int32_t *count_dev, int cap, float *fine_xy, int32_t *best, cofi_stream_t stream);
+/* Everything that follows the match selection of a test-mode forward in ONE launch (model/network.py:153-161 + the caller's fine
+ * matching, evaluation/eval_all.py:99-105): per accepted match i < count_dev[0] (sel[i] = its stage-4 point, coarse_xy[., i] its pixel)
+ *   coarse_pts[i] = pts4[sel[i]];  node = point2node(pts1 (N1,3), that point) (network.py:250-264);  fine_pc[i] = fine_pc_all[node];
+ *   patches[i] (C,16) = extract_patch(fmap (H2*W2, C) pixel-major, center_scale * xy) (network.py:206-226);  fine_xy / best = cofi_fine_match.
+ * Bit-identical to cofi_gather_points_sel + cofi_nearest_node_sel + cofi_gather_rows_sel + cofi_extract_patches_nhwc + cofi_fine_match.
+ * C <= 128; outputs sized at capacity `cap` (fine_xy (2, cap)). */
+int cofi_match_finish(const float *pts4, const float *pts1, int N1, const int32_t *sel, const int32_t *count_dev, int cap,
+                      const float *fmap, int ldf, int C, int H2, int W2, const float *coarse_xy, int ldxy, float center_scale,
+                      const float *fine_pc_all, int ldfpc, float *coarse_pts, float *patches, float *fine_pc, int ldo,
+                      float *fine_xy, int32_t *best, cofi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row f3, first part: the training losses of model/loss.py with their gradients w.r.t. the network outputs

@@ -591,6 +591,87 @@ def test_matching_chain(ops, mg):
     assert np.array_equal(fxy.cpu().numpy(), mg["fm_xy"])
 
 
+def test_match_finish_equals_the_five_kernels(ops):
+    """cofi_match_finish (coarse point + point2node + fine descriptor + 4x4 patch + fine matching in one launch) against the chain of
+    the five stand-alone kernels: bit-identical, incl. patches over the image border and distance ties in the node search"""
+    g = torch.Generator().manual_seed(11)
+    N4, N1, C, H2, W2 = 160, 1500, 64, 40, 128
+    pts1 = torch.round(torch.randn(N1, 3, generator=g) * 4) / 4          # a lattice: exact distance ties
+    pts4 = pts1[torch.randperm(N1, generator=g)[:N4]] + torch.round(torch.randn(N4, 3, generator=g)) / 8
+    fmap, fpc = torch.randn(H2 * W2, C, generator=g), torch.randn(N1, C, generator=g)
+    n = 97
+    sel = torch.full((N4,), 0, dtype=torch.int32)
+    sel[:n] = torch.sort(torch.randperm(N4, generator=g)[:n]).values.int()
+    xy = torch.zeros(2, N4)
+    xy[0, :n] = torch.randint(0, W2 // 4, (n,), generator=g).float()     # coarse pixels incl. 0 and the last column / row: patches leave the map
+    xy[1, :n] = torch.randint(0, H2 // 4, (n,), generator=g).float()
+    cnt = torch.tensor([n, 0], dtype=torch.int32)
+    a = [G(t) for t in (pts4, pts1, sel, cnt, fmap, xy, fpc)]
+    cp, pat, fp, fxy, best = ops.match_finish(a[0], a[1], a[2], a[3], a[4], H2, W2, a[5], a[6], 4.0)
+    cp0 = ops.gather_points_sel(a[0], a[2], a[3])
+    node = ops.nearest_node_sel(a[1], a[0], a[2], a[3])
+    pat0 = ops.extract_patches_nhwc(a[4], H2, W2, a[5], a[3], N4, 4.0)
+    fp0 = ops.gather_rows_sel(a[6], node, a[3], N4)
+    fxy0, best0 = ops.fine_match(pat0, fp0, a[5], a[3], 4.0)
+    for got, want in ((cp, cp0), (pat, pat0), (fp, fp0), (best, best0)):
+        assert torch.equal(got[:n], want[:n])
+    assert torch.equal(fxy[:, :n], fxy0[:, :n])
+    d = ((pts4[sel[:n].long()][:, None, :] - pts1[None]) ** 2).sum(-1)   # the node is a nearest one (lowest index among exact ties)
+    assert torch.equal(fp[:n].cpu(), fpc[d.argmin(1)]) or float((d.gather(1, node[:n].cpu().long()[:, None])[:, 0] - d.min(1).values).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16x6"])
+def test_l2norm_epilogue(ops, monkeypatch, mode):
+    """COFI_GEMM_L2NORM: F.normalize(dim=1) of the output rows in the GEMM / convolution epilogue (un-split and split-K plans, bias /
+    residual / ReLU in front of it) against the stand-alone l2norm_rows of the same contraction; l2norm_rows2 = l2norm_rows twice"""
+    monkeypatch.setattr(ops, "GEMM_MODE", mode)
+    g = torch.Generator().manual_seed(31)
+    for M, N, K in [(10240, 64, 768), (1280, 128, 512), (200, 100, 60), (1280, 64, 7680)]:
+        a, w, b = G(torch.randn(M, K, generator=g)), G(torch.randn(N, K, generator=g) / K ** 0.5), G(torch.randn(N, generator=g))
+        close(ops.gemm(a, w, bias=b, l2norm=True), ops.l2norm_rows(ops.gemm(a, w, bias=b)), 2e-6)
+    H, W, Cin, Cout = 40, 128, 64, 64
+    x, wt = G(torch.randn(H * W, Cin, generator=g)), G(torch.randn(Cout, 9 * Cin, generator=g) / 24)
+    b, res = G(torch.randn(Cout, generator=g)), G(torch.randn(H * W, Cout, generator=g))
+    y = ops.conv2d_nhwc(x, H, W, wt, 3, bias=b, res=res, act=ops.ACT_RELU, l2norm=True)[0]
+    close(y, ops.l2norm_rows(ops.conv2d_nhwc(x, H, W, wt, 3, bias=b, res=res, act=ops.ACT_RELU)[0]), 2e-6)
+    with pytest.raises(Exception):
+        ops.gemm(a, G(torch.randn(256, 7680, generator=g)), l2norm=True)   # a row must fit one tile
+    o1, o2 = torch.empty((300, 96), device=DEV), torch.empty((300, 200), device=DEV)[:, 8:104]
+    xs = G(torch.randn(300, 96, generator=g))
+    ops.l2norm_rows2(xs, o1, o2)
+    assert torch.equal(o1, ops.l2norm_rows(xs)) and torch.equal(o2, o1)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16x6"])
+def test_128_row_tiles_with_a_half_empty_last_tile(ops, monkeypatch, mode):
+    """a 128 x 128 plan on M % 128 in (0, 64]: the last tile has ONE statistics slab - nothing may be written behind the table
+    (round 4: the second half's zero sums went to slab nslab, past the allocation)"""
+    import ctypes
+
+    monkeypatch.setattr(ops, "GEMM_MODE", mode)
+    lib = ops._lib.load()
+    force = lib.cofi_tune_force_plan
+    force.argtypes, force.restype = [ctypes.c_int] * 3, ctypes.c_int
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 320, 256, 128
+    a, w = G(torch.randn(M, K, generator=g)), G(torch.randn(N, K, generator=g) / K ** 0.5)
+    want, wpart = ops.gemm_colstats(a, w)
+    big = torch.full((8, N, 2), 7.0, device=DEV)    # the (5, N, 2) table lives in front of 3 canary slabs
+    try:
+        assert force(128, 128, 1) == 0
+        ws = ops._WS_GEMM.get(lib.cofi_gemm_f32_workspace(M, N, K), a.device)
+        wp, wld, wflag = ops._wargs(w)
+        out = torch.empty((M, N), device=DEV)
+        rc = lib.cofi_gemm_f32_fused(ops._p(a), K, None, wp, wld, ops._p(out), N, M, N, K, None, None, ops._gemm_flag() | wflag, ops._p(big), 1, ops._p(ws),
+                                     0 if ws is None else ws.numel(), 1, ops._stream())
+        assert rc == 0
+    finally:
+        force(0, 0, 0)
+    torch.cuda.synchronize()
+    assert bool((big[5:] == 7.0).all())
+    close(out, want, 1e-5), close(big[:5], wpart, 1e-3)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 128), (1280, 512, 7680), (77, 33, 60), (2560, 1024, 3072), (1280, 128, 256), (20480, 32, 64),
                                    # small grids with >= 3 K-tiles per workgroup: the two-tiles-in-flight configuration (odd / even / ragged tile counts)
                                    (320, 256, 2304), (80, 512, 4608), (1280, 128, 1152), (100, 64, 1000), (64, 64, 384), (130, 60, 516),
