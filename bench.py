@@ -4,9 +4,11 @@
     python bench.py --gpus N --steps K --warmup W
 
 One process per GPU (torchrun for N > 1; frames shard across ranks, no data-path collective:
-"scaling": "weak").  A step = ONE KITTI-shaped synthetic frame (160x512 image, 20 480 points, KNN-128
-pyramid already resident in HBM) through `CoFiI2P.forward(mode='test')` + the caller-side fine
-matching (evaluation/eval_all.py:99-105), fp32, batch 1 — BASELINE.json configs[1].
+"scaling": "weak").  A step = ONE submission of KITTI-shaped synthetic frames (160x512 image, 20 480 points, KNN-128
+pyramid already resident in HBM) through `CoFiI2P.forward(mode='test')` + the caller-side fine matching
+(evaluation/eval_all.py:99-105) in the fp32-grade arithmetic the reference-named class ships ("bf16x6").  Default: stack-mode
+batches of 16 frames (BASELINE.json configs[2]), 4 submissions in flight; `--batch 1` = one frame per submission (configs[1],
+also measured by every default run and reported as `batch1_pipeline` / `config.batch1_frames_per_s`).
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
 timed live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle = a port of the
 reference's forward, timed on a bounded sample on the host cores).
@@ -190,7 +192,8 @@ class KernelTimer:
             return 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)
         if name == "loftr_tail":
             L = a[0].shape[0]
-            return 2.0 * L * (128 * 128 + 256 * 256 + 256 * 128), 4.0 * (3 * L * 128 + 128 * 128 + 256 * 256 + 256 * 128)
+            pn = sum(pw.shape[1] for pw, _y, _p in k.get("proj", ()))   # fused projections of the following layers
+            return 2.0 * L * (128 * 128 + 256 * 256 + 256 * 128 + 128 * pn), 4.0 * (3 * L * 128 + 128 * 128 + 256 * 256 + 256 * 128 + pn * (128 + L))
         if name == "conv2d_nhwc":
             x, H, W, w, ks = a[0], a[1], a[2], a[3], a[4]
             stride = a[5] if len(a) > 5 else k.get("stride", 1)
@@ -309,7 +312,10 @@ def kernel_rooflines(model, dev, args, Bsz, frame=None, batch=None):
     if d["flops_per_frame"] > 0:
         ach = d["flops_per_frame"] / d["seconds_per_frame"] / 1e12
         # the bf16-split GEMM issues 3 bf16 MFMA flops per algorithmic flop: its MFMA roof for ALGORITHMIC flops is 2500/3
-        peak = BF16_MFMA_PEAK_TF / 3.0 if (dom == "gemm" and args.gemm == "bf16x3") else FP32_MFMA_PEAK_TF
+        # ... and the 6-term split 6: 2500 / 6
+        peak = FP32_MFMA_PEAK_TF
+        if dom == "gemm" and args.gemm in ("bf16x3", "bf16x6"):
+            peak = BF16_MFMA_PEAK_TF / (3.0 if args.gemm == "bf16x3" else 6.0)
         pmc = pmc_traffic(dom) if (Bsz == 1 and args.gemm == "bf16x3" and args.points == 20480 and Opt.img_H == 160) else None
         out["roofline"] = {"kernel": "cofi_" + dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                            # HBM bytes per launch from the committed rocprofv3 PMC passes of the default command (stamped with
@@ -476,6 +482,40 @@ class Pipeline:
         return self.run(max(warmup, 2 * self.NSLOT, math.lcm(self.NSLOT, len(self.frames))), 0)
 
 
+class BatchPipeline:
+    """Stack-mode submissions: `Bsz` frames per submission through the same launches (CoFiI2P.stack_frames), `S` submissions in flight on S
+    frame streams, one hipGraph slot per stream; two distinct batches alternate.  A step = one submission."""
+
+    def __init__(self, model, dev, frames, Bsz, S, copy_inputs, slot_base=0):
+        from cofii2p_amd.network import CoFiI2P
+
+        self.model, self.S, self.Bsz, self.copy_inputs, self.slot_base = model, S, Bsz, copy_inputs, slot_base
+        self.batches = []
+        for b in range(2):
+            grp = [frames[(b * Bsz + i) % len(frames)] for i in range(Bsz)]
+            self.batches.append(CoFiI2P.stack_frames([g[0] for g in grp], [g[1] for g in grp]))
+        self.streams = make_streams(dev, S)
+        self.pending = [None] * S
+
+    def run(self, nsteps, base=0):
+        nm, model = 0, self.model
+        for i in range(nsteps):
+            sl = i % self.S
+            if self.pending[sl] is not None:
+                nm = model.finish(self.pending[sl])[0][4].shape[0]
+            pyr, img = self.batches[i % len(self.batches)]
+            with torch.cuda.stream(self.streams[sl]):
+                self.pending[sl] = model.forward_async(self.slot_base + sl, pyr, img, inputs_stable=not self.copy_inputs)
+        for sl in range(self.S):
+            if self.pending[sl] is not None:
+                nm = model.finish(self.pending[sl])[0][4].shape[0]
+                self.pending[sl] = None
+        return nm
+
+    def warm(self, warmup):
+        return self.run(max(warmup, 2 * self.S * len(self.batches)))
+
+
 class optional_leg:
     """Everything after the headline measurement is additional information: a leg that fails (a worker pool that cannot spawn, a missing
     fixture, ...) is recorded in the line as `<name>_error` instead of costing the line."""
@@ -525,13 +565,14 @@ def main():
     ap.add_argument("--copy-inputs", action="store_true", help="stage every frame's inputs into per-slot static buffers (one 27 MB copy launch per frame) "
                     "instead of letting the hipGraph read the resident input tensors in place (forward_async(inputs_stable=True))")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the extra stack-mode batch-4/16 measurements")
-    ap.add_argument("--batch", type=int, default=1, help="frames per submission in stack mode (BASELINE configs[2] uses 16); a step is then one batch")
+    ap.add_argument("--batch", type=int, default=16, help="frames per submission (stack mode; BASELINE configs[2] = 16, configs[1] = 1); a step is one submission")
     ap.add_argument("--stress", action="store_true", help="bench BASELINE configs[4] instead: 896x1600 image, 40960 points (implies --points 40960)")
     ap.add_argument("--repeats", type=int, default=0, help="timed regions of --steps steps each; the median is reported (0 = 5 when --steps < 100, else 1)")
     ap.add_argument("--distinct-frames", type=int, default=16, help="distinct synthetic frames per rank cycled by the timed loop (16 x 27 MB of "
                     "tables do not fit the 256 MB Infinity Cache)")
-    ap.add_argument("--no-f32", action="store_true", help="skip the extra exact-fp32 measurement (value_f32)")
-    ap.add_argument("--gemm", default=os.environ.get("COFI_GEMM", "bf16x3"), choices=["f32", "bf16x3", "bf16x6"],
+    ap.add_argument("--no-f32", action="store_true", help="skip the extra measurements in the other arithmetics (other_arithmetics)")
+    ap.add_argument("--no-steady", action="store_true", help="skip the long-region re-measurement of the headline loop (steady_state)")
+    ap.add_argument("--gemm", default=os.environ.get("COFI_GEMM", "bf16x6"), choices=["f32", "bf16x3", "bf16x6"],
                     help="arithmetic of the dense contractions: exact fp32 MFMA, 3-term bf16 split, or 6-term bf16 split (fp32-grade), all with fp32 accumulation")
     args = ap.parse_args()
     if args.stress:
@@ -582,6 +623,7 @@ def main():
     from cofii2p_amd.parallel import shard_frames
 
     cofi_ops.GEMM_MODE = args.gemm
+    CoFiI2P.MAX_STABLE_GRAPHS = 512   # this process measures the same loops in three arithmetics and several pipelines: one graph per (slot, input set, arithmetic)
     model = CoFiI2P(Opt()).to(dev)
     _model_ref.append(model)
     if not args.eager:
@@ -600,33 +642,12 @@ def main():
     S = max(1, args.inflight) if not args.eager else 1
     Bsz = max(1, args.batch)
     repeats = args.repeats if args.repeats > 0 else (5 if args.steps < 100 else 1)
-    pipe = None
+    pipe = bpipe = None
     if Bsz > 1:
         # stack mode: Bsz frames per submission through the same launches, S submissions in flight
-        batches = []
-        for b in range(2):
-            grp = [frames[(b * Bsz + i) % len(frames)] for i in range(Bsz)]
-            batches.append(CoFiI2P.stack_frames([g[0] for g in grp], [g[1] for g in grp]))
-        streams = make_streams(dev, S)
-        pending = [None] * S
-
-        def runb(nsteps):
-            nm = 0
-            for i in range(nsteps):
-                sl = i % S
-                if pending[sl] is not None:
-                    nm = model.finish(pending[sl])[0][4].shape[0]
-                pyr, img = batches[i % len(batches)]
-                with torch.cuda.stream(streams[sl]):
-                    pending[sl] = model.forward_async(sl, pyr, img, inputs_stable=not args.copy_inputs)
-            for sl in range(S):
-                if pending[sl] is not None:
-                    nm = model.finish(pending[sl])[0][4].shape[0]
-                    pending[sl] = None
-            return nm
-
-        nmatch = runb(max(args.warmup, 2 * S))
-        dts = timed_repeats(runb, barrier, args.steps, repeats)
+        bpipe = BatchPipeline(model, dev, frames, Bsz, S, args.copy_inputs)
+        nmatch = bpipe.warm(args.warmup)
+        dts = timed_repeats(bpipe.run, barrier, args.steps, repeats)
     elif S == 1:
         def run1(nsteps):
             for i in range(nsteps):
@@ -640,9 +661,11 @@ def main():
         pipe = Pipeline(model, dev, frames, S, args.slots_per_stream, args.copy_inputs)
         nmatch = pipe.warm(args.warmup)
         dts = timed_repeats(pipe.run, barrier, args.steps, repeats)
+    headline = bpipe if bpipe is not None else pipe
     dt = float(np.median(dts))   # this rank's seconds per timed region of args.steps steps
     peak_headline_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30   # weights + planes + inputs + one private pool per captured hipGraph
     gathered = per_rank = gather_ms = None
+    rccl = None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         allt = [torch.zeros_like(t) for _ in range(world)]
@@ -660,54 +683,95 @@ def main():
         torch.cuda.synchronize()
         gather_ms = 1e3 * (time.perf_counter() - t0)
         assert sorted(set(int(r) for r in gathered[:, 1].tolist())) == list(range(world))
+        # proof of the ranks for the driver's scaling run: the ranks the process group reports, the distinct devices they sit on (an
+        # all_gather of every rank's PCI bus id), the collective library's version
+        bus = torch.tensor([torch.cuda.get_device_properties(local).pci_bus_id, local, rank], dtype=torch.int64,
+                           device=dev if args.dist_backend == "nccl" else "cpu")
+        allb = [torch.zeros_like(bus) for _ in range(world)]
+        dist.all_gather(allb, bus)
+        rccl = {"backend": args.dist_backend, "ranks": dist.get_world_size(), "rank_devices": [[int(v) for v in b.tolist()] for b in allb],
+                "distinct_devices": len({int(b[0]) for b in allb}) if not args.share_device else 1,
+                "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if args.dist_backend == "nccl" else None}
+    fps = world * args.steps * Bsz / dt
+    arith_note = {"f32": "on the exact fp32 MFMA (bit-equal to an fmaf chain)",
+                  "bf16x3": "as a 3-term bf16 split (hi*hi + hi*lo + lo*hi) on the bf16 matrix cores: ~2^-16 per product, 2e-5 max abs deviation from the "
+                            "reference's outputs on the golden frame (budget 1e-3) - narrower than the reference's fp32",
+                  "bf16x6": "as a 6-term bf16 split (hi/mid/lo planes of both operands = all 24 mantissa bits, six products on v_mfma_f32_32x32x16_bf16): "
+                            "fp32-GRADE - the same error against fp64 as the exact-fp32 kernel (2e-6 on the golden frame); the arithmetic the "
+                            "reference-named class model.network.CoFiI2P ships"}[args.gemm]
     result = {
-        "metric": "I2P frames/sec (160x512 img, 20480 pts)", "value": world * args.steps * Bsz / dt, "unit": "frames/s", "n_gpus": world,
+        "metric": "I2P frames/sec (160x512 img, 20480 pts)", "value": fps, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        # the arithmetic the dense contractions compute in ("bf16x3": 3-term bf16 split on the bf16 matrix cores, fp32 accumulate;
-        # "f32": exact fp32 MFMA); storage, accumulation, KPConv aggregation and attention are fp32 either way
+        # the arithmetic the dense contractions compute in; storage, accumulation, KPConv aggregation and attention are fp32 in all of them
         "dtype": args.gemm,
         "repeats": repeats, "seconds_per_repeat": [round(x, 6) for x in dts], "distinct_frames_per_rank": len(frames),
+        "frames_per_step": Bsz, "ms_per_frame": 1e3 * dt / (args.steps * Bsz),
         "peak_mem_GB": round(peak_headline_gb, 2),
         "data": "synthetic", "launch": "eager" if args.eager else "hipGraph replay",
         "input_staging": "copied into per-slot static buffers" if (args.copy_inputs or args.eager) else "read in place (inputs resident in HBM, forward_async(inputs_stable=True))", "gemm_mode": args.gemm,
-        "ranks": world if dist is None else dist.get_world_size(), "dist_backend": None if dist is None else args.dist_backend,
+        "ranks": world if dist is None else dist.get_world_size(), "dist_backend": None if dist is None else args.dist_backend, "rccl": rccl,
         "gathered_frame_results": None if gathered is None else int(gathered.shape[0]),
         "per_rank_frames_per_s": None if per_rank is None else [round(args.steps * Bsz / x, 2) for x in per_rank],
         "result_gather_ms": gather_ms, "numa_node": numa_node,
-        "arithmetic": "fp32 storage and accumulation everywhere; dense contractions " + (
-            "on the exact fp32 MFMA" if args.gemm == "f32" else
-            "as a 3-term bf16 split (hi*hi + hi*lo + lo*hi) on the bf16 matrix cores: 4e-6 max abs deviation from the reference's "
-            "outputs on the golden frame (budget 1e-3)"),
+        "arithmetic": "fp32 storage and accumulation everywhere; dense contractions " + arith_note,
         # north star / SURVEY.md 8(d): throughput as a fraction of the attention roofline = frames/s x 13.42 GFLOP of attention per
-        # frame (4 self + 4 cross layers over both token streams: 4 * 512 * (1280 + 1280)^2) / the fp32 MFMA peak of the GPUs used (attention runs on v_mfma_f32_16x16x4_f32)
-        "attention_roofline_frac": (world * args.steps * Bsz / dt) * 4 * 512 * ((Opt.img_H // 8) * (Opt.img_W // 8) + args.points // 16) ** 2
-                                   / (world * FP32_MFMA_PEAK_TF * 1e12),
-        "config": {"workload": "%s synthetic frame (%dx%d image, %d points, KNN-128 pyramid resident in HBM), batch %d, "
-                               "CoFiI2P.forward(mode='test') + fine matching, one %s per step per GPU"
-                               % ("KITTI-shape" if not args.stress else "stress (BASELINE configs[4])", Opt.img_H, Opt.img_W, args.points, Bsz,
-                                  "frame" if Bsz == 1 else "stack-mode batch of %d frames" % Bsz),
+        # frame (4 self + 4 cross layers over both token streams: 4 * 512 * (1280 + 1280)^2) / the fp32 MFMA peak of the GPUs used (attention runs on v_mfma_f32_32x32x2_f32)
+        "attention_roofline_frac": fps * 4 * 512 * ((Opt.img_H // 8) * (Opt.img_W // 8) + args.points // 16) ** 2 / (world * FP32_MFMA_PEAK_TF * 1e12),
+        "config": {"workload": "%s synthetic frames (%dx%d image, %d points, KNN-128 pyramid resident in HBM), CoFiI2P.forward(mode='test') + fine "
+                               "matching, %s per step per GPU, %d submissions in flight%s"
+                               % ("KITTI-shape" if not args.stress else "stress (BASELINE configs[4])", Opt.img_H, Opt.img_W, args.points,
+                                  "one frame (batch 1, BASELINE configs[1])" if Bsz == 1 else
+                                  "one stack-mode batch of %d frames%s" % (Bsz, " (BASELINE configs[2])" if Bsz == 16 else ""), S,
+                                  "" if Bsz == 1 else "; the batch-1 pipeline (configs[1]) is in config.batch1_frames_per_s"),
+                   "batch": Bsz, "arithmetic": args.gemm,
                    "matches_per_frame": int(nmatch), "parallelism": "frame-parallel x%d" % world, "frame_streams_per_gpu": S,
                    "hipgraph_slots_per_stream": max(1, args.slots_per_stream) if (S > 1 and Bsz == 1) else 1},
     }
-
-    if rank == 0 and world == 1 and Bsz == 1 and pipe is not None and args.gemm == "bf16x3" and not args.no_f32:
-        with optional_leg(result, "value_f32"):
-            # the same pipelined loop in the two fp32-grade arithmetics, on record next to `value`: every dense contraction on the exact fp32
-            # MFMA (bit-equal to an fmaf chain), and on the 6-term bf16 split (three planes per operand: the same error against fp64 as the
-            # fp32 kernel, tools/x6_probe.py)
-            for key, mode, note in (("value_f32", "f32", "identical loop, COFI_GEMM=f32: every GEMM / convolution on v_mfma_f32_32x32x2_f32 (bit-equal to an fmaf chain)"),
-                                    ("value_bf16x6", "bf16x6", "identical loop, COFI_GEMM=bf16x6: hi/mid/lo bf16 planes of both operands, six products on "
-                                                               "v_mfma_f32_32x32x16_bf16, fp32 accumulation - fp32-grade results (the reference-named shim's default)")):
+    extras = rank == 0 and world == 1 and not args.eager and not args.no_batch_sweep
+    if rank == 0 and world == 1 and not args.eager and S > 1 and not args.no_steady:
+        with optional_leg(result, "steady_state"):
+            # the driver's 20 steps put a pipeline fill and drain inside a short timed region: the same loop over a longer one, on record
+            nst = max(args.steps, (1600 + Bsz - 1) // Bsz if Bsz > 1 else 400)
+            d_long = float(np.median(timed_repeats(headline.run, barrier, nst, 1)))
+            result["steady_state"] = {"steps": nst, "frames_per_s": nst * Bsz / d_long, "seconds": round(d_long, 4),
+                                      "note": "identical loop, one long timed region: `value` (%d steps) carries the fill / drain of the %d-deep pipeline" % (args.steps, S)}
+            result["config"]["steps_for_steady_state"] = nst
+            result["config"]["steady_state_frames_per_s"] = nst * Bsz / d_long
+    if extras and Bsz != 1 and S > 1:
+        with optional_leg(result, "batch1_pipeline"):
+            # BASELINE configs[1]: one frame per submission, S frame streams x slots_per_stream hipGraph slots (the round 1-3 headline pipeline)
+            pipe = Pipeline(model, dev, frames, S, args.slots_per_stream, args.copy_inputs)
+            pipe.warm(args.warmup)
+            n1 = max(args.steps, 200)
+            d1 = float(np.median(timed_repeats(pipe.run, barrier, n1, 3)))
+            result["batch1_pipeline"] = {"frames_per_s": n1 / d1, "ms_per_frame": 1e3 * d1 / n1, "frames": n1, "arithmetic": args.gemm, "frames_in_flight": S * max(1, args.slots_per_stream),
+                                         "note": "BASELINE configs[1]: ONE frame per submission (batch 1), %d frame streams x %d hipGraph slots" % (S, max(1, args.slots_per_stream))}
+            result["config"]["batch1_frames_per_s"] = n1 / d1
+    if extras and not args.no_f32:
+        with optional_leg(result, "other_arithmetics"):
+            # the same loops in the other two arithmetics, on record next to `value`: the narrower 3-term split (faster) and the exact fp32 MFMA
+            oth = {}
+            for mode in ("bf16x3", "bf16x6", "f32"):
+                if mode == args.gemm:
+                    continue
                 cofi_ops.GEMM_MODE = mode
                 try:
-                    pipe.warm(args.warmup)
-                    dts32 = timed_repeats(pipe.run, barrier, args.steps, repeats)
+                    headline.warm(args.warmup)
+                    dh = float(np.median(timed_repeats(headline.run, barrier, args.steps, repeats)))
+                    ent = {"frames_per_s": args.steps * Bsz / dh}
+                    if pipe is not None and headline is not pipe:
+                        pipe.warm(args.warmup)
+                        db = float(np.median(timed_repeats(pipe.run, barrier, max(args.steps, 100), 1)))
+                        ent["batch1_frames_per_s"] = max(args.steps, 100) / db
                 finally:
                     cofi_ops.GEMM_MODE = args.gemm
-                d32 = float(np.median(dts32))
-                result[key] = {"frames_per_s": args.steps / d32, "ms_per_frame": 1e3 * d32 / args.steps, "repeats": repeats, "note": note}
-    if rank == 0 and world == 1 and Bsz == 1 and not args.eager and not args.no_batch_sweep:
+                oth[mode] = ent
+                result["config"]["frames_per_s_" + mode] = ent["frames_per_s"]
+            result["other_arithmetics"] = oth
+            result["other_arithmetics"]["note"] = ("identical loops with COFI_GEMM=<mode>: bf16x3 = 3-term split (~2^-16 per product, narrower than fp32), "
+                                                   "f32 = exact fp32 MFMA, bf16x6 = fp32-grade 6-term split")
+    if extras:
         with optional_leg(result, "forward_sync"):
             # the reference-surface call pattern (evaluation/eval_all.py:94-96): model(...) per frame, one host synchronisation per
             # frame, nothing in flight behind it - what a caller gets without forward_async / finish
@@ -746,18 +810,23 @@ def main():
             if Bsz == 1:
                 result.update(kernel_rooflines(model, dev, args, 1, frame=frames[0]))
             else:
-                result.update(kernel_rooflines(model, dev, args, Bsz, batch=batches[0]))
+                result.update(kernel_rooflines(model, dev, args, Bsz, batch=bpipe.batches[0]))
+                if extras:   # ... and the same rows for one frame per submission (BASELINE configs[1])
+                    result["batch1_rooflines"] = kernel_rooflines(model, dev, args, 1, frame=frames[0])
             rf = result.get("roofline", {})
             if rf.get("bound") == "mfma" and "algorithmic_gflop_per_frame" in rf:
-                # `frac` prices one launch at a time (isolated replay); with frames in flight the kernels share the chip, so the family's
+                # `frac` prices one launch at a time (isolated replay); with submissions in flight the kernels share the chip, so the family's
                 # share of the chip over the whole timed region is its work per frame x frames/s (per GPU) over the same peak
                 rf["chip_level_frac"] = rf["algorithmic_gflop_per_frame"] * 1e9 * (result["value"] / world) / (rf["peak"] * 1e12)
-    if rank == 0 and world == 1 and Bsz == 1 and not args.eager and not args.no_batch_sweep:
+            rc = result.get("roofline_cross_attention")
+            if rc:   # the north star's second number, where the driver's parser keeps it
+                result["config"]["cross_attention_mfma_frac"] = rc["frac"]
+    if extras:
         with optional_leg(result, "stack_mode_batches"):
-            # additional information (BASELINE configs[2]): the same frames in stack-mode batches through the same kernels
+            # additional information: the same frames in stack-mode batches of other sizes through the same kernels
             model.enable_graphs(True)
             sweep = {}
-            for bsz in (4, 16):
+            for bsz in [b for b in (4, 8, 16) if b != Bsz]:
                 grp = [frames[i % len(frames)] for i in range(bsz)]
                 pyr_b, img_b = CoFiI2P.stack_frames([g[0] for g in grp], [g[1] for g in grp])
                 st = make_streams(dev, S)
@@ -779,13 +848,13 @@ def main():
                     torch.cuda.synchronize()
                     dtb = time.perf_counter() - t0
                 sweep["batch_%d" % bsz] = {"frames_per_s": nst * bsz / dtb, "ms_per_frame": 1e3 * dtb / (nst * bsz), "submissions_in_flight": S}
-                if bsz == 16 and not args.no_kernel_timing:   # BASELINE configs[2]: the same roofline rows for the stacked batch
+                if bsz == 16 and Bsz == 1 and not args.no_kernel_timing:   # BASELINE configs[2]: the same roofline rows for the stacked batch
                     model.enable_graphs(False)
                     sweep["batch_16"].update(kernel_rooflines(model, dev, args, bsz, batch=(pyr_b, img_b)))
                     model.enable_graphs(True)
                 del pyr_b, img_b
             result["stack_mode_batches"] = sweep
-    if rank == 0 and world == 1 and Bsz == 1 and not args.no_batch_sweep:
+    if rank == 0 and world == 1 and not args.no_batch_sweep:
         with optional_leg(result, "knn_pyramid"):
             # additional information, outside `value` (the reference's DataLoader builds the pyramid, preprocess_data.py:36-107): the 13
             # KNN-128 searches of one frame's pyramid on this GPU, cell-grid search vs the brute-force kernel (identical tables)
@@ -855,7 +924,7 @@ def main():
                                                                                     "outputs bit-identical"},
                                                 "note": "pyramid construction (5 cell grids + 9 KNN-128 searches + 4 row gathers, one hipGraph) + forward + fine matching per "
                                                         "frame on the same GPU; not the headline"}
-    if rank == 0 and world == 1 and Bsz == 1 and not args.no_batch_sweep and not args.eager:
+    if extras:
         with optional_leg(result, "with_dataside"):
             # row f2: the whole data side of a frame on this GPU (data/kitti.py:259-393: calibration transform, 0.1 m voxel grid, resample to
             # num_pc, random SE(3), KNN pyramid, image resize / crop, labels) from a raw 120 000-point scan + 376 x 1241 image already in
@@ -948,10 +1017,10 @@ def main():
                                                "forward + fine matching, pipelined (cofii2p_amd/loader.py): raw scan and image resident in HBM, voxel count "
                                                "read asynchronously, Mersenne-Twister draws in worker processes, labels finished when the frame's forward is "
                                                "collected; loader_ms_per_frame = the synchronous FramePreparer.prepare() alone; not the headline"}
-    if rank == 0 and world == 1 and Bsz == 1 and not args.eager and not args.no_batch_sweep and not args.stress:
+    if extras and not args.stress:
         with optional_leg(result, "stress_config"):
             result["stress_config"] = stress_summary(dev, args)
-    if rank == 0 and world == 1 and Bsz == 1 and not args.no_batch_sweep and not args.stress:
+    if rank == 0 and world == 1 and not args.no_batch_sweep and not args.stress:
         # row f3, outside `value`: one optimisation step of train.py:186-286 on the same frame (forward(mode='train') -> the three losses ->
         # backward -> Adam), fp32-grade contractions (bf16x6); a separate module instance so the served one keeps its weights
         try:
