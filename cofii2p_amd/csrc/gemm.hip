@@ -956,7 +956,8 @@ Plan make_plan(int M, int N, int K, bool fused_ln, int arith = 1) {   // arith: 
         if (fused_ln && p.ksplit == 1 && p.bn < N) { p.bm = 64; p.bn = 128; }
         return p;
     }
-    if (arith == 2)
+    static const bool x6_table = !(getenv("COFI_GEMM_X6_PLANS") && atoi(getenv("COFI_GEMM_X6_PLANS")) == 0);   // A/B switch (tools)
+    if (arith == 2 && x6_table)
         for (const TunedPlan &t : kTunedPlansX6)
             if (t.M == M && t.N == N && t.K == K) {
                 p = finish_plan(K, t.bm, t.bn, t.ks);
