@@ -516,6 +516,74 @@ class BatchPipeline:
         return self.run(max(warmup, 2 * self.S * len(self.batches)))
 
 
+def dataside_inputs(dev, points):
+    """raw KITTI-shaped scan + image resident in HBM, the calibration, and the options of the device-side loader (row f2)"""
+    from cofii2p_amd import dataside, synth as _synth
+
+    raw, rimg, rK = _synth.make_raw_scan(0)
+    cal = dataside.calib_matrices(_synth.KITTI_CALIB_LINES)
+    P_Tr = np.dot(cal["P2"], cal["Tr"])
+    opt_ds = Opt()
+    for k_, v_ in dict(num_pc=points, num_kpt=64, P_tx_amplitude=10, P_ty_amplitude=0, P_tz_amplitude=10, P_Rx_amplitude=0.0, P_Ry_amplitude=2.0 * np.pi, P_Rz_amplitude=0.0).items():
+        setattr(opt_ds, k_, v_)
+    return opt_ds, raw, torch.from_numpy(raw).to(dev), torch.from_numpy(rimg).to(dev), rK, P_Tr
+
+
+def loader_pipeline(model, dev, opt_ds, st, slots_per_stream, nfr, upk, raw_d, img_d, rK, P_Tr, slot_base, workers=4):
+    """The pipelined loader (cofii2p_amd/loader.py) in front of the forward: voxel grid enqueued LOOK frames ahead, draws in worker
+    processes, resample + pyramid + image as one hipGraph per slot, tables read in place by the forward's graph; INFL forwards in flight.
+    Two passes (the first captures the graphs) -> (frames/s of the second, host seconds inside each call, INFL, LOOK)."""
+    from cofii2p_amd.loader import FrameLoader
+
+    LOOK, INFL = len(st), len(st) * max(1, slots_per_stream)
+    NSL = INFL + LOOK
+    loader = FrameLoader(opt_ds, dev, slots=NSL, workers=workers, capture_stream=st[0], upsample_k=upk)
+    pend = [None] * NSL
+    host = {"begin": 0.0, "complete": 0.0, "forward": 0.0, "collect": 0.0}   # host seconds inside each call (timed phase)
+
+    def timed(name, fn, *a, **k):
+        t_ = time.perf_counter()
+        r = fn(*a, **k)
+        host[name] += time.perf_counter() - t_
+        return r
+
+    def collect(sl):
+        h, smp = pend[sl]
+        model.finish(h)
+        smp["finish_labels"]()
+        loader.release(sl)
+        pend[sl] = None
+
+    try:
+        for phase in range(2):
+            for k_ in host:
+                host[k_] = 0.0
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for j in range(min(LOOK, nfr)):
+                with torch.cuda.stream(st[j % len(st)]):
+                    loader.begin(j % NSL, raw_d, img_d, rK, P_Tr, j)
+            for i in range(nfr):
+                sl, nxt = i % NSL, i + LOOK
+                with torch.cuda.stream(st[i % len(st)]):
+                    if nxt < nfr:   # the voxel grid of frame i + LOOK goes onto this stream AHEAD of frame i's own work
+                        if pend[nxt % NSL] is not None:
+                            timed("collect", collect, nxt % NSL)
+                        timed("begin", loader.begin, nxt % NSL, raw_d, img_d, rK, P_Tr, nxt)
+                    loader.poll()
+                    smp = timed("complete", loader.complete, sl)
+                    pend[sl] = (timed("forward", model.forward_async, slot_base + sl, smp["pc_data_dict"], smp["img"][None], inputs_stable=True), smp)
+                loader.poll()
+            for k in range(NSL):
+                if pend[(nfr + k) % NSL] is not None:
+                    timed("collect", collect, (nfr + k) % NSL)
+            torch.cuda.synchronize()
+            dtl = time.perf_counter() - t0
+    finally:
+        loader.close()
+    return nfr / dtl, dict(host), INFL, LOOK
+
+
 class optional_leg:
     """Everything after the headline measurement is additional information: a leg that fails (a worker pool that cannot spawn, a missing
     fixture, ...) is recorded in the line as `<name>_error` instead of costing the line."""
@@ -571,6 +639,7 @@ def main():
     ap.add_argument("--distinct-frames", type=int, default=16, help="distinct synthetic frames per rank cycled by the timed loop (16 x 27 MB of "
                     "tables do not fit the 256 MB Infinity Cache)")
     ap.add_argument("--no-f32", action="store_true", help="skip the extra measurements in the other arithmetics (other_arithmetics)")
+    ap.add_argument("--loader-leg", action="store_true", help="N > 1: every rank also runs the device-side loader pipeline (row f2) next to the others")
     ap.add_argument("--no-steady", action="store_true", help="skip the long-region re-measurement of the headline loop (steady_state)")
     ap.add_argument("--gemm", default=os.environ.get("COFI_GEMM", "bf16x6"), choices=["f32", "bf16x3", "bf16x6"],
                     help="arithmetic of the dense contractions: exact fp32 MFMA, 3-term bf16 split, or 6-term bf16 split (fp32-grade), all with fp32 accumulation")
@@ -728,6 +797,22 @@ def main():
                    "matches_per_frame": int(nmatch), "parallelism": "frame-parallel x%d" % world, "frame_streams_per_gpu": S,
                    "hipgraph_slots_per_stream": max(1, args.slots_per_stream) if (S > 1 and Bsz == 1) else 1},
     }
+    if world > 1 and args.loader_leg and not args.eager:
+        # multi-GPU readiness: every rank runs the device-side loader (its own FrameLoader worker pool, its NUMA pinning)
+        # in front of its forwards at the same time as the other ranks; the per-rank rates are gathered over the process group
+        leg_err = None
+        try:
+            opt_ds, _raw, raw_d, img_d, rK, P_Tr = dataside_inputs(dev, args.points)
+            st = make_streams(dev, max(S, 1))
+            model.enable_graphs(True)
+            rate = loader_pipeline(model, dev, opt_ds, st, args.slots_per_stream, max(8, 2 * args.steps), 1, raw_d, img_d, rK, P_Tr, 100, workers=2)[0]
+        except Exception as e:   # noqa: BLE001 - an extra leg: reported, never fatal
+            rate, leg_err = 0.0, "%s: %s" % (type(e).__name__, e)
+        rates = [None] * world
+        dist.all_gather_object(rates, (rate, leg_err))
+        result["loader_leg"] = {"per_rank_frames_per_s": [r[0] for r in rates], "errors": [r[1] for r in rates if r[1]],
+                                "note": "FrameLoader (voxel grid + resample + KNN pyramid + image, nearest-only up-sampling tables) + forward + fine matching, "
+                                        "pipelined, on every rank concurrently"}
     extras = rank == 0 and world == 1 and not args.eager and not args.no_batch_sweep
     if rank == 0 and world == 1 and not args.eager and S > 1 and not args.no_steady:
         with optional_leg(result, "steady_state"):
@@ -929,15 +1014,9 @@ def main():
             # row f2: the whole data side of a frame on this GPU (data/kitti.py:259-393: calibration transform, 0.1 m voxel grid, resample to
             # num_pc, random SE(3), KNN pyramid, image resize / crop, labels) from a raw 120 000-point scan + 376 x 1241 image already in
             # HBM, alone and in front of the forward
-            from cofii2p_amd import dataside, synth as _synth
+            from cofii2p_amd import dataside
 
-            raw, rimg, rK = _synth.make_raw_scan(0)
-            cal = dataside.calib_matrices(_synth.KITTI_CALIB_LINES)
-            P_Tr = np.dot(cal["P2"], cal["Tr"])
-            raw_d, img_d = torch.from_numpy(raw).to(dev), torch.from_numpy(rimg).to(dev)
-            opt_ds = Opt()
-            for k_, v_ in dict(num_pc=args.points, num_kpt=64, P_tx_amplitude=10, P_ty_amplitude=0, P_tz_amplitude=10, P_Rx_amplitude=0.0, P_Ry_amplitude=2.0 * np.pi, P_Rz_amplitude=0.0).items():
-                setattr(opt_ds, k_, v_)
+            opt_ds, raw, raw_d, img_d, rK, P_Tr = dataside_inputs(dev, args.points)
             st = make_streams(dev, max(S, 1))
             prep0 = dataside.FramePreparer(opt_ds, dev)
             for i in range(3):
@@ -951,62 +1030,12 @@ def main():
             loader_ms = 1e3 * (time.perf_counter() - t0) / nl
             voxels = prep0.last["voxels"]
             del prep0
-            # the pipelined loader (cofii2p_amd/loader.py): voxel grid enqueued LOOK frames ahead, draws in worker processes, resample +
-            # pyramid + image as one hipGraph per slot, tables read in place by the forward's graph; INFL forwards in flight
-            from cofii2p_amd.loader import FrameLoader
-
             model.enable_graphs(True)
-            LOOK, INFL = len(st), len(st) * max(1, args.slots_per_stream)
-            NSL = INFL + LOOK
             ds_rates = {}
+            nfr = max(args.steps, 3 * (len(st) * (max(1, args.slots_per_stream) + 1)))
             for upk in (None, 1):   # the reference's (N, 128) up-sampling tables / nearest-only tables derived without a search (outputs bit-identical)
-                loader = FrameLoader(opt_ds, dev, slots=NSL, workers=4, capture_stream=st[0], upsample_k=upk)
-                pend = [None] * NSL
-
-                host = {"begin": 0.0, "complete": 0.0, "forward": 0.0, "collect": 0.0}   # host seconds inside each call (timed phase)
-
-                def timed(name, fn, *a, **k):
-                    t_ = time.perf_counter()
-                    r = fn(*a, **k)
-                    host[name] += time.perf_counter() - t_
-                    return r
-
-                def collect(sl):
-                    h, smp = pend[sl]
-                    model.finish(h)
-                    smp["finish_labels"]()
-                    loader.release(sl)
-                    pend[sl] = None
-
-                try:
-                    for phase in range(2):
-                        nfr = max(args.steps, 3 * NSL)
-                        for k_ in host:
-                            host[k_] = 0.0
-                        torch.cuda.synchronize()
-                        t0 = time.perf_counter()
-                        for j in range(min(LOOK, nfr)):
-                            with torch.cuda.stream(st[j % len(st)]):
-                                loader.begin(j % NSL, raw_d, img_d, rK, P_Tr, j)
-                        for i in range(nfr):
-                            sl, nxt = i % NSL, i + LOOK
-                            with torch.cuda.stream(st[i % len(st)]):
-                                if nxt < nfr:   # the voxel grid of frame i + LOOK goes onto this stream AHEAD of frame i's own work
-                                    if pend[nxt % NSL] is not None:
-                                        timed("collect", collect, nxt % NSL)
-                                    timed("begin", loader.begin, nxt % NSL, raw_d, img_d, rK, P_Tr, nxt)
-                                loader.poll()
-                                smp = timed("complete", loader.complete, sl)
-                                pend[sl] = (timed("forward", model.forward_async, (60 if upk is None else 80) + sl, smp["pc_data_dict"], smp["img"][None], inputs_stable=True), smp)
-                            loader.poll()
-                        for k in range(NSL):
-                            if pend[(nfr + k) % NSL] is not None:
-                                timed("collect", collect, (nfr + k) % NSL)
-                        torch.cuda.synchronize()
-                        dtl = time.perf_counter() - t0
-                finally:
-                    loader.close()
-                ds_rates[upk] = (nfr / dtl, dict(host))
+                rate, hst, INFL, LOOK = loader_pipeline(model, dev, opt_ds, st, args.slots_per_stream, nfr, upk, raw_d, img_d, rK, P_Tr, 60 if upk is None else 80)
+                ds_rates[upk] = (rate, hst)
             dtl, host = nfr / ds_rates[None][0], ds_rates[None][1]
             result["with_dataside"] = {"loader_ms_per_frame": loader_ms, "loader_frames_per_s": 1e3 / loader_ms, "frames_per_s": nfr / dtl,
                                        "ms_per_frame": 1e3 * dtl / nfr, "voxels": voxels, "raw_points": int(raw.shape[1]),
