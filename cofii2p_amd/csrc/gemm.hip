@@ -511,7 +511,17 @@ __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
     static_assert(!X6 || (!WSPLIT && !ASPLIT), "bf16x6 splits both operands on the fly");
     constexpr int NPL = X6 ? 3 : 2;   // bf16 planes per operand
     constexpr int NT = 256;
-    constexpr int BROW3 = BK3 * 2 + 16;   // bytes per LDS row: bf16 values + 16 B pad (68 / 36 dwords: conflict-free b128 reads)
+    // bytes per LDS row.  64- / 128-deep K-tiles: bf16 values + 16 B pad (36 / 68 dwords: conflict-free b128 reads, and a 16-lane group of
+    // the b64 plane stores covers one row).  32-deep K-tiles (the wide bf16x6 tiles): that padding (20 dwords) lets two rows of a store group
+    // overlap mod 32 banks - a third of the LDS cycles of the 128 x 128 bf16x6 kernel were bank conflicts (PMC, round 4) - so the rows stay
+    // UNPADDED (64 B) and the four 16-byte chunks of row r are XOR-swizzled by (r >> 2) & 3: the 16 rows a b128 read group touches
+    // ({0-3, 12-15, 20-27} and its shifts) land on 16 distinct 4-bank groups, a store group writes two whole rows = all 32 banks once.
+    constexpr bool SWZ = BK3 == 32;
+    constexpr int BROW3 = SWZ ? 64 : BK3 * 2 + 16;
+    auto loff = [](int row, int kbyte) -> int {   // byte offset of (row, byte kbyte of the row's K-slice) inside a plane
+        if constexpr (SWZ) return row * 64 + ((((kbyte >> 4) ^ (row >> 2)) & 3) << 4) + (kbyte & 15);
+        else return row * BROW3 + kbyte;
+    };
     constexpr int LPR = BK3 / 4;          // lanes per row slice (float4 each)
     constexpr int RPP = NT / LPR;         // rows per staging pass
     constexpr int A_LD4 = BM / RPP, W_LD4 = BN / RPP;            // float4 loads per thread and tile
@@ -698,7 +708,7 @@ __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < A_CH; ++j) {
                 const int c = tid + NT * j;
-                unsigned char *p = lds_raw + (c / CPR) * BROW3 + (c % CPR) * 16;
+                unsigned char *p = lds_raw + loff(c / CPR, (c % CPR) * 16);
                 *reinterpret_cast<f32x4 *>(p) = st.rah[j];
                 *reinterpret_cast<f32x4 *>(p + PLANE_A) = st.ral[j];
             }
@@ -706,7 +716,7 @@ __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < A_LD4; ++j) {
                 const f32x4 v = (st.afull || ((st.amask >> j) & 1u)) ? st.ra[j] : zero;
-                unsigned char *p = lds_raw + (lrow + RPP * j) * BROW3 + lk * 2;
+                unsigned char *p = lds_raw + loff(lrow + RPP * j, lk * 2);
                 uint2 hi, lo;
                 if constexpr (X6) {   // planes: hi | mid | lo
                     uint2 mid;
@@ -724,7 +734,7 @@ __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < W_CH; ++j) {
                 const int c = tid + NT * j;
-                unsigned char *p = lds_raw + NPL * PLANE_A + (c / CPR) * BROW3 + (c % CPR) * 16;
+                unsigned char *p = lds_raw + NPL * PLANE_A + loff(c / CPR, (c % CPR) * 16);
                 *reinterpret_cast<f32x4 *>(p) = st.rwh[j];
                 *reinterpret_cast<f32x4 *>(p + PLANE_W) = st.rwl[j];
             }
@@ -732,7 +742,7 @@ __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < W_LD4; ++j) {
                 uint2 hi, lo;
-                unsigned char *p = lds_raw + NPL * PLANE_A + (lrow + RPP * j) * BROW3 + lk * 2;
+                unsigned char *p = lds_raw + NPL * PLANE_A + loff(lrow + RPP * j, lk * 2);
                 if constexpr (X6) {
                     uint2 mid;
                     split4x3(st.rw[j], hi, mid, lo);
@@ -758,41 +768,53 @@ __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
     const int li = lane & 31, lh = lane >> 5;
     union Frag { uint4 u; bf16x8 v; };
     constexpr int STEPS = BK3 / 16;   // 16-deep MFMA steps per tile
-    const unsigned char *as = lds_raw + (wm * 32 * TM + li) * BROW3 + lh * 16;
-    const unsigned char *bs = lds_raw + NPL * PLANE_A + (wn * 32 * TN + li) * BROW3 + lh * 16;
+    // lane (li, lh) reads chunk 2 s2 + lh of its row; every row this lane touches is li mod 32, so the swizzle term is a lane constant
+    const unsigned char *as = lds_raw + (wm * 32 * TM + li) * BROW3 + (SWZ ? 0 : lh * 16);
+    const unsigned char *bs = lds_raw + NPL * PLANE_A + (wn * 32 * TN + li) * BROW3 + (SWZ ? 0 : lh * 16);
+    const int swz = (li >> 2) & 3;
+    auto koff = [&](int s2) -> int { return SWZ ? (((2 * s2 + lh) ^ swz) << 4) : s2 * 32; };
     auto compute = [&]() {
 #pragma unroll
         for (int s2 = 0; s2 < STEPS; ++s2) {  // lane (i,h) owns k = 16*s2 + 8h .. +7
             Frag ah[TM], al[TM], bh[TN], bl[TN], am[X6 ? TM : 1], bm[X6 ? TN : 1];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                ah[i].u = *reinterpret_cast<const uint4 *>(as + i * 32 * BROW3 + s2 * 32);
-                al[i].u = *reinterpret_cast<const uint4 *>(as + (NPL - 1) * PLANE_A + i * 32 * BROW3 + s2 * 32);
-                if constexpr (X6) am[i].u = *reinterpret_cast<const uint4 *>(as + PLANE_A + i * 32 * BROW3 + s2 * 32);
+                ah[i].u = *reinterpret_cast<const uint4 *>(as + i * 32 * BROW3 + koff(s2));
+                al[i].u = *reinterpret_cast<const uint4 *>(as + (NPL - 1) * PLANE_A + i * 32 * BROW3 + koff(s2));
+                if constexpr (X6) am[i].u = *reinterpret_cast<const uint4 *>(as + PLANE_A + i * 32 * BROW3 + koff(s2));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                bh[j].u = *reinterpret_cast<const uint4 *>(bs + j * 32 * BROW3 + s2 * 32);
-                bl[j].u = *reinterpret_cast<const uint4 *>(bs + (NPL - 1) * PLANE_W + j * 32 * BROW3 + s2 * 32);
-                if constexpr (X6) bm[j].u = *reinterpret_cast<const uint4 *>(bs + PLANE_W + j * 32 * BROW3 + s2 * 32);
+                bh[j].u = *reinterpret_cast<const uint4 *>(bs + j * 32 * BROW3 + koff(s2));
+                bl[j].u = *reinterpret_cast<const uint4 *>(bs + (NPL - 1) * PLANE_W + j * 32 * BROW3 + koff(s2));
+                if constexpr (X6) bm[j].u = *reinterpret_cast<const uint4 *>(bs + PLANE_W + j * 32 * BROW3 + koff(s2));
             }
+            // product-major order: consecutive MFMAs go to DIFFERENT accumulator tiles (TM x TN independent chains), so none waits for
+            // the result of the one issued right before it; per accumulator the order of the terms is unchanged (smallest first)
+            auto term = [&](auto pa, auto pb) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if constexpr (X6) {   // smallest terms first: 2^-16 (lo*hi, hi*lo, mid*mid), 2^-8 (mid*hi, hi*mid), 1 (hi*hi)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].v, bh[j].v, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bl[j].v, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i].v, bm[j].v, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i].v, bh[j].v, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bm[j].v, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bh[j].v, acc[i][j], 0, 0, 0);
-                    } else {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].v, bh[j].v, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bl[j].v, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bh[j].v, acc[i][j], 0, 0, 0);
-                    }
-                }
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa(i), pb(j), acc[i][j], 0, 0, 0);
+            };
+            auto AH = [&](int i) { return ah[i].v; };
+            auto AL = [&](int i) { return al[i].v; };
+            auto BH = [&](int j) { return bh[j].v; };
+            auto BL = [&](int j) { return bl[j].v; };
+            if constexpr (X6) {   // smallest terms first: 2^-16 (lo*hi, hi*lo, mid*mid), 2^-8 (mid*hi, hi*mid), 1 (hi*hi)
+                auto AM = [&](int i) { return am[i].v; };
+                auto BM_ = [&](int j) { return bm[j].v; };
+                term(AL, BH);
+                term(AH, BL);
+                term(AM, BM_);
+                term(AM, BH);
+                term(AH, BM_);
+                term(AH, BH);
+            } else {
+                term(AL, BH);
+                term(AH, BL);
+                term(AH, BH);
+            }
         }
     };
     // One LDS buffer + a register-staged next tile: issue global loads (t+1) -> MFMAs on tile t -> barrier -> split + write
