@@ -13,6 +13,12 @@ import os
 from . import ops
 
 JOINT_SELF = True   # the four self layers run ONCE over [image | point] tokens (shared weights); tests flip it for the per-stream form
+# The fused layer tail owns 32 token rows per workgroup and streams ~1 MB of weight planes per tile through one wave per SIMD: built for
+# the latency of a 1280-row call.  Above this many rows per call (stack-mode batches) the layer runs as plain GEMM launches instead,
+# which are efficient at that size (batch 16, bf16x6: 165 us per fused tail vs ~110 us for merge + three GEMMs + the next projection;
+# whole pipeline, frames/s with / without the fused tail: batch 16 601 / 619, batch 8 578 / 596, batch 4 555 / 569, batch 2 519 / 526,
+# batch 1 - 1280 rows - 478 / 457).
+TAIL_MAX_ROWS = int(os.environ.get("COFI_TAIL_MAX_ROWS", "2048"))
 
 
 def pack_layer(sd: Dict[str, torch.Tensor], p: str) -> Dict[str, torch.Tensor]:
@@ -52,7 +58,7 @@ def _layer(w, xcat: torch.Tensor, src: torch.Tensor, out: torch.Tensor, self_att
         kv = ops.gemm(src, w["kv.weight"])
         k, v = kv[:, :C], kv[:, C:]
     # the attention kernel folds the partials into the per-frame token-axis norm of Q itself
-    fused_tail = ops.tail_planes() > 0 and C == 128
+    fused_tail = ops.tail_planes() > 0 and C == 128 and x.shape[0] <= TAIL_MAX_ROWS
     rows_q = x.shape[0] // frames
     if frames > 1 and rows_q % 64:   # the projection's 64-row statistics slabs straddle frames: explicit per-frame column norms
         qs = torch.stack([ops.col_inv_norm(q[f * rows_q:(f + 1) * rows_q]) for f in range(frames)])
@@ -113,6 +119,7 @@ def _chain_ok(ts: "TokenStreams", kinds, frames: int) -> bool:
     multiples of 64 (the first projection's statistics slabs; the tails work on 32-row tiles - KITTI: 1280 / 1280), one of the bf16-split arithmetics."""
     L = ts.img[0].shape[0] // frames
     return (FUSED_CHAIN and JOINT_SELF and ts.C == 128 and ops.tail_planes() > 0 and ts.joint and L % 64 == 0 and len(kinds) >= 2
+            and ts.img[0].shape[0] <= TAIL_MAX_ROWS
             and all(k == ("self", "cross")[i & 1] for i, k in enumerate(kinds)))
 
 
