@@ -87,7 +87,7 @@ SIGNATURES = {
     "cofi_pos_sine": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _P, _I, _P]),
     "cofi_l2norm_rows": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
     "cofi_l2norm_rows2": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P]),
-    "cofi_transpose": (_I, [_P, _I, _I, _I, _P, _I, _P]),
+    "cofi_transpose": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
     "cofi_col_mean": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "cofi_conv2d_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _Z, _I, _P]),
     "cofi_conv2d_nhwc_fused": (_I, [_P, _I, _N, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _Z, _I, _P]),
@@ -96,7 +96,7 @@ SIGNATURES = {
     "cofi_upsample2x_cat_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P]),
     "cofi_extract_patches_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _F, _P, _I, _P, _P]),
     "cofi_row_argmin_1m": (_I, [_P, _I, _I, _I, _P, _P]),
-    "cofi_select_matches": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P]),
+    "cofi_select_matches": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _I, _P]),
     "cofi_gather_points_sel": (_I, [_P, _P, _P, _I, _P, _P]),
     "cofi_gather_rows_sel": (_I, [_P, _I, _I, _P, _P, _I, _P, _I, _P]),
     "cofi_multi_copy": (_I, [_P, _I, _I, _P]),
@@ -123,7 +123,7 @@ SIGNATURES = {
     "cofi_attention_bwd_workspace": (_Z, [_I, _I]),
     "cofi_attention_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _I, _P, _I, _P, _I, _P, _Z, _P]),
     "cofi_pnp_ransac": (_I, [_P, _P, _P, _I, _F, _F, _F, _F, _I, _F, ctypes.c_uint, _I, _P, _Z, _P, _P, _P, _P]),
-    "cofi_match_finish": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P, _I, _F, _P, _I, _P, _P, _P, _I, _P, _P, _P]),
+    "cofi_match_finish": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P, _I, _F, _P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "cofi_fine_match": (_I, [_P, _P, _I, _I, _P, _I, _F, _P, _I, _P, _P, _P]),
     "cofi_kpconv_fused_slab_rows": (_I, [_I, _I, _I]),
     "cofi_kpconv_fused": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _F, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P, _P]),

@@ -37,17 +37,22 @@ struct SelArgs {
     float thr[64];
 };
 
-// single workgroup: threshold search + ordered compaction (ascending point index)
-__global__ __launch_bounds__(1024) void select_matches_kernel(SelArgs a) {
-    __shared__ int s_cnt[16];
+// one workgroup per frame (stack mode: frame f reads score / pix rows [f N, (f + 1) N) and owns sel[f], xy[f] (2, N), count[f]):
+// threshold search + ordered compaction (ascending point index).  256 threads: a 1024-thread workgroup needs a whole CU's wave slots
+// and waits for one to drain while other submissions' kernels fill the chip (86 us on average at batch 16, round 4 - for 5 us of work)
+constexpr int SEL_NT = 256, SEL_NW = SEL_NT / 64;
+__global__ __launch_bounds__(SEL_NT) void select_matches_kernel(SelArgs a) {
+    __shared__ int s_cnt[SEL_NW];
     __shared__ int s_thr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f = blockIdx.x;
+    a.score += (size_t)f * a.N; a.pix += (size_t)f * a.N; a.sel += (size_t)f * a.N; a.xy += (size_t)f * 2 * a.N; a.count += 2 * f;
     // pass 1: find the first threshold with enough survivors
     if (tid == 0) s_thr = -1;
     __syncthreads();
     for (int t = 0; t < a.n_thr; ++t) {
         int c = 0;
-        for (int n = tid; n < a.N; n += 1024) {
+        for (int n = tid; n < a.N; n += SEL_NT) {
             const int p = a.pix[n];
             const int x = p % a.W8, y = p / a.W8;
             const bool ok = a.score[n] >= a.thr[t] && x >= 2 && x <= a.xmax && y >= 2 && y <= a.ymax;
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(1024) void select_matches_kernel(SelArgs a) {
         if (lane == 0) s_cnt[wave] = c;
         __syncthreads();
         int tot = 0;
-        for (int w = 0; w < 16; ++w) tot += s_cnt[w];
+        for (int w = 0; w < SEL_NW; ++w) tot += s_cnt[w];
         __syncthreads();
         if (tot >= a.min_matches) {
             if (tid == 0) s_thr = t;
@@ -72,9 +77,9 @@ __global__ __launch_bounds__(1024) void select_matches_kernel(SelArgs a) {
         return;
     }
     const float thr = a.thr[tsel];
-    // pass 2: ordered compaction in chunks of 1024 points
+    // pass 2: ordered compaction in chunks of SEL_NT points
     int base = 0;
-    for (int n0 = 0; n0 < a.N; n0 += 1024) {
+    for (int n0 = 0; n0 < a.N; n0 += SEL_NT) {
         const int n = n0 + tid;
         bool ok = false;
         int x = 0, y = 0;
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(1024) void select_matches_kernel(SelArgs a) {
         int off = base;
         for (int w = 0; w < wave; ++w) off += s_cnt[w];
         int tot = 0;
-        for (int w = 0; w < 16; ++w) tot += s_cnt[w];
+        for (int w = 0; w < SEL_NW; ++w) tot += s_cnt[w];
         if (ok) {
             const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
             a.sel[pos] = n;
@@ -179,14 +184,20 @@ struct FinishArgs {
     int32_t *best;
     int N1, cap, ldf, C, H2, W2, ldxy, ldfpc, ldo;
     float cscale;
+    int N4;   // stage-4 points per frame (stack mode: frame f = blockIdx.x / cap; every per-frame array advances by its own frame size)
 };
 constexpr int FIN_MAXC = 128;
 
 __global__ __launch_bounds__(256) void match_finish_kernel(FinishArgs a) {
     __shared__ u64 s_key[4];
     __shared__ float s_f[FIN_MAXC], s_p[FIN_MAXC * 16];
-    const int i = blockIdx.x;
+    const int f = blockIdx.x / a.cap, i = blockIdx.x - f * a.cap;
+    a.count += 2 * f;
     if (i >= min(*a.count, a.cap)) return;
+    a.pts4 += (size_t)f * a.N4 * 3; a.pts1 += (size_t)f * a.N1 * 3; a.sel += (size_t)f * a.cap; a.xy += (size_t)f * 2 * a.ldxy;
+    a.fmap += (size_t)f * a.H2 * a.W2 * a.ldf; a.fpc += (size_t)f * a.N1 * a.ldfpc;
+    a.coarse_pts += (size_t)f * a.cap * 3; a.patches += (size_t)f * a.cap * a.C * 16; a.fine_pc += (size_t)f * a.cap * a.ldo;
+    a.fine_xy += (size_t)f * 2 * a.cap; a.best += (size_t)f * a.cap;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t n = (size_t)a.sel[i];
     const float qx = a.pts4[3 * n], qy = a.pts4[3 * n + 1], qz = a.pts4[3 * n + 2];
@@ -270,14 +281,14 @@ __global__ __launch_bounds__(256) void match_finish_kernel(FinishArgs a) {
 extern "C" int cofi_match_finish(const float *pts4, const float *pts1, int N1, const int32_t *sel, const int32_t *count_dev, int cap,
                                  const float *fmap, int ldf, int C, int H2, int W2, const float *coarse_xy, int ldxy, float center_scale,
                                  const float *fine_pc_all, int ldfpc, float *coarse_pts, float *patches, float *fine_pc, int ldo,
-                                 float *fine_xy, int32_t *best, cofi_stream_t stream) {
+                                 float *fine_xy, int32_t *best, int N4, int frames, cofi_stream_t stream) {
     if (!pts4 || !pts1 || !sel || !count_dev || !fmap || !coarse_xy || !fine_pc_all || !coarse_pts || !patches || !fine_pc || !fine_xy || !best)
         return COFI_EINVAL;
-    if (N1 <= 0 || cap <= 0 || C <= 0 || H2 <= 0 || W2 <= 0 || ldf < C || ldfpc < C || ldo < C) return COFI_EINVAL;
+    if (N1 <= 0 || cap <= 0 || C <= 0 || H2 <= 0 || W2 <= 0 || ldf < C || ldfpc < C || ldo < C || N4 <= 0 || frames <= 0) return COFI_EINVAL;
     if (C > FIN_MAXC) return COFI_EUNSUPPORTED;
     FinishArgs a{pts4, pts1, fmap, coarse_xy, fine_pc_all, sel, count_dev, coarse_pts, patches, fine_pc, fine_xy, best,
-                 N1, cap, ldf, C, H2, W2, ldxy, ldfpc, ldo, center_scale};
-    hipLaunchKernelGGL(match_finish_kernel, dim3(cap), dim3(256), 0, cofi_s(stream), a);
+                 N1, cap, ldf, C, H2, W2, ldxy, ldfpc, ldo, center_scale, N4};
+    hipLaunchKernelGGL(match_finish_kernel, dim3(cap * frames), dim3(256), 0, cofi_s(stream), a);
     return cofi_launch_status();
 }
 
@@ -288,14 +299,14 @@ extern "C" int cofi_row_argmin_1m(const float *sim, int lds, int N, int P, int32
 }
 
 extern "C" int cofi_select_matches(const float *score, const int32_t *pix, int N, int W8, int H8, int x_max, int y_max, const float *thr_host,
-                                   int n_thr, int min_matches, int32_t *sel, float *coarse_xy, int32_t *count_dev, cofi_stream_t stream) {
-    if (!score || !pix || !thr_host || !sel || !coarse_xy || !count_dev || N <= 0 || W8 <= 0 || H8 <= 0 || n_thr <= 0 || n_thr > 64)
+                                   int n_thr, int min_matches, int32_t *sel, float *coarse_xy, int32_t *count_dev, int frames, cofi_stream_t stream) {
+    if (!score || !pix || !thr_host || !sel || !coarse_xy || !count_dev || N <= 0 || W8 <= 0 || H8 <= 0 || n_thr <= 0 || n_thr > 64 || frames <= 0)
         return COFI_EINVAL;
     SelArgs a;
     a.score = score; a.pix = pix; a.sel = sel; a.count = count_dev; a.xy = coarse_xy;
     a.N = N; a.W8 = W8; a.H8 = H8; a.n_thr = n_thr; a.min_matches = min_matches; a.xmax = x_max; a.ymax = y_max;
     for (int i = 0; i < 64; ++i) a.thr[i] = i < n_thr ? thr_host[i] : 0.f;
-    hipLaunchKernelGGL(select_matches_kernel, dim3(1), dim3(1024), 0, cofi_s(stream), a);
+    hipLaunchKernelGGL(select_matches_kernel, dim3(frames), dim3(SEL_NT), 0, cofi_s(stream), a);
     return cofi_launch_status();
 }
 

@@ -451,6 +451,8 @@ __global__ __launch_bounds__(256) void col_mean_kernel(const float *x, int ldx, 
 // transposes - up to 39 MB - ran at 1.1 TB/s through the scalar kernel below)
 __global__ __launch_bounds__(256) void transpose_vec_kernel(const float *x, int ldx, int M, int C, float *y, int ldy) {
     __shared__ float tile[64][65];
+    x += (size_t)blockIdx.z * M * ldx;   // frames stacked along the rows of x; frame f writes its own (C, M) block of y
+    y += (size_t)blockIdx.z * C * ldy;
     const int m0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int q = threadIdx.x & 15, r = threadIdx.x >> 4;   // 16 float4 per tile row, 16 rows per pass
 #pragma unroll
@@ -522,6 +524,8 @@ __global__ __launch_bounds__(256) void transpose_pair_kernel(TransposePairArgs a
 
 __global__ void transpose_kernel(const float *x, int ldx, int M, int C, float *y, int ldy) {
     __shared__ float tile[32][33];
+    x += (size_t)blockIdx.z * M * ldx;
+    y += (size_t)blockIdx.z * C * ldy;
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
     for (int i = ty; i < 32; i += 8) {
@@ -712,12 +716,12 @@ extern "C" int cofi_col_mean(const float *x, int ldx, int M, int C, float *out, 
     return cofi_launch_status();
 }
 
-extern "C" int cofi_transpose(const float *x, int ldx, int M, int C, float *y, int ldy, cofi_stream_t stream) {
-    if (!x || !y || M <= 0 || C <= 0 || ldx < C || ldy < M) return COFI_EINVAL;
+extern "C" int cofi_transpose(const float *x, int ldx, int M, int C, float *y, int ldy, int frames, cofi_stream_t stream) {
+    if (!x || !y || M <= 0 || C <= 0 || ldx < C || ldy < M || frames <= 0) return COFI_EINVAL;
     if (!((M | C | ldx | ldy) & 3) && !(((uintptr_t)x | (uintptr_t)y) & 15) && (long)M * C >= 64 * 64)
-        hipLaunchKernelGGL(transpose_vec_kernel, dim3(cofi_cdiv(C, 64), cofi_cdiv(M, 64)), dim3(256), 0, cofi_s(stream), x, ldx, M, C, y, ldy);
+        hipLaunchKernelGGL(transpose_vec_kernel, dim3(cofi_cdiv(C, 64), cofi_cdiv(M, 64), frames), dim3(256), 0, cofi_s(stream), x, ldx, M, C, y, ldy);
     else
-        hipLaunchKernelGGL(transpose_kernel, dim3(cofi_cdiv(C, 32), cofi_cdiv(M, 32)), dim3(256), 0, cofi_s(stream), x, ldx, M, C, y, ldy);
+        hipLaunchKernelGGL(transpose_kernel, dim3(cofi_cdiv(C, 32), cofi_cdiv(M, 32), frames), dim3(256), 0, cofi_s(stream), x, ldx, M, C, y, ldy);
     return cofi_launch_status();
 }
 

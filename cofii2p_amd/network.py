@@ -288,38 +288,50 @@ class CoFiI2P(nn.Module):
             taps.update(up2=up2, fine_pc=fine_pc, tok_img_out=tok_img, tok_pc_out=tok_pc)
         N1 = points[1].shape[0] // B
         P2 = H2 * W2
+        # ---- per-frame output layouts + matching: one launch each for all B frames (network.py:145-161; the count stays on the device)
+        if img_desc_t is None:   # B > 1 (or no fused chain): channel-major descriptor outputs of every frame
+            img_t, pc_t = ops.transpose(img_desc_tok, frames=B).reshape(B, C, T_img), ops.transpose(pc_desc_tok, frames=B).reshape(B, C, N4)
+        else:
+            img_t, pc_t = img_desc_t[None], pc_desc_t[None]
+        test = mode not in ("train", "val")
+        if test:
+            sim = torch.empty((B * N4, T_img), dtype=torch.float32, device=dev)
+            for f in range(B):   # <pc, pixel> per frame (the only per-frame launches left)
+                ops.gemm(pc_desc_tok[f * N4:(f + 1) * N4], img_desc_tok[f * T_img:(f + 1) * T_img], out=sim[f * N4:(f + 1) * N4])
+            pix = ops.row_argmin_1m(sim)
+            sel, xy, cnt = ops.select_matches(pc_score.reshape(-1), pix, W8, H8, score_thresholds(), 4, frames=B)
+            sel, xy, cnt = sel.reshape(B, N4), xy.reshape(B, 2, N4), cnt.reshape(B, 2)
+            if C2 <= 128:   # coarse point, point2node, patch, fine descriptor and the caller's fine matching (eval_all.py:99-105): one launch
+                cpts, pat, fpcs, fxy, fbest = (t if B > 1 else t[None] for t in
+                                               ops.match_finish(points[-1], points[1], sel, cnt, up2, H2, W2, xy, fine_pc, 4.0, frames=B))
         outs = []
-        for f in range(B):  # per-frame tail: output layouts + matching (small kernels)
-            pdt, idt = pc_desc_tok[f * N4:(f + 1) * N4], img_desc_tok[f * T_img:(f + 1) * T_img]
-            o = {"img_desc": (ops.transpose(idt) if img_desc_t is None else img_desc_t).reshape(1, C, H8, W8),
-                 "pc_desc": ops.transpose(pdt) if pc_desc_t is None else pc_desc_t,
+        for f in range(B):  # per-frame views
+            o = {"img_desc": img_t[f].reshape(1, C, H8, W8), "pc_desc": pc_t[f],
                  "img_score": img_score[f * T_img:(f + 1) * T_img].reshape(1, 1, H8, W8), "pc_score": pc_score[f * N4:(f + 1) * N4].reshape(1, 1, N4)}
             fpc = fine_pc[f * N1:(f + 1) * N1]
             up2_f = up2[f * P2:(f + 1) * P2]
-            if mode in ("train", "val"):
+            if not test:
                 K = fine_center_kpt_coors.shape[1]
-                cnt = torch.zeros((2,), dtype=torch.int32, device=dev)
-                cnt[:1].fill_(K)   # a fill kernel, not a host-to-device copy: capturable in a hipGraph
+                cntk = torch.zeros((2,), dtype=torch.int32, device=dev)
+                cntk[:1].fill_(K)   # a fill kernel, not a host-to-device copy: capturable in a hipGraph
                 ctr = fine_center_kpt_coors.to(torch.float32).contiguous()
-                pat = ops.extract_patches_nhwc(up2_f, H2, W2, ctr, cnt, K, 1.0)
-                o["patches"] = pat.reshape(K, C2, 4, 4)
+                pat_k = ops.extract_patches_nhwc(up2_f, H2, W2, ctr, cntk, K, 1.0)
+                o["patches"] = pat_k.reshape(K, C2, 4, 4)
                 o["fine_pc"] = ops.gather_rows(fpc, self._as_idx32(fine_pc_inline_index.reshape(-1)))
             else:
-                # ---- test mode: coarse matching + patch extraction (network.py:145-161), count stays on the device
-                pts4, pts1 = points[-1][f * N4:(f + 1) * N4], points[1][f * N1:(f + 1) * N1]
-                sim = ops.gemm(pdt, idt)  # (N4, T): <pc, pixel>
-                pix = ops.row_argmin_1m(sim)
-                sel, xy, cnt = ops.select_matches(o["pc_score"].reshape(-1), pix, W8, H8, score_thresholds(), 4)
-                if C2 <= 128:   # coarse point, point2node, patch, fine descriptor and the caller's fine matching (eval_all.py:99-105): one launch
-                    o["coarse_pts"], o["patches"], o["fine_pc"], o["fine_xy"], o["fine_best"] = ops.match_finish(pts4, pts1, sel, cnt, up2_f, H2, W2, xy, fpc, 4.0)
+                if C2 <= 128:
+                    o["coarse_pts"], o["patches"], o["fine_pc"], o["fine_xy"], o["fine_best"] = cpts[f], pat[f], fpcs[f], fxy[f], fbest[f]
                 else:
-                    o["coarse_pts"] = ops.gather_points_sel(pts4, sel, cnt)
-                    node = ops.nearest_node_sel(pts1, pts4, sel, cnt)
-                    o["patches"] = ops.extract_patches_nhwc(up2_f, H2, W2, xy, cnt, N4, 4.0)
-                    o["fine_pc"] = ops.gather_rows_sel(fpc, node, cnt, N4)
-                    o["fine_xy"], o["fine_best"] = ops.fine_match(o["patches"], o["fine_pc"], xy, cnt, 4.0)  # eval_all.py:99-105
-                o.update(sel=sel, coarse_xy=xy, count=cnt)
+                    pts4, pts1 = points[-1][f * N4:(f + 1) * N4], points[1][f * N1:(f + 1) * N1]
+                    o["coarse_pts"] = ops.gather_points_sel(pts4, sel[f], cnt[f])
+                    node = ops.nearest_node_sel(pts1, pts4, sel[f], cnt[f])
+                    o["patches"] = ops.extract_patches_nhwc(up2_f, H2, W2, xy[f], cnt[f], N4, 4.0)
+                    o["fine_pc"] = ops.gather_rows_sel(fpc, node, cnt[f], N4)
+                    o["fine_xy"], o["fine_best"] = ops.fine_match(o["patches"], o["fine_pc"], xy[f], cnt[f], 4.0)  # eval_all.py:99-105
+                o.update(sel=sel[f], coarse_xy=xy[f], count=cnt[f])
             outs.append(o)
+        if test:
+            outs[0]["count_all"] = cnt   # (B, 2): one device-to-host copy serves every frame of the submission
         br_dead.join()
         return outs
 
@@ -481,8 +493,7 @@ class CoFiI2P(nn.Module):
         host = hosts.get((slot, len(outs)))
         if host is None:
             host = hosts[(slot, len(outs))] = torch.empty((len(outs), 2), dtype=torch.int32, pin_memory=True)
-        for f, o in enumerate(outs):
-            host[f].copy_(o["count"], non_blocking=True)
+        host.copy_(outs[0]["count_all"], non_blocking=True)
         done = torch.cuda.Event()
         done.record()
         return {"out": outs, "count_host": host, "done": done}

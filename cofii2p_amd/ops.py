@@ -641,13 +641,17 @@ def col_mean(x, frames: int = 1):
     return out
 
 
-def transpose(x, out=None):
+def transpose(x, out=None, frames: int = 1):
+    """(M, C) -> (C, M); frames > 1: x holds `frames` row blocks of M / frames rows, out = (frames, C, M / frames), one launch."""
     lib = _lib.load()
     _mat(x, "x")
     M, C = x.shape
+    if M % frames:
+        raise _lib.CofiError("transpose: rows are not a multiple of the frame count")
+    M //= frames
     if out is None:
-        out = torch.empty((C, M), dtype=torch.float32, device=x.device)
-    _lib.check(lib.cofi_transpose(_p(x), _ld(x), M, C, _p(out), _ld(out), _stream()), "cofi_transpose")
+        out = torch.empty((C, M) if frames == 1 else (frames, C, M), dtype=torch.float32, device=x.device)
+    _lib.check(lib.cofi_transpose(_p(x), _ld(x), M, C, _p(out), out.stride(-2), frames, _stream()), "cofi_transpose")
     return out
 
 
@@ -1032,17 +1036,21 @@ def row_argmin_1m(sim):
     return out
 
 
-def select_matches(score, pix, W8: int, H8: int, thresholds: np.ndarray, min_matches: int = 4, x_max: int = 62, y_max: int = 18):
-    """-> sel (N,) int32, coarse_xy (2,N) float32, count_dev (2,) int32 [n, threshold index].  Border rule of the reference
+def select_matches(score, pix, W8: int, H8: int, thresholds: np.ndarray, min_matches: int = 4, x_max: int = 62, y_max: int = 18, frames: int = 1):
+    """-> sel (N,) int32, coarse_xy (2,N) float32, count_dev (2,) int32 [n, threshold index] - with frames > 1 (score / pix hold `frames` blocks
+    of N points) (frames, N), (frames, 2, N), (frames, 2) from one launch.  Border rule of the reference
     (model/network.py:184): 2 <= x <= 62, 2 <= y <= 18 - hard-coded there for the KITTI 64x20 map and kept for every image size."""
     lib = _lib.load()
-    N = score.numel()
-    sel = torch.empty((N,), dtype=torch.int32, device=score.device)
-    xy = torch.empty((2, N), dtype=torch.float32, device=score.device)
-    cnt = torch.empty((2,), dtype=torch.int32, device=score.device)
+    if score.numel() % frames or not score.is_contiguous() or not pix.is_contiguous():
+        raise _lib.CofiError("select_matches: contiguous score / pix of frames * N elements expected")
+    N = score.numel() // frames
+    lead = () if frames == 1 else (frames,)
+    sel = torch.empty(lead + (N,), dtype=torch.int32, device=score.device)
+    xy = torch.empty(lead + (2, N), dtype=torch.float32, device=score.device)
+    cnt = torch.empty(lead + (2,), dtype=torch.int32, device=score.device)
     thr = np.ascontiguousarray(thresholds, dtype=np.float32)
     rc = lib.cofi_select_matches(_p(score), _p(pix), N, W8, H8, x_max, y_max, thr.ctypes.data_as(ctypes.c_void_p), len(thr), min_matches,
-                                 _p(sel), _p(xy), _p(cnt), _stream())
+                                 _p(sel), _p(xy), _p(cnt), frames, _stream())
     _lib.check(rc, "cofi_select_matches")
     return sel, xy, cnt
 
@@ -1085,20 +1093,24 @@ def fine_match(patches, pc_feats, xy, cnt, center_scale: float):
     return fine_xy, best
 
 
-def match_finish(pts4, pts1, sel, cnt, fmap, H2: int, W2: int, xy, fine_pc_all, center_scale: float):
+def match_finish(pts4, pts1, sel, cnt, fmap, H2: int, W2: int, xy, fine_pc_all, center_scale: float, frames: int = 1):
     """The tail of a test-mode forward in one launch (cofi_match_finish): -> coarse_pts (cap,3), patches (cap,C,16), fine_pc (cap,C),
     fine_xy (2,cap), best (cap,) - bit-identical to gather_points_sel + nearest_node_sel + gather_rows_sel + extract_patches_nhwc +
-    fine_match."""
+    fine_match.  frames > 1 (stack mode: every input holds `frames` equally sized blocks; sel (frames, cap), xy (frames, 2, cap), cnt (frames, 2)):
+    the outputs gain a leading frame axis."""
     lib = _lib.load()
     _mat(fmap, "fmap"), _mat(fine_pc_all, "fine_pc_all")
-    cap, C, dev = sel.numel(), fmap.shape[1], fmap.device
-    coarse_pts = torch.empty((cap, 3), dtype=torch.float32, device=dev)
-    patches = torch.empty((cap, C, 16), dtype=torch.float32, device=dev)
-    fine_pc = torch.empty((cap, C), dtype=torch.float32, device=dev)
-    fine_xy = torch.empty((2, cap), dtype=torch.float32, device=dev)
-    best = torch.empty((cap,), dtype=torch.int32, device=dev)
-    rc = lib.cofi_match_finish(_p(pts4.contiguous()), _p(pts1.contiguous()), pts1.shape[0], _p(sel), _p(cnt), cap, _p(fmap), _ld(fmap), C, H2, W2,
-                               _p(xy), xy.stride(0), float(center_scale), _p(fine_pc_all), _ld(fine_pc_all), _p(coarse_pts), _p(patches), _p(fine_pc),
-                               C, _p(fine_xy), _p(best), _stream())
+    if sel.numel() % frames or pts4.shape[0] % frames or pts1.shape[0] % frames or fmap.shape[0] != frames * H2 * W2 or not (sel.is_contiguous() and xy.is_contiguous()):
+        raise _lib.CofiError("match_finish: shape mismatch")
+    cap, C, dev = sel.numel() // frames, fmap.shape[1], fmap.device
+    lead = () if frames == 1 else (frames,)
+    coarse_pts = torch.empty(lead + (cap, 3), dtype=torch.float32, device=dev)
+    patches = torch.empty(lead + (cap, C, 16), dtype=torch.float32, device=dev)
+    fine_pc = torch.empty(lead + (cap, C), dtype=torch.float32, device=dev)
+    fine_xy = torch.empty(lead + (2, cap), dtype=torch.float32, device=dev)
+    best = torch.empty(lead + (cap,), dtype=torch.int32, device=dev)
+    rc = lib.cofi_match_finish(_p(pts4.contiguous()), _p(pts1.contiguous()), pts1.shape[0] // frames, _p(sel), _p(cnt), cap, _p(fmap), _ld(fmap), C, H2, W2,
+                               _p(xy), xy.stride(-2), float(center_scale), _p(fine_pc_all), _ld(fine_pc_all), _p(coarse_pts), _p(patches), _p(fine_pc),
+                               C, _p(fine_xy), _p(best), pts4.shape[0] // frames, frames, _stream())
     _lib.check(rc, "cofi_match_finish")
     return coarse_pts, patches, fine_pc, fine_xy, best

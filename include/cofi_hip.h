@@ -377,7 +377,8 @@ int cofi_l2norm_rows(const float *x, int ldx, int M, int C, float *y, int ldy, i
 /* the same rows into two destinations (y2 row-major, ldy2): the normalised 1/8 image map is both the transformer's input and the
  * up-sampler's (model/network.py:90,110,129) */
 int cofi_l2norm_rows2(const float *x, int ldx, int M, int C, float *y, int ldy, float *y2, int ldy2, cofi_stream_t stream);
-int cofi_transpose(const float *x, int ldx, int M, int C, float *y, int ldy, cofi_stream_t stream);
+int cofi_transpose(const float *x, int ldx, int M, int C, float *y, int ldy, int frames /* x holds frames * M rows; y = frames blocks of (C, M) ldy */,
+                   cofi_stream_t stream);
 /* out (frames, C) = column means over the M / frames rows of each frame: nn.AdaptiveAvgPool2d(1) on an NHWC map
  * (model/imagenet.py:145,215). */
 int cofi_col_mean(const float *x, int ldx, int M, int C, float *out, int frames, cofi_stream_t stream);
@@ -427,7 +428,9 @@ int cofi_upsample2x_cat_nhwc(const float *low, int ldl, int C1, int h, int w, co
  */
 int cofi_row_argmin_1m(const float *sim, int lds, int N, int P, int32_t *pix, cofi_stream_t stream);
 int cofi_select_matches(const float *score, const int32_t *pix, int N, int W8, int H8, int x_max, int y_max, const float *thr_host,
-                        int n_thr, int min_matches, int32_t *sel, float *coarse_xy, int32_t *count_dev, cofi_stream_t stream);
+                        int n_thr, int min_matches, int32_t *sel, float *coarse_xy, int32_t *count_dev,
+                        int frames /* stack mode: score / pix (frames, N), sel (frames, N), coarse_xy (frames, 2, N), count_dev (frames, 2) */,
+                        cofi_stream_t stream);
 int cofi_gather_points_sel(const float *pts, const int32_t *sel, const int32_t *count_dev, int cap, float *out,
                            cofi_stream_t stream);
 int cofi_extract_patches_nhwc(const float *fmap, int ldf, int C, int H2, int W2, const float *coarse_xy, int ldxy, float center_scale,
@@ -445,7 +448,9 @@ int cofi_fine_match(const float *patches, const float *pc_feats, int ldp, int C,
 int cofi_match_finish(const float *pts4, const float *pts1, int N1, const int32_t *sel, const int32_t *count_dev, int cap,
                       const float *fmap, int ldf, int C, int H2, int W2, const float *coarse_xy, int ldxy, float center_scale,
                       const float *fine_pc_all, int ldfpc, float *coarse_pts, float *patches, float *fine_pc, int ldo,
-                      float *fine_xy, int32_t *best, cofi_stream_t stream);
+                      float *fine_xy, int32_t *best, int N4 /* rows of pts4 per frame */,
+                      int frames /* stack mode: every array holds `frames` equally sized blocks (coarse_xy (frames, 2, ldxy), count_dev (frames, 2)) */,
+                      cofi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row f3, first part: the training losses of model/loss.py with their gradients w.r.t. the network outputs
