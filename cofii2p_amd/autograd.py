@@ -47,11 +47,13 @@ class TableCache:
         self._t = {}
 
     def get(self, idx: torch.Tensor, N: int, first_column: bool = False) -> TransposedTable:
+        # the entry keeps `idx` itself: a temporary index tensor (pix.to(int32), ...) would otherwise be freed after the forward op and the
+        # allocator could hand its address to another index tensor of the same shape - which would silently get this table
         key = (idx.data_ptr(), tuple(idx.shape), N, first_column)
-        t = self._t.get(key)
-        if t is None:
-            t = self._t[key] = TransposedTable(idx[:, :1] if first_column and idx.dim() == 2 else idx, N)
-        return t
+        ent = self._t.get(key)
+        if ent is None:
+            ent = self._t[key] = (idx, TransposedTable(idx[:, :1] if first_column and idx.dim() == 2 else idx, N))
+        return ent[1]
 
 
 # ------------------------------------------------------------------------------------------ helpers

@@ -32,6 +32,7 @@ from .sampler import NUM_STAGES, draw_frame, sampler_from_state, worker_init, wo
 class _Slot:
     def __init__(self):
         self.phase = "idle"   # idle -> voxel (begin) -> drawing (job in the pool) -> ready (complete returned)
+        self.generation = 0   # bumped by release(): a sample's lazy finish_labels() refuses to read the slot's buffers after that
         self.h = self.future = None
         self.graphs = {}      # image shape -> (graph, outputs)
         self.stage = None     # pinned staging + static device buffers of the draws
@@ -160,8 +161,11 @@ class FrameLoader:
                "K": torch.from_numpy(K_2.astype(np.float32)).to(dev, non_blocking=True), "K_4": torch.from_numpy(K_4.astype(np.float32)).to(dev, non_blocking=True),
                "P": torch.from_numpy(np.linalg.inv(P).astype(np.float32)).to(dev, non_blocking=True)}
         coarse_host = buf["coarse_host"]
+        generation = st.generation
 
         def finish_labels():
+            if st.generation != generation:   # the slot's pinned buffer and static tensors belong to another frame by now
+                raise _lib.CofiError("FrameLoader: finish_labels() called after the slot was released - call it before release(slot)")
             ready.synchronize()
             lab = dataside.project_labels(coarse_host.numpy(), P, K_2, K_4, opt, s, dataset=self.dataset)
             kpt = torch.from_numpy(lab["pc_kpt_idx"]).to(dev)
@@ -179,3 +183,4 @@ class FrameLoader:
         """the forward that read the slot's tensors has been collected: the slot may begin() another frame"""
         st = self.slots[slot]
         st.phase, st.h, st.future = "idle", None, None
+        st.generation += 1

@@ -527,8 +527,8 @@ class CoFiI2P(nn.Module):
         module's parameters whose operators (every weight contraction, the KPConv aggregation, attention, the neighbour gathers) are
         HIP kernels in both directions; BatchNorm of the up-sampler then uses batch statistics and updates its running buffers, as the
         reference's module does under train().  norm == 'gn' only.
-        INFERENCE: everything else - evaluation/eval_all.py, train.py's validation pass (model.eval(), mode='val' under
-        torch.no_grad(), train.py:66-70) - runs the fused, folded kernel sequence (optionally a hipGraph) and returns tensors without a
+        INFERENCE: everything else - evaluation/eval_all.py, train.py's validation pass (test_acc, train.py:27-70: model.eval() and
+        mode='val', with autograd still enabled there - nothing requires grad, so it lands here) - runs the fused, folded kernel sequence (optionally a hipGraph) and returns tensors without a
         graph.  mode='test' is never differentiable (its match selection is a host-visible count, network.py:145-151): inputs that
         require grad are refused there instead of silently losing their gradient."""
         if mode in ("train", "val") and (self.training or (mode == "train" and torch.is_grad_enabled())

@@ -36,7 +36,10 @@ def _gemm_flag() -> int:
 class arithmetic:
     """Context manager: run the enclosed launches with the given contraction arithmetic ("bf16x3" | "bf16x6" | "f32"; None = leave the
     process default, COFI_GEMM).  "bf16x6": three bf16 planes per operand, six products - fp32-grade results on the bf16 matrix cores
-    (include/cofi_hip.h COFI_GEMM_BF16X6).  `CoFiI2P(opt, arithmetic=...)` wraps its forwards in it, so two models with different arithmetic coexist."""
+    (include/cofi_hip.h COFI_GEMM_BF16X6).  `CoFiI2P(opt, arithmetic=...)` wraps its forwards in it, so two models with different arithmetic
+    coexist - when they are driven from ONE host thread: the mode is a module global (it also keys the hipGraph cache), so two threads
+    entering / leaving the context concurrently can interleave and run a forward in the other's arithmetic.  Drive models that differ in
+    arithmetic from one thread (backward passes stash the mode per autograd node: autograd._Linear)."""
 
     def __init__(self, mode):
         if mode not in (None, "bf16x3", "bf16x6", "f32"):

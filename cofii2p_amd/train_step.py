@@ -114,6 +114,11 @@ class GraphedTrainStep:
         self._lr: List[torch.Tensor] = []
         self.replays = 0
 
+    def _capture_stream(self, dev) -> torch.cuda.Stream:
+        if getattr(self, "_cap", None) is None or self._cap.device != torch.device(dev):
+            self._cap = torch.cuda.Stream(device=dev)
+        return self._cap
+
     # ---- learning rate: a device scalar per parameter group
     def _sync_lr(self, dev):
         if not self._lr:
@@ -176,7 +181,9 @@ class GraphedTrainStep:
         spc, simg, sbatch = self._static
         self.optimizer.zero_grad(set_to_none=True)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # captured on the stream the warm-up step ran on: every per-(stream, slot) scratch buffer of cofii2p_amd.ops (and the side stream of
+        # the forward's branches) was grown there, in the ordinary allocator pool - nothing is first allocated inside the graph's private pool
+        with torch.cuda.graph(graph, stream=self._capture_stream(spc["feats"].device)):
             _o, _m, (l_desc, l_coarse, l_fine) = step_losses(self.model, spc, simg, sbatch, self.opt)
             (l_desc + l_coarse + l_fine).backward()
             self.optimizer.step()
@@ -199,11 +206,17 @@ class GraphedTrainStep:
         if self._graph is None and not self._warm:
             self._warm = True
             spc, simg, sbatch = self._static
-            self.optimizer.zero_grad()
-            _o, _m, (l_desc, l_coarse, l_fine) = step_losses(self.model, spc, simg, sbatch, self.opt)
-            (l_desc + l_coarse + l_fine).backward()
-            self.optimizer.step()
-            return torch.stack([l_desc.detach(), l_coarse.detach(), l_fine.detach()])
+            cap, cur = self._capture_stream(dev), torch.cuda.current_stream(dev)
+            cap.wait_stream(cur)
+            with torch.cuda.stream(cap):   # the eager warm-up step runs where the recording will be captured (see _record)
+                self.optimizer.zero_grad()
+                _o, _m, (l_desc, l_coarse, l_fine) = step_losses(self.model, spc, simg, sbatch, self.opt)
+                (l_desc + l_coarse + l_fine).backward()
+                self.optimizer.step()
+                out = torch.stack([l_desc.detach(), l_coarse.detach(), l_fine.detach()])
+            cur.wait_stream(cap)
+            out.record_stream(cur)
+            return out
         if self._graph is None:
             self._record()
         self._graph.replay()

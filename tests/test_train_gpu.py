@@ -330,7 +330,7 @@ def test_train_step_matches_reference(gold, arith, tol, monkeypatch):
     from cofii2p_amd.network import CoFiI2P
     from cofii2p_amd.train_step import step_losses
 
-    monkeypatch.setattr(ops, "GEMM_MODE", arith or "bf16x3")   # arithmetic=None: the process default is bf16x3, training still computes in f32
+    monkeypatch.setattr(ops, "GEMM_MODE", arith or "bf16x3")   # arithmetic=None: the process default is bf16x3, training still computes fp32-grade (bf16x6, network.py forward())
     dd, img, batch, sopt = _train_inputs(gold)
     m = CoFiI2P(Opt(), arithmetic=arith).to(DEV)
     m.train()
@@ -476,9 +476,9 @@ def test_training_changes_the_served_weights(gold):
 def test_graphed_train_step_equals_eager(gold, fused):
     """train_step.GraphedTrainStep (forward + losses + backward + Adam as ONE hipGraph, replayed per frame) against the eager step with
     the same capturable optimizer: two alternating frames of one signature (the static inputs are restaged every call), a learning-rate
-    change the way train.py:326-330 makes it, then the validation forward on the updated weights.  The step's own kernels are
-    bit-reproducible; torch's bilinear-resize backward (atomics) is not, and Adam turns a last-bit difference of a near-zero gradient
-    into a visible one - hence "losses to 1e-4, all but a sliver of the parameters to 1e-5" rather than bit equality."""
+    change the way train.py:326-330 makes it, then the validation forward on the updated weights.  The step's kernels (incl. the
+    package's own upsample2x backward) are bit-reproducible launch by launch, but the recording runs its branches on other streams than the
+    eager step and Adam turns a last-bit difference of a near-zero gradient into a visible one - hence "losses to 1e-4, all but a sliver of the parameters to 1e-5" rather than bit equality."""
     from cofii2p_amd.network import CoFiI2P
     from cofii2p_amd.train_step import GraphedTrainStep, train_step
 
