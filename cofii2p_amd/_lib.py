@@ -60,7 +60,7 @@ SIGNATURES = {
     "cofi_gather_rows": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P]),
     "cofi_gemm_f32_workspace": (_Z, [_I, _I, _I]),
     "cofi_gemm_f32": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _Z, _P]),
-    "cofi_split_bf16_planes": (_I, [_P, _I, _I, _I, _P, _I, _P]),
+    "cofi_split_bf16_planes": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
     "cofi_gemm_f32_stat_slabs": (_I, [_I, _I, _I]),
     "cofi_gemm_f32_colstats": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _Z, _P]),
     "cofi_gemm_f32_fused": (_I, [_P, _I, _N, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _Z, _I, _P]),

@@ -473,16 +473,18 @@ __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
 
 // Static operands (weights) are split once: planes (2, N, ldp) bf16 = [hi | lo], rows zero-padded to ldp (multiple of 8).
 // Same rounding as split4, so a pre-split launch is bit-identical to splitting on the fly.
-__global__ void split_planes_kernel(const float *W, int ldw, int N, int K, unsigned *planes, int ldp) {
+__global__ void split_planes_kernel(const float *W, int ldw, int N, int K, unsigned *planes, int ldp, int nplanes) {
     const int hp = ldp >> 1;   // bf16 pairs per row
     const size_t total = (size_t)N * hp;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int n = (int)(i / hp), k = 2 * (int)(i - (size_t)n * hp);
         const float a = k < K ? W[(size_t)n * ldw + k] : 0.f, b = k + 1 < K ? W[(size_t)n * ldw + k + 1] : 0.f;
         const unsigned hi = cvt_pk_bf16(a, b);
-        const unsigned lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+        const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+        const unsigned lo = cvt_pk_bf16(ra, rb);   // two planes: lo; three planes: mid
         planes[i] = hi;
         planes[total + i] = lo;
+        if (nplanes == 3) planes[2 * total + i] = cvt_pk_bf16(ra - __uint_as_float(lo << 16), rb - __uint_as_float(lo & 0xffff0000u));
     }
 }
 
@@ -508,7 +510,7 @@ __global__ void split_planes_kernel(const float *W, int ldw, int N, int K, unsig
 template <int BM, int BN, int TM, int TN, int BK3, bool WSPLIT = false, int WPE = 1, bool ANORM = false, bool ASPLIT = false, bool X6 = false>
 __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
     static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 waves");
-    static_assert(!X6 || (!WSPLIT && !ASPLIT), "bf16x6 splits both operands on the fly");
+    static_assert(!X6 || !ASPLIT, "bf16x6: A is split on the fly (W may arrive as three pre-split planes)");
     constexpr int NPL = X6 ? 3 : 2;   // bf16 planes per operand
     constexpr int NT = 256;
     // bytes per LDS row.  64- / 128-deep K-tiles: bf16 values + 16 B pad (36 / 68 dwords: conflict-free b128 reads, and a 16-lane group of
@@ -555,6 +557,7 @@ __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
         f32x4 rah[ASPLIT ? A_CH : 1], ral[ASPLIT ? A_CH : 1];   // pre-split A: 16-B chunks (8 bf16) of the hi / lo plane
         f32x4 rw[WSPLIT ? 1 : W_LD4];                            // fp32 W: W_LD4 chunks of 4
         f32x4 rwh[WSPLIT ? W_CH : 1], rwl[WSPLIT ? W_CH : 1];   // pre-split W: 16-B chunks (8 bf16) of the hi / lo plane, as opaque bits
+        f32x4 rwm[(WSPLIT && X6) ? W_CH : 1];                    // ... and of the mid plane (bf16x6: planes hi | mid | lo)
         unsigned amask;                                          // validity of the A values (see gload)
         bool afull;                                              // uniform: the A registers hold a full dense tile (no zeroing needed)
         int achan;                                               // ANORM: first of the 4 channels the staged float4s of this thread belong to
@@ -667,7 +670,8 @@ __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < W_CH; ++j) {
                     st.rwh[j] = *reinterpret_cast<const f32x4 *>(wt + woff[j]);
-                    st.rwl[j] = *reinterpret_cast<const f32x4 *>(wt + wlo + woff[j]);
+                    st.rwl[j] = *reinterpret_cast<const f32x4 *>(wt + (NPL - 1) * wlo + woff[j]);
+                    if constexpr (X6) st.rwm[j] = *reinterpret_cast<const f32x4 *>(wt + wlo + woff[j]);
                 }
             } else {  // chunks that start past the K range re-read the first chunk of their row (plane rows are padded to 8 values)
 #pragma unroll
@@ -676,7 +680,8 @@ __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
                     const bool cin = kbeg + t * BK3 + c8 < kend;
                     const char *q = cin ? wt + woff[j] : wbase + (woff[j] - 2u * c8);
                     st.rwh[j] = *reinterpret_cast<const f32x4 *>(q);
-                    st.rwl[j] = *reinterpret_cast<const f32x4 *>(q + wlo);
+                    st.rwl[j] = *reinterpret_cast<const f32x4 *>(q + (NPL - 1) * wlo);
+                    if constexpr (X6) st.rwm[j] = *reinterpret_cast<const f32x4 *>(q + wlo);
                 }
             }
         } else {
@@ -736,7 +741,8 @@ __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
                 const int c = tid + NT * j;
                 unsigned char *p = lds_raw + NPL * PLANE_A + loff(c / CPR, (c % CPR) * 16);
                 *reinterpret_cast<f32x4 *>(p) = st.rwh[j];
-                *reinterpret_cast<f32x4 *>(p + PLANE_W) = st.rwl[j];
+                *reinterpret_cast<f32x4 *>(p + (NPL - 1) * PLANE_W) = st.rwl[j];
+                if constexpr (X6) *reinterpret_cast<f32x4 *>(p + PLANE_W) = st.rwm[j];
             }
         } else {
 #pragma unroll
@@ -1109,7 +1115,11 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
         // bf16x6: three planes per operand; K-tiles of 64 (64 x 64 tile: 54 KB of LDS) / 32 (wider tiles: 41 / 60 KB)
 #define COFI_LAUNCH_BF16X6(BM_, BN_, TM_, TN_, BK_)                                                                        \
     do {                                                                                                                  \
-        if (g.an.part)                                                                                                    \
+        if (g.wsplit && g.an.part)                                                                                        \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, true, 1, true, false, true>), grid, dim3(256), 0, s, g);    \
+        else if (g.wsplit)                                                                                                \
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, true, 1, false, false, true>), grid, dim3(256), 0, s, g);   \
+        else if (g.an.part)                                                                                               \
             hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, false, 1, true, false, true>), grid, dim3(256), 0, s, g);   \
         else                                                                                                              \
             hipLaunchKernelGGL((gemm_bf16x3_kernel<BM_, BN_, TM_, TN_, BK_, false, 1, false, false, true>), grid, dim3(256), 0, s, g);  \
@@ -1178,7 +1188,7 @@ int stat_shift_of(int width, int N) {
 // Runs on the bf16x3 kernels with pre-split weights and on the bf16x6 kernels.
 int set_a_norm(GemmArgs &g, const cofi_norm_desc_t *a_norm, int channels, int a_rows_per_frame, int frames, const Plan &p) {
     if (!a_norm) return 0;
-    if (!(g.bf16x3 == 1 && g.wsplit) && g.bf16x3 != 2) return COFI_EUNSUPPORTED;   // 3-term kernel: pre-split weights; 6-term kernel: fp32 weights
+    if (!(g.bf16x3 == 1 && g.wsplit) && g.bf16x3 != 2) return COFI_EUNSUPPORTED;   // 3-term kernel: pre-split weights; 6-term kernel: fp32 or pre-split weights
     if (a_norm->channels != channels) return COFI_EINVAL;
     if (int rc = make_norm_src(a_norm, a_rows_per_frame, frames, 512, &g.an)) return rc;
     if (!(g.an.slope >= 0.f && g.an.slope <= 1.f)) return COFI_EINVAL;
@@ -1199,7 +1209,8 @@ int gemm_entry(const float *A, int lda, const cofi_norm_desc_t *a_norm, const fl
     const int l2n = (act & COFI_GEMM_L2NORM) ? 1 : 0;
     act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT | COFI_GEMM_A_SPLIT | COFI_GEMM_L2NORM);
     if (l2n && (N > 128 || asplit)) return COFI_EUNSUPPORTED;
-    if (act < 0 || act > 3 || (wsplit && (bf16x3 != 1 || (ldw & 7))) || frames <= 0) return COFI_EINVAL;
+    if (act < 0 || act > 3 || (wsplit && (bf16x3 == 0 || (ldw & 7))) || frames <= 0) return COFI_EINVAL;
+    if (asplit && bf16x3 != 1) return COFI_EINVAL;
     if (asplit && (!wsplit || a_norm || (lda & 7) || (K & 7))) return COFI_EINVAL;
     const int sshift = colpart ? stat_shift_of(stat_width, N) : 0;
     if (sshift < 0) return COFI_EINVAL;
@@ -1227,7 +1238,7 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
     const int wsplit = (act & COFI_GEMM_W_SPLIT) ? 1 : 0;
     const int l2n = (act & COFI_GEMM_L2NORM) ? 1 : 0;
     act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT | COFI_GEMM_L2NORM);
-    if (act < 0 || act > 3 || (wsplit && bf16x3 != 1) || act_col0 < 0 || act_col0 > Cout) return COFI_EINVAL;
+    if (act < 0 || act > 3 || (wsplit && bf16x3 == 0) || act_col0 < 0 || act_col0 > Cout) return COFI_EINVAL;
     if (l2n && Cout > 128) return COFI_EUNSUPPORTED;
     const int sshift = colpart ? stat_shift_of(stat_width, Cout) : 0;
     if (sshift < 0) return COFI_EINVAL;
@@ -1288,7 +1299,7 @@ extern "C" int cofi_gemm_f32_layernorm(const float *A, int lda, const float *W, 
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
     const int wsplit = (relu & COFI_GEMM_W_SPLIT) ? 1 : 0;
     relu &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT);
-    if (wsplit && (bf16x3 != 1 || (ldw & 7))) return COFI_EINVAL;
+    if (wsplit && (bf16x3 == 0 || (ldw & 7))) return COFI_EINVAL;
     GemmArgs g{};
     g.A = A; g.W = W; g.C = C; g.bias = bias; g.ws = (float *)ws; g.ln_gamma = gamma; g.ln_beta = beta; g.res = res;
     g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr; g.M = M; g.N = N; g.K = K; g.ksplit = 1; g.ln_relu = relu; g.ln_eps = eps;
@@ -1309,11 +1320,11 @@ extern "C" int cofi_conv2d_nhwc_fused(const float *x, int ldx, const cofi_norm_d
                       ws_bytes, frames, stream);
 }
 
-extern "C" int cofi_split_bf16_planes(const float *W, int ldw, int N, int K, void *planes, int ldp, cofi_stream_t stream) {
-    if (!W || !planes || N <= 0 || K <= 0 || ldw < K || ldp < K || (ldp & 7) || ((uintptr_t)planes & 15)) return COFI_EINVAL;
+extern "C" int cofi_split_bf16_planes(const float *W, int ldw, int N, int K, void *planes, int ldp, int nplanes, cofi_stream_t stream) {
+    if (!W || !planes || N <= 0 || K <= 0 || ldw < K || ldp < K || (ldp & 7) || ((uintptr_t)planes & 15) || (nplanes != 2 && nplanes != 3)) return COFI_EINVAL;
     const size_t total = (size_t)N * (ldp >> 1);
     hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, cofi_s(stream),
-                       W, ldw, N, K, (unsigned *)planes, ldp);
+                       W, ldw, N, K, (unsigned *)planes, ldp, nplanes);
     return cofi_launch_status();
 }
 

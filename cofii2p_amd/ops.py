@@ -60,11 +60,16 @@ class arithmetic:
 
 
 GEMM_W_SPLIT = 0x200
+# bf16x6 reading the weights as three pre-split planes (COFI_GEMM_W_SPLIT with 3 planes): bit-identical to splitting W on the fly, and
+# SLOWER on MI355X - 6 instead of 4 bytes per weight element through L2 -> LDS cost more than the conversion instructions they replace
+# (round 4, same box: 40960 x 1024 x 3072 1333 -> 1410 us; batch-16 pipeline 622 -> 608 frames/s, batch 1 479 = 479).  Off by default.
+X6_W_SPLIT = os.environ.get("COFI_X6_W_SPLIT", "0") == "1"
 
 
 class SplitW:
-    """A static GEMM operand (weight) with its bf16 hi/lo planes, split ONCE (cofi_split_bf16_planes).  Accepted wherever a
-    weight matrix is: the bf16x3 kernels read the planes (no on-the-fly conversion of W), the exact-fp32 kernels read `.w`."""
+    """A static GEMM operand (weight) with its bf16 planes, split ONCE (cofi_split_bf16_planes): `planes` (2, N, ldp) = hi / lo for the
+    3-term arithmetic, `planes3` (3, N, ldp) = hi / mid / lo for the 6-term one.  Accepted wherever a weight matrix is: the bf16-split
+    kernels read the planes of their arithmetic (no on-the-fly conversion of W), the exact-fp32 kernels read `.w`."""
 
     def __init__(self, w: torch.Tensor):
         lib = _lib.load()
@@ -74,8 +79,17 @@ class SplitW:
         N, K = w.shape
         self.ldp = (K + 7) // 8 * 8
         self.planes = torch.empty((2, N, self.ldp), dtype=torch.int16, device=w.device)
-        _lib.check(lib.cofi_split_bf16_planes(_p(w), _ld(w), N, K, _p(self.planes), self.ldp, _stream()), "cofi_split_bf16_planes")
+        _lib.check(lib.cofi_split_bf16_planes(_p(w), _ld(w), N, K, _p(self.planes), self.ldp, 2, _stream()), "cofi_split_bf16_planes")
+        self._planes3 = None
 
+    @property
+    def planes3(self):
+        """(3, N, ldp) hi / mid / lo planes, built on first use (only the opt-in X6_W_SPLIT path reads them; not inside a graph capture)"""
+        if self._planes3 is None:
+            N, K = self.w.shape
+            self._planes3 = torch.empty((3, N, self.ldp), dtype=torch.int16, device=self.w.device)
+            _lib.check(_lib.load().cofi_split_bf16_planes(_p(self.w), _ld(self.w), N, K, _p(self._planes3), self.ldp, 3, _stream()), "cofi_split_bf16_planes")
+        return self._planes3
 
     def numel(self):
         return self.w.numel()
@@ -93,6 +107,8 @@ def _wargs(w):
     if isinstance(w, SplitW):
         if GEMM_MODE == "bf16x3":
             return _p(w.planes), w.ldp, GEMM_W_SPLIT
+        if GEMM_MODE == "bf16x6" and X6_W_SPLIT:
+            return _p(w.planes3), w.ldp, GEMM_W_SPLIT
         w = w.w
     return _p(w), _ld(w), 0
 

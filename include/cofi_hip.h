@@ -76,9 +76,9 @@ typedef struct cofi_norm_desc {
  * (hi*hi + hi*lo + lo*hi, fp32 accumulate) on the bf16 matrix cores instead of the exact fp32 MFMA:
  * ~2^-16 relative error per product, 5.3x the MFMA rate. */
 #define COFI_GEMM_BF16X3 0x100
-/* with COFI_GEMM_BF16X3: W is PRE-SPLIT (cofi_split_bf16_planes): `W` points at the bf16 hi plane, N rows of `ldw` bf16
- * (ldw % 8 == 0, rows zero-padded past K), immediately followed by the lo plane of the same shape.  Weights are static:
- * splitting them once removes half of the on-the-fly conversion work of every launch. */
+/* with COFI_GEMM_BF16X3 / COFI_GEMM_BF16X6: W is PRE-SPLIT (cofi_split_bf16_planes with 2 / 3 planes): `W` points at the bf16 hi plane, N rows
+ * of `ldw` bf16 (ldw % 8 == 0, rows zero-padded past K), immediately followed by the lo plane (bf16x6: the mid plane, then the lo plane) of
+ * the same shape.  Weights are static: splitting them once removes half of the on-the-fly conversion work of every launch. */
 #define COFI_GEMM_W_SPLIT 0x200
 /* with COFI_GEMM_W_SPLIT, cofi_gemm_f32_fused only: A is PRE-SPLIT too - `A` points at its bf16 hi plane, M rows of `lda` bf16
  * (lda % 8 == 0, K % 8 == 0), immediately followed by the lo plane (M * lda elements later): what cofi_kpconv_aggregate writes with
@@ -89,8 +89,8 @@ typedef struct cofi_norm_desc {
 /* fp32-GRADE arithmetic on the bf16 matrix cores: every fp32 operand is split on the fly into THREE bf16 planes (hi + mid + lo = all 24
  * mantissa bits) and the product formed as hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi with fp32 accumulation - what is dropped is
  * below 2^-24 of |a||b|, so the result differs from an exact-fp32 contraction only by accumulation-order rounding (measured: same error
- * against fp64 as the fp32 MFMA kernel) at 16/6 = 2.7x its matrix rate.  Plain fp32 operands only (no COFI_GEMM_W_SPLIT / A_SPLIT, no
- * normalising loader).  Accepted by cofi_gemm_f32*, cofi_conv2d_nhwc*. */
+ * against fp64 as the fp32 MFMA kernel) at 16/6 = 2.7x its matrix rate.  A is split on the fly (no COFI_GEMM_A_SPLIT); W is fp32 or - with
+ * COFI_GEMM_W_SPLIT - three pre-split planes; the normalising loader (a_norm) works with both.  Accepted by cofi_gemm_f32*, cofi_conv2d_nhwc*. */
 #define COFI_GEMM_BF16X6 0x800
 /* OR-ed into `act` of cofi_gemm_f32_fused / cofi_conv2d_nhwc_fused (N <= 128): every output row is L2-normalised after bias, residual
  * and activation - y = v / max(|v|, 1e-12), F.normalize(dim=1) of model/network.py:83-84, 90 - in the epilogue (a tile, or the split-K
@@ -202,9 +202,11 @@ int cofi_gather_rows(const float *x, int ldx, int N, int C, const int32_t *idx, 
 size_t cofi_gemm_f32_workspace(int M, int N, int K);
 int cofi_gemm_f32(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K, const float *bias,
                   const float *rowdiv, int act, void *ws, size_t ws_bytes, cofi_stream_t stream);
-/* Split a static fp32 operand W (N,K) ldw once into bf16 planes for COFI_GEMM_W_SPLIT: planes = (2, N, ldp) bf16,
- * [hi = bf16(W) RNE | lo = bf16(W - hi)], ldp % 8 == 0, ldp >= K, rows zero-padded; 16-byte aligned. */
-int cofi_split_bf16_planes(const float *W, int ldw, int N, int K, void *planes, int ldp, cofi_stream_t stream);
+/* Split a static fp32 operand W (N,K) ldw once into bf16 planes for COFI_GEMM_W_SPLIT: planes = (nplanes, N, ldp) bf16,
+ * nplanes = 2 (COFI_GEMM_BF16X3): [hi = bf16(W) RNE | lo = bf16(W - hi)]; nplanes = 3 (COFI_GEMM_BF16X6): [hi | mid = bf16(W - hi) |
+ * lo = bf16(W - hi - mid)] - the roundings of the kernels' own on-the-fly split, so a pre-split launch is bit-identical to one that
+ * splits W itself.  ldp % 8 == 0, ldp >= K, rows zero-padded; 16-byte aligned. */
+int cofi_split_bf16_planes(const float *W, int ldw, int N, int K, void *planes, int ldp, int nplanes, cofi_stream_t stream);
 /* Same contraction with fused COLUMN STATISTICS: colpart (nslab, N, 2) receives, per row slab, the sum and
  * the sum of squares of every output column (after bias / rowdiv / act), nslab =
  * cofi_gemm_f32_stat_slabs(M,N,K).  cofi_group_stats_from_colpart / cofi_col_inv_norm_from_colpart turn

@@ -642,6 +642,31 @@ def test_l2norm_epilogue(ops, monkeypatch, mode):
     assert torch.equal(o1, ops.l2norm_rows(xs)) and torch.equal(o2, o1)
 
 
+def test_bf16x6_presplit_weight_planes_are_bit_identical(ops, monkeypatch):
+    """COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT (three pre-split weight planes, opt-in ops.X6_W_SPLIT) = the on-the-fly split, bit for bit:
+    dense, split-K, normalising loader and convolution launches"""
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x6")
+    g = torch.Generator().manual_seed(17)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    for M, N, K in [(1280, 128, 128), (1280, 512, 7680), (300, 200, 36), (20480, 64, 576)]:
+        a, w, b = G(rn(M, K)), ops.presplit(G(rn(N, K) / K ** 0.5)), G(rn(N))
+        res = []
+        for flag in (False, True):
+            monkeypatch.setattr(ops, "X6_W_SPLIT", flag)
+            res.append(ops.gemm_colstats(a, w, bias=b, act=ops.ACT_LEAKY01))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), (M, N, K)
+    H, W, Cin, Cout = 20, 64, 128, 128
+    x, wt = G(rn(H * W, Cin)), ops.presplit(G(rn(Cout, 9 * Cin) / 34))
+    y0, p0 = ops.gemm_colstats(G(rn(H * W, 64)), G(rn(Cin, 64) / 8))
+    nx = ops.Normed(y0, ops.ColStats(p0, H * W, Cin), slope=0.0)
+    res = []
+    for flag in (False, True):
+        monkeypatch.setattr(ops, "X6_W_SPLIT", flag)
+        res.append((ops.conv2d_nhwc(x, H, W, wt, 3, colstats=True), ops.conv2d_nhwc(nx, H, W, wt, 3, colstats=True)))
+    for i in range(2):
+        assert torch.equal(res[0][i][0], res[1][i][0]) and torch.equal(res[0][i][1], res[1][i][1])
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16x6"])
 def test_128_row_tiles_with_a_half_empty_last_tile(ops, monkeypatch, mode):
     """a 128 x 128 plan on M % 128 in (0, 64]: the last tile has ONE statistics slab - nothing may be written behind the table
