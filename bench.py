@@ -1002,7 +1002,44 @@ def main():
                         dte = time.perf_counter() - t0
                     rates[upk] = (nfr / dte, 1e3 * dte / nfr)
                     del pgs
-                result["with_pyramid_build"] = {"frames_per_s": rates[None][0], "ms_per_frame": rates[None][1],
+                stacked = None
+                if Bsz > 1:
+                    # ... and the same chain feeding the headline's stack-mode submissions: S PyramidGraphs (one per stream) build the frames of a
+                    # batch one after the other, each is copied into its row block of a static stack (preprocess.FrameStack, one launch), the
+                    # forward of the whole batch follows on the same stream; 2 S stacks in the ring
+                    from cofii2p_amd.preprocess import FrameStack
+
+                    stacked = {}
+                    img0 = frames[0][1]
+                    for upk in (None, 1):
+                        pgs = [PyramidGraph(args.points, sub_sizes, dev, capture_stream=st[0], upsample_k=upk) for _ in range(S)]
+                        tmpl = pgs[0].run(p0, sub)
+                        stacks = [FrameStack(tmpl, feats0, img0, Bsz) for _ in range(2 * S)]
+                        pendb = [None] * (2 * S)
+                        nsub = max(4 * S, args.steps)
+                        for phase in range(2):
+                            torch.cuda.synchronize()
+                            t0 = time.perf_counter()
+                            for i in range(nsub):
+                                j = i % (2 * S)
+                                if pendb[j] is not None:
+                                    model.finish(pendb[j])
+                                with torch.cuda.stream(st[i % S]):
+                                    for f in range(Bsz):
+                                        stacks[j].put(f, pgs[i % S].run(p0, sub), feats0, img0)
+                                    pendb[j] = model.forward_async((120 if upk is None else 140) + j, stacks[j].pyr, stacks[j].img, inputs_stable=True)
+                            for j in range(2 * S):
+                                if pendb[j] is not None:
+                                    model.finish(pendb[j])
+                                    pendb[j] = None
+                            torch.cuda.synchronize()
+                            dts_ = time.perf_counter() - t0
+                        stacked["reference_tables" if upk is None else "nearest_only_upsampling"] = {"frames_per_s": nsub * Bsz / dts_, "ms_per_frame": 1e3 * dts_ / (nsub * Bsz)}
+                        del pgs, stacks
+                    stacked["note"] = ("every frame's pyramid built on the GPU (one hipGraph per frame) and copied into its row block of a static stack "
+                                       "(preprocess.FrameStack), then ONE stack-mode forward of %d frames: the headline's submissions with the pyramid in the chain" % Bsz)
+                    result["config"]["with_pyramid_build_frames_per_s"] = stacked["nearest_only_upsampling"]["frames_per_s"]
+                result["with_pyramid_build"] = {"frames_per_s": rates[None][0], "ms_per_frame": rates[None][1], "stack_mode_submissions": stacked,
                                                 "nearest_only_upsampling": {"frames_per_s": rates[1][0], "ms_per_frame": rates[1][1],
                                                                             "note": "build_pyramid(upsample_k=1): the four up-sampling tables hold their first column only - "
                                                                                     "all the forward reads (functional.py:20) - derived from neighbors[i] without a search; "

@@ -102,6 +102,40 @@ class PyramidGraph:
         return self.out
 
 
+class FrameStack:
+    """A stack-mode input (CoFiI2P.stack_frames layout: every tensor of B equally sized frames concatenated along its rows, index tables
+    frame-local int32, images (B, 3, H, W)) that a loader fills FRAME BY FRAME: `put(f, pyramid, feats, img)` writes frame f's tensors
+    into their row blocks with ONE batched copy launch (27 MB for a KITTI frame, ~10 us), so per-frame producers (PyramidGraph, FrameLoader
+    slots) can feed `forward_async(slot, stack.pyr, stack.img, inputs_stable=True)` submissions of B frames without a gather pass or a
+    host synchronisation.  The buffers are static: a ring of stacks = one hipGraph of the forward per stack."""
+    KEYS = ("points", "neighbors", "subsampling", "upsampling")
+
+    def __init__(self, pyramid: Dict, feats: torch.Tensor, img: torch.Tensor, B: int):
+        dev = feats.device
+        self.B = B
+        self.pyr = {k: [torch.empty((B * t.shape[0],) + tuple(t.shape[1:]), dtype=torch.float32 if k == "points" else torch.int32, device=dev)
+                        for t in pyramid[k]] for k in self.KEYS}
+        self.pyr["feats"] = torch.empty((B * feats.shape[0], feats.shape[1]), dtype=torch.float32, device=dev)
+        self.img = torch.empty((B,) + tuple(img.shape[-3:]), dtype=torch.float32, device=dev)
+        self._mc = ops.MultiCopy(dev)
+        self._mc.MAX_TABLES = 1 << 16   # one cached descriptor table per (producer slot, frame position): a few hundred bytes each
+
+    def put(self, f: int, pyramid: Dict, feats: torch.Tensor, img: torch.Tensor):
+        """frame f (0 <= f < B) <- the producer's tensors (int32 tables, contiguous), enqueued on the current stream"""
+        if not 0 <= f < self.B:
+            raise ValueError("frame position %d outside the stack of %d" % (f, self.B))
+        srcs, dsts = [], []
+        for k in self.KEYS:
+            for t, d in zip(pyramid[k], self.pyr[k]):
+                n = t.shape[0]
+                srcs.append(t)
+                dsts.append(d[f * n:(f + 1) * n])
+        n = feats.shape[0]
+        srcs += [feats, img.reshape(self.img.shape[1:])]
+        dsts += [self.pyr["feats"][f * n:(f + 1) * n], self.img[f]]
+        self._mc.run(srcs, dsts)
+
+
 def precompute_point_cloud_stack_mode(points, intensity, normals, lengths, num_stages, device="cuda", rng: Optional[np.random.RandomState] = None):
     """Signature of preprocess_data.py:36.  points (3,N) numpy; intensity / normals are carried by the
     caller (kitti.py:293) and ignored here, exactly as in the reference."""

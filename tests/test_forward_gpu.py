@@ -467,6 +467,39 @@ def test_stack_mode_batch_equals_single_frames(model):
                                                  seq[k][6].cpu().numpy()) > 0.9
 
 
+def test_frame_stack_equals_stack_frames(model):
+    """preprocess.FrameStack filled frame by frame (one batched copy launch per frame) = CoFiI2P.stack_frames of the same frames, and a
+    stack-mode forward reads it in place"""
+    from cofii2p_amd.network import CoFiI2P
+    from cofii2p_amd.preprocess import FrameStack, build_pyramid
+    from cofii2p_amd.synth import make_frame, subsample_indices
+
+    B, pyrs, imgs = 3, [], []
+    for b in range(B):
+        fr = make_frame(70 + b, 4096)
+        sub = [torch.from_numpy(s_).to(DEV) for s_ in subsample_indices(4096, 5, seed=70 + b)]
+        pyr = build_pyramid(torch.from_numpy(fr.points).to(DEV), sub)
+        pyr["feats"] = torch.from_numpy(fr.feats).to(DEV)
+        pyrs.append(pyr); imgs.append(torch.from_numpy(fr.img)[None].to(DEV))
+    want, wimg = CoFiI2P.stack_frames(pyrs, imgs)
+    stack = FrameStack(pyrs[0], pyrs[0]["feats"], imgs[0], B)
+    for rep in range(2):   # the second round hits the cached descriptor tables
+        for b in (2, 0, 1):
+            stack.put(b, pyrs[b], pyrs[b]["feats"], imgs[b])
+    torch.cuda.synchronize()
+    for k in ("points", "neighbors", "subsampling", "upsampling"):
+        for a, w in zip(stack.pyr[k], want[k]):
+            assert torch.equal(a, w), k
+    assert torch.equal(stack.pyr["feats"], want["feats"]) and torch.equal(stack.img, wimg)
+    model.enable_graphs(True)
+    got = model.finish(model.forward_async(11, stack.pyr, stack.img, inputs_stable=True))
+    ref = model.finish(model.forward_async(12, want, wimg))
+    model.enable_graphs(False)
+    for b in range(B):
+        for i in range(8):
+            assert torch.equal(got[b][i], ref[b][i]), (b, i)
+
+
 @pytest.mark.parametrize("fid,gemm", [(41, "bf16x3"), (42, "f32")])
 def test_other_kitti_frames_vs_oracle(model, monkeypatch, fid, gemm):
     """KITTI-shaped frames the golden files do not hold, in both arithmetics, through the hipGraph path with two frames in
