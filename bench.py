@@ -316,7 +316,10 @@ def kernel_rooflines(model, dev, args, Bsz, frame=None, batch=None):
         peak = FP32_MFMA_PEAK_TF
         if dom == "gemm" and args.gemm in ("bf16x3", "bf16x6"):
             peak = BF16_MFMA_PEAK_TF / (3.0 if args.gemm == "bf16x3" else 6.0)
-        pmc = pmc_traffic(dom) if (Bsz == 1 and args.gemm == "bf16x3" and args.points == 20480 and Opt.img_H == 160) else None
+        # committed PMC passes exist for the two default pipelines in the fp32-grade arithmetic: stack-mode batches of 16 and batch 1
+        pmc = None
+        if args.gemm == "bf16x6" and args.points == 20480 and Opt.img_H == 160 and Bsz in (1, 16):
+            pmc = pmc_traffic(dom, "pmc_traffic.json" if Bsz == 16 else "pmc_traffic_batch1.json")
         out["roofline"] = {"kernel": "cofi_" + dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                            # HBM bytes per launch from the committed rocprofv3 PMC passes of the default command (stamped with
                            # the commit they were collected on); None for any other configuration
@@ -345,12 +348,12 @@ def kernel_rooflines(model, dev, args, Bsz, frame=None, batch=None):
     return out
 
 
-def pmc_traffic(kernel_family):
+def pmc_traffic(kernel_family, fname="pmc_traffic.json"):
     """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic.json, produced by tools/pmc_to_json.py from separate FETCH_SIZE / WRITE_SIZE runs of this
     same command; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  -> the family's record with the commit the
     passes were collected on, or None if absent."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", fname)
     if not os.path.exists(path):
         return None
     try:

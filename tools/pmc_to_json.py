@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """profiles/<tag>_fetch_pmc.md + <tag>_write_pmc.md (tools/rocpd_pmc_summary.py tables) -> profiles/pmc_traffic.json.
-    python tools/pmc_to_json.py FETCH.md WRITE.md <submissions | auto> [commit stamp] [attention launches per submission]
+    python tools/pmc_to_json.py FETCH.md WRITE.md <submissions | auto> [commit stamp] [attention launches per submission] [frames per submission]
 Kernel families: gemm = every gemm_*kernel + splitk epilogues (the launches behind cofi_gemm_f32* / cofi_conv2d_nhwc),
 attention, kpconv_aggregate, neighbor_maxpool, group_norm_apply.
 HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in KB and on gfx950 FETCH_SIZE counts
@@ -30,7 +30,9 @@ def main():
         frames = sum(v[0] for k, v in fetch.items() if "attention_flat_kernel" in k) // per
     else:
         frames = int(sys.argv[3])
-    res = {"collected_on": sys.argv[4] if len(sys.argv) > 4 else "unknown"}
+    fps = int(sys.argv[6]) if len(sys.argv) > 6 else 1   # stack mode: frames per submission
+    frames *= fps
+    res = {"collected_on": sys.argv[4] if len(sys.argv) > 4 else "unknown", "frames_per_submission": fps}
     for fam, pats in FAMILIES.items():
         f = sum(v[1] for k, v in fetch.items() if any(p in k for p in pats))
         w = sum(v[1] for k, v in write.items() if any(p in k for p in pats))
