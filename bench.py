@@ -178,7 +178,7 @@ class KernelTimer:
     algorithmic work.  Pass 2 replays, per entry point, exactly those launches back-to-back inside one
     hipGraph and times the replay with events: no CPU launch gaps, the same shapes/data as the frame."""
 
-    NAMES = ("gemm", "gemm_colstats", "gemm_layernorm", "conv2d_nhwc", "loftr_tail", "group_stats_from_colpart", "col_inv_norm_from_colpart", "kpconv_aggregate", "attention", "neighbor_maxpool", "group_stats", "group_norm_apply", "layer_norm", "l2norm_rows",
+    NAMES = ("gemm", "gemm_colstats", "gemm_layernorm", "conv2d_nhwc", "loftr_tail", "group_stats_from_colpart", "col_inv_norm_from_colpart", "kpconv_aggregate", "attention_parts", "neighbor_maxpool", "group_stats", "group_norm_apply", "layer_norm", "l2norm_rows",
              "gather_rows", "row_sum_positive", "col_inv_norm")
 
     def __init__(self):
@@ -207,7 +207,7 @@ class KernelTimer:
             C = feats.shape[1]
             # algorithmic bytes: every source row once + index table + output (the gather itself must come from cache)
             return 2.0 * M * H * 15 * C, 4.0 * (feats.shape[0] * C + M * H + M * 15 * C)
-        if name == "attention":
+        if name == "attention_parts":
             L, HD = a[0].shape
             S = a[1].shape[0]
             return 4.0 * L * S * HD / k.get("frames", 1), 4.0 * (2 * L * HD + 2 * S * HD)
@@ -288,7 +288,7 @@ def kernel_rooflines(model, dev, args, Bsz, frame=None, batch=None):
         kt.record_fn(lambda: model._run_device(P_b, pyr_b["points"], pyr_b["neighbors"], pyr_b["subsampling"], pyr_b["upsampling"],
                                                pyr_b["feats"], img_b, "test", None, None))
     # cross-attention launches (frames == Bsz: one stream attends to the other) apart from the joint self-attention ones (2 Bsz)
-    att = kt.calls.get("attention", [])
+    att = kt.calls.get("attention_parts", [])
     cross = [c for c in att if c[2].get("frames", 1) == Bsz]
     if cross and len(cross) != len(att):
         kt.calls["attention_cross"] = cross
@@ -339,7 +339,8 @@ def kernel_rooflines(model, dev, args, Bsz, frame=None, batch=None):
                 "frac": ach / FP32_MFMA_PEAK_TF, "launches_per_frame": a["launches_per_frame"],
                 "avg_launch_us": 1e6 * a["seconds_per_frame"] * Bsz / (a["launches_per_frame"] * Bsz)}
 
-    if per.get("attention"):
+    if per.get("attention_parts"):
+        per["attention"] = per.pop("attention_parts")   # the attention KERNEL (cofi_attention_parts); the slot merge is the consumer's
         out["roofline_attention"] = att_row(per["attention"], "all (cross + joint self)")
     if across:
         out["roofline_cross_attention"] = att_row(across, "cross-attention only")

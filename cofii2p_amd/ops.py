@@ -811,11 +811,10 @@ class AttnParts:
         return out
 
 
-def attention(q, k, v, q_colscale=None, nhead: int = 4, out=None, frames: int = 1, q_colpart=None, q_eps: float = 1e-12,
-              parts: bool = False):
-    """Stack mode: q (frames*L, HD), k/v (frames*S, HD), q_colscale (frames, HD).  q_colpart (nslab, ncols, 2): the column
-    partials of the GEMM that produced q (its first HD columns) - the token-axis norm of Q is then folded inside the kernel.
-    parts=True: return the kernel's partial slots (AttnParts) instead of the merged matrix."""
+def attention_parts(q, k, v, q_colscale=None, nhead: int = 4, frames: int = 1, q_colpart=None, q_eps: float = 1e-12) -> "AttnParts":
+    """The attention kernel itself (cofi_attention_parts): -> the partial slots (AttnParts) in a per-stream workspace.
+    Stack mode: q (frames*L, HD), k/v (frames*S, HD), q_colscale (frames, HD).  q_colpart (nslab, ncols, 2): the column
+    partials of the GEMM / fused tail that produced q (its first HD columns) - the token-axis norm of Q is then folded inside the kernel."""
     lib = _lib.load()
     _mat(q, "q"), _mat(k, "k"), _mat(v, "v")
     L, HD = q.shape
@@ -833,7 +832,14 @@ def attention(q, k, v, q_colscale=None, nhead: int = 4, out=None, frames: int = 
                                   0 if q_colpart is None else q_colpart.shape[0], 0 if q_colpart is None else q_colpart.shape[1], q_eps,
                                   L, S, nhead, D, 1.0 / math.sqrt(D), frames, _p(ws), ws.numel(), _stream())
     _lib.check(rc, "cofi_attention_parts")
-    res = AttnParts(ws, L, S, nhead, D, frames)
+    return AttnParts(ws, L, S, nhead, D, frames)
+
+
+def attention(q, k, v, q_colscale=None, nhead: int = 4, out=None, frames: int = 1, q_colpart=None, q_eps: float = 1e-12,
+              parts: bool = False):
+    """attention_parts + (parts=False) the merge of the partial slots into the plain (frames*L, H*D) matrix; parts=True: the slots
+    themselves (the fused layer tail merges them in its loader)."""
+    res = attention_parts(q, k, v, q_colscale=q_colscale, nhead=nhead, frames=frames, q_colpart=q_colpart, q_eps=q_eps)
     return res if parts else res.merge(out)
 
 
