@@ -104,6 +104,38 @@ def train_step_summary(dev, frame, steps=8, warmup=3, arith="bf16x6", eager=True
     peak = torch.cuda.max_memory_allocated() - base
     if eager:
         del _o, _m, ls, loss
+    # row f3 measured like the forward: every C-ABI call of ONE eager optimisation step (forward + backward go through the same ops.*
+    # entry points; the backward's contractions are ops.gemm on transposed operands) is recorded, each family's launches are replayed
+    # back to back in a hipGraph and timed with HIP events -> kernel_ms_per_step, and the roofline of the dominant family
+    breakdown = None
+    try:
+        kt = KernelTimer()
+
+        def one():
+            optim.zero_grad()
+            _o2, _m2, ls2 = step_losses(model, pyr, img, batch, StepOpt)
+            (ls2[0] + ls2[1] + ls2[2]).backward()
+
+        kt.record_fn(one)
+        per = kt.measure(reps=3)
+        gsum = {"seconds_per_frame": 0.0, "flops_per_frame": 0.0, "launches_per_frame": 0}
+        for n in ("gemm", "gemm_colstats", "gemm_layernorm", "conv2d_nhwc"):
+            if n in per:
+                for k in gsum:
+                    gsum[k] += per[n][k]
+        peak_tf = BF16_MFMA_PEAK_TF / (6.0 if arith == "bf16x6" else 3.0) if arith in ("bf16x6", "bf16x3") else FP32_MFMA_PEAK_TF
+        breakdown = {"kernel_ms_per_step": {n: round(1e3 * v["seconds_per_frame"], 3) for n, v in sorted(per.items(), key=lambda kv: -kv[1]["seconds_per_frame"])},
+                     "recorded_entry_point_calls_per_step": int(sum(v["launches_per_frame"] for v in per.values())),
+                     "roofline": {"kernel": "cofi_gemm (forward + backward contractions)", "bound": "mfma", "unit": "TFLOP/s", "peak": peak_tf,
+                                  "achieved": gsum["flops_per_frame"] / max(gsum["seconds_per_frame"], 1e-12) / 1e12,
+                                  "frac": gsum["flops_per_frame"] / max(gsum["seconds_per_frame"], 1e-12) / 1e12 / peak_tf,
+                                  "algorithmic_gflop_per_step": gsum["flops_per_frame"] / 1e9, "calls_per_step": gsum["launches_per_frame"],
+                                  "ms_per_step": 1e3 * gsum["seconds_per_frame"]},
+                     "note": "one eager step recorded through the ops.* entry points; torch's own element-wise kernels (autograd glue, Adam) are not in these rows"}
+        del kt, per
+        optim.zero_grad(set_to_none=True)
+    except Exception as e:  # noqa: BLE001 - additional information
+        breakdown = {"error": "%s: %s" % (type(e).__name__, e)}
     del optim     # the recording below must not find last step's autograd graph alive (its AccumulateGrad nodes sit on this stream)
     # the same step as one hipGraph (cofii2p_amd.train_step.GraphedTrainStep): the eager step is bound by the Python thread issuing ~3 800 launches
     from cofii2p_amd.train_step import GraphedTrainStep
@@ -129,7 +161,7 @@ def train_step_summary(dev, frame, steps=8, warmup=3, arith="bf16x6", eager=True
     del model
     torch.cuda.empty_cache()
     return {"ms_per_step": sum(t) / steps, "forward_ms": t[0] / steps, "backward_ms": t[1] / steps, "optimizer_ms": t[2] / steps, "steps": steps,
-            "graphed": graphed,
+            "graphed": graphed, "breakdown": breakdown,
             "arithmetic": arith, "num_kpt": 64, "peak_mem_GB": peak / 2 ** 30, "loss": losses,
             "note": "train.py:186-286 on the bench frame: model.train(); forward(mode='train'); desc / overlap / fine-circle losses; backward; Adam. "
                     "HIP kernels in both directions for every weight contraction, KPConv aggregation, attention and neighbour gather "
@@ -486,6 +518,15 @@ class Pipeline:
         return self.run(max(warmup, 2 * self.NSLOT, math.lcm(self.NSLOT, len(self.frames))), 0)
 
 
+def _nccl_version():
+    """version of the collective library behind torch's "nccl" backend (RCCL on ROCm), or None when torch cannot say"""
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:   # noqa: BLE001 - informational
+        return None
+
+
 class BatchPipeline:
     """Stack-mode submissions: `Bsz` frames per submission through the same launches (CoFiI2P.stack_frames), `S` submissions in flight on S
     frame streams, one hipGraph slot per stream; two distinct batches alternate.  A step = one submission."""
@@ -764,7 +805,7 @@ def main():
         dist.all_gather(allb, bus)
         rccl = {"backend": args.dist_backend, "ranks": dist.get_world_size(), "rank_devices": [[int(v) for v in b.tolist()] for b in allb],
                 "distinct_devices": len({int(b[0]) for b in allb}) if not args.share_device else 1,
-                "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if args.dist_backend == "nccl" else None}
+                "nccl_version": _nccl_version() if args.dist_backend == "nccl" else None}
     fps = world * args.steps * Bsz / dt
     arith_note = {"f32": "on the exact fp32 MFMA (bit-equal to an fmaf chain)",
                   "bf16x3": "as a 3-term bf16 split (hi*hi + hi*lo + lo*hi) on the bf16 matrix cores: ~2^-16 per product, 2e-5 max abs deviation from the "
