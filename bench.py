@@ -574,6 +574,74 @@ def dataside_inputs(dev, points):
     return opt_ds, raw, torch.from_numpy(raw).to(dev), torch.from_numpy(rimg).to(dev), rK, P_Tr
 
 
+def loader_stack_pipeline(model, dev, opt_ds, st, Bsz, nsub, upk, raw_d, img_d, rK, P_Tr, slot_base, workers=4, KS=4):
+    """The device-side loader feeding the headline's stack-mode submissions: stream s prepares the Bsz frames of a batch one after the other
+    in its own KS loader slots (voxel grid of the next frames enqueued ahead), every finished frame is copied into its row block of a
+    static stack (preprocess.FrameStack: one launch; the slot is free again at once), the forward of the whole batch follows on the same
+    stream; the labels of a batch (kitti.py:333-420) are computed from one device-to-host copy of its coarsest points when its forward
+    is collected.  2 S stacks in the ring.  -> (frames/s of the second pass, host seconds by call)."""
+    from cofii2p_amd.loader import FrameLoader
+    from cofii2p_amd.preprocess import FrameStack
+
+    S = len(st)
+    loader = FrameLoader(opt_ds, dev, slots=S * KS, workers=workers, capture_stream=st[0], upsample_k=upk)
+    stacks, pend, ctxs = [None] * (2 * S), [None] * (2 * S), [[] for _ in range(2 * S)]
+    host = {"begin": 0.0, "complete": 0.0, "put": 0.0, "forward": 0.0, "collect": 0.0}
+
+    def timed(name, fn, *a, **k):
+        t_ = time.perf_counter()
+        r = fn(*a, **k)
+        host[name] += time.perf_counter() - t_
+        return r
+
+    def collect(j):
+        model.finish(pend[j])
+        pyr = stacks[j].pyr
+        n4, n1 = pyr["points"][-1].shape[0] // Bsz, pyr["points"][1].shape[0] // Bsz
+        coarse = pyr["points"][-1].cpu().numpy()   # one copy for the labels of the whole batch
+        for f, ctx in enumerate(ctxs[j]):
+            loader.labels_from(coarse[f * n4:(f + 1) * n4], pyr["points"][1][f * n1:(f + 1) * n1], pyr["points"][-1][f * n4:(f + 1) * n4], ctx)
+        ctxs[j] = []
+        pend[j] = None
+
+    try:
+        for phase in range(2):
+            for k_ in host:
+                host[k_] = 0.0
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            # batch q is prepared frame after frame on stream q % S while the other streams execute the forwards of the batches before it: the
+            # loader's chains of small kernels run under big stack-mode launches.  (Filling S stacks at the same time, a frame each in turn,
+            # measured 374-384 frames/s against 422-459: four loader chains, then four forwards, each phase alone on the chip.)
+            for q in range(nsub):
+                s_, j = q % S, q % (2 * S)
+                if pend[j] is not None:
+                    timed("collect", collect, j)
+                with torch.cuda.stream(st[s_]):
+                    begun = 0
+                    for f in range(Bsz):
+                        while begun < min(Bsz, f + KS):   # the voxel grids of the next KS - 1 frames of this batch are already enqueued
+                            timed("begin", loader.begin, s_ * KS + begun % KS, raw_d, img_d, rK, P_Tr, q * Bsz + begun)
+                            begun += 1
+                        loader.poll()
+                        smp = timed("complete", loader.complete, s_ * KS + f % KS)
+                        if stacks[j] is None:
+                            stacks[j] = FrameStack(smp["pc_data_dict"], smp["pc_data_dict"]["feats"], smp["img"], Bsz)
+                        timed("put", stacks[j].put, f, smp["pc_data_dict"], smp["pc_data_dict"]["feats"], smp["img"])
+                        ctxs[j].append(smp["label_ctx"])
+                        loader.release(s_ * KS + f % KS)
+                    pend[j] = timed("forward", model.forward_async, slot_base + j, stacks[j].pyr, stacks[j].img, inputs_stable=True)
+            for j in range(2 * S):
+                if pend[j] is not None:
+                    timed("collect", collect, j)
+            torch.cuda.synchronize()
+            dtl = time.perf_counter() - t0
+            nframes = nsub * Bsz
+    finally:
+        loader.close()
+    return nframes / dtl, {k_: v_ / nframes for k_, v_ in host.items()}
+
+
 def loader_pipeline(model, dev, opt_ds, st, slots_per_stream, nfr, upk, raw_d, img_d, rK, P_Tr, slot_base, workers=4):
     """The pipelined loader (cofii2p_amd/loader.py) in front of the forward: voxel grid enqueued LOOK frames ahead, draws in worker
     processes, resample + pyramid + image as one hipGraph per slot, tables read in place by the forward's graph; INFL forwards in flight.
@@ -1118,11 +1186,22 @@ def main():
             for upk in (None, 1):   # the reference's (N, 128) up-sampling tables / nearest-only tables derived without a search (outputs bit-identical)
                 rate, hst, INFL, LOOK = loader_pipeline(model, dev, opt_ds, st, args.slots_per_stream, nfr, upk, raw_d, img_d, rK, P_Tr, 60 if upk is None else 80)
                 ds_rates[upk] = (rate, hst)
+            stacked_ds = None
+            if Bsz > 1:
+                with optional_leg(result, "with_dataside_stack"):
+                    stacked_ds = {}
+                    for upk in (None, 1):
+                        r_, h_ = loader_stack_pipeline(model, dev, opt_ds, st, Bsz, max(3 * len(st), args.steps // 2), upk, raw_d, img_d, rK, P_Tr, 160 if upk is None else 180)
+                        stacked_ds["reference_tables" if upk is None else "nearest_only_upsampling"] = {
+                            "frames_per_s": r_, "host_ms_per_frame_in": {k_: round(1e3 * v_, 4) for k_, v_ in h_.items()}}
+                    stacked_ds["note"] = ("the loader feeding the headline's stack-mode submissions of %d frames (preprocess.FrameStack; labels of a batch computed "
+                                          "when its forward is collected)" % Bsz)
+                    result["config"]["with_dataside_frames_per_s"] = stacked_ds["nearest_only_upsampling"]["frames_per_s"]
             dtl, host = nfr / ds_rates[None][0], ds_rates[None][1]
             result["with_dataside"] = {"loader_ms_per_frame": loader_ms, "loader_frames_per_s": 1e3 / loader_ms, "frames_per_s": nfr / dtl,
                                        "ms_per_frame": 1e3 * dtl / nfr, "voxels": voxels, "raw_points": int(raw.shape[1]),
                                        "frames_in_flight": INFL, "voxel_grids_ahead": LOOK, "draw_workers": 4,
-                                       "nearest_only_upsampling_frames_per_s": ds_rates[1][0],
+                                       "nearest_only_upsampling_frames_per_s": ds_rates[1][0], "stack_mode_submissions": stacked_ds,
                                        "host_ms_per_frame_in": {k_: round(1e3 * v_ / nfr, 4) for k_, v_ in host.items()},
                                        "note": "kitti.py:259-393 on the device (voxel grid + resample + SE(3) + KNN pyramid + image + labels) in front of the "
                                                "forward + fine matching, pipelined (cofii2p_amd/loader.py): raw scan and image resident in HBM, voxel count "

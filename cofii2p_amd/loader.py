@@ -162,22 +162,33 @@ class FrameLoader:
                "P": torch.from_numpy(np.linalg.inv(P).astype(np.float32)).to(dev, non_blocking=True)}
         coarse_host = buf["coarse_host"]
         generation = st.generation
+        # everything the labels need besides the frame's points: a caller that copies the frame out of the slot (preprocess.FrameStack)
+        # releases the slot at once and computes the labels later with labels_from() on its own copy of the points
+        out["label_ctx"] = {"P": P, "K_2": K_2, "K_4": K_4, "sampler": s}
 
         def finish_labels():
             if st.generation != generation:   # the slot's pinned buffer and static tensors belong to another frame by now
-                raise _lib.CofiError("FrameLoader: finish_labels() called after the slot was released - call it before release(slot)")
+                raise _lib.CofiError("FrameLoader: finish_labels() called after the slot was released - call it before release(slot), or "
+                                     "use labels_from() on a copy of the frame's points")
             ready.synchronize()
-            lab = dataside.project_labels(coarse_host.numpy(), P, K_2, K_4, opt, s, dataset=self.dataset)
-            kpt = torch.from_numpy(lab["pc_kpt_idx"]).to(dev)
-            out["fine_pc_inline_index"] = ops.nearest_node(pyr["points"][1], pyr["points"][-1][kpt].contiguous()).to(torch.int64)   # point2node, kitti.py:374
-            for k, v in lab.items():
-                out[k] = torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v
+            out.update(self.labels_from(coarse_host.numpy(), pyr["points"][1], pyr["points"][-1], out["label_ctx"]))
             out.pop("finish_labels", None)
             return out
 
         out["finish_labels"] = finish_labels
         st.phase = "ready"
         return out
+
+    def labels_from(self, coarse_np: np.ndarray, points1: torch.Tensor, points4: torch.Tensor, ctx: Dict) -> Dict:
+        """kitti.py:333-420 for one frame from its coarsest-stage points (host array), the device tensors of stages 1 and 4 and the
+        `label_ctx` of its sample: the label arrays (device tensors) incl. fine_pc_inline_index = point2node (kitti.py:374)."""
+        dev = self.device
+        lab = dataside.project_labels(coarse_np, ctx["P"], ctx["K_2"], ctx["K_4"], self.opt, ctx["sampler"], dataset=self.dataset)
+        kpt = torch.from_numpy(lab["pc_kpt_idx"]).to(dev)
+        res = {"fine_pc_inline_index": ops.nearest_node(points1, points4[kpt].contiguous()).to(torch.int64)}
+        for k, v in lab.items():
+            res[k] = torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v
+        return res
 
     def release(self, slot: int):
         """the forward that read the slot's tensors has been collected: the slot may begin() another frame"""
