@@ -127,6 +127,54 @@ def test_loader_feeds_the_model_in_place():
         loader.close()
 
 
+def test_loader_frames_into_a_stack_with_deferred_labels():
+    """the loader feeding stack-mode submissions: every sample is copied into its row block of a preprocess.FrameStack (the slot is released
+    at once and refilled), the labels come from `labels_from` on the stack's copy of the points - equal to the sample's own
+    `finish_labels()`; the stack-mode forward over the stack agrees with the per-frame forwards"""
+    import copy
+
+    import bench
+    from cofii2p_amd import synth
+    from cofii2p_amd.loader import FrameLoader
+    from cofii2p_amd.network import CoFiI2P
+    from cofii2p_amd.preprocess import FrameStack
+
+    opt, P_Tr = kitti_opt(), calib_P_Tr()
+    raw, img, K = synth.make_raw_scan(0)
+    model = CoFiI2P(bench.Opt()).to(DEV)
+    model.enable_graphs(True)
+    st = model.frame_streams(1)[0]
+    loader = FrameLoader(opt, DEV, slots=2, workers=1, capture_stream=st)
+    B, stack, ctxs, want_labels, want_out = 3, None, [], [], []
+    try:
+        with torch.cuda.stream(st):
+            for f in range(B):
+                slot = f % 2                      # two slots serve three frames: slot 0 is reused while its frame lives on in the stack
+                loader.begin(slot, raw, img, K, P_Tr, 10 + f)
+                smp = loader.complete(slot)
+                if stack is None:
+                    stack = FrameStack(smp["pc_data_dict"], smp["pc_data_dict"]["feats"], smp["img"], B)
+                stack.put(f, smp["pc_data_dict"], smp["pc_data_dict"]["feats"], smp["img"])
+                ctxs.append(copy.deepcopy(smp["label_ctx"]))   # the sampler inside is a random stream: each label computation consumes its own copy
+                want_out.append([t.clone() for t in model.finish(model.forward_async(f, smp["pc_data_dict"], smp["img"][None]))[:6]])
+                lab = smp["finish_labels"]()
+                want_labels.append({k: lab[k].clone() for k in ("fine_pc_inline_index", "pc_kpt_idx", "pc_outline_idx", "coarse_img_kpt_idx", "fine_xy_coors")})
+                loader.release(slot)
+                with pytest.raises(Exception):   # the slot's buffers are another frame's from now on
+                    smp["finish_labels"]()
+            got = model.finish(model.forward_async(8, stack.pyr, stack.img, inputs_stable=True))
+        n4, n1 = stack.pyr["points"][-1].shape[0] // B, stack.pyr["points"][1].shape[0] // B
+        coarse = stack.pyr["points"][-1].cpu().numpy()
+        for f in range(B):
+            lab = loader.labels_from(coarse[f * n4:(f + 1) * n4], stack.pyr["points"][1][f * n1:(f + 1) * n1], stack.pyr["points"][-1][f * n4:(f + 1) * n4], ctxs[f])
+            for k, v in want_labels[f].items():
+                assert torch.equal(lab[k], v), (f, k)
+            for a, b in zip(want_out[f][:4], got[f][:4]):   # stack mode runs other launch shapes than a single frame: fp32 rounding apart
+                assert float((a - b).abs().max()) < 2e-5, f
+    finally:
+        loader.close()
+
+
 def test_pyramid_graph_equals_build_pyramid():
     from cofii2p_amd.preprocess import PyramidGraph, build_pyramid
     from cofii2p_amd.synth import make_frame, subsample_indices
