@@ -28,6 +28,47 @@ def test_library_exports_every_declared_symbol():
     assert lib.cofi_group_stats_workspace(1280, 2048, 32, 16) == 2 * 16 * 32 * 2 * 8  # 16 frames of 80 rows: 2 slabs each
 
 
+def test_descriptor_structs_mirror_the_header():
+    """the ctypes mirrors of the two descriptor structs of the C ABI declare the header's fields, in the header's order, with matching
+    C types (a drifted field would silently shift every later argument), and the argument counts of the binding table equal the header's
+    parameter counts for every entry point"""
+    import ctypes
+    import re
+
+    from cofii2p_amd import _lib
+
+    text = re.sub(r"/\*.*?\*/", "", open(_lib.HEADER_PATH).read(), flags=re.S)
+    ctype_of = {"int": ctypes.c_int, "float": ctypes.c_float, "size_t": ctypes.c_size_t}
+
+    def fields_of(struct_name):
+        body = re.search(r"typedef struct[^{}]*\{([^{}]*)\}\s*%s;" % struct_name, text).group(1)
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            base = re.match(r"(const\s+)?(\w+)", decl).group(2)
+            for part in decl[re.match(r"(const\s+)?\w+", decl).end():].split(","):
+                part = part.strip()
+                ptr = part.startswith("*")
+                m = re.match(r"\*?\s*(\w+)(\[(\d+)\])?", part)
+                t = ctypes.c_void_p if ptr else ctype_of[base]
+                out.append((m.group(1), t * int(m.group(3)) if m.group(3) else t))
+        return out
+
+    for cname, mirror in (("cofi_norm_desc_t", _lib.NormDesc), ("cofi_loftr_tail_desc_t", _lib.TailDesc)):
+        want, got = fields_of(cname), list(mirror._fields_)
+        assert [n for n, _ in want] == [n for n, _ in got], cname
+        for (n, tw), (_, tg) in zip(want, got):
+            assert ctypes.sizeof(tw) == ctypes.sizeof(tg) and (tw is tg or issubclass(tg, ctypes.Array) == issubclass(tw, ctypes.Array)), (cname, n)
+    for name, (_res, args) in _lib.SIGNATURES.items():
+        m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, text, flags=re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert n == len(args), (name, n, len(args))
+
+
 def test_code_object_targets_gfx950_only():
     from cofii2p_amd import _lib
 
