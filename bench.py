@@ -946,6 +946,32 @@ def main():
             result["batch1_pipeline"] = {"frames_per_s": n1 / d1, "ms_per_frame": 1e3 * d1 / n1, "frames": n1, "arithmetic": args.gemm, "frames_in_flight": S * max(1, args.slots_per_stream),
                                          "note": "BASELINE configs[1]: ONE frame per submission (batch 1), %d frame streams x %d hipGraph slots" % (S, max(1, args.slots_per_stream))}
             result["config"]["batch1_frames_per_s"] = n1 / d1
+    if extras and Bsz > 1:
+        with optional_leg(result, "single_frame_api"):
+            # the same frames handed over ONE AT A TIME (cofii2p_amd.serving.FrameBatcher.submit / result): every frame is copied into the
+            # stack being filled (one launch, 27 MB) and the stack runs as a stack-mode submission of Bsz frames - the batch rate behind a
+            # single-frame API
+            from cofii2p_amd.serving import FrameBatcher
+
+            fb = FrameBatcher(model, batch=Bsz, streams=S, slot_base=220)
+            nfr = max(args.steps, 40) * Bsz
+            for phase in range(2):   # 0: captures the graphs of the ring's slots
+                tickets = []
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(nfr if phase else 2 * S * Bsz):
+                    pyr_i, img_i, _ = frames[i % len(frames)]
+                    tickets.append(fb.submit(pyr_i, img_i))
+                    if len(tickets) > (2 * S - 1) * Bsz:        # read results one ring behind the submissions
+                        fb.result(tickets.pop(0))
+                while tickets:
+                    fb.result(tickets.pop(0))
+                torch.cuda.synchronize()
+                d_api = time.perf_counter() - t0
+            result["single_frame_api"] = {"frames_per_s": nfr / d_api, "ms_per_frame": 1e3 * d_api / nfr, "frames": nfr, "batch": Bsz,
+                                          "note": "serving.FrameBatcher: submit(frame) / result(ticket) per frame, executed as stack-mode submissions of %d frames "
+                                                  "(each frame copied into its stack by one launch)" % Bsz}
+            result["config"]["single_frame_api_frames_per_s"] = nfr / d_api
     if extras and not args.no_f32:
         with optional_leg(result, "other_arithmetics"):
             # the same loops in the other two arithmetics, on record next to `value`: the narrower 3-term split (faster) and the exact fp32 MFMA

@@ -500,6 +500,43 @@ def test_frame_stack_equals_stack_frames(model):
             assert torch.equal(got[b][i], ref[b][i]), (b, i)
 
 
+def test_frame_batcher_single_frame_api(model):
+    """serving.FrameBatcher: frames go in one at a time, run as stack-mode submissions of `batch` frames (a partly filled stack is padded
+    by its last frame), every ticket returns its own frame's 8-tuple = the stack-mode forward of the same frames; a ticket whose stack
+    has been reused is refused"""
+    from cofii2p_amd.network import CoFiI2P
+    from cofii2p_amd.preprocess import build_pyramid
+    from cofii2p_amd.serving import FrameBatcher
+    from cofii2p_amd.synth import make_frame, subsample_indices
+
+    frames = []
+    for b in range(5):
+        fr = make_frame(80 + b, 4096)
+        sub = [torch.from_numpy(s_).to(DEV) for s_ in subsample_indices(4096, 5, seed=80 + b)]
+        pyr = build_pyramid(torch.from_numpy(fr.points).to(DEV), sub, int64=(b % 2 == 1))   # int64 tables (the reference's) are accepted too
+        pyr["feats"] = torch.from_numpy(fr.feats).to(DEV)
+        frames.append((pyr, torch.from_numpy(fr.img)[None].to(DEV)))
+    model.enable_graphs(True)
+    fb = FrameBatcher(model, batch=2, streams=2, ring=2, slot_base=20)
+    tickets = [fb.submit(p, im) for p, im in frames]         # 2 + 2 + 1 frames: the third stack is flushed by result()
+    got = {}
+    for i in (4, 2, 3):                                      # stack 0's second round (frame 4, padded) and stack 1
+        got[i] = [t.clone() for t in fb.result(tickets[i])]
+    with pytest.raises(RuntimeError):
+        fb.result(tickets[0])                                # stack 0 was reused for frame 4
+    assert fb.submissions == 3
+    for pair in ((2, 3), (4, 4)):
+        pyrs = [{k: ([CoFiI2P._as_idx32(t) for t in frames[i][0][k]] if k != "points" else frames[i][0][k]) for k in ("points", "neighbors", "subsampling", "upsampling")} for i in pair]
+        for i, p in zip(pair, pyrs):
+            p["feats"] = frames[i][0]["feats"]
+        st, im = CoFiI2P.stack_frames(pyrs, [frames[i][1] for i in pair])
+        ref = model.finish(model.forward_async(28, st, im))
+        for pos, i in enumerate(pair[:1] if pair[0] == pair[1] else pair):
+            for a, b in zip(got[i], ref[pos]):
+                assert torch.equal(a, b), (i,)
+    model.enable_graphs(False)
+
+
 @pytest.mark.parametrize("fid,gemm", [(41, "bf16x3"), (42, "f32")])
 def test_other_kitti_frames_vs_oracle(model, monkeypatch, fid, gemm):
     """KITTI-shaped frames the golden files do not hold, in both arithmetics, through the hipGraph path with two frames in
