@@ -60,6 +60,12 @@ class arithmetic:
 
 
 GEMM_W_SPLIT = 0x200
+# frames per submission from which pending normalisations are finalized ONCE (cofi_norm_finalize -> per-channel scale | shift) instead of
+# folded from the statistics partials by every consumer workgroup; 0 = never (COFI_NORM_FINALIZE_FRAMES).  Round 4, same box, bf16x6,
+# frames/s without / with: batch 1 479.5 / 483.6, batch 2 515.6 / 524.8, batch 4 567.6 / 581.1, batch 16 620 / 635 (the fold of a
+# 320-slab table in each of the thousands of workgroups of a stack-mode launch is real work; rounds 2-3 measured "equal" at batch 1 when the
+# chain was a third longer).  Same fixed-order fp64 fold in both forms: identical bits.
+FINALIZE_MIN_FRAMES = int(os.environ.get("COFI_NORM_FINALIZE_FRAMES", "1"))
 # bf16x6 reading the weights as three pre-split planes (COFI_GEMM_W_SPLIT with 3 planes): bit-identical to splitting W on the fly, and
 # SLOWER on MI355X - 6 instead of 4 bytes per weight element through L2 -> LDS cost more than the conversion instructions they replace
 # (round 4, same box: 40960 x 1024 x 3072 1333 -> 1410 us; batch-16 pipeline 622 -> 608 frames/s, batch 1 479 = 479).  Off by default.
@@ -221,9 +227,9 @@ def set_workspace_slot(slot: int):
     Workspace.slot = int(slot)
 
 
-# Statistics partials -> per-channel scale / shift: every consumer workgroup folds the table itself (stat_fold.h).  A separate
-# cofi_norm_finalize launch per normalisation + consumers reading the finished vectors measured equal within noise (443 vs 446
-# frames/s) for ~80 more launches per frame; the entry point stays for callers that want the vectors (ColStats.scale_shift).
+# Statistics partials -> per-channel scale / shift: finalized once per (statistics, affine pair) by cofi_norm_finalize and read by every
+# consumer (FINALIZE_MIN_FRAMES above; round 4), or - COFI_NORM_FINALIZE_FRAMES=0, the form of rounds 2-3 - folded by every consumer
+# workgroup itself (stat_fold.h).
 
 
 # ------------------------------------------------------------------------------------------ dense
@@ -263,6 +269,10 @@ class ColStats:
         d.eps, d.slope = self.eps, slope
         d.slab_rows = self.slab_rows
         d.scale_shift = None
+        if 0 < FINALIZE_MIN_FRAMES <= self.frames and self.width * self.part.shape[1] == self.C:
+            # stack-mode batches: one finalize launch per (statistics, affine pair) instead of a fold of the whole table in EVERY consumer
+            # workgroup (thousands per launch at batch 16); the tensor is kept on the statistics object, the descriptor holds its address
+            d.scale_shift = self.scale_shift(d, gamma, beta).data_ptr()
         return d
 
     def scale_shift(self, d, gamma, beta) -> torch.Tensor:
