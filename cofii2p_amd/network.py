@@ -526,7 +526,7 @@ class CoFiI2P(nn.Module):
         'val' on a module in train() mode - runs `train_forward.forward_train`: the same network as a torch.autograd graph over this
         module's parameters whose operators (every weight contraction, the KPConv aggregation, attention, the neighbour gathers) are
         HIP kernels in both directions; BatchNorm of the up-sampler then uses batch statistics and updates its running buffers, as the
-        reference's module does under train().  norm == 'gn' only.
+        reference's module does under train(); opt.norm == 'bn': the point encoder's BatchNorm1d layers likewise (train_forward._Norm).
         INFERENCE: everything else - evaluation/eval_all.py, train.py's validation pass (test_acc, train.py:27-70: model.eval() and
         mode='val', with autograd still enabled there - nothing requires grad, so it lands here) - runs the fused, folded kernel sequence (optionally a hipGraph) and returns tensors without a
         graph.  mode='test' is never differentiable (its match selection is a host-visible count, network.py:145-151): inputs that
@@ -545,7 +545,8 @@ class CoFiI2P(nn.Module):
             raise NotImplementedError("mode='test' is not differentiable (host-side match selection, network.py:145-151): call it under "
                                       "torch.no_grad(); gradients flow through mode='train'")
         if self.training and self.pc_norm_kind == "bn":
-            raise NotImplementedError("opt.norm == 'bn' is served with running statistics (module.eval()); batch statistics need the reference's model")
+            raise NotImplementedError("mode='test' on a module in train() mode with opt.norm == 'bn': the inference sequence folds BatchNorm on its "
+                                      "running statistics - call module.eval() (evaluation/eval_all.py does), or mode 'train' / 'val' for batch statistics")
         with torch.no_grad(), ops.arithmetic(self.arithmetic):
             return self._forward(pc_data_dict, img, fine_center_kpt_coors, fine_pc_inline_index, mode, taps)
 

@@ -14,7 +14,7 @@ Differences from the inference path, all the reference's own train()-mode semant
     (imagenet.py:381-394 under model.train(), train.py:188);
   * nothing is folded, fused across layers or captured in a hipGraph; ResNet layer3 / layer4 / avg-pool, which feed nothing
     (network.py:87-89) and hold no state, are skipped.
-One frame per call (train.py's batch: `torch.squeeze` of a batch of 1).  norm == 'gn' only (the shipped configuration).
+One frame per call (train.py's batch: `torch.squeeze` of a batch of 1).  opt.norm: 'gn' (the shipped configuration), 'bn', 'ln' (`_Norm`).
 """
 from typing import Dict, List
 
@@ -59,6 +59,27 @@ def batch_norm_rows(x, P, B, p: str, training: bool, slope: float = 1.0, res=Non
     return y
 
 
+class _Norm:
+    """get_norm() of the point encoder (modules.py:51-60) on (N, C) rows, with the residual join and LeakyReLU that follow it in the
+    reference's blocks.  'gn': the GroupNorm wrapper (keys p + "norm.weight"); 'bn': nn.BatchNorm1d over the rows - batch statistics and
+    moving buffers while the module trains, running statistics under eval() - on the same HIP kernels as the image branch's BatchNorm2d;
+    'ln': nn.LayerNorm over the channels of a row (row-local: torch's differentiable op, as in the point MLP)."""
+
+    def __init__(self, kind: str, P, B, training: bool):
+        self.kind, self.P, self.B, self.training = kind, P, B, training
+
+    def __call__(self, p: str, x, slope: float = 1.0, res=None):
+        P = self.P
+        if self.kind == "gn":
+            return group_norm_rows(x, P[p + "norm.weight"], P[p + "norm.bias"], slope, res)
+        if self.kind == "bn":
+            return batch_norm_rows(x, P, self.B, p, self.training, slope, res)
+        y = F.layer_norm(x, (x.shape[1],), P[p + "weight"], P[p + "bias"], 1e-5)
+        if res is not None:
+            y = y + res
+        return F.leaky_relu(y, slope) if slope != 1.0 else y
+
+
 def pos_sine_table(coords: torch.Tensor) -> torch.Tensor:
     """position_encoding.py:7-50 as a constant (no parameters, inputs need no gradient): (T, n) -> (T, 128)."""
     out = torch.zeros((coords.shape[0], D_MODEL), dtype=torch.float32, device=coords.device)
@@ -66,11 +87,11 @@ def pos_sine_table(coords: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------ point encoder (kp_backbone.py:79-128)
-def _unary(P, p, x, relu: bool = True, norm: bool = True, res=None):
-    """UnaryBlock (modules.py:63-94): Linear -> GroupNorm -> LeakyReLU; `res` joins before the activation (the residual tail, :236-240)"""
+def _unary(P, nrm, p, x, relu: bool = True, norm: bool = True, res=None):
+    """UnaryBlock (modules.py:63-94): Linear -> get_norm() -> LeakyReLU; `res` joins before the activation (the residual tail, :236-240)"""
     y = ag.linear(x, P[p + "mlp.weight"], P[p + "mlp.bias"])
     if norm:
-        return group_norm_rows(y, P[p + "norm.norm.weight"], P[p + "norm.norm.bias"], LRELU if relu else 1.0, res)
+        return nrm(p + "norm.", y, LRELU if relu else 1.0, res)
     return F.leaky_relu(y, LRELU) if relu else y
 
 
@@ -82,21 +103,23 @@ def _kpconv(P, B, p, feats, q_pts, s_pts, idx, sigma, tables):
     return ag.linear(agg, w2, P[p + "KPConv.bias"], rowdiv=cnt)
 
 
-def _block(P, B, blk, feats, q_pts, s_pts, idx, tables):
+def _block(P, B, nrm, blk, feats, q_pts, s_pts, idx, tables):
     p = "pc_encoder.%s." % blk.name
     if blk.kind == "conv":   # modules.py:155-159
         y = _kpconv(P, B, p, feats, q_pts, s_pts, idx, blk.sigma, tables)
-        return group_norm_rows(y, P[p + "norm.norm.weight"], P[p + "norm.norm.bias"], LRELU)
-    x = _unary(P, p + "unary1.", feats) if blk.cin != blk.mid else feats   # modules.py:222-240
+        return nrm(p + "norm.", y, LRELU)
+    x = _unary(P, nrm, p + "unary1.", feats) if blk.cin != blk.mid else feats   # modules.py:222-240
     x = _kpconv(P, B, p, x, q_pts, s_pts, idx, blk.sigma, tables)
-    x = group_norm_rows(x, P[p + "norm_conv.norm.weight"], P[p + "norm_conv.norm.bias"], LRELU)
+    x = nrm(p + "norm_conv.", x, LRELU)
     sc = ag.neighbor_maxpool(feats, idx, tables) if blk.strided else feats
     if blk.has_shortcut_unary:
-        sc = _unary(P, p + "unary_shortcut.", sc, relu=False)
-    return _unary(P, p + "unary2.", x, relu=True, res=sc)   # leaky(GroupNorm(unary2) + shortcut)
+        sc = _unary(P, nrm, p + "unary_shortcut.", sc, relu=False)
+    return _unary(P, nrm, p + "unary2.", x, relu=True, res=sc)   # leaky(norm(unary2) + shortcut)
 
 
-def kpconv_fpn(P, B, points, neighbors, subsampling, upsampling, feats, tables) -> List[torch.Tensor]:
+def kpconv_fpn(P, B, points, neighbors, subsampling, upsampling, feats, tables, kind: str = "gn", training: bool = True, taps=None) -> List[torch.Tensor]:
+    """kp_backbone.py:79-128.  taps (optional dict): every encoder block's output by name, for tests"""
+    nrm = _Norm(kind, P, B, training)
     x = feats
     stage_out = {}
     for blk in ENCODER:
@@ -105,12 +128,14 @@ def kpconv_fpn(P, B, points, neighbors, subsampling, upsampling, feats, tables) 
             q, s, idx = points[st], points[st - 1], subsampling[st - 1]
         else:
             q, s, idx = points[st], points[st], neighbors[st]
-        x = _block(P, B, blk, x, q, s, idx, tables)
+        x = _block(P, B, nrm, blk, x, q, s, idx, tables)
         stage_out[st] = x
+        if taps is not None:
+            taps[blk.name] = x
     s5 = stage_out[4]
     dec = {name: norm for name, _, _, norm in DECODERS}
-    l4 = _unary(P, "pc_encoder.decoder4.", torch.cat([ag.gather_rows(s5, upsampling[3], tables), stage_out[3]], 1), norm=dec["decoder4"])
-    l3 = _unary(P, "pc_encoder.decoder3.", torch.cat([ag.gather_rows(l4, upsampling[2], tables), stage_out[2]], 1), norm=dec["decoder3"])
+    l4 = _unary(P, nrm, "pc_encoder.decoder4.", torch.cat([ag.gather_rows(s5, upsampling[3], tables), stage_out[3]], 1), norm=dec["decoder4"])
+    l3 = _unary(P, nrm, "pc_encoder.decoder3.", torch.cat([ag.gather_rows(l4, upsampling[2], tables), stage_out[2]], 1), norm=dec["decoder3"])
     l2 = ag.linear(torch.cat([ag.gather_rows(l3, upsampling[1], tables), stage_out[1]], 1), P["pc_encoder.decoder2.mlp.weight"],
                    P["pc_encoder.decoder2.mlp.bias"])
     return [l2, l3, l4, s5]
@@ -232,8 +257,6 @@ def forward_train(model, pc_data_dict: Dict, img: torch.Tensor, fine_center_kpt_
     """-> the reference's 8-tuple (fine_center_xy = coarse_pc_points = None) with a graph behind every tensor."""
     if not img.is_cuda:
         raise _lib.CofiError("CoFiI2P.forward needs CUDA (HIP) tensors: there is no CPU path")
-    if model.pc_norm_kind != "gn":
-        raise NotImplementedError("the training path serves opt.norm == 'gn' (the shipped configuration)")
     if img.dim() != 4 or img.shape[0] != 1:
         raise ValueError("training runs one frame per forward (train.py squeezes a batch of 1)")
     _lib.load()
@@ -277,7 +300,7 @@ def forward_train(model, pc_data_dict: Dict, img: torch.Tensor, fine_center_kpt_
         pix = (rows[:, :, None] * W2 + cols[:, None, :]).reshape(-1)             # (K 16,)
         patches = ag.gather_rows(up2, pix.to(torch.int32), tables).reshape(ctr.shape[1], 4, 4, -1).permute(0, 3, 1, 2)
 
-    pc_set = kpconv_fpn(P, B, points, neighbors, subsampling, upsampling, feats, tables)
+    pc_set = kpconv_fpn(P, B, points, neighbors, subsampling, upsampling, feats, tables, model.pc_norm_kind, training)
     fine_pc = ag.normalize_rows(pc_set[0])                                   # network.py:83
     pc_mid = ag.normalize_rows(pc_feature_mlp(P, pc_set[-1]))                # network.py:84
     tok_pc = pc_mid + pos_sine_table(points[-1])                              # network.py:107,111

@@ -127,11 +127,11 @@ def leaky(x: Tensor) -> Tensor:
 
 def pc_norm(sd, p: str, x: Tensor) -> Tensor:
     """get_norm() of modules.py:51-60 applied to (N, C) rows, picked by the keys the state_dict holds under prefix p ("...norm." /
-    "...norm_conv."): GroupNorm wrapper (p + "norm.weight"), BatchNorm1d in eval mode (running statistics), LayerNorm."""
+    "...norm_conv."): GroupNorm wrapper (p + "norm.weight"), BatchNorm1d (running statistics; batch statistics + buffer update when the module trains), LayerNorm."""
     if (p + "norm.weight") in sd:
         return group_norm_rows(x, sd[p + "norm.weight"], sd[p + "norm.bias"])
     if (p + "running_mean") in sd:
-        return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"], False, 0.1, 1e-5)
+        return _bn_eval(sd, p, x)   # nn.BatchNorm1d over the rows: running statistics, or batch statistics under forward(train_bn=True)
     return F.layer_norm(x, (x.shape[1],), sd[p + "weight"], sd[p + "bias"], 1e-5)
 
 

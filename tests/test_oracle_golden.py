@@ -239,8 +239,10 @@ def test_loss_oracle_against_reference_losses(tag):
     close(pf.grad, g[tag + "_fine_gpc"])
 
 
-def test_oracle_train_step_against_reference_train_step():
-    """One optimisation step of train.py:186-285 through the ORACLE - forward(mode='train', train_bn=True), the caller-side gathers and mask,
+@pytest.mark.parametrize("norm", ["gn", "bn", "ln"])
+def test_oracle_train_step_against_reference_train_step(norm):
+    """(norm = opt.norm of get_norm(), modules.py:51-60: 'gn' the shipped configuration; 'bn' - BatchNorm1d on batch statistics, running buffers
+    moved; 'ln' - LayerNorm.)  One optimisation step of train.py:186-285 through the ORACLE - forward(mode='train', train_bn=True), the caller-side gathers and mask,
     the loss oracle, torch.autograd - against the step recorded from the reference's module in train() mode (tests/golden/train_ref.npz):
     outputs, losses, BatchNorm buffers, which parameters get a gradient, and every gradient's fingerprint (judged as in
     tests/test_train_gpu.py: against the float64 values, within the reference's own fp32 deviation where that exceeds 1e-3)."""
@@ -248,10 +250,12 @@ def test_oracle_train_step_against_reference_train_step():
 
     import loss_oracle as LO
 
-    gold = load_golden("train_ref.npz")
+    from cofii2p_amd.spec import synth_state_dict
+
+    gold = load_golden("train_ref.npz" if norm == "gn" else "train_ref_%s.npz" % norm)
     fr, data = frame_inputs(int(gold["frame_id"]), int(gold["num_points"]), int(gold["pyr_seed"]))
     lab = {k[4:]: T(gold[k]) for k in gold.files if k.startswith("lab_")}
-    sd = {k: v.clone() for k, v in synth_sd().items()}
+    sd = {k: torch.from_numpy(v).clone() for k, v in synth_state_dict(norm=norm).items()}
     names = [str(n) for n in gold["g_names"]]
     for n in names:
         sd[n] = sd[n].clone().requires_grad_()
@@ -259,7 +263,8 @@ def test_oracle_train_step_against_reference_train_step():
     outs = O.forward(sd, data, img, lab["fine_center_kpt_coors"].float(), lab["fine_pc_inline_index"], "train", train_bn=True)
     img_f, pc_f, _img_s, pc_s, patches, fine_pc = outs[:6]
     for n_, t in zip(("img_desc", "pc_desc", "img_score", "pc_score", "patches", "fine_pc"), outs[:6]):
-        assert float((t.detach() - T(gold["train_" + n_]).reshape(t.shape)).abs().max()) < 2e-5, n_
+        # 'bn': batch statistics over 2048 ... 128 rows of a synthetic-weight network pass a different summation order on (observed 2.0e-5)
+        assert float((t.detach() - T(gold["train_" + n_]).reshape(t.shape)).abs().max()) < (5e-5 if norm == "bn" else 2e-5), n_
     K = int(gold["num_kpt"])
     kp, ko, ci = lab["pc_kpt_idx"], lab["pc_outline_idx"], lab["coarse_img_kpt_idx"]
     H8, W8 = img_f.shape[2:]
@@ -284,11 +289,14 @@ def test_oracle_train_step_against_reference_train_step():
         flat = g_.double().reshape(-1)
         norm_ref = float(gold["g_norm64"][i])
         if norm_ref < 1e-6 * total:
-            assert float(flat.norm()) < 1e-5 * total, name
+            # mathematically zero (a bias in front of a normalisation): fp32 leaves rounding noise - the reference's own is g_norm
+            assert float(flat.norm()) < max(1e-5 * total, 3.0 * float(gold["g_norm"][i])), name
             continue
         got, ref = flat[T(gold["g_pos"][i])].numpy(), gold["g_val64"][i]
         scale = max(np.linalg.norm(ref), norm_ref * math.sqrt(len(ref) / flat.numel()))
-        allow = max(1e-3, 2.5 * float(gold["g_err32"][i]))
+        # 'bn': batch statistics make this synthetic-weight network's gradients ill-conditioned in fp32 - the reference's own fp32 gradients are a
+        # median 1.8e-3 (up to 6e-2) away from its fp64 ones (g_err32); another summation order lands within a few times that
+        allow = max(1e-3, (5.0 if norm == "bn" else 2.5) * float(gold["g_err32"][i]))
         assert float(np.linalg.norm(got - ref) / scale) < allow and abs(float(flat.norm()) - norm_ref) / norm_ref < allow, name
     for k in gold.files:
         if k.startswith("buf/"):

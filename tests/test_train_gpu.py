@@ -306,6 +306,99 @@ def gold():
     return load_golden("train_ref.npz")
 
 
+def _check_step_against(gold, m, tol, zero_mult=3.0, err32_mult=2.5, err32_floor=0.0):
+    """one train.py-shaped step of module `m` against a train_ref*.npz recording: outputs, mask, losses, gradients (judged in float64, see
+    test_train_step_matches_reference), buffers.  -> (worst error, its parameter)"""
+    from cofii2p_amd.train_step import step_losses
+
+    dd, img, batch, sopt = _train_inputs(gold)
+    outs, mask, (l_desc, l_coarse, l_fine) = step_losses(m, dd, img, batch, sopt)
+    assert np.array_equal(mask.cpu().numpy(), gold["mask"])
+    for n_, t in zip(("img_desc", "pc_desc", "img_score", "pc_score", "patches", "fine_pc"), outs[:6]):
+        ref = gold["train_" + n_]
+        assert tuple(t.shape) == ref.shape, n_
+        assert float((t.detach().cpu() - torch.from_numpy(ref)).abs().max()) < 1e-3, n_
+    for name, val in (("loss_desc", l_desc), ("loss_coarse", l_coarse), ("loss_fine", l_fine)):
+        assert abs(float(val.detach()) - float(gold[name])) < 1e-3 * max(1.0, abs(float(gold[name]))), name
+    (l_desc + l_coarse + l_fine).backward()
+    names = [str(n) for n in gold["g_names"]]
+    params = dict(m.named_parameters())
+    assert names == list(params)
+    total = float(np.sqrt((gold["g_norm64"] ** 2).sum()))
+    worst = (0.0, None)
+    bad = []
+    if err32_floor == "median":   # the reference's own typical fp32 deviation in this configuration (1.7e-6 'gn' / 'ln', 1.8e-3 'bn')
+        live = (gold["g_has"] != 0) & (gold["g_norm64"] >= 1e-6 * total)
+        err32_floor = float(np.median(gold["g_err32"][live]))
+    for i, name in enumerate(names):
+        p = params[name]
+        if not int(gold["g_has"][i]):
+            assert p.grad is None, name
+            continue
+        assert p.grad is not None, name
+        flat = p.grad.detach().double().reshape(-1).cpu()
+        norm_ref = float(gold["g_norm64"][i])
+        if norm_ref < 1e-6 * total:
+            assert float(flat.norm()) < max(1e-5 * total, zero_mult * float(gold["g_norm"][i])), "%s: mathematically zero gradient, got |g| = %.3g" % (name, float(flat.norm()))
+            continue
+        got, ref = flat[torch.from_numpy(gold["g_pos"][i])].numpy(), gold["g_val64"][i]
+        scale = max(np.linalg.norm(ref), norm_ref * math.sqrt(len(ref) / flat.numel()))
+        e_samp = float(np.linalg.norm(got - ref) / scale)
+        e_norm = abs(float(flat.norm()) - norm_ref) / norm_ref
+        allow = max(tol, err32_mult * max(float(gold["g_err32"][i]), err32_floor))
+        worst = max(worst, (max(e_samp, e_norm) / allow, name))
+        if not (e_samp < allow and e_norm < allow):
+            bad.append("%s: sampled entries off by %.3g (allowed %.3g; reference fp32 %.3g), norm by %.3g (relative)" % (name, e_samp, allow, float(gold["g_err32"][i]), e_norm))
+    assert not bad, "%d parameters beyond their allowance:\n" % len(bad) + "\n".join(bad[:40])
+    bufs = dict(m.named_buffers())
+    nbuf = 0
+    for k in gold.files:
+        if k.startswith("buf/"):
+            nbuf += 1
+            # BatchNorm1d of the point encoder ('bn'): the batch statistics inherit the forward's fp32 conditioning - 1e-4 relative at the last
+            # stage between any two fp32 evaluations (tools/diag_norm_train.py) - times the momentum 0.1
+            rtol, atol = (2e-3, 2e-4) if k.startswith("buf/pc_encoder") else (1e-4, 1e-5)
+            got, ref = bufs[k[4:]].detach().cpu().double(), torch.from_numpy(np.asarray(gold[k])).double()
+            assert torch.allclose(got, ref, rtol=rtol, atol=atol), "%s: max abs difference %.3g" % (k, float((got - ref).abs().max()))
+    return worst, nbuf
+
+
+@pytest.mark.parametrize("norm", ["bn", "ln"])
+def test_train_step_other_point_norms_match_reference(norm):
+    """opt.norm = 'bn' / 'ln' (get_norm(), modules.py:51-60) in train() mode against the REFERENCE built with that option and run through one
+    train.py-shaped step (tests/golden/train_ref_{bn,ln}.npz, tests/tools/make_golden_train.py --norm ...): train-mode outputs, losses, every
+    parameter gradient, and - 'bn' - the running_mean / running_var / num_batches_tracked of all 47 BatchNorm1d layers of the point encoder
+    after the step (batch statistics, momentum 0.1, unbiased variance).  'bn': batch statistics make the synthetic-weight network's gradients
+    ill-conditioned in fp32 - the reference's own fp32 gradients sit a median 1.8e-3 (up to 6e-2) from its fp64 ones (g_err32) - and the
+    forward too (two fp32 evaluations differ by 1e-4 at the last encoder stage: tools/diag_norm_train.py shows the HIP path and the
+    oracle's fp32 evaluation equally far from fp64, block by block).  That forward difference flips ReLUs whose input is ~0 (the point
+    score head holds pre-ReLU values of 3e-5 ... 3e-4 in rows that carry a loss gradient: tools/diag_norm_mid.py traced the whole
+    downstream deviation to ONE such row), which changes that row's gradient as a whole: parameters behind the encoder, where the
+    reference's own fp32 run happens to agree with fp64 to 1e-5, see 1e-3 ... 4e-3 from any evaluation with another summation order.  So
+    under 'bn' a parameter passes within 5x of max(its own g_err32, the median g_err32 of the configuration); 'ln' is judged like 'gn'."""
+    from cofii2p_amd.network import CoFiI2P
+
+    gold = load_golden("train_ref_%s.npz" % norm)
+    assert str(gold["norm"]) == norm
+
+    class OptN(Opt):
+        pass
+
+    OptN.norm = norm
+    m = CoFiI2P(OptN(), arithmetic="bf16x6").to(DEV)
+    m.train()
+    worst, nbuf = _check_step_against(gold, m, GRAD_TOL, err32_mult=5.0 if norm == "bn" else 2.5, err32_floor="median" if norm == "bn" else 0.0)
+    print("worst parameter (error / allowance) %.3g (%s); %d buffers compared" % (worst + (nbuf,)))
+    assert nbuf == (36 + 3 * 47 if norm == "bn" else 36)   # 12 BatchNorm2d of the up-samplers (+ 47 BatchNorm1d), three buffers each
+    # eval(): the same module on its (moved) running statistics still differentiates (BatchNorm as constants)
+    m.eval()
+    m.zero_grad()
+    dd, img, batch, _ = _train_inputs(gold)
+    outs = m(dd, img, batch["fine_center_kpt_coors"], batch["fine_xy"], batch["fine_pc_inline_index"], "train")
+    sum(o.square().sum() for o in outs[:6]).backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
 def _train_inputs(gold):
     fr, data = frame_inputs(int(gold["frame_id"]), int(gold["num_points"]), int(gold["pyr_seed"]))
     assert sha(fr.points) == str(gold["sha_points"]) and sha(fr.img) == str(gold["sha_img"])
@@ -363,7 +456,8 @@ def test_train_step_matches_reference(gold, arith, tol, monkeypatch):
         flat = p.grad.detach().double().reshape(-1).cpu()
         norm_ref = float(gold["g_norm64"][i])
         if norm_ref < zero_floor:
-            assert float(flat.norm()) < 1e-5 * total, "%s: mathematically zero gradient, got |g| = %.3g" % (name, float(flat.norm()))
+            # fp32 leaves rounding noise where the gradient is mathematically zero; the reference's own noise is g_norm (1.5e-3 under 'bn')
+            assert float(flat.norm()) < max(1e-5 * total, 3.0 * float(gold["g_norm"][i])), "%s: mathematically zero gradient, got |g| = %.3g" % (name, float(flat.norm()))
             continue
         got = flat[torch.from_numpy(gold["g_pos"][i])].numpy()
         ref = gold["g_val64"][i]
@@ -538,13 +632,14 @@ def test_train_mode_refusals():
     from cofii2p_amd import _lib
     from cofii2p_amd.network import CoFiI2P
 
-    class OptLn(Opt):
-        norm = "ln"
+    class OptBn(Opt):
+        norm = "bn"
 
-    m = CoFiI2P(OptLn()).to(DEV)
     dd = {"points": [torch.zeros((8, 3), device=DEV)], "neighbors": [], "subsampling": [], "upsampling": [], "feats": torch.zeros((8, 4), device=DEV)}
-    with pytest.raises(NotImplementedError):
-        m(dd, torch.zeros((1, 3, 160, 512), device=DEV), None, None, None, "train")
+    m = CoFiI2P(OptBn()).to(DEV)
+    m.train()
+    with pytest.raises(NotImplementedError), torch.no_grad():   # the folded inference sequence has no batch statistics: eval(), or mode 'train' / 'val'
+        m(dd, torch.zeros((1, 3, 160, 512), device=DEV), None, None, None, "test")
     m = CoFiI2P(Opt()).to(DEV)
     with pytest.raises(ValueError):
         m(dd, torch.zeros((2, 3, 160, 512), device=DEV), None, None, None, "train")
