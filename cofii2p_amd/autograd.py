@@ -99,7 +99,7 @@ class _Linear(torch.autograd.Function):
         y = ops.gemm(_pad4_cols(xd), _pad4_cols(wd), bias=None if bias is None else bias.detach().contiguous(),
                      rowdiv=None if rowdiv is None else rowdiv.contiguous())
         ctx.save_for_backward(xd, wd, rowdiv)
-        ctx.has_bias, ctx.arith = bias is not None, ops.GEMM_MODE   # the backward (run later, by the caller's loss.backward()) computes in the same arithmetic
+        ctx.has_bias, ctx.arith = bias is not None, ops.gemm_mode()   # the backward (run later, by the caller's loss.backward()) computes in the same arithmetic
         return y
 
     @staticmethod

@@ -95,7 +95,7 @@ def _kpconv(P, p: str, feats, q_pts, s_pts, idx, sigma: float, frames: int = 1, 
         y, part, sr = ops.kpconv_fused(feats, q_pts, s_pts, idx, P[p + "KPConv.kernel_points"], sigma, w, P[p + "KPConv.bias"], stat_width=sw,
                                        frames=frames, order=order)
         return y, ops.ColStats(part, y.shape[0], GN_GROUPS, frames, width=sw, slab_rows=sr)
-    planes = (ops.GEMM_MODE == "bf16x3" and isinstance(w, ops.SplitW)
+    planes = (ops.gemm_mode() == "bf16x3" and isinstance(w, ops.SplitW)
               and (AGG_PLANES == "all" or (AGG_PLANES not in ("0", "off") and frames >= AGG_PLANES_MIN_FRAMES)))
     agg, cnt = ops.kpconv_aggregate(feats, q_pts, s_pts, idx, P[p + "KPConv.kernel_points"], sigma, frames=frames, order=order, planes=planes)
     y, part = ops.gemm_colstats(agg, w, bias=P[p + "KPConv.bias"], rowdiv=cnt, stat_width=sw)

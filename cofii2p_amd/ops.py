@@ -14,6 +14,7 @@ import torch
 from . import _lib
 
 import os
+import threading
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_LEAKY01 = 0, 1, 2, 3
 GEMM_BF16X3 = 0x100
@@ -29,17 +30,28 @@ GEMM_MODE = os.environ.get("COFI_GEMM", "bf16x3")
 BRANCH_MASK = 7
 
 
+_TLS = threading.local()
+
+
+def gemm_mode() -> str:
+    """The contraction arithmetic of the CALLING thread: the innermost `arithmetic(...)` context this thread is inside, else the process
+    default GEMM_MODE (COFI_GEMM).  Everything that depends on the arithmetic - kernel flags, operand planes, hipGraph cache keys - reads
+    it through this function."""
+    return getattr(_TLS, "mode", None) or GEMM_MODE
+
+
 def _gemm_flag() -> int:
-    return GEMM_BF16X3 if GEMM_MODE == "bf16x3" else (GEMM_BF16X6 if GEMM_MODE == "bf16x6" else 0)
+    m = gemm_mode()
+    return GEMM_BF16X3 if m == "bf16x3" else (GEMM_BF16X6 if m == "bf16x6" else 0)
 
 
 class arithmetic:
     """Context manager: run the enclosed launches with the given contraction arithmetic ("bf16x3" | "bf16x6" | "f32"; None = leave the
     process default, COFI_GEMM).  "bf16x6": three bf16 planes per operand, six products - fp32-grade results on the bf16 matrix cores
-    (include/cofi_hip.h COFI_GEMM_BF16X6).  `CoFiI2P(opt, arithmetic=...)` wraps its forwards in it, so two models with different arithmetic
-    coexist - when they are driven from ONE host thread: the mode is a module global (it also keys the hipGraph cache), so two threads
-    entering / leaving the context concurrently can interleave and run a forward in the other's arithmetic.  Drive models that differ in
-    arithmetic from one thread (backward passes stash the mode per autograd node: autograd._Linear)."""
+    (include/cofi_hip.h COFI_GEMM_BF16X6).  `CoFiI2P(opt, arithmetic=...)` wraps its forwards in it, so models with different arithmetic
+    coexist.  The override is THREAD-LOCAL (`gemm_mode()`): a loader thread running inference while another thread trains, or two
+    threads driving models of different arithmetic, cannot flip each other's mode; backward passes run on autograd's own thread and
+    re-enter the arithmetic their forward node recorded (autograd._Linear)."""
 
     def __init__(self, mode):
         if mode not in (None, "bf16x3", "bf16x6", "f32"):
@@ -47,15 +59,13 @@ class arithmetic:
         self.mode = mode
 
     def __enter__(self):
-        global GEMM_MODE
-        self.saved = GEMM_MODE
+        self.saved = getattr(_TLS, "mode", None)
         if self.mode is not None:
-            GEMM_MODE = self.mode
+            _TLS.mode = self.mode
         return self
 
     def __exit__(self, *exc):
-        global GEMM_MODE
-        GEMM_MODE = self.saved
+        _TLS.mode = self.saved
         return False
 
 
@@ -111,9 +121,9 @@ def presplit(w):
 def _wargs(w):
     """(pointer, leading dimension, extra flag) of a weight operand for the current GEMM mode."""
     if isinstance(w, SplitW):
-        if GEMM_MODE == "bf16x3":
+        if gemm_mode() == "bf16x3":
             return _p(w.planes), w.ldp, GEMM_W_SPLIT
-        if GEMM_MODE == "bf16x6" and X6_W_SPLIT:
+        if gemm_mode() == "bf16x6" and X6_W_SPLIT:
             return _p(w.planes3), w.ldp, GEMM_W_SPLIT
         w = w.w
     return _p(w), _ld(w), 0
@@ -303,7 +313,7 @@ class Normed:
         return self.y.numel()
 
     def fusable(self, tile_rows_ok: bool = True) -> bool:
-        return (GEMM_MODE in ("bf16x3", "bf16x6") and self.stats.fusable() and self.y.shape[1] <= self.MAX_FUSED_CHANNELS and 0.0 <= self.slope <= 1.0
+        return (gemm_mode() in ("bf16x3", "bf16x6") and self.stats.fusable() and self.y.shape[1] <= self.MAX_FUSED_CHANNELS and 0.0 <= self.slope <= 1.0
                 and tile_rows_ok)
 
     def desc(self):
@@ -343,7 +353,7 @@ def _gemm_impl(a, w, out, bias, rowdiv, act, stat_width, frames, l2norm=False):
     M0 = a.shape[0]
     aflag = 0
     if isinstance(a, SplitA):
-        if GEMM_MODE != "bf16x3" or not isinstance(w, SplitW):
+        if gemm_mode() != "bf16x3" or not isinstance(w, SplitW):
             raise _lib.CofiError("gemm: a pre-split activation needs the bf16x3 arithmetic and a pre-split weight")
         asplit, nd, aflag = a, None, GEMM_A_SPLIT
         a_ptr, a_ld, (M, K) = _p(a.planes), a.planes.shape[2], a.shape
@@ -485,7 +495,7 @@ def kpconv_aggregate(feats, q_pts, s_pts, idx, kernel_points, sigma: float, row_
 
 def kpconv_fused_slab_rows(C: int, M: int, frames: int = 1) -> int:
     """Rows per statistics slab of `kpconv_fused` for M queries per frame; 0 = shape not served by the fused kernel."""
-    if GEMM_MODE != "bf16x3":
+    if gemm_mode() != "bf16x3":
         return 0
     return int(_lib.load().cofi_kpconv_fused_slab_rows(C, M, frames))
 
@@ -874,7 +884,7 @@ def split_planes(w: torch.Tensor, n: int) -> torch.Tensor:
 
 def tail_planes() -> int:
     """bf16 planes per operand of the fused layer tail for the current arithmetic; 0 = not served (exact fp32)."""
-    return {"bf16x3": 2, "bf16x6": 3}.get(GEMM_MODE, 0)
+    return {"bf16x3": 2, "bf16x6": 3}.get(gemm_mode(), 0)
 
 
 def loftr_tail(msg, x, w, out, eps: float = 1e-5, proj=(), out_l2=None, out_l2t=None):

@@ -2,7 +2,7 @@
 
 The reference evaluates one frame per `model(...)` call (`evaluation/eval_all.py:63-131`, `data/options.py:46` val_batch_size = 1).  On
 MI355X one KITTI frame is a chain of ~250 dependent launches that cannot fill 256 CUs; B frames through the SAME launches (stack mode,
-`CoFiI2P.stack_frames`) can: 475-480 frames/s with one frame per submission, 526 / 569 / 596 / 619 with 2 / 4 / 8 / 16 (bf16x6, DESIGN.md
+`CoFiI2P.stack_frames`) can: 480 frames/s with one frame per submission, 525 / 580 / 598 / 635 with 2 / 4 / 8 / 16 (bf16x6, DESIGN.md
 section 12).  `FrameBatcher` keeps the caller's side at one frame per call:
 
     fb = FrameBatcher(model, batch=16)

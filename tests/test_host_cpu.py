@@ -265,12 +265,24 @@ def test_arithmetic_is_an_explicit_option_and_the_shim_is_strict():
     assert Shim(o).arithmetic == "bf16x3" and Native(o).arithmetic == "bf16x3"
     with pytest.raises(ValueError):
         Native(Opt(), arithmetic="fp16")
-    before = ops.GEMM_MODE
+    before = ops.gemm_mode()
+    assert before == ops.GEMM_MODE   # no context: the process default (COFI_GEMM)
     with ops.arithmetic("f32"):
-        assert ops.GEMM_MODE == "f32"
+        assert ops.gemm_mode() == "f32" and ops.GEMM_MODE == before   # the override is the thread's, the process default stays
         with ops.arithmetic(None):
-            assert ops.GEMM_MODE == "f32"
-    assert ops.GEMM_MODE == before
+            assert ops.gemm_mode() == "f32"
+        with ops.arithmetic("bf16x6"):
+            assert ops.gemm_mode() == "bf16x6"
+        assert ops.gemm_mode() == "f32"
+        # another thread does not see this thread's override (a loader thread doing inference during a backward pass)
+        import threading
+
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(ops.gemm_mode()))
+        t.start()
+        t.join()
+        assert seen == [before]
+    assert ops.gemm_mode() == before
     assert list(Shim(Opt()).state_dict().keys()) == list(Native(Opt()).state_dict().keys())   # same 430-key layout
 
 
