@@ -976,11 +976,11 @@ Plan finish_plan(int K, int bm, int bn, int ks) {
 
 // Heuristic: largest tile that still gives >= ~1 workgroup per CU, then split K until the chip
 // (256 CUs) is covered about twice, keeping >= 2 k-tiles (64 values) per split.
-Plan make_plan(int M, int N, int K, bool fused_ln, int arith = 1) {   // arith: GemmArgs::bf16x3 (2 = bf16x6: its own table first)
+Plan make_plan_base(int M, int N, int K, bool fused_ln, int arith) {
     Plan p;
     p.pcfg = -1;
     if (g_force_bm) {
-        p = finish_plan(K, g_force_bm, g_force_bn, g_force_ks);
+        p = finish_plan(K, g_force_bm, (g_force_bm == 128 && g_force_bn == 64 && arith != 2) ? 128 : g_force_bn, g_force_ks);   // 128 x 64: bf16x6 only
         if (fused_ln && p.ksplit == 1 && p.bn < N) { p.bm = 64; p.bn = 128; }
         return p;
     }
@@ -1029,6 +1029,19 @@ Plan make_plan(int M, int N, int K, bool fused_ln, int arith = 1) {   // arith: 
         p.bm = 64;
         p.bn = 128;
     }
+    return p;
+}
+
+// bf16x6, <= 64 output columns over many rows (stack-mode batches of >= 4 frames): a 128 x 64 tile (waves of 64 x 32) splits a W tile once
+// per 128 rows instead of once per 64 and reads 3/4 of the fragment bytes per MFMA.  Measured on the batch-16 shapes (tools/tall_tile_probe.py,
+// outputs bit-equal to the 64 x 64 tile's): -12 ... -31 % per launch from 640 tiles up (M >= 81920), +-3 % at 320 tiles, +35 % at 160 - hence
+// the threshold.  COFI_GEMM_TALL_TILE=0 switches it off (A/B), any other value is the threshold in tiles.
+Plan make_plan(int M, int N, int K, bool fused_ln, int arith = 1) {   // arith: GemmArgs::bf16x3 (2 = bf16x6: its own table first)
+    Plan p = make_plan_base(M, N, K, fused_ln, arith);
+    static const long tall = getenv("COFI_GEMM_TALL_TILE") ? atol(getenv("COFI_GEMM_TALL_TILE")) : 512;
+    if (arith == 2 && !g_force_bm && tall > 0 && p.pcfg < 0 && p.bm == 64 && p.bn == 64 && p.ksplit == 1 && N <= 64 &&
+        (long)cofi_cdiv(M, 128) * cofi_cdiv(N, 64) >= tall)
+        p.bm = 128;
     return p;
 }
 
@@ -1128,6 +1141,8 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
             COFI_LAUNCH_BF16X6(128, 128, 2, 2, 32);
         else if (p.bm == 64 && p.bn == 128)
             COFI_LAUNCH_BF16X6(64, 128, 1, 2, 32);
+        else if (p.bm == 128 && p.bn == 64)
+            COFI_LAUNCH_BF16X6(128, 64, 2, 1, 32);
         else
             COFI_LAUNCH_BF16X6(64, 64, 1, 1, 64);
 #undef COFI_LAUNCH_BF16X6
@@ -1215,6 +1230,7 @@ int gemm_entry(const float *A, int lda, const cofi_norm_desc_t *a_norm, const fl
     const int sshift = colpart ? stat_shift_of(stat_width, N) : 0;
     if (sshift < 0) return COFI_EINVAL;
     Plan p = (asplit && g_force_pcfg != -2) ? make_planes_plan(M, N, K) : make_plan(M, N, K, l2n != 0, bf16x3);
+    if (a_norm && frames > 1 && p.pcfg < 0 && p.bm == 128 && p.bn == 64 && (M / frames) % 128) p.bm = 64;   // a normalising tile stays inside one frame
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
     GemmArgs g{};
     g.A = A; g.W = W; g.C = C; g.bias = bias; g.rowdiv = rowdiv; g.ws = (float *)ws; g.colpart = colpart;
@@ -1244,6 +1260,7 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
     if (sshift < 0) return COFI_EINVAL;
     const int ldw = wsplit ? (K + 7) / 8 * 8 : K;   // pre-split planes: rows padded to 8 values
     Plan p = make_plan(M, Cout, K, l2n != 0, bf16x3);
+    if (x_norm && frames > 1 && p.bm == 128 && p.bn == 64 && (Ho * Wo) % 128) p.bm = 64;   // a normalising tile stays inside one frame
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * Cout * sizeof(float))) return COFI_EWORKSPACE;
     GemmArgs g{};
     g.A = x; g.W = Wt; g.C = y; g.bias = bias; g.ws = (float *)ws; g.colpart = colpart; g.res = res;
@@ -1337,7 +1354,7 @@ extern "C" int cofi_tune_force_planes(int cfg, int ksplit) {
 }
 
 extern "C" int cofi_tune_force_plan(int bm, int bn, int ksplit) {
-    const bool ok = (bm == 0 && bn == 0) || ((bm == 64 || bm == 128) && (bn == 64 || bn == 128) && !(bm == 128 && bn == 64));
+    const bool ok = (bm == 0 && bn == 0) || ((bm == 64 || bm == 128) && (bn == 64 || bn == 128));   // 128 x 64: bf16x6 only (make_plan widens it otherwise)
     if (!ok || ksplit < 0) return COFI_EINVAL;
     g_force_bm = bm; g_force_bn = bn; g_force_ks = ksplit;
     return 0;

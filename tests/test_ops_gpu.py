@@ -1115,3 +1115,80 @@ def test_knn_stress_size_properties(ops):
     rows = np.random.RandomState(0).choice(40960, 256, replace=False)
     ic, dc = knn_c.knn(pts, pts[rows], 128, True)
     assert np.array_equal(i[rows], ic) and np.array_equal(d[rows], dc)
+
+
+@pytest.mark.parametrize("M,N,K,frames", [(81920, 64, 96, 4), (65536 + 77, 64, 60, 1), (131072, 32, 128, 8), (66560, 48, 160, 4)])
+def test_tall_tiles_for_narrow_outputs_bf16x6(ops, monkeypatch, M, N, K, frames):
+    """bf16x6, <= 64 output columns over >= 512 tiles of 128 rows (stack-mode batches): make_plan takes 128 x 64 tiles
+    (gemm.hip `make_plan`, measured in DESIGN.md section 12.2).  Same products in the same K order as the 64 x 64 tile: output, column
+    statistics and the normalising loader's result must be BIT-equal to the forced 64 x 64 plan's, ragged last tiles and
+    per-frame statistics included; and right against fp64."""
+    import ctypes
+
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x6")
+    lib = ops._lib.load()
+    force = lib.cofi_tune_force_plan
+    force.argtypes, force.restype = [ctypes.c_int] * 3, ctypes.c_int
+    g = torch.Generator().manual_seed(M + N)
+    a = G(torch.randn(M, K, generator=g))
+    w = G(torch.randn(N, K, generator=g) / K ** 0.5)
+    bias = G(torch.randn(N, generator=g))
+    w2 = ops.presplit(G(torch.randn(40, N, generator=g) / N ** 0.5))
+    gam, bet = G(torch.randn(N, generator=g)), G(torch.randn(N, generator=g))
+    groups = N // 2
+
+    def run():
+        y, part = ops.gemm_colstats(a, w, bias=bias, frames=frames) if M % frames == 0 and (M // frames) % 64 == 0 else ops.gemm_colstats(a, w, bias=bias)
+        fr = frames if M % frames == 0 and (M // frames) % 64 == 0 else 1
+        st = ops.ColStats(part, M, groups, fr)
+        z = ops.gemm(ops.Normed(y, st, gam, bet, 0.1), w2, frames=fr) if st.fusable() else None
+        return y.clone(), part.clone(), None if z is None else z.clone()
+
+    tall = run()
+    try:
+        assert force(64, 64, 1) == 0
+        flat = run()
+    finally:
+        force(0, 0, 0)
+    for t, f in zip(tall, flat):
+        assert (t is None) == (f is None)
+        if t is not None:
+            assert torch.equal(t, f)
+    ref = a.double().cpu() @ w.double().cpu().t() + bias.double().cpu()
+    scale = a.double().cpu().abs() @ w.double().cpu().abs().t() + bias.double().cpu().abs()
+    assert float(((tall[0].double().cpu() - ref).abs() / scale).max()) < 2e-6
+
+
+def test_tall_tiles_convolution_bf16x6(ops, monkeypatch):
+    """the 3 x 3 convolutions with 64 output channels of a stack-mode batch (implicit GEMM, 128 x 64 tiles): bit-equal to the 64 x 64 plan,
+    pending InstanceNorm + ReLU of the producer applied by the loader included"""
+    import ctypes
+
+    from cofii2p_amd.image import _nhwc_weight
+
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x6")
+    lib = ops._lib.load()
+    force = lib.cofi_tune_force_plan
+    force.argtypes, force.restype = [ctypes.c_int] * 3, ctypes.c_int
+    frames, Cin, Cout, H, W = 4, 64, 64, 80, 256
+    g = torch.Generator().manual_seed(11)
+    x = G(torch.randn(frames * H * W, Cin, generator=g))
+    wa = ops.presplit(G(_nhwc_weight(torch.randn(Cin, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)))
+    wb = ops.presplit(G(_nhwc_weight(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)))
+
+    def run():
+        y1, p1, _, _ = ops.conv2d_nhwc(x, H, W, wa, 3, 1, 1, colstats=True, frames=frames)
+        nm = ops.Normed(y1, ops.ColStats(p1, y1.shape[0], Cin, frames), slope=0.0)
+        y2, p2, _, _ = ops.conv2d_nhwc(nm, H, W, wb, 3, 1, 1, colstats=True, frames=frames)
+        return y1.clone(), p1.clone(), y2.clone(), p2.clone()
+
+    tall = run()
+    try:
+        assert force(64, 64, 1) == 0
+        flat = run()
+    finally:
+        force(0, 0, 0)
+    for t, f in zip(tall, flat):
+        assert torch.equal(t, f)
+    ref = torch.nn.functional.conv2d(x.cpu().reshape(frames, H, W, Cin).permute(0, 3, 1, 2), wa.w.cpu().reshape(Cin, 3, 3, Cin).permute(0, 3, 1, 2), padding=1)
+    close(tall[0], ref.permute(0, 2, 3, 1).reshape(-1, Cin), 2e-5)
