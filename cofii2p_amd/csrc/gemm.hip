@@ -24,6 +24,7 @@
 #include "stat_fold.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -59,6 +60,7 @@ struct GemmArgs {
     // frame (tiles never straddle frames: host-checked).
     NormSrc an;
     int an_rows;
+    int dbg;          // timing experiments of tools/ (cofi_tune_big_debug): never set by the product path
 };
 
 // Tile coordinates of this workgroup.  The dispatcher hands workgroup L (x fastest, then y, then the K-split slice z) to XCD
@@ -133,46 +135,203 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+// apply_act for a workgroup-UNIFORM activation code: ReLU / LeakyReLU are computed branch-free and chosen with scalar-condition
+// selects; only the sigmoid (score heads) sits behind a - uniform - branch.  Same expressions as apply_act: identical bits.
+__device__ __forceinline__ float apply_act_uniform(float v, int act) {
+    if (act == COFI_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    const float relu = fmaxf(v, 0.0f), leaky = v >= 0.0f ? v : v * 0.1f;
+    return act == COFI_ACT_RELU ? relu : (act == COFI_ACT_LEAKY01 ? leaky : v);
+}
+
+// Column statistics of a slab: fold the per-thread sums of the RPP row phases in a fixed order (deterministic).  red = (RPP, BN, 2) floats
+// of LDS that every thread has finished reading (the caller's barrier); all threads of the workgroup call.  One barrier inside.
+template <int BN, int RPP>
+__device__ __forceinline__ void colstat_fold(const GemmArgs &g, float *red, const float (&cs)[4], const float (&cq)[4], int slab, int n0, int tr, int tc) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[(tr * BN + 4 * tc + e) * 2 + 0] = cs[e];
+        red[(tr * BN + 4 * tc + e) * 2 + 1] = cq[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < BN && n0 + (int)threadIdx.x < g.N) {
+        float s = 0.f, q = 0.f;
+        for (int p = 0; p < RPP; ++p) {
+            s += red[(p * BN + threadIdx.x) * 2 + 0];
+            q += red[(p * BN + threadIdx.x) * 2 + 1];
+        }
+        if (g.stat_shift) {
+            // one table entry per 2^stat_shift adjacent columns (<= BN, aligned: a group never leaves the tile, and N is a
+            // multiple of the width, so the lanes of a group are all active): fp64 butterfly, fixed order
+            double ds = s, dq = q;
+            for (int o = 1; o < (1 << g.stat_shift); o <<= 1) {
+                ds += __shfl_xor(ds, o, 64);
+                dq += __shfl_xor(dq, o, 64);
+            }
+            if ((threadIdx.x & ((1u << g.stat_shift) - 1)) == 0) {
+                float *o = g.colpart + ((size_t)slab * (g.N >> g.stat_shift) + ((n0 + threadIdx.x) >> g.stat_shift)) * 2;
+                o[0] = (float)ds;
+                o[1] = (float)dq;
+            }
+        } else {
+            float *o = g.colpart + ((size_t)slab * g.N + n0 + threadIdx.x) * 2;
+            o[0] = s;
+            o[1] = q;
+        }
+    }
+}
+
+// The straight-line form of the row-wise epilogue (no fused LayerNorm / L2 normalisation, whole float4 columns inside N, aligned output):
+// x[p][e] = value of row row0 + p * RPP, column col + e.  Every option is a workgroup-uniform scalar and guards a whole BLOCK of the
+// NP x 4 elements (a guard around a single element gets if-converted: the compiler then runs e.g. the 10-instruction division for every
+// element and selects afterwards - measured: 20 us of epilogue for one 256 x 128 tile, 4500 cycles per 64-row slab).  Same operations in
+// the same order per element as the generic path: identical bits.
+template <int NP, int RPP, bool RES>
+__device__ __forceinline__ void epi_fast_apply(const GemmArgs &g, float (&x)[NP][4], const float (&bias4)[4], const float (&rd)[NP],
+                                               const float (&rs)[NP][4], int col, int row0, float (&cs)[4], float (&cq)[4]) {
+    if (g.rowdiv) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[p][e] = x[p][e] / rd[p];
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[p][e] = (x[p][e] + bias4[e]) + (RES ? rs[p][e] : 0.f);   // residual before the activation; the zero keeps -0.0 + 0.0 = +0.0 of the generic path
+    const int act = g.act;
+    if (act != COFI_ACT_NONE) {
+        bool on[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) on[e] = col + e >= g.act_col0;
+        if (act == COFI_ACT_RELU) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[p][e] = on[e] ? fmaxf(x[p][e], 0.0f) : x[p][e];
+        } else if (act == COFI_ACT_LEAKY01) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[p][e] = (on[e] && !(x[p][e] >= 0.0f)) ? x[p][e] * 0.1f : x[p][e];
+        } else {
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[p][e] = on[e] ? 1.0f / (1.0f + expf(-x[p][e])) : x[p][e];
+        }
+    }
+    if (g.colpart) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            if (row0 + p * RPP < g.M) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    cs[e] += x[p][e];
+                    cq[e] += x[p][e] * x[p][e];
+                }
+            }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+        if (row0 + p * RPP < g.M) *reinterpret_cast<float4 *>(g.C + (size_t)(row0 + p * RPP) * g.ldc + col) = make_float4(x[p][0], x[p][1], x[p][2], x[p][3]);
+}
+
 // Row-wise epilogue over a ROWS x BN tile held row-major in LDS (`tile`, leading dimension TLD) or summed
 // from split-K partials.  Thread (tr, tc): row phase tr, float4 column chunk tc.  NT threads.
+// The operands it reads from global memory come in two groups that a caller working through several slabs of one tile may load AHEAD:
+// column-indexed parameters (EpiCols: once per tile) and row-indexed ones (EpiRows: per slab).  vmcnt counts stores too, so a load
+// issued behind the stores of the previous slab makes its consumer wait for those stores' round trip: a multi-slab epilogue issues the
+// next slab's loads before the current slab's stores (gemm_x6_big_kernel).
+struct EpiCols { float bias4[4], gam4[4], bet4[4]; };
+template <int NP> struct EpiRows { float rs[NP][4], rd[NP]; };
+
+template <int BN>
+__device__ __forceinline__ EpiCols epi_load_cols(const GemmArgs &g, int n0) {
+    constexpr int TPR = BN / 4;
+    const int col = n0 + 4 * ((int)threadIdx.x % TPR);
+    EpiCols c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { c.bias4[e] = 0.f; c.gam4[e] = 1.f; c.bet4[e] = 0.f; }
+    if (!g.bias && !g.ln_gamma) return c;   // uniform
+    if (n0 + BN <= g.N) {                   // uniform: no column tail in this tile
+        if (g.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c.bias4[e] = g.bias[col + e];
+        }
+        if (g.ln_gamma) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { c.gam4[e] = g.ln_gamma[col + e]; c.bet4[e] = g.ln_beta[col + e]; }
+        }
+        return c;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (col + e < g.N) {
+            if (g.bias) c.bias4[e] = g.bias[col + e];
+            if (g.ln_gamma) { c.gam4[e] = g.ln_gamma[col + e]; c.bet4[e] = g.ln_beta[col + e]; }
+        }
+    }
+    return c;
+}
+
+template <int ROWS, int BN, int NT>
+__device__ __forceinline__ EpiRows<ROWS / (NT / (BN / 4))> epi_load_rows(const GemmArgs &g, int m0, int n0) {
+    constexpr int TPR = BN / 4, RPP = NT / TPR, NP = ROWS / RPP;
+    const int tc = threadIdx.x % TPR, tr = threadIdx.x / TPR;
+    const int col = n0 + 4 * tc;
+    const bool res_vec = g.res && ((g.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.res) & 15) == 0) && col + 3 < g.N;
+    EpiRows<NP> r;
+    if (!g.rowdiv && !g.res) {   // uniform: nothing to load
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            r.rd[p] = 1.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r.rs[p][e] = 0.f;
+        }
+        return r;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int row = m0 + p * RPP + tr;
+        const bool rin = row < g.M;
+        r.rd[p] = (g.rowdiv && rin) ? g.rowdiv[row] : 1.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r.rs[p][e] = 0.f;
+        if (g.res && rin) {
+            const float *rp = g.res + (size_t)row * g.ldr + col;
+            if (res_vec) {
+                const float4 t = *reinterpret_cast<const float4 *>(rp);
+                r.rs[p][0] = t.x; r.rs[p][1] = t.y; r.rs[p][2] = t.z; r.rs[p][3] = t.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < g.N) r.rs[p][e] = rp[e];
+            }
+        }
+    }
+    return r;
+}
+
 template <int ROWS, int BN, bool FROM_WS, int NT = 256>
-__device__ __forceinline__ void rowwise_epilogue(const GemmArgs &g, const float *tile, int TLD, int m0, int n0, int slab, float *red) {
+__device__ __forceinline__ void rowwise_epilogue_pre(const GemmArgs &g, const float *tile, int TLD, int m0, int n0, int slab, float *red,
+                                                     const EpiCols &ec, const EpiRows<ROWS / (NT / (BN / 4))> &er) {
     constexpr int TPR = BN / 4;        // threads per row
     constexpr int RPP = NT / TPR;      // rows per pass
     constexpr int NP = ROWS / RPP;     // passes
     const int tc = threadIdx.x % TPR, tr = threadIdx.x / TPR;
     const int col = n0 + 4 * tc;
     const bool vec_ok = ((g.N & 3) == 0) && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
-    const bool res_vec = g.res && ((g.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.res) & 15) == 0) && col + 3 < g.N;
     float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
-    // column-indexed parameters are loop invariant: load them once
-    float bias4[4] = {0.f, 0.f, 0.f, 0.f}, gam4[4] = {1.f, 1.f, 1.f, 1.f}, bet4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-        if (col + e < g.N) {
-            if (g.bias) bias4[e] = g.bias[col + e];
-            if (g.ln_gamma) { gam4[e] = g.ln_gamma[col + e]; bet4[e] = g.ln_beta[col + e]; }
-        }
-    // phase 1: issue every row-indexed load of all passes (independent, so their latencies overlap)
-    float v[NP][4], rs[NP][4], rd[NP];
+    const float (&bias4)[4] = ec.bias4, (&gam4)[4] = ec.gam4, (&bet4)[4] = ec.bet4;
+    const float (&rs)[NP][4] = er.rs, (&rd)[NP] = er.rd;
+    // phase 1: the tile values of all passes (split-K: every partial load of all passes is independent, so their latencies overlap)
+    const bool fast = !g.ln_gamma && !g.l2n && vec_ok && n0 + BN <= g.N && !(g.dbg & 64);   // dbg 64 (tools only): the generic path
+    float v[NP][4];
+    if (FROM_WS || !fast) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const int rl = p * RPP + tr, row = m0 + rl;
         const bool rin = row < g.M;
-        rd[p] = (g.rowdiv && rin) ? g.rowdiv[row] : 1.0f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) rs[p][e] = 0.f;
-        if (g.res && rin) {
-            const float *rp = g.res + (size_t)row * g.ldr + col;
-            if (res_vec) {
-                const float4 t = *reinterpret_cast<const float4 *>(rp);
-                rs[p][0] = t.x; rs[p][1] = t.y; rs[p][2] = t.z; rs[p][3] = t.w;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (col + e < g.N) rs[p][e] = rp[e];
-            }
-        }
         if constexpr (FROM_WS) {
             v[p][0] = v[p][1] = v[p][2] = v[p][3] = 0.f;
             if (rin) {
@@ -194,7 +353,33 @@ __device__ __forceinline__ void rowwise_epilogue(const GemmArgs &g, const float 
             v[p][0] = t.x; v[p][1] = t.y; v[p][2] = t.z; v[p][3] = t.w;
         }
     }
-    // phase 2: arithmetic + stores
+    }
+    // phase 2: arithmetic + stores.
+    // FAST PATH - no fused LayerNorm / L2 normalisation, whole float4 columns inside N, aligned output: every decision is taken ONCE per
+    // workgroup (uniform scalars), the loops below are straight-line code.  The generic path further down decides per element and costs
+    // ~10 000 cycles per 64-row slab (measured on MI355X: 20 us of epilogue for one 256 x 128 tile), which was most of a short-K launch.
+    // Same operations in the same order as the generic path: identical bits.
+    if (fast) {
+        // two passes at a time: blocks large enough not to be if-converted, small enough for the register budget of the kernels that
+        // rely on two or three workgroups per CU (all NP x 4 values in flight through every stage cost them a workgroup); a tile in LDS
+        // is read chunk by chunk
+        constexpr int CH = NP >= 2 ? 2 : 1;
+#pragma unroll
+        for (int c = 0; c < NP / CH; ++c) {
+            if constexpr (!FROM_WS) {
+#pragma unroll
+                for (int p = c * CH; p < (c + 1) * CH; ++p) {
+                    const float4 t = *reinterpret_cast<const float4 *>(tile + (p * RPP + tr) * TLD + 4 * tc);
+                    v[p][0] = t.x; v[p][1] = t.y; v[p][2] = t.z; v[p][3] = t.w;
+                }
+            }
+            float (&vx)[CH][4] = reinterpret_cast<float (&)[CH][4]>(v[c * CH]);
+            const float (&rdx)[CH] = reinterpret_cast<const float (&)[CH]>(rd[c * CH]);
+            const float (&rsx)[CH][4] = reinterpret_cast<const float (&)[CH][4]>(rs[c * CH]);
+            if (g.res) epi_fast_apply<CH, RPP, true>(g, vx, bias4, rdx, rsx, col, m0 + tr + c * CH * RPP, cs, cq);
+            else epi_fast_apply<CH, RPP, false>(g, vx, bias4, rdx, rsx, col, m0 + tr + c * CH * RPP, cs, cq);
+        }
+    } else
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const int row = m0 + p * RPP + tr;
@@ -229,8 +414,14 @@ __device__ __forceinline__ void rowwise_epilogue(const GemmArgs &g, const float 
                 v[p][e] = x + rs[p][e];
             }
         } else {
+            // residual before the activation.  The activation code is workgroup-uniform, the columns it applies to (>= act_col0) are
+            // a per-lane mask: a select, not a per-element divergent branch (three exec-masked regions per element made this loop
+            // the longest part of a short-K launch)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[p][e] = apply_act(v[p][e] + rs[p][e], col + e >= g.act_col0 ? g.act : COFI_ACT_NONE);  // residual before the activation
+            for (int e = 0; e < 4; ++e) {
+                const float x = v[p][e] + rs[p][e];
+                v[p][e] = (col + e >= g.act_col0) ? apply_act_uniform(x, g.act) : x;
+            }
             if (g.l2n) {   // F.normalize(row, dim = 1): x / max(|x|, 1e-12); the TPR threads of a row are adjacent lanes
                 float q = 0.f;
 #pragma unroll
@@ -261,40 +452,16 @@ __device__ __forceinline__ void rowwise_epilogue(const GemmArgs &g, const float 
         }
     }
     if (g.colpart) {
-        // fold the RPP row phases in a fixed order (deterministic): red is (RPP, BN, 2) floats
         __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            red[(tr * BN + 4 * tc + e) * 2 + 0] = cs[e];
-            red[(tr * BN + 4 * tc + e) * 2 + 1] = cq[e];
-        }
-        __syncthreads();
-        if (threadIdx.x < BN && n0 + (int)threadIdx.x < g.N) {
-            float s = 0.f, q = 0.f;
-            for (int p = 0; p < RPP; ++p) {
-                s += red[(p * BN + threadIdx.x) * 2 + 0];
-                q += red[(p * BN + threadIdx.x) * 2 + 1];
-            }
-            if (g.stat_shift) {
-                // one table entry per 2^stat_shift adjacent columns (<= BN, aligned: a group never leaves the tile, and N is a
-                // multiple of the width, so the lanes of a group are all active): fp64 butterfly, fixed order
-                double ds = s, dq = q;
-                for (int o = 1; o < (1 << g.stat_shift); o <<= 1) {
-                    ds += __shfl_xor(ds, o, 64);
-                    dq += __shfl_xor(dq, o, 64);
-                }
-                if ((threadIdx.x & ((1u << g.stat_shift) - 1)) == 0) {
-                    float *o = g.colpart + ((size_t)slab * (g.N >> g.stat_shift) + ((n0 + threadIdx.x) >> g.stat_shift)) * 2;
-                    o[0] = (float)ds;
-                    o[1] = (float)dq;
-                }
-            } else {
-                float *o = g.colpart + ((size_t)slab * g.N + n0 + threadIdx.x) * 2;
-                o[0] = s;
-                o[1] = q;
-            }
-        }
+        colstat_fold<BN, RPP>(g, red, cs, cq, slab, n0, tr, tc);
     }
+}
+
+template <int ROWS, int BN, bool FROM_WS, int NT = 256>
+__device__ __forceinline__ void rowwise_epilogue(const GemmArgs &g, const float *tile, int TLD, int m0, int n0, int slab, float *red) {
+    const EpiCols ec = epi_load_cols<BN>(g, n0);
+    const auto er = epi_load_rows<ROWS, BN, NT>(g, m0, n0);
+    rowwise_epilogue_pre<ROWS, BN, FROM_WS, NT>(g, tile, TLD, m0, n0, slab, red, ec, er);
 }
 
 template <int BM, int BN, int TM, int TN>
@@ -912,6 +1079,7 @@ __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
 }
 
 #include "gemm_planes.inc"
+#include "gemm_x6_big.inc"
 
 // split-K tail, same row-wise epilogue reading the partial sums.  Two tilings:
 //   64 rows x 32 columns  (plain / column statistics): slabs of 64 rows keep the statistics table small and
@@ -930,6 +1098,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_ln_kernel(GemmArgs g) {
 struct Plan {
     int bm, bn, ksplit, kchunk;
     int pcfg;   // >= 0: gemm_planes_kernel configuration (kPlanesCfg) - both operands are bf16 planes; -1: the register-staged kernels
+    int big;    // 1: gemm_x6_big_kernel (bf16x6, 256 x 128 tile, one workgroup per CU)
 };
 
 // Configurations of gemm_planes_kernel: tile, K-tile depth, wave grid, LDS stages, workgroups per CU the register budget allows.
@@ -964,6 +1133,7 @@ int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;
 Plan finish_plan(int K, int bm, int bn, int ks) {
     Plan p;
     p.pcfg = -1;
+    p.big = 0;
     p.bm = bm; p.bn = bn;
     int ktiles = cofi_cdiv(K, BK);
     if (ks < 1) ks = 1;
@@ -979,6 +1149,7 @@ Plan finish_plan(int K, int bm, int bn, int ks) {
 Plan make_plan_base(int M, int N, int K, bool fused_ln, int arith) {
     Plan p;
     p.pcfg = -1;
+    p.big = 0;
     if (g_force_bm) {
         p = finish_plan(K, g_force_bm, (g_force_bm == 128 && g_force_bn == 64 && arith != 2) ? 128 : g_force_bn, g_force_ks);   // 128 x 64: bf16x6 only
         if (fused_ln && p.ksplit == 1 && p.bn < N) { p.bm = 64; p.bn = 128; }
@@ -1045,6 +1216,52 @@ Plan make_plan(int M, int N, int K, bool fused_ln, int arith = 1) {   // arith: 
     return p;
 }
 
+// ---- gemm_x6_big_kernel (256 x 128 tiles, ONE workgroup per CU): which shapes take it, and with which K split.
+// One workgroup per CU means whole rounds of 256 workgroups: a grid of 320 tiles takes two rounds like one of 512.  The split is chosen
+// to minimise  rounds x (k-tiles per workgroup + fixed cost)  plus the partial-sum traffic a split adds (ks x M x N x 4 bytes written
+// and read again), in units of one K-tile of the main loop (~1.5 us).
+// tuning hook (tools only): g_force_big = 1 forces the kernel on every eligible launch (split g_force_big_ks, 0 = chosen here), -1 disables it
+int g_force_big = 0, g_force_big_ks = 0, g_big_dbg = 0;
+struct TunedBig { int M, N, K, ks; };   // ks = 0: keep the small-tile kernel for this shape
+#include "gemm_plans_big.inc"
+
+bool big_plan(int M, int N, int K, Plan &p) {
+    static const int mode = getenv("COFI_GEMM_BIG") ? atoi(getenv("COFI_GEMM_BIG")) : 1;   // A/B switch: 0 = never
+    if (g_force_big < 0 || (mode == 0 && g_force_big == 0) || g_force_bm) return false;
+    if ((K % 32) || N < 128 || M < 256) return false;
+    const long tiles = (long)cofi_cdiv(M, 256) * cofi_cdiv(N, 128);
+    const int ktiles = K / 32;
+    int ks = 0;
+    if (g_force_big > 0 && g_force_big_ks > 0) ks = g_force_big_ks;
+    if (!ks && g_force_big == 0) {
+        bool listed = false;
+        for (const TunedBig &t : kTunedBig)
+            if (t.M == M && t.N == N && t.K == K) { ks = t.ks; listed = true; break; }
+        if (listed && ks == 0) return false;
+        if (!listed && (tiles < 160 || K < 512)) return false;   // short loops / small grids: two or three small workgroups per CU overlap their prologues and epilogues
+    }
+    if (!ks) {
+        double best = 1e30;
+        for (int c = 1; c <= 8; ++c) {
+            const int chunk = cofi_cdiv(cofi_cdiv(ktiles, c), 4) * 4;   // k-chunks in multiples of 128, as the other kernels
+            const int eff = cofi_cdiv(ktiles, chunk);
+            if (eff != c || chunk < 8) continue;
+            const double rounds = (double)cofi_cdiv(tiles * c, 256);
+            const double partial = c > 1 ? 2.0 * c * (double)M * N * 4.0 / 4.0e12 / 1.5e-6 : 0.0;   // in K-tile units
+            const double cost = rounds * (chunk + 6.0) + partial + (c > 1 ? 4.0 : 0.0);
+            if (cost < best) { best = cost; ks = c; }
+        }
+        if (!ks) return false;
+    }
+    p.pcfg = -1;
+    p.big = 1;
+    p.bm = 256; p.bn = 128;
+    const int chunk = cofi_cdiv(cofi_cdiv(ktiles, ks), 4) * 4;
+    p.kchunk = chunk * 32;
+    p.ksplit = cofi_cdiv(K, p.kchunk);
+    return true;
+}
+
 // ---- plans of gemm_planes_kernel (both operands pre-split): {M, N, K, configuration, split-K}, tuned on MI355X by
 // tools/tune_gemm.py --planes; anything not listed falls through to the heuristic.
 struct TunedPlanes { int M, N, K, cfg, ks; };
@@ -1057,6 +1274,7 @@ int g_force_pcfg = -1, g_force_pks = 0;
 Plan finish_planes_plan(int K, int cfg, int ks) {
     Plan p;
     p.pcfg = cfg;
+    p.big = 0;
     p.bm = kPlanesCfg[cfg].bm;
     p.bn = kPlanesCfg[cfg].bn;
     const int ktiles = cofi_cdiv(K, 128);   // K chunks in multiples of 128, as finish_plan: equal splits give equal bits in both kernels
@@ -1113,6 +1331,8 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
     g.kchunk = p.kchunk;
     dim3 grid(cofi_cdiv(g.N, p.bn), cofi_cdiv(g.M, p.bm), p.ksplit);
     g.xcd = xcd_order(g, grid);
+    static const int env_dbg = getenv("COFI_GEMM_DBG") ? atoi(getenv("COFI_GEMM_DBG")) : 0;   // timing experiments of tools/ only
+    g.dbg = g_big_dbg | env_dbg;
     g.xcd_rcp_gy = grid.y > 1 ? (unsigned)((0x100000000ULL + grid.y - 1) / grid.y) : 0u;   // 0: gy = 1
     if (p.pcfg >= 0) {
         switch (p.pcfg) {
@@ -1124,6 +1344,12 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
 #undef X
         default: return COFI_EINVAL;
         }
+    } else if (p.big) {
+        const bool cv = g.cv_ks != 0;
+        if (g.an.part && cv) hipLaunchKernelGGL((gemm_x6_big_kernel<true, true>), grid, dim3(256), 0, s, g);
+        else if (g.an.part) hipLaunchKernelGGL((gemm_x6_big_kernel<true, false>), grid, dim3(256), 0, s, g);
+        else if (cv) hipLaunchKernelGGL((gemm_x6_big_kernel<false, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_x6_big_kernel<false, false>), grid, dim3(256), 0, s, g);
     } else if (g.bf16x3 == 2) {
         // bf16x6: three planes per operand; K-tiles of 64 (64 x 64 tile: 54 KB of LDS) / 32 (wider tiles: 41 / 60 KB)
 #define COFI_LAUNCH_BF16X6(BM_, BN_, TM_, TN_, BK_)                                                                        \
@@ -1230,6 +1456,7 @@ int gemm_entry(const float *A, int lda, const cofi_norm_desc_t *a_norm, const fl
     const int sshift = colpart ? stat_shift_of(stat_width, N) : 0;
     if (sshift < 0) return COFI_EINVAL;
     Plan p = (asplit && g_force_pcfg != -2) ? make_planes_plan(M, N, K) : make_plan(M, N, K, l2n != 0, bf16x3);
+    if (bf16x3 == 2 && !wsplit && !asplit && !l2n && !(a_norm && frames > 1 && (M / frames) % 256)) big_plan(M, N, K, p);   // the 256 x 128 kernel for the large shapes
     if (a_norm && frames > 1 && p.pcfg < 0 && p.bm == 128 && p.bn == 64 && (M / frames) % 128) p.bm = 64;   // a normalising tile stays inside one frame
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
     GemmArgs g{};
@@ -1260,6 +1487,10 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
     if (sshift < 0) return COFI_EINVAL;
     const int ldw = wsplit ? (K + 7) / 8 * 8 : K;   // pre-split planes: rows padded to 8 values
     Plan p = make_plan(M, Cout, K, l2n != 0, bf16x3);
+    // the 256 x 128 kernel: 3 x 3 / stride 1 / pad <= 1 convolutions whose K-tiles of 32 lie inside one tap, 32-bit byte offsets into the input
+    if (bf16x3 == 2 && !wsplit && !l2n && ks == 3 && stride == 1 && pad <= 1 && (Cin % 32) == 0 &&
+        (size_t)frames * H * W * ldx * sizeof(float) < 0xffffffffull && !(x_norm && frames > 1 && (Ho * Wo) % 256))
+        big_plan(M, Cout, K, p);
     if (x_norm && frames > 1 && p.bm == 128 && p.bn == 64 && (Ho * Wo) % 128) p.bm = 64;   // a normalising tile stays inside one frame
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * Cout * sizeof(float))) return COFI_EWORKSPACE;
     GemmArgs g{};
@@ -1279,7 +1510,9 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
 extern "C" size_t cofi_gemm_f32_workspace(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const Plan p = make_plan(M, N, K, false), q = make_planes_plan(M, N, K), r = make_plan(M, N, K, false, 2);   // whichever kernel the operands select
-    const int ks = std::max(p.ksplit, std::max(q.ksplit, r.ksplit));
+    Plan b = r;
+    big_plan(M, N, K, b);
+    const int ks = std::max(std::max(p.ksplit, b.ksplit), std::max(q.ksplit, r.ksplit));
     return ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
 }
 
@@ -1350,6 +1583,18 @@ extern "C" int cofi_split_bf16_planes(const float *W, int ldw, int N, int K, voi
 extern "C" int cofi_tune_force_planes(int cfg, int ksplit) {
     if (cfg < -2 || cfg >= kNumPlanesCfg || ksplit < 0) return COFI_EINVAL;
     g_force_pcfg = cfg; g_force_pks = ksplit;
+    return 0;
+}
+
+// 256 x 128 bf16x6 kernel: mode 1 = on every eligible launch (ksplit 0 = chosen by big_plan), -1 = never, 0 = table + heuristic
+extern "C" int cofi_tune_force_big(int mode, int ksplit) {
+    if (mode < -1 || mode > 1 || ksplit < 0 || ksplit > 64) return COFI_EINVAL;
+    g_force_big = mode; g_force_big_ks = ksplit;
+    return 0;
+}
+
+extern "C" int cofi_tune_big_debug(int flags) {   // timing experiments only (results are WRONG with any flag set)
+    g_big_dbg = flags;
     return 0;
 }
 

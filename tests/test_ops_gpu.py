@@ -1192,3 +1192,93 @@ def test_tall_tiles_convolution_bf16x6(ops, monkeypatch):
         assert torch.equal(t, f)
     ref = torch.nn.functional.conv2d(x.cpu().reshape(frames, H, W, Cin).permute(0, 3, 1, 2), wa.w.cpu().reshape(Cin, 3, 3, Cin).permute(0, 3, 1, 2), padding=1)
     close(tall[0], ref.permute(0, 2, 3, 1).reshape(-1, Cin), 2e-5)
+
+
+def _force_hooks(ops):
+    import ctypes
+
+    lib = ops._lib.load()
+    fp, fb = lib.cofi_tune_force_plan, lib.cofi_tune_force_big
+    fp.argtypes, fp.restype = [ctypes.c_int] * 3, ctypes.c_int
+    fb.argtypes, fb.restype = [ctypes.c_int] * 2, ctypes.c_int
+    return fp, fb
+
+
+@pytest.mark.parametrize("M,N,K,frames,ks", [(4096, 256, 512, 1, 1), (4096 + 77, 256, 1024, 1, 1), (8192, 192, 512, 2, 1), (2048, 512, 2560, 2, 2),
+                                            (1024, 128, 7680, 1, 3), (333, 130, 96, 1, 1), (20480, 512, 1536, 4, 1)])
+def test_big_tiles_bf16x6(ops, monkeypatch, M, N, K, frames, ks):
+    """The 256 x 128 bf16x6 kernel (csrc/gemm_x6_big.inc: one workgroup per CU, split of tile t + 1 behind the MFMAs of tile t): same
+    products in the same K order as the small-tile kernel, so at an equal K split output, column statistics and the normalising loader's
+    result are BIT-equal to the forced 128 x 128 plan's - ragged last tiles in M and N, per-frame statistics, split-K included; and right
+    against fp64."""
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x6")
+    fp, fb = _force_hooks(ops)
+    g = torch.Generator().manual_seed(M + N + K)
+    a = G(torch.randn(M, K, generator=g))
+    w = G(torch.randn(N, K, generator=g) / K ** 0.5)
+    bias = G(torch.randn(N, generator=g))
+    N2 = 256
+    w2 = ops.presplit(G(torch.randn(N2, N, generator=g) / N ** 0.5))
+    gam, bet = G(torch.randn(N, generator=g)), G(torch.randn(N, generator=g))
+    groups = 32 if N % 32 == 0 else 2
+    per_frame = M % frames == 0 and (M // frames) % 256 == 0
+    fr = frames if per_frame else 1
+
+    def run():
+        y, part = ops.gemm_colstats(a, w, bias=bias, frames=fr)
+        st = ops.ColStats(part, M, groups, fr)
+        z = ops.gemm(ops.Normed(y, st, gam, bet, 0.1), w2, frames=fr) if (st.fusable() and N % 32 == 0) else None
+        return y.clone(), part.clone(), None if z is None else z.clone()
+
+    try:
+        assert fb(1, ks) == 0
+        big = run()
+        assert fb(-1, 0) == 0 and fp(128, 128, ks) == 0
+        small = run()
+    finally:
+        fp(0, 0, 0)
+        fb(0, 0)
+    for t, f in zip(big, small):
+        assert (t is None) == (f is None)
+        if t is not None:
+            assert torch.equal(t, f)
+    ref = a.double().cpu() @ w.double().cpu().t() + bias.double().cpu()
+    scale = a.double().cpu().abs() @ w.double().cpu().abs().t() + bias.double().cpu().abs()
+    assert float(((big[0].double().cpu() - ref).abs() / scale).max()) < 2e-6
+
+
+@pytest.mark.parametrize("pad", [1, 0])
+def test_big_tiles_convolution_bf16x6(ops, monkeypatch, pad):
+    """3 x 3 / stride 1 convolutions on the 256 x 128 kernel (implicit GEMM whose K-tiles lie inside one tap: per-row address register +
+    scalar tap offset, validity mask per row): bit-equal to the small-tile plan, pending InstanceNorm + ReLU of the producer applied by
+    the loader included, stack mode (frames), and right against torch's convolution."""
+    from cofii2p_amd.image import _nhwc_weight
+
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x6")
+    fp, fb = _force_hooks(ops)
+    frames, Cin, Cmid, Cout, H, W = 2, 64, 128, 256, 40 + 2 * (1 - pad), 128 + 2 * (1 - pad)
+    g = torch.Generator().manual_seed(12)
+    x = G(torch.randn(frames * H * W, Cin, generator=g))
+    wa = ops.presplit(G(_nhwc_weight(torch.randn(Cmid, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)))
+    wb = ops.presplit(G(_nhwc_weight(torch.randn(Cout, Cmid, 3, 3, generator=g) / (Cmid * 9) ** 0.5)))
+
+    def run():
+        y1, p1, Ho, Wo = ops.conv2d_nhwc(x, H, W, wa, 3, 1, pad, colstats=True, frames=frames)
+        if pad == 1:
+            nm = ops.Normed(y1, ops.ColStats(p1, y1.shape[0], Cmid, frames), slope=0.0)
+            y2, p2, _, _ = ops.conv2d_nhwc(nm, Ho, Wo, wb, 3, 1, 1, colstats=True, frames=frames)
+            return y1.clone(), p1.clone(), y2.clone(), p2.clone()
+        return y1.clone(), p1.clone()
+
+    try:
+        assert fb(1, 1) == 0
+        big = run()
+        assert fb(-1, 0) == 0 and fp(128, 128, 1) == 0
+        small = run()
+    finally:
+        fp(0, 0, 0)
+        fb(0, 0)
+    for t, f in zip(big, small):
+        assert torch.equal(t, f)
+    ref = torch.nn.functional.conv2d(x.cpu().reshape(frames, H, W, Cin).permute(0, 3, 1, 2), wa.w.cpu().reshape(Cmid, 3, 3, Cin).permute(0, 3, 1, 2), padding=pad)
+    close(big[0], ref.permute(0, 2, 3, 1).reshape(-1, Cmid), 2e-5)
