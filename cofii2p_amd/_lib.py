@@ -39,6 +39,8 @@ class TailDesc(ctypes.Structure):
 
 _T = ctypes.POINTER(TailDesc)
 
+ABI_VERSION = 2   # COFI_ABI_VERSION of include/cofi_hip.h this table mirrors
+
 # name -> (restype, argtypes); mirrors include/cofi_hip.h declaration by declaration
 SIGNATURES = {
     "cofi_abi_version": (_I, []),
@@ -171,8 +173,8 @@ def load():
             raise CofiError("libcofi_hip.so does not export %s (stale build?)" % name)
         fn.restype = res
         fn.argtypes = args
-    if lib.cofi_abi_version() != 1:
-        raise CofiError("ABI version mismatch")
+    if lib.cofi_abi_version() != ABI_VERSION:
+        raise CofiError("ABI version mismatch: libcofi_hip.so reports %d, this binding mirrors include/cofi_hip.h version %d" % (lib.cofi_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -506,13 +506,23 @@ class CoFiI2P(nn.Module):
         return (o["img_desc"], o["pc_desc"], o["img_score"], o["pc_score"], o["patches"][:n], o["fine_pc"][:n], o["coarse_xy"][:, :n] * 4,
                 o["coarse_pts"][:n])
 
-    def finish(self, handle):
+    def finish(self, handle, per_frame_errors: bool = False):
         """-> the reference's 8-tuple for a single-frame submission, or a list of B 8-tuples for a stack-mode one
-        (`handle["fine_xy"]` then holds the per-frame fine matches)."""
+        (`handle["fine_xy"]` then holds the per-frame fine matches).  A frame with fewer than 4 coarse matches at every threshold raises
+        (the reference would loop forever, network.py:148); with per_frame_errors=True the exception is RETURNED in that frame's place
+        instead, so the other frames of a stack-mode submission keep their results (serving.FrameBatcher)."""
         handle["done"].synchronize()
         res, fine, per_frame = [], [], []
         for f, o in enumerate(handle["out"]):
-            res.append(self._slice_result(o, int(handle["count_host"][f, 0]), int(handle["count_host"][f, 1])))
+            try:
+                res.append(self._slice_result(o, int(handle["count_host"][f, 0]), int(handle["count_host"][f, 1])))
+            except RuntimeError as e:
+                if not per_frame_errors:
+                    raise
+                res.append(e)
+                fine.append(None)
+                per_frame.append(None)
+                continue
             fine.append(self.last_match["fine_xy"])
             per_frame.append(self.last_match)
         handle["fine_xy"] = fine

@@ -279,7 +279,9 @@ class ColStats:
         d.eps, d.slope = self.eps, slope
         d.slab_rows = self.slab_rows
         d.scale_shift = None
-        if 0 < FINALIZE_MIN_FRAMES <= self.frames and self.width * self.part.shape[1] == self.C:
+        # cofi_norm_finalize serves groups of <= 64 table columns (norm.hip); a wider group keeps d.scale_shift = None and its consumers
+        # fold the partials themselves, as before the finalize launch existed
+        if 0 < FINALIZE_MIN_FRAMES <= self.frames and self.part.shape[1] // max(1, min(self.groups, self.part.shape[1])) <= 64:
             # stack-mode batches: one finalize launch per (statistics, affine pair) instead of a fold of the whole table in EVERY consumer
             # workgroup (thousands per launch at batch 16); the tensor is kept on the statistics object, the descriptor holds its address
             d.scale_shift = self.scale_shift(d, gamma, beta).data_ptr()

@@ -52,9 +52,16 @@ class FrameBatcher:
         return self._streams[j % self.S]
 
     def _collect(self, j: int):
-        if self._handles[j] is not None:
-            res = self.model.finish(self._handles[j])
+        """read out the stack's pending submission.  A frame the model cannot serve (fewer than 4 coarse matches at every threshold -
+        padding frames, copies of the last real one, can be such frames too) keeps its exception as ITS result: the other frames of the
+        stack keep theirs, and the handle is cleared whatever happens, so one bad frame cannot wedge the ring."""
+        h = self._handles[j]
+        if h is None:
+            return
+        try:
+            res = self.model.finish(h, per_frame_errors=True)
             self._results[j] = res if isinstance(res, list) else [res]
+        finally:
             self._handles[j] = None
 
     def _launch(self, j: int):
@@ -73,15 +80,19 @@ class FrameBatcher:
         if self._fill == 0:
             self._collect(j)                      # the stack's previous submission must have been read out before it is overwritten
             self._serial[j] += 1
-        pyr = {k: ([CoFiI2P._as_idx32(t) for t in pc_data_dict[k]] if k != "points" else [p.contiguous() for p in pc_data_dict[k]])
-               for k in FrameStack.KEYS}
-        feats = pc_data_dict["feats"].contiguous()
-        if self._stacks[j] is None:
-            self._stacks[j] = FrameStack(pyr, feats, img, self.B)
         cur = torch.cuda.current_stream(img.device)
         s = self._stream(j)
         s.wait_stream(cur)                        # the frame may have been produced on the caller's stream
         with torch.cuda.stream(s):
+            # conversions (int64 tables -> int32, non-contiguous inputs -> copies) run ON the submission's stream: their temporaries are
+            # blocks of that stream's allocator pool, reused only behind the copy kernel that reads them.  (Made on the caller's stream
+            # they could be handed to the NEXT frame's conversions while this stream, queued behind an earlier stack's forward, had not
+            # copied them yet.)
+            pyr = {k: ([CoFiI2P._as_idx32(t) for t in pc_data_dict[k]] if k != "points" else [p.contiguous() for p in pc_data_dict[k]])
+                   for k in FrameStack.KEYS}
+            feats = pc_data_dict["feats"].contiguous()
+            if self._stacks[j] is None:
+                self._stacks[j] = FrameStack(pyr, feats, img, self.B)
             self._stacks[j].put(self._fill, pyr, feats, img)
         self._last = (pyr, feats, img)
         ticket = (j, self._serial[j], self._fill)
@@ -113,7 +124,10 @@ class FrameBatcher:
         self._collect(j)
         if self._results[j] is None:
             raise RuntimeError("FrameBatcher: no submission is pending for this ticket")
-        return self._results[j][f]
+        r = self._results[j][f]
+        if isinstance(r, Exception):
+            raise r                               # this frame only: the other tickets of the stack are served
+        return r
 
     @property
     def submissions(self) -> int:

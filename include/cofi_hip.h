@@ -35,7 +35,9 @@
 extern "C" {
 #endif
 
-#define COFI_ABI_VERSION 1
+/* 2: cofi_split_bf16_planes (nplanes), cofi_transpose (frames) and cofi_select_matches (frames) gained positional arguments (round 4);
+ * a caller built against version 1 must not bind this library */
+#define COFI_ABI_VERSION 2
 
 #define COFI_EINVAL (-1)      /* bad shape / alignment / null pointer */
 #define COFI_EWORKSPACE (-2)  /* workspace too small */

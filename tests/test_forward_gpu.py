@@ -537,6 +537,42 @@ def test_frame_batcher_single_frame_api(model):
     model.enable_graphs(False)
 
 
+def test_frame_batcher_one_bad_frame_does_not_wedge_the_ring(model, monkeypatch):
+    """a frame with fewer than 4 coarse matches at every threshold (CoFiI2P._slice_result raises for it) fails ITS ticket only: the other
+    frame of the stack is served, the handle is cleared, and the stack is reused by later submissions"""
+    from cofii2p_amd.preprocess import build_pyramid
+    from cofii2p_amd.serving import FrameBatcher
+    from cofii2p_amd.synth import make_frame, subsample_indices
+
+    frames = []
+    for b in range(4):
+        fr = make_frame(90 + b, 4096)
+        sub = [torch.from_numpy(s_).to(DEV) for s_ in subsample_indices(4096, 5, seed=90 + b)]
+        pyr = build_pyramid(torch.from_numpy(fr.points).to(DEV), sub, int64=True)
+        pyr["feats"] = torch.from_numpy(fr.feats).to(DEV)
+        frames.append((pyr, torch.from_numpy(fr.img)[None].to(DEV)))
+    model.enable_graphs(True)
+    fb = FrameBatcher(model, batch=2, streams=1, ring=2, slot_base=40)
+    real = model._slice_result
+    calls = {"n": 0}
+
+    def flaky(o, n, thr_i):
+        calls["n"] += 1
+        if calls["n"] == 2:                      # the second frame of the first stack
+            return real(o, n, -1)                # -> RuntimeError, as for a frame without matches
+        return real(o, n, thr_i)
+
+    monkeypatch.setattr(model, "_slice_result", flaky)
+    t = [fb.submit(p, im) for p, im in frames]   # two full stacks
+    assert len(fb.result(t[0])) == 8
+    with pytest.raises(RuntimeError):
+        fb.result(t[1])
+    assert len(fb.result(t[2])) == 8 and len(fb.result(t[3])) == 8
+    t4 = fb.submit(*frames[0])                   # stack 0 again: its handle was cleared, nothing re-raises
+    assert len(fb.result(t4)) == 8
+    model.enable_graphs(False)
+
+
 @pytest.mark.parametrize("fid,gemm", [(41, "bf16x3"), (42, "f32")])
 def test_other_kitti_frames_vs_oracle(model, monkeypatch, fid, gemm):
     """KITTI-shaped frames the golden files do not hold, in both arithmetics, through the hipGraph path with two frames in

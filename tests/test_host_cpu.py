@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cofi_abi_version() == 1 and lib.cofi_target_arch() == b"gfx950"
+    assert lib.cofi_abi_version() == 2 and lib.cofi_target_arch() == b"gfx950"
     # pure host-side queries are callable without a GPU
     assert lib.cofi_gemm_f32_workspace(1280, 512, 7680) > 0
     assert lib.cofi_gemm_f32_workspace(20480, 128, 64) == 0

@@ -1282,3 +1282,23 @@ def test_big_tiles_convolution_bf16x6(ops, monkeypatch, pad):
         assert torch.equal(t, f)
     ref = torch.nn.functional.conv2d(x.cpu().reshape(frames, H, W, Cin).permute(0, 3, 1, 2), wa.w.cpu().reshape(Cmid, 3, 3, Cin).permute(0, 3, 1, 2), padding=pad)
     close(big[0], ref.permute(0, 2, 3, 1).reshape(-1, Cmid), 2e-5)
+
+
+def test_pending_norm_with_groups_wider_than_the_finalize_kernel(ops, monkeypatch):
+    """ColStats.desc: cofi_norm_finalize serves groups of <= 64 table columns; a wider group (256 channels in 2 groups) must fall back to the
+    consumers' own fold of the partials instead of raising COFI_EUNSUPPORTED - same result as the materialised normalisation"""
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x6")
+    g = torch.Generator().manual_seed(5)
+    M, C, N2 = 4096, 256, 128
+    a = G(torch.randn(M, 64, generator=g))
+    w = G(torch.randn(C, 64, generator=g) / 8)
+    w2 = ops.presplit(G(torch.randn(N2, C, generator=g) / 16))
+    gam, bet = G(torch.randn(C, generator=g)), G(torch.randn(C, generator=g))
+    y, part = ops.gemm_colstats(a, w)
+    st = ops.ColStats(part, M, 2, 1)
+    d = st.desc(gam, bet, 0.1)
+    assert not d.scale_shift            # no finalize launch for this table
+    nm = ops.Normed(y, st, gam, bet, 0.1)
+    z = ops.gemm(nm, w2)
+    z_ref = ops.gemm(nm.materialize(), w2)
+    close(z, z_ref, 1e-5)
