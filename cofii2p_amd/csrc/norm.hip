@@ -3,6 +3,7 @@
 // and the sine position embedding.  All HBM/L2-bound streaming kernels: float4 accesses where the
 // layout allows, one pass over the data per kernel.
 #include "common.h"
+#include <stdlib.h>
 #include "stat_fold.h"
 
 namespace {
@@ -668,7 +669,9 @@ extern "C" int cofi_group_norm_apply_partials(const float *x, int ldx, int M, in
     fa.a = GnApplyArgs{x, nullptr, norm->gamma, norm->beta, res, nullptr, res_norm ? res_norm->gamma : nullptr, res_norm ? res_norm->beta : nullptr,
                        y, ldx, ldr, ldy, Mf, C, C / norm->groups, norm->slope, norm->groups, row_pos};
     int nb = cofi_cdiv(Mf, rpb * 4);
-    if (nb > 2048) nb = 2048;
+    static const int cap = getenv("COFI_GN_APPLY_WGS") ? atoi(getenv("COFI_GN_APPLY_WGS")) : 2048;   // workgroups per launch (A/B switch of tools/)
+    const int cap_f = cap / frames > 0 ? cap / frames : 1;
+    if (nb > cap_f) nb = cap_f;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(group_norm_apply_fused_kernel, dim3(nb, frames), dim3(256), 0, cofi_s(stream), fa);
     return cofi_launch_status();

@@ -18,6 +18,7 @@ No extra HIP stream is created: HIP serves a process's streams from 4 hardware q
 more than the loader gains (DESIGN.md section 3 "Concurrency").  Stage A of a later frame is enqueued on its stream BEFORE the
 resample / forward work of the frame the host is about to submit there, so its count is known long before it is needed."""
 import multiprocessing as mp
+import os
 from concurrent.futures import ProcessPoolExecutor
 from typing import Dict, List, Optional
 
@@ -50,11 +51,25 @@ class FrameLoader:
         self.upsample_k = upsample_k
         self.preps = [dataside.FramePreparer(opt, device, dataset=dataset, mode=mode) for _ in range(slots)]
         self.slots = [_Slot() for _ in range(slots)]
-        self.pool = ProcessPoolExecutor(max_workers=max(1, workers), mp_context=mp.get_context("spawn"), initializer=worker_init)
+        workers = self.worker_budget(workers)
+        self.workers = workers
+        self.pool = ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn"), initializer=worker_init)
         self._amp = tuple(getattr(opt, k) for k in ("P_tx_amplitude", "P_ty_amplitude", "P_tz_amplitude", "P_Rx_amplitude", "P_Ry_amplitude", "P_Rz_amplitude"))
         self._capture_stream = capture_stream
         # start every worker now (spawn + imports take seconds), not inside the first timed frames: W tasks that each hold a worker
-        list(self.pool.map(worker_warm, [0.3] * max(1, workers)))
+        list(self.pool.map(worker_warm, [0.3] * workers))
+
+    @staticmethod
+    def worker_budget(requested: int, affinity=None, local_world: Optional[int] = None, online: Optional[int] = None) -> int:
+        """Draw workers this process may start: the host cores its rank can count on, minus one for the launch thread.  One process per GPU
+        (bench.py --gpus N, parallel.py): N ranks x `requested` workers must not oversubscribe the node - the cores are the smaller of this
+        process's affinity mask (`os.sched_getaffinity`, e.g. the GPU's NUMA node after bench.pin_to_gpu_numa_node) and an equal share of
+        the online cores among the LOCAL_WORLD_SIZE ranks of the node."""
+        aff = len(affinity) if affinity is not None else len(os.sched_getaffinity(0))
+        lw = local_world if local_world is not None else int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
+        on = online if online is not None else (os.cpu_count() or aff)
+        share = max(1, min(aff, on // max(1, lw)))
+        return max(1, min(int(requested), share - 1))
 
     def close(self):
         self.pool.shutdown(wait=False, cancel_futures=True)

@@ -71,3 +71,27 @@ def test_gather_keeps_large_frame_ids_exact():
 
     with pytest.raises(ValueError):
         gather_frame_results([total], torch.zeros(1, 1), total)
+
+
+def test_loader_worker_pools_do_not_oversubscribe_a_node(monkeypatch):
+    """eight ranks' FrameLoader pools (one process per GPU) are sized from the cores the rank can count on - its affinity mask and an equal
+    share of the node among LOCAL_WORLD_SIZE ranks, one core kept for the launch thread - not from the requested count alone"""
+    import os
+
+    from cofii2p_amd.loader import FrameLoader
+
+    wb = FrameLoader.worker_budget
+    # 8 ranks on a 64-core node, 4 workers requested each: 8 x (4 + 1 launch thread) = 40 <= 64
+    assert wb(4, affinity=range(64), local_world=8, online=64) == 4
+    # ... on a 32-core node: the share of a rank is 4 cores -> 3 workers, 8 x (3 + 1) = 32
+    assert wb(4, affinity=range(32), local_world=8, online=32) == 3
+    # a rank pinned to 2 cores keeps one worker whatever was asked for
+    assert wb(4, affinity=range(2), local_world=1, online=64) == 1
+    for lw in (1, 2, 4, 8):
+        for cores in (8, 16, 96, 192):
+            w = wb(4, affinity=range(cores), local_world=lw, online=cores)
+            assert 1 <= w <= 4 and (lw * (w + 1) <= cores or w == 1)
+    # defaults come from the process itself: os.sched_getaffinity and LOCAL_WORLD_SIZE
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    n = len(os.sched_getaffinity(0))
+    assert wb(4) == max(1, min(4, max(1, min(n, (os.cpu_count() or n) // 8)) - 1))

@@ -1,2 +1,6 @@
 cd $GRAFT_REPO_ROOT
-for d in 0 4096 8192 12288 4 4100 8196 12292; do python tools/gemm_one.py --shape 40960x1024x3072 --kernel big --ks 1 --time --dbg $d; done
+export COFI_GEMM=bf16x6
+timeout 900 python -m pytest tests/test_ops_gpu.py -x -q 2>&1 | tail -4
+for m in 0 1; do echo "inlaunch $m"; COFI_GEMM_INLAUNCH=$m python tools/gemm_shapes.py --batch 1 2>/dev/null | tail -n 1;  COFI_GEMM_INLAUNCH=$m python tools/gemm_shapes.py --batch 16 2>/dev/null | tail -n 1; done
+ROUNDS=2 BENCH_ARGS="--batch 1" bash tools/ab_env.sh "COFI_GEMM_INLAUNCH=0" "COFI_GEMM_INLAUNCH=1"
+ROUNDS=1 bash tools/ab_env.sh "COFI_GEMM_INLAUNCH=0" "COFI_GEMM_INLAUNCH=1"

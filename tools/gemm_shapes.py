@@ -52,9 +52,9 @@ def main():
         r[0] += 1
         r[1] += t
     tot = sum(r[1] for r in rows.values())
-    print("%-46s %5s %9s %9s %8s" % ("shape", "calls", "us/call", "TF/s", "% time"))
+    print("%-46s %5s %9s %9s %8s %9s" % ("shape", "calls", "us/call", "TF/s", "% time", "GB/s (algorithmic)"))
     for key, r in sorted(rows.items(), key=lambda kv: -kv[1][1]):
-        print("%-46s %5d %9.2f %9.2f %8.1f" % (str(key), r[0], 1e6 * r[1] / r[0], r[2] / (r[1] / r[0]) / 1e12, 100 * r[1] / tot))
+        print("%-46s %5d %9.2f %9.2f %8.1f %9.1f" % (str(key), r[0], 1e6 * r[1] / r[0], r[2] / (r[1] / r[0]) / 1e12, 100 * r[1] / tot, r[3] / (r[1] / r[0]) / 1e9))
     print("total %.1f us per submission (batch %d: %.1f us per frame)" % (1e6 * tot, args.batch, 1e6 * tot / args.batch))
 
 
