@@ -341,6 +341,19 @@ def kernel_rooflines(model, dev, args, Bsz, frame=None, batch=None):
     per["gemm"] = gsum
     dom = max(per, key=lambda n: per[n]["seconds_per_frame"])
     d = per[dom]
+    if dom != "gemm" and per["gemm"]["seconds_per_frame"] > 0:
+        # the contraction family next to a dominant attention kernel (the stress configuration): its own row, counter traffic from the
+        # committed PMC passes of that configuration when they exist
+        gd = per["gemm"]
+        gpeak = BF16_MFMA_PEAK_TF / (3.0 if args.gemm == "bf16x3" else 6.0) if args.gemm in ("bf16x3", "bf16x6") else FP32_MFMA_PEAK_TF
+        gach = gd["flops_per_frame"] / gd["seconds_per_frame"] / 1e12
+        gp = pmc_traffic("gemm", "pmc_traffic_stress.json") if (args.gemm == "bf16x6" and args.points == 40960 and Opt.img_H == 896 and Bsz == 1) else None
+        out["roofline_gemm"] = {"kernel": "cofi_gemm", "bound": "mfma", "achieved": gach, "peak": gpeak, "unit": "TFLOP/s", "frac": gach / gpeak,
+                                "traffic": None if gp is None else gp.get("traffic_bytes_per_launch"),
+                                "traffic_collected_on": None if gp is None else gp.get("collected_on"),
+                                "algorithmic_bytes_per_launch": gd["bytes_per_frame"] / gd["launches_per_frame"],
+                                "launches_per_frame": gd["launches_per_frame"], "avg_launch_us": 1e6 * gd["seconds_per_frame"] / gd["launches_per_frame"],
+                                "algorithmic_gflop_per_frame": gd["flops_per_frame"] / 1e9, "ms_per_frame": 1e3 * gd["seconds_per_frame"]}
     if d["flops_per_frame"] > 0:
         ach = d["flops_per_frame"] / d["seconds_per_frame"] / 1e12
         # the bf16-split GEMM issues 3 bf16 MFMA flops per algorithmic flop: its MFMA roof for ALGORITHMIC flops is 2500/3

@@ -9,7 +9,7 @@ import json
 import re
 import sys
 
-FAMILIES = {"gemm": ("gemm_kernel", "gemm_bf16x3_kernel", "gemm_planes_kernel", "splitk_epilogue"), "attention": ("attention_flat_kernel", "attention_fwd_kernel"),
+FAMILIES = {"gemm": ("gemm_kernel", "gemm_bf16x3_kernel", "gemm_planes_kernel", "gemm_x6_big_kernel", "splitk_epilogue"), "attention": ("attention_flat_kernel", "attention_fwd_kernel"),
             "kpconv_aggregate": ("kpconv_aggregate",), "neighbor_maxpool": ("neighbor_maxpool_kernel",),
             "group_norm_apply": ("group_norm_apply",), "loftr_tail": ("loftr_tail_kernel",)}
 
