@@ -1276,8 +1276,12 @@ struct TunedBig { int M, N, K, ks; };   // ks = 0: keep the small-tile kernel fo
 bool big_plan(int M, int N, int K, Plan &p) {
     static const int mode = getenv("COFI_GEMM_BIG") ? atoi(getenv("COFI_GEMM_BIG")) : 1;   // A/B switch: 0 = never
     if (g_force_big < 0 || (mode == 0 && g_force_big == 0) || g_force_bm) return false;
+    // N <= 64: the 256 x 64 instantiation of the kernel (four waves of 64 x 64) exists in the template and is bit-equal, but LOSES to the
+    // 128 x 64 small tiles (round 5 probe, profiles/r05/big_gemm_probe_n64.txt: 327680 x 64 x 576 222 vs 209 us, 81920 x 64 x 576 80 vs 64 us -
+    // the split of the A operand is 4.6 VALU instructions per MFMA there, and one workgroup per CU has nobody to overlap them with): not built.
     if ((K % 32) || N < 128 || M < 256) return false;
-    const long tiles = (long)cofi_cdiv(M, 256) * cofi_cdiv(N, 128);
+    const int bn = 128;
+    const long tiles = (long)cofi_cdiv(M, 256) * cofi_cdiv(N, bn);
     const int ktiles = K / 32;
     int ks = 0;
     if (g_force_big > 0 && g_force_big_ks > 0) ks = g_force_big_ks;
@@ -1303,7 +1307,7 @@ bool big_plan(int M, int N, int K, Plan &p) {
     }
     p.pcfg = -1;
     p.big = 1;
-    p.bm = 256; p.bn = 128;
+    p.bm = 256; p.bn = bn;
     const int chunk = cofi_cdiv(cofi_cdiv(ktiles, ks), 4) * 4;
     p.kchunk = chunk * 32;
     p.ksplit = cofi_cdiv(K, p.kchunk);
@@ -1408,10 +1412,15 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
         }
     } else if (p.big) {
         const bool cv = g.cv_ks != 0;
-        if (g.an.part && cv) hipLaunchKernelGGL((gemm_x6_big_kernel<true, true>), grid, dim3(256), 0, s, g);
-        else if (g.an.part) hipLaunchKernelGGL((gemm_x6_big_kernel<true, false>), grid, dim3(256), 0, s, g);
-        else if (cv) hipLaunchKernelGGL((gemm_x6_big_kernel<false, true>), grid, dim3(256), 0, s, g);
-        else hipLaunchKernelGGL((gemm_x6_big_kernel<false, false>), grid, dim3(256), 0, s, g);
+#define COFI_LAUNCH_BIG(BN_)                                                                                                  \
+    do {                                                                                                                      \
+        if (g.an.part && cv) hipLaunchKernelGGL((gemm_x6_big_kernel<true, true, BN_>), grid, dim3(256), 0, s, g);            \
+        else if (g.an.part) hipLaunchKernelGGL((gemm_x6_big_kernel<true, false, BN_>), grid, dim3(256), 0, s, g);            \
+        else if (cv) hipLaunchKernelGGL((gemm_x6_big_kernel<false, true, BN_>), grid, dim3(256), 0, s, g);                   \
+        else hipLaunchKernelGGL((gemm_x6_big_kernel<false, false, BN_>), grid, dim3(256), 0, s, g);                          \
+    } while (0)
+        COFI_LAUNCH_BIG(128);
+#undef COFI_LAUNCH_BIG
     } else if (g.bf16x3 == 2) {
         // bf16x6: three planes per operand; K-tiles of 64 (64 x 64 tile: 54 KB of LDS) / 32 (wider tiles: 41 / 60 KB)
 #define COFI_LAUNCH_BF16X6(BM_, BN_, TM_, TN_, BK_)                                                                        \

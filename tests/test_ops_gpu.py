@@ -1247,8 +1247,8 @@ def test_big_tiles_bf16x6(ops, monkeypatch, M, N, K, frames, ks):
     assert float(((big[0].double().cpu() - ref).abs() / scale).max()) < 2e-6
 
 
-@pytest.mark.parametrize("pad", [1, 0])
-def test_big_tiles_convolution_bf16x6(ops, monkeypatch, pad):
+@pytest.mark.parametrize("pad,cmid", [(1, 128), (0, 128)])
+def test_big_tiles_convolution_bf16x6(ops, monkeypatch, pad, cmid):
     """3 x 3 / stride 1 convolutions on the 256 x 128 kernel (implicit GEMM whose K-tiles lie inside one tap: per-row address register +
     scalar tap offset, validity mask per row): bit-equal to the small-tile plan, pending InstanceNorm + ReLU of the producer applied by
     the loader included, stack mode (frames), and right against torch's convolution."""
@@ -1256,7 +1256,7 @@ def test_big_tiles_convolution_bf16x6(ops, monkeypatch, pad):
 
     monkeypatch.setattr(ops, "GEMM_MODE", "bf16x6")
     fp, fb = _force_hooks(ops)
-    frames, Cin, Cmid, Cout, H, W = 2, 64, 128, 256, 40 + 2 * (1 - pad), 128 + 2 * (1 - pad)
+    frames, Cin, Cmid, Cout, H, W = 2, 64, cmid, 256, 40 + 2 * (1 - pad), 128 + 2 * (1 - pad)
     g = torch.Generator().manual_seed(12)
     x = G(torch.randn(frames * H * W, Cin, generator=g))
     wa = ops.presplit(G(_nhwc_weight(torch.randn(Cmid, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)))

@@ -52,7 +52,7 @@ def main():
     for name in ("gemm", "gemm_colstats", "conv2d_nhwc"):
         for fn, a, k, (fl, by) in kt.calls.get(name, []):
             sh = shape_of(name, a, k)   # (M, N, K)
-            if sh[1] >= 128 and sh[2] >= mink and sh[2] % 32 == 0 and sh[0] >= 4096:
+            if int(os.environ.get("PROBE_MINN", "128")) <= sh[1] <= int(os.environ.get("PROBE_MAXN", "100000")) and sh[2] >= mink and sh[2] % 32 == 0 and sh[0] >= 4096:
                 seen.setdefault((name,) + tuple(sh), [fn, a, k, 0, fl])[3] += 1
     tot = {}
     print("%-44s %3s %9s | %s" % ("shape", "x", "small us", "  ".join("big ks=%d" % k for k in ks_list)))
@@ -63,7 +63,7 @@ def main():
         force_big(-1, 0)
         t0 = time_graph(run, reps=6) * 1e6
         # bit-equality at equal split (ks = 1): the 128 x 128 small-tile plan against the big kernel
-        force_plan(128, 128, 1)
+        force_plan(128, 128 if key[2] > 64 else 64, 1)
         r0 = outs(run())
         force_plan(0, 0, 0)
         force_big(1, 1)
