@@ -38,6 +38,6 @@ run_pmc stress_write "WRITE_SIZE" "--stress --batch 1 --inflight 1 --steps 6 --w
 # HBM bytes per launch / per frame of the kernel families (FETCH doubled per the gfx950 note of MI355X_MICROARCH.md)
 python $R/tools/pmc_to_json.py $OUT/b16_fetch_pmc.md $OUT/b16_write_pmc.md auto "$STAMP (round 5; bf16x6, stack-mode batches of 16, one submission in flight)" 12 16 > $OUT/pmc_traffic.json
 python $R/tools/pmc_to_json.py $OUT/b1_fetch_pmc.md $OUT/b1_write_pmc.md auto "$STAMP (round 5; bf16x6, batch 1, one frame in flight)" 12 1 > $OUT/pmc_traffic_batch1.json
-python $R/tools/pmc_to_json.py $OUT/stress_fetch_pmc.md $OUT/stress_write_pmc.md auto "$STAMP (round 5; bf16x6, stress configuration 896 x 1600 / 40960 points, one frame in flight)" 12 1 > $OUT/pmc_traffic_stress.json
+python $R/tools/pmc_to_json.py $OUT/stress_fetch_pmc.md $OUT/stress_write_pmc.md auto "$STAMP (round 5; bf16x6, stress configuration 896 x 1600 / 40960 points, one frame in flight)" 16 1 > $OUT/pmc_traffic_stress.json
 grep -h '"value"' $OUT/*.log | cut -c1-120
 ls -la $OUT
