@@ -306,7 +306,7 @@ def gold():
     return load_golden("train_ref.npz")
 
 
-def _check_step_against(gold, m, tol, zero_mult=3.0, err32_mult=2.5, err32_floor=0.0):
+def _check_step_against(gold, m, tol, zero_mult=3.0, err32_mult=2.5, err32_floor=0.0, ratios=None):
     """one train.py-shaped step of module `m` against a train_ref*.npz recording: outputs, mask, losses, gradients (judged in float64, see
     test_train_step_matches_reference), buffers.  -> (worst error, its parameter)"""
     from cofii2p_amd.train_step import step_losses
@@ -347,6 +347,9 @@ def _check_step_against(gold, m, tol, zero_mult=3.0, err32_mult=2.5, err32_floor
         e_norm = abs(float(flat.norm()) - norm_ref) / norm_ref
         allow = max(tol, err32_mult * max(float(gold["g_err32"][i]), err32_floor))
         worst = max(worst, (max(e_samp, e_norm) / allow, name))
+        if ratios is not None:   # statistical judgement by the caller: error / allowance of every parameter
+            ratios.append((max(e_samp, e_norm) / allow, name))
+            continue
         if not (e_samp < allow and e_norm < allow):
             bad.append("%s: sampled entries off by %.3g (allowed %.3g; reference fp32 %.3g), norm by %.3g (relative)" % (name, e_samp, allow, float(gold["g_err32"][i]), e_norm))
     assert not bad, "%d parameters beyond their allowance:\n" % len(bad) + "\n".join(bad[:40])
@@ -397,6 +400,34 @@ def test_train_step_other_point_norms_match_reference(norm):
     outs = m(dd, img, batch["fine_center_kpt_coors"], batch["fine_xy"], batch["fine_pc_inline_index"], "train")
     sum(o.square().sum() for o in outs[:6]).backward()
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+def test_train_step_bn_second_label_seed_statistical():
+    """'bn' again, with the label seed the main fixture had to avoid (seed 5: a gradient-carrying row of the point score head holds a
+    pre-ReLU value of 2.7e-5, which ANY two fp32 evaluations of the ill-conditioned batch-statistics forward disagree about - see
+    test_train_step_other_point_norms_match_reference).  ADVICE r4: the seed must not be doing the work.  Forward outputs, losses and
+    BatchNorm buffers are held to the same hard bounds as with seed 10; the gradients are judged statistically: the bulk of the parameters
+    must sit inside the same allowance (>= 98 %, median error / allowance <= 0.5) and nothing may be far off (<= 3 x) - a flipped
+    ReLU moves the rows behind it, it does not excuse a wrong backward.  Measured on MI355X: 99.6 % inside, median 0.115, worst 1.22 x
+    (pc_score_layer.0.weight, the layer behind that row)."""
+    from cofii2p_amd.network import CoFiI2P
+
+    gold = load_golden("train_ref_bn_s5.npz")
+    assert str(gold["norm"]) == "bn"
+
+    class OptN(Opt):
+        pass
+
+    OptN.norm = "bn"
+    m = CoFiI2P(OptN(), arithmetic="bf16x6").to(DEV)
+    m.train()
+    ratios = []
+    _check_step_against(gold, m, GRAD_TOL, err32_mult=5.0, err32_floor="median", ratios=ratios)
+    r = np.array(sorted(x for x, _ in ratios))
+    inside = float((r < 1.0).mean())
+    print("label seed 5: %d parameters, inside the allowance %.1f %%, median %.3g, p95 %.3g, worst %.3g (%s)" % (
+        len(r), 100 * inside, float(np.median(r)), float(np.quantile(r, 0.95)), r[-1], max(ratios)[1]))
+    assert inside >= 0.98 and float(np.median(r)) <= 0.5 and r[-1] <= 3.0
 
 
 def _train_inputs(gold):

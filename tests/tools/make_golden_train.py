@@ -117,6 +117,8 @@ def main():
     # forward values differ by more than that input disagree in the whole row's gradient.  Under 'bn' the forward itself is ill-conditioned
     # (batch statistics: two fp32 evaluations differ by ~1e-4 at the last encoder stage), and with seed 5 a gradient row holds a pre-ReLU
     # value of 2.7e-5; seed 10 keeps every such value above 3e-4 (tools/diag_norm_mid.py, round 4).
+    # (tests/golden/train_ref_bn_s5.npz = `--norm bn --label-seed 5 --out train_ref_bn_s5.npz`: the statistical second check of
+    # tests/test_train_gpu.py::test_train_step_bn_second_label_seed_statistical - the seed must not be doing the work)
     ap.add_argument("--label-seed", type=int, default=None, help="default: 5 ('gn', 'ln'), 10 ('bn')")
     ap.add_argument("--out", default=None, help="file name under tests/golden (default: train_ref[_norm].npz)")
     args = ap.parse_args()
