@@ -61,7 +61,6 @@ struct GemmArgs {
     NormSrc an;
     int an_rows;
     int dbg;          // timing experiments of tools/ (cofi_tune_big_debug): never set by the product path
-    unsigned *tile_cnt;   // split-K reduced IN the launch: one arrival counter per output tile (zero before and after every launch); nullptr: separate fold launch
 };
 
 // Tile coordinates of this workgroup.  The dispatcher hands workgroup L (x fastest, then y, then the K-split slice z) to XCD
@@ -470,41 +469,6 @@ __device__ __forceinline__ void rowwise_epilogue(const GemmArgs &g, const float 
     rowwise_epilogue_pre<ROWS, BN, FROM_WS, NT>(g, tile, TLD, m0, n0, slab, red, ec, er);
 }
 
-// Split-K combined inside the launch (gfx950: 8 XCDs with private L2s; the placement-independent hand-off of the CDNA4 guide, Guideline 16):
-// every K-slice workgroup has written its fp32 partial tile to ws with plain stores; each wave drains its stores, the workgroup meets,
-// ONE lane publishes with an agent-scope release and takes a ticket on the tile's counter; the workgroup that draws the last ticket
-// acquires (agent scope), re-arms the counter for the next launch and reduces the slices in the fixed order z = 0 .. ksplit - 1 through the
-// same row-wise epilogue as the stand-alone fold kernel (rowwise_epilogue<.., FROM_WS>): identical bits, one launch and one kernel
-// boundary less per split contraction.  Returns true in the reducing workgroup (all of its threads), false elsewhere.
-// `flag`: 4 bytes of LDS nobody else uses at this point.
-__device__ __forceinline__ bool splitk_last_arriver(const GemmArgs &g, int tile, unsigned *flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial stores have left the CU
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-back is complete before the ticket is visible (hipcc may drop its own wait)
-        const unsigned prev = __hip_atomic_fetch_add(g.tile_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = prev == (unsigned)g.ksplit - 1u;
-        if (last) {
-            __hip_atomic_store(g.tile_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every other slice has arrived: re-arm
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        *flag = last ? 1u : 0u;
-    }
-    __syncthreads();
-    return *flag != 0u;
-}
-
-// the reducing workgroup's epilogue over its BM x BN tile, 64-row slab by slab (red: >= (NT / (BN / 4)) * BN * 2 floats of LDS)
-template <int BM, int BN, int NT>
-__device__ __forceinline__ void splitk_reduce_tile(const GemmArgs &g, int m0, int n0, float *red) {
-    for (int h = 0; h < BM / 64; ++h) {
-        if (m0 + 64 * h >= g.M) break;
-        rowwise_epilogue<64, BN, true, NT>(g, nullptr, 0, m0 + 64 * h, n0, (m0 >> 6) + h, red);
-        __syncthreads();
-    }
-}
-
 template <int BM, int BN, int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 waves");
@@ -600,8 +564,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                     if (row < g.M && col < g.N) g.ws[((size_t)bid.z * g.M + row) * g.N + col] = acc[i][j][r];
                 }
             }
-        if (g.tile_cnt && splitk_last_arriver(g, bid.y * gridDim.x + bid.x, reinterpret_cast<unsigned *>(lds)))
-            splitk_reduce_tile<BM, BN, 256>(g, m0, n0, lds + 4);
         return;
     }
     if constexpr (BM == 128) {
@@ -1084,8 +1046,6 @@ __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
                     if (row < g.M && col < g.N) g.ws[((size_t)bid.z * g.M + row) * g.N + col] = acc[i][j][r];
                 }
             }
-        if (g.tile_cnt && splitk_last_arriver(g, bid.y * gridDim.x + bid.x, reinterpret_cast<unsigned *>(lds)))
-            splitk_reduce_tile<BM, BN, 256>(g, m0, n0, lds + 4);
         return;
     }
     if constexpr (BM == 128) {
@@ -1139,8 +1099,6 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs g) {
 __global__ __launch_bounds__(256) void splitk_epilogue_ln_kernel(GemmArgs g) {
     rowwise_epilogue<SKLN_ROWS, 128, true>(g, nullptr, 0, blockIdx.y * SKLN_ROWS, blockIdx.x * 128, blockIdx.y, nullptr);
 }
-
-constexpr size_t kSplitCounterBytes = 65536;   // arrival counters of the in-launch split-K reduction: the head of every split-K workspace
 
 struct Plan {
     int bm, bn, ksplit, kchunk;
@@ -1269,7 +1227,6 @@ Plan make_plan(int M, int N, int K, bool fused_ln, int arith = 1) {   // arith: 
 // and read again), in units of one K-tile of the main loop (~1.5 us).
 // tuning hook (tools only): g_force_big = 1 forces the kernel on every eligible launch (split g_force_big_ks, 0 = chosen here), -1 disables it
 int g_force_big = 0, g_force_big_ks = 0, g_big_dbg = 0;
-int g_force_inlaunch = -1;   // tools / tests: 0 = stand-alone fold launch, 1 = in-launch reduction, -1 = COFI_GEMM_INLAUNCH (default off)
 struct TunedBig { int M, N, K, ks; };   // ks = 0: keep the small-tile kernel for this shape
 #include "gemm_plans_big.inc"
 
@@ -1383,20 +1340,6 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
     g.kchunk = p.kchunk;
     dim3 grid(cofi_cdiv(g.N, p.bn), cofi_cdiv(g.M, p.bm), p.ksplit);
     g.xcd = xcd_order(g, grid);
-    // split-K: the partial sums live behind a 64 KiB block of per-tile arrival counters at the head of the workspace (zero before and
-    // after every launch: cofi_gemm_f32_workspace).  COFI_GEMM_INLAUNCH=1: the last-arriving slice of a tile reduces it inside the launch
-    // (a fused LayerNorm / L2 normalisation needs the whole row in the reducing tile; at most 16384 tiles); otherwise the fold launch.
-    g.tile_cnt = nullptr;
-    if (p.ksplit > 1) {
-        // OFF by default: measured on MI355X (round 5, same box) the in-launch form LOSES - GEMM time per frame 2.55 -> 2.91 ms at batch 1,
-        // 16.5 -> 17.6 ms per batch-16 submission; pipeline 480 -> 431 and 692 -> 660 frames/s.  Every K-slice workgroup pays an agent-scope
-        // release (buffer_wbl2 behind 16-128 KB of fresh partials: ~6 us) where the fold launch pays one kernel boundary for all of them.
-        static const bool env_inlaunch = getenv("COFI_GEMM_INLAUNCH") && atoi(getenv("COFI_GEMM_INLAUNCH")) != 0;
-        const bool inlaunch = g_force_inlaunch < 0 ? env_inlaunch : g_force_inlaunch != 0;
-        const bool row_ok = !(g.ln_gamma || g.l2n) || p.bn >= g.N;
-        if (inlaunch && row_ok && (long)grid.x * grid.y <= (long)(kSplitCounterBytes / sizeof(unsigned))) g.tile_cnt = reinterpret_cast<unsigned *>(g.ws);
-        g.ws = reinterpret_cast<float *>(reinterpret_cast<char *>(g.ws) + kSplitCounterBytes);
-    }
     static const int env_dbg = getenv("COFI_GEMM_DBG") ? atoi(getenv("COFI_GEMM_DBG")) : 0;   // timing experiments of tools/ only
     g.dbg = g_big_dbg | env_dbg;
     g.xcd_rcp_gy = grid.y > 1 ? (unsigned)((0x100000000ULL + grid.y - 1) / grid.y) : 0u;   // 0: gy = 1
@@ -1470,7 +1413,7 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
         hipLaunchKernelGGL((gemm_kernel<64, 128, 1, 2>), grid, dim3(256), 0, s, g);
     else
         hipLaunchKernelGGL((gemm_kernel<64, 64, 1, 1>), grid, dim3(256), 0, s, g);
-    if (p.ksplit > 1 && !g.tile_cnt) {
+    if (p.ksplit > 1) {
         if (g.ln_gamma || g.l2n)
             hipLaunchKernelGGL(splitk_epilogue_ln_kernel, dim3(1, cofi_cdiv(g.M, SKLN_ROWS)), dim3(256), 0, s, g);
         else if (g.colpart && g.stat_shift > 5)
@@ -1529,7 +1472,7 @@ int gemm_entry(const float *A, int lda, const cofi_norm_desc_t *a_norm, const fl
     Plan p = (asplit && g_force_pcfg != -2) ? make_planes_plan(M, N, K) : make_plan(M, N, K, l2n != 0, bf16x3);
     if (bf16x3 == 2 && !wsplit && !asplit && !l2n && !(a_norm && frames > 1 && (M / frames) % 256)) big_plan(M, N, K, p);   // the 256 x 128 kernel for the large shapes
     if (a_norm && frames > 1 && p.pcfg < 0 && p.bm == 128 && p.bn == 64 && (M / frames) % 128) p.bm = 64;   // a normalising tile stays inside one frame
-    if (p.ksplit > 1 && (!ws || ws_bytes < kSplitCounterBytes + (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
+    if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
     GemmArgs g{};
     g.A = A; g.W = W; g.C = C; g.bias = bias; g.rowdiv = rowdiv; g.ws = (float *)ws; g.colpart = colpart;
     g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.act = act; g.ksplit = 1;
@@ -1563,7 +1506,7 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
         (size_t)frames * H * W * ldx * sizeof(float) < 0xffffffffull && !(x_norm && frames > 1 && (Ho * Wo) % 256))
         big_plan(M, Cout, K, p);
     if (x_norm && frames > 1 && p.bm == 128 && p.bn == 64 && (Ho * Wo) % 128) p.bm = 64;   // a normalising tile stays inside one frame
-    if (p.ksplit > 1 && (!ws || ws_bytes < kSplitCounterBytes + (size_t)p.ksplit * M * Cout * sizeof(float))) return COFI_EWORKSPACE;
+    if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * Cout * sizeof(float))) return COFI_EWORKSPACE;
     GemmArgs g{};
     g.A = x; g.W = Wt; g.C = y; g.bias = bias; g.ws = (float *)ws; g.colpart = colpart; g.res = res;
     g.lda = ldx; g.ldw = ldw; g.ldc = ldy; g.ldr = ldr; g.M = M; g.N = Cout; g.K = K; g.act = act; g.ksplit = 1;
@@ -1584,7 +1527,7 @@ extern "C" size_t cofi_gemm_f32_workspace(int M, int N, int K) {
     Plan b = r;
     big_plan(M, N, K, b);
     const int ks = std::max(std::max(p.ksplit, b.ksplit), std::max(q.ksplit, r.ksplit));
-    return ks > 1 ? kSplitCounterBytes + (size_t)ks * M * N * sizeof(float) : 0;
+    return ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
 }
 
 extern "C" int cofi_gemm_f32_stat_slabs(int M, int N, int K) {
@@ -1617,7 +1560,7 @@ extern "C" int cofi_gemm_f32_layernorm(const float *A, int lda, const float *W, 
     if (M == 0) return 0;
     const int bf16x3 = (relu & COFI_GEMM_BF16X6) ? 2 : ((relu & COFI_GEMM_BF16X3) ? 1 : 0);
     Plan p = make_plan(M, N, K, true, bf16x3);
-    if (p.ksplit > 1 && (!ws || ws_bytes < kSplitCounterBytes + (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
+    if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
     const int wsplit = (relu & COFI_GEMM_W_SPLIT) ? 1 : 0;
     relu &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT);
     if (wsplit && (bf16x3 == 0 || (ldw & 7))) return COFI_EINVAL;
@@ -1661,12 +1604,6 @@ extern "C" int cofi_tune_force_planes(int cfg, int ksplit) {
 extern "C" int cofi_tune_force_big(int mode, int ksplit) {
     if (mode < -1 || mode > 1 || ksplit < 0 || ksplit > 64) return COFI_EINVAL;
     g_force_big = mode; g_force_big_ks = ksplit;
-    return 0;
-}
-
-extern "C" int cofi_tune_splitk_inlaunch(int mode) {   // -1 default, 0 stand-alone fold, 1 in-launch
-    if (mode < -1 || mode > 1) return COFI_EINVAL;
-    g_force_inlaunch = mode;
     return 0;
 }
 

@@ -157,9 +157,6 @@ def _vec(t: Optional[torch.Tensor], name: str, n: int, dtype=torch.float32):
     return t
 
 
-GEMM_WS_COUNTER_BYTES = 65536   # COFI_GEMM_WS_COUNTER_BYTES of include/cofi_hip.h
-
-
 class Workspace:
     """Grow-only device scratch, one per (purpose, device, stream).  Kernels are stream ordered, so reuse by
     consecutive calls on ONE stream is safe; concurrent streams (forked branches of the forward graph) each
@@ -168,12 +165,9 @@ class Workspace:
 
     slot = 0  # frames-in-flight slot: concurrently replayed graphs must not share scratch (set_workspace_slot)
 
-    def __init__(self, zero_head: int = 0):
+    def __init__(self):
         self.bufs = {}
         self.retired = []   # outgrown buffers stay alive: a captured hipGraph may still hold their address
-        # bytes at the head of every buffer that are ZERO when the buffer is handed out for the first time (the GEMM workspace: arrival
-        # counters of the in-launch split-K reduction, which every launch leaves at zero again - include/cofi_hip.h, cofi_gemm_f32_workspace)
-        self.zero_head = zero_head
 
     def get(self, nbytes: int, device) -> Optional[torch.Tensor]:
         if nbytes == 0:
@@ -184,8 +178,6 @@ class Workspace:
             if buf is not None:
                 self.retired.append(buf)
             buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
-            if self.zero_head:
-                buf[:self.zero_head].zero_()   # stream ordered before the first launch that reads it (inside a capture: a 64 KB memset node)
             self.bufs[key] = buf
         return buf
 
@@ -236,7 +228,7 @@ class Branch:
                     t.record_stream(cur)
 
 
-_WS_GEMM = Workspace(zero_head=GEMM_WS_COUNTER_BYTES)
+_WS_GEMM = Workspace()
 _WS_STATS = Workspace()
 
 

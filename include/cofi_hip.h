@@ -199,13 +199,8 @@ int cofi_gather_rows(const float *x, int ldx, int N, int C, const int32_t *idx, 
  * model/network.py:29,42-43; KPConv weights (15,Cin,Cout) are packed once to (Cout, 15*Cin),
  * kpconv.py:107-110).  K % 4 == 0, lda % 4 == 0, ldw % 4 == 0, 16-byte aligned bases.
  * bias / rowdiv may be NULL.  Deep-K problems are split over K into `ws` and reduced in a fixed
- * order (deterministic, no float atomics) by a fold launch - or, with COFI_GEMM_INLAUNCH=1 in the environment, inside the launch by the
- * last-arriving K-slice of every output tile (measured slower on MI355X: off by default).
- * WORKSPACE CONTRACT (all cofi_gemm_f32* / cofi_conv2d_nhwc* entry points): cofi_gemm_f32_workspace() bytes, 16-byte aligned; the first
- * COFI_GEMM_WS_COUNTER_BYTES hold the per-tile arrival counters and must be ZERO when the buffer is first used; every call leaves them zero,
- * so one memset at allocation serves all later calls.  Launches that run CONCURRENTLY (different streams) need different workspaces.
+ * order (deterministic, no float atomics) by a fold launch.  Launches that run CONCURRENTLY (different streams) need different workspaces.
  */
-#define COFI_GEMM_WS_COUNTER_BYTES 65536
 size_t cofi_gemm_f32_workspace(int M, int N, int K);
 int cofi_gemm_f32(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K, const float *bias,
                   const float *rowdiv, int act, void *ws, size_t ws_bytes, cofi_stream_t stream);

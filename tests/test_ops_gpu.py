@@ -1302,57 +1302,3 @@ def test_pending_norm_with_groups_wider_than_the_finalize_kernel(ops, monkeypatc
     z = ops.gemm(nm, w2)
     z_ref = ops.gemm(nm.materialize(), w2)
     close(z, z_ref, 1e-5)
-
-
-@pytest.mark.parametrize("M,N,K,ks,bm,bn", [(1280, 512, 7680, 6, 64, 64), (320, 256, 2304, 8, 64, 64), (2560, 1024, 3072, 3, 128, 128), (700, 200, 2048, 4, 64, 128),
-                                           (5120, 128, 4096, 5, 128, 64)])
-def test_split_k_reduced_inside_the_launch(ops, monkeypatch, M, N, K, ks, bm, bn):
-    """the opt-in in-launch split-K reduction (COFI_GEMM_INLAUNCH=1; measured slower than the fold launch on MI355X, hence off by default):
-    contractions are combined by the last-arriving K-slice of every output tile inside the launch (arrival counters at the head
-    of the workspace; agent-scope release / acquire, csrc/gemm.hip splitk_last_arriver): repeated launches on one workspace give the same
-    bits every time - the counters are left at zero, the slices are summed in the fixed order z = 0 .. ks - 1 -, statistics, row divisor,
-    bias and activation ride along, ragged tiles included; and the result is right against fp64."""
-    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x6")
-    fp, fb = _force_hooks(ops)
-    g = torch.Generator().manual_seed(M + K)
-    a = G(torch.randn(M, K, generator=g))
-    w = G(torch.randn(N, K, generator=g) / K ** 0.5)
-    bias = G(torch.randn(N, generator=g))
-    div = G(torch.rand(M, generator=g) + 0.5)
-    import ctypes
-
-    hook = ops._lib.load().cofi_tune_splitk_inlaunch
-    hook.argtypes, hook.restype = [ctypes.c_int], ctypes.c_int
-    try:
-        assert hook(1) == 0 and fb(-1, 0) == 0 and fp(bm, bn, ks) == 0
-        runs = []
-        for _ in range(4):
-            if N % 4 == 0 and N >= 64:
-                y, part = ops.gemm_colstats(a, w, bias=bias, rowdiv=div, act=ops.ACT_LEAKY01)
-                runs.append((y.clone(), part.clone()))
-            else:
-                runs.append((ops.gemm(a, w, bias=bias, rowdiv=div, act=ops.ACT_LEAKY01).clone(),))
-    finally:
-        hook(-1)
-        fp(0, 0, 0)
-        fb(0, 0)
-    for r in runs[1:]:
-        for x, y in zip(runs[0], r):
-            assert torch.equal(x, y)
-    # ... and the same output bits as the stand-alone fold launch (splitk_epilogue_kernel) it replaces
-    try:
-        assert hook(0) == 0 and fb(-1, 0) == 0 and fp(bm, bn, ks) == 0
-        y2 = ops.gemm_colstats(a, w, bias=bias, rowdiv=div, act=ops.ACT_LEAKY01) if (N % 4 == 0 and N >= 64) else (ops.gemm(a, w, bias=bias, rowdiv=div, act=ops.ACT_LEAKY01),)
-    finally:
-        hook(-1)
-        fp(0, 0, 0)
-        fb(0, 0)
-    assert torch.equal(runs[0][0], y2[0])
-    if len(y2) > 1:   # the statistics partials: the fold launch sums a column's 64 rows in 32 + 32, the tile's own epilogue in 4 x 16 (or 8 x 8)
-        close(runs[0][1], y2[1], 2e-5)
-    ws = ops._WS_GEMM.get(1, a.device)
-    assert int(ws[:ops.GEMM_WS_COUNTER_BYTES].view(torch.int32).abs().max()) == 0          # every counter is back at zero
-    ref = (a.double().cpu() @ w.double().cpu().t()) / div.double().cpu()[:, None] + bias.double().cpu()
-    ref = torch.where(ref >= 0, ref, ref * 0.1)
-    scale = (a.double().cpu().abs() @ w.double().cpu().abs().t()) / div.double().cpu()[:, None] + bias.double().cpu().abs()
-    assert float(((runs[0][0].double().cpu() - ref).abs() / scale).max()) < 3e-6
