@@ -1205,7 +1205,9 @@ def _force_hooks(ops):
 
 
 @pytest.mark.parametrize("M,N,K,frames,ks", [(4096, 256, 512, 1, 1), (4096 + 77, 256, 1024, 1, 1), (8192, 192, 512, 2, 1), (2048, 512, 2560, 2, 2),
-                                            (1024, 128, 7680, 1, 3), (333, 130, 96, 1, 1), (20480, 512, 1536, 4, 1)])
+                                            (1024, 128, 7680, 1, 3), (333, 130, 96, 1, 1), (20480, 512, 1536, 4, 1),
+                                            # one / two K-tiles: the loop's prologue and its first, MFMA-less iteration alone
+                                            (512, 128, 32, 1, 1), (768, 256, 64, 2, 1), (256, 128, 128, 1, 1)])
 def test_big_tiles_bf16x6(ops, monkeypatch, M, N, K, frames, ks):
     """The 256 x 128 bf16x6 kernel (csrc/gemm_x6_big.inc: one workgroup per CU, split of tile t + 1 behind the MFMAs of tile t): same
     products in the same K order as the small-tile kernel, so at an equal K split output, column statistics and the normalising loader's
