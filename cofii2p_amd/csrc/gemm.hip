@@ -1085,6 +1085,7 @@ __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
 
 #include "gemm_planes.inc"
 #include "gemm_x6_big.inc"
+#include "conv_direct.inc"
 
 // split-K tail, same row-wise epilogue reading the partial sums.  Two tilings:
 //   64 rows x 32 columns  (plain / column statistics): slabs of 64 rows keep the statistics table small and
@@ -1227,6 +1228,7 @@ Plan make_plan(int M, int N, int K, bool fused_ln, int arith = 1) {   // arith: 
 // and read again), in units of one K-tile of the main loop (~1.5 us).
 // tuning hook (tools only): g_force_big = 1 forces the kernel on every eligible launch (split g_force_big_ks, 0 = chosen here), -1 disables it
 int g_force_big = 0, g_force_big_ks = 0, g_big_dbg = 0;
+int g_force_direct = 0;   // tools / tests: 1 = the direct 3 x 3 kernel on every eligible convolution (no tile-count threshold), 2 = ... with 4-row tiles, -1 = never, 0 = default
 struct TunedBig { int M, N, K, ks; };   // ks = 0: keep the small-tile kernel for this shape
 #include "gemm_plans_big.inc"
 
@@ -1500,6 +1502,38 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
     const int sshift = colpart ? stat_shift_of(stat_width, Cout) : 0;
     if (sshift < 0) return COFI_EINVAL;
     const int ldw = wsplit ? (K + 7) / 8 * 8 : K;   // pre-split planes: rows padded to 8 values
+    // narrow 3 x 3 convolutions of a stack-mode batch: the direct kernel (conv_direct.inc: input halo split once, 9 taps read it shifted)
+    {
+        static const int direct_env = getenv("COFI_CONV_DIRECT") ? atoi(getenv("COFI_CONV_DIRECT")) : 1;   // A/B switch: 0 = never
+        const int mode = g_force_direct ? g_force_direct : (direct_env ? 0 : -1);
+        const long tiles4 = (long)frames * (H / 4) * (W / 64);
+        const int th = (tiles4 >= 768 || g_force_direct == 2) ? 4 : 2;   // 4-row tiles once they fill the chip's workgroup slots (2 per CU) one and a half times
+        const long tiles = (long)frames * (H / th) * (W / 64);
+        const bool ok = bf16x3 == 2 && !wsplit && !l2n && ks == 3 && stride == 1 && pad == 1 && Cout == 64 && (Cin % 16) == 0 && Cin <= 512 && (W % 64) == 0 &&
+                        (H % 4) == 0 && (!x_norm || x_norm->scale_shift) && (size_t)frames * H * W * ldx * sizeof(float) < 0xffffffffull &&
+                        (size_t)Cout * K * sizeof(float) < 0xffffffffull;
+        if (ok && mode >= 0 && (mode > 0 || tiles >= 256) && !g_force_bm) {
+            GemmArgs g{};
+            g.A = x; g.W = Wt; g.C = y; g.bias = bias; g.colpart = colpart; g.res = res;
+            g.lda = ldx; g.ldw = K; g.ldc = ldy; g.ldr = ldr; g.M = M; g.N = Cout; g.K = K; g.act = act; g.ksplit = 1;
+            g.bf16x3 = 2;
+            g.cv_ks = 3; g.cv_H = H; g.cv_W = W; g.cv_Cin = Cin; g.cv_Wo = Wo; g.cv_stride = 1; g.cv_pad = 1; g.cv_Pout = Ho * Wo;
+            g.stat_shift = sshift;
+            g.act_col0 = act_col0;
+            Plan dp{};
+            dp.bm = 64; dp.bn = 64; dp.ksplit = 1; dp.pcfg = -1;
+            if (int rc = set_a_norm(g, x_norm, Cin, H * W, frames, dp)) return rc;
+            const dim3 grid(Cout / 64, (unsigned)tiles);
+            if (th == 4) {
+                if (g.an.part) hipLaunchKernelGGL((conv3x3_direct_kernel<true, 4>), grid, dim3(256), 0, cofi_s(stream), g);
+                else hipLaunchKernelGGL((conv3x3_direct_kernel<false, 4>), grid, dim3(256), 0, cofi_s(stream), g);
+            } else {
+                if (g.an.part) hipLaunchKernelGGL((conv3x3_direct_kernel<true, 2>), grid, dim3(256), 0, cofi_s(stream), g);
+                else hipLaunchKernelGGL((conv3x3_direct_kernel<false, 2>), grid, dim3(256), 0, cofi_s(stream), g);
+            }
+            return cofi_launch_status();
+        }
+    }
     Plan p = make_plan(M, Cout, K, l2n != 0, bf16x3);
     // the 256 x 128 kernel: 3 x 3 / stride 1 / pad <= 1 convolutions whose K-tiles of 32 lie inside one tap, 32-bit byte offsets into the input
     if (bf16x3 == 2 && !wsplit && !l2n && ks == 3 && stride == 1 && pad <= 1 && (Cin % 32) == 0 &&
@@ -1604,6 +1638,12 @@ extern "C" int cofi_tune_force_planes(int cfg, int ksplit) {
 extern "C" int cofi_tune_force_big(int mode, int ksplit) {
     if (mode < -1 || mode > 1 || ksplit < 0 || ksplit > 64) return COFI_EINVAL;
     g_force_big = mode; g_force_big_ks = ksplit;
+    return 0;
+}
+
+extern "C" int cofi_tune_force_conv_direct(int mode) {
+    if (mode < -1 || mode > 2) return COFI_EINVAL;
+    g_force_direct = mode;
     return 0;
 }
 

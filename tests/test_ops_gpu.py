@@ -1182,12 +1182,16 @@ def test_tall_tiles_convolution_bf16x6(ops, monkeypatch):
         y2, p2, _, _ = ops.conv2d_nhwc(nm, H, W, wb, 3, 1, 1, colstats=True, frames=frames)
         return y1.clone(), p1.clone(), y2.clone(), p2.clone()
 
-    tall = run()
+    direct = lib.cofi_tune_force_conv_direct   # this test is about the two implicit-GEMM tilings: keep the direct 3 x 3 kernel out of it
+    direct.argtypes, direct.restype = [ctypes.c_int], ctypes.c_int
     try:
+        assert direct(-1) == 0
+        tall = run()
         assert force(64, 64, 1) == 0
         flat = run()
     finally:
         force(0, 0, 0)
+        direct(0)
     for t, f in zip(tall, flat):
         assert torch.equal(t, f)
     ref = torch.nn.functional.conv2d(x.cpu().reshape(frames, H, W, Cin).permute(0, 3, 1, 2), wa.w.cpu().reshape(Cin, 3, 3, Cin).permute(0, 3, 1, 2), padding=1)
@@ -1304,3 +1308,49 @@ def test_pending_norm_with_groups_wider_than_the_finalize_kernel(ops, monkeypatc
     z = ops.gemm(nm, w2)
     z_ref = ops.gemm(nm.materialize(), w2)
     close(z, z_ref, 1e-5)
+
+
+@pytest.mark.parametrize("H,W,Cin,frames,res_act,force", [(8, 64, 64, 2, False, 1), (40, 128, 64, 2, True, 1), (12, 192, 32, 1, False, 1),
+                                                          (8, 64, 64, 2, True, 2), (40, 128, 64, 2, False, 2), (80, 256, 64, 1, True, 2)])
+def test_direct_3x3_convolution_bf16x6(ops, monkeypatch, H, W, Cin, frames, res_act, force):
+    """the direct 3 x 3 / stride 1 / pad 1 kernel for 64 output channels (csrc/conv_direct.inc: the input halo of a 4 x 64-pixel tile split once
+    into LDS planes, nine taps read it at shifted offsets) against the implicit-GEMM plan it replaces - other summation order of the same
+    products: fp32-grade agreement, not bit equality -, against torch's convolution, with the producer's pending InstanceNorm + ReLU applied by
+    the halo loader, column statistics, bias / residual / ReLU and stack mode; force = 1: 2-row tiles (small grids), 2: 4-row tiles."""
+    import ctypes
+
+    from cofii2p_amd.image import _nhwc_weight
+
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x6")
+    hook = ops._lib.load().cofi_tune_force_conv_direct
+    hook.argtypes, hook.restype = [ctypes.c_int], ctypes.c_int
+    Cout = 64
+    g = torch.Generator().manual_seed(H + W)
+    x = G(torch.randn(frames * H * W, Cin, generator=g))
+    wa = ops.presplit(G(_nhwc_weight(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)))
+    wb = ops.presplit(G(_nhwc_weight(torch.randn(Cout, Cout, 3, 3, generator=g) / (Cout * 9) ** 0.5)))
+    bias = G(torch.randn(Cout, generator=g))
+    res = G(torch.randn(frames * H * W, Cout, generator=g))
+
+    def run():
+        y1, p1, _, _ = ops.conv2d_nhwc(x, H, W, wa, 3, 1, 1, colstats=True, frames=frames)
+        nm = ops.Normed(y1, ops.ColStats(p1, y1.shape[0], Cout, frames), slope=0.0)
+        if res_act:
+            y2, p2, _, _ = ops.conv2d_nhwc(nm, H, W, wb, 3, 1, 1, bias=bias, res=res, act=ops.ACT_RELU, colstats=True, frames=frames)
+        else:
+            y2, p2, _, _ = ops.conv2d_nhwc(nm, H, W, wb, 3, 1, 1, colstats=True, frames=frames)
+        return y1.clone(), p1.clone(), y2.clone(), p2.clone()
+
+    try:
+        assert hook(force) == 0
+        direct = run()
+        assert hook(-1) == 0
+        implicit = run()
+    finally:
+        hook(0)
+    for d, i in zip(direct, implicit):
+        scale = float(i.abs().max())
+        assert float((d - i).abs().max()) <= 3e-6 * max(scale, 1.0) * (30 if d.dim() == 3 else 1), (float((d - i).abs().max()), scale)
+    ref = torch.nn.functional.conv2d(x.cpu().reshape(frames, H, W, Cin).permute(0, 3, 1, 2).double(), wa.w.cpu().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2).double(), padding=1)
+    refm = ref.permute(0, 2, 3, 1).reshape(-1, Cout)
+    assert float((direct[0].double().cpu() - refm).abs().max()) < 2e-6 * max(1.0, float(refm.abs().max())) * 4
