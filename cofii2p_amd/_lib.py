@@ -82,6 +82,7 @@ SIGNATURES = {
     "cofi_loftr_tail_parts_bf16x3": (_I, [_P, _Z, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P]),
     "cofi_attention_workspace": (_Z, [_I, _I, _I, _I, _I]),
     "cofi_attention_parts": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _F, _I, _I, _I, _I, _F, _I, _P, _Z, _P]),
+    "cofi_attention_parts_bf16x6": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _F, _I, _I, _I, _I, _F, _I, _P, _Z, _P]),
     "cofi_attention_merge": (_I, [_P, _Z, _I, _I, _I, _I, _I, _P, _I, _P]),
     "cofi_attention_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P, _Z, _I, _P]),
     "cofi_attention_fwd_colpart": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _F, _P, _I, _I, _I, _I, _I, _F, _P, _Z, _I, _P]),

@@ -27,6 +27,7 @@
 // final 1/l are plain per-lane multiplies.  The wave issues the QK^T chain of step t before the softmax / PV of step t-1 (whose
 // V operand it keeps in registers), so the softmax VALU work runs under matrix-core time.
 #include "attention_parts.h"
+#include "bf16_split.h"
 #include "common.h"
 #include <stdlib.h>
 
@@ -322,6 +323,8 @@ __global__ __launch_bounds__(64 * NW, LIGHT ? 4 : 2) void attention_flat_kernel(
     }
 }
 
+#include "attention_x6.inc"
+
 // O[row, h*32 + d] = sum_slots O_s * 2^(m_s - m) / sum_slots l_s * 2^(m_s - m): thread = (query row, head, 16-byte chunk)
 __global__ __launch_bounds__(256) void attention_merge_kernel(const float *parts, AttnLayout lay, int L, int H, int frames, float *O, int ldo) {
     const size_t total = (size_t)frames * L * H * 8;
@@ -343,9 +346,19 @@ int attention_check(const float *Q, int ldq, const float *K, int ldk, const floa
     return 0;
 }
 
-int launch_parts(AttnArgs a, int frames, hipStream_t stream) {
+int g_x6_wpe = 0;   // tuning hook: variant of the bf16x6 kernel (0 / 4: two workgroups per CU; 2: one; +1: staging split pinned behind the barrier)
+
+int launch_parts(AttnArgs a, int frames, bool x6, hipStream_t stream) {
     a.lay = attn_layout(a.L, a.S, a.H, frames);
     const dim3 grid(a.lay.nwg), block(64 * NW);
+    if (x6) {
+        switch (g_x6_wpe) {
+        case 2: hipLaunchKernelGGL((attention_x6_kernel<2, false>), grid, block, 0, stream, a); break;
+        case 3: hipLaunchKernelGGL((attention_x6_kernel<2, true>), grid, block, 0, stream, a); break;
+        default: hipLaunchKernelGGL((attention_x6_kernel<4, false>), grid, block, 0, stream, a); break;
+        }
+        return cofi_launch_status();
+    }
     if (a.lay.light)
         hipLaunchKernelGGL((attention_flat_kernel<true>), grid, block, 0, stream, a);
     else
@@ -360,9 +373,9 @@ extern "C" size_t cofi_attention_workspace(int L, int S, int H, int D_, int fram
     return attn_layout(L, S, H, frames).bytes;
 }
 
-extern "C" int cofi_attention_parts(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, const float *q_colscale,
-                                    const float *q_colpart, int q_nslab, int q_ncols, float q_eps, int L, int S, int H, int D_, float scale,
-                                    int frames, void *parts, size_t parts_bytes, cofi_stream_t stream) {
+static int attention_parts_entry(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, const float *q_colscale,
+                                 const float *q_colpart, int q_nslab, int q_ncols, float q_eps, int L, int S, int H, int D_, float scale,
+                                 int frames, void *parts, size_t parts_bytes, bool x6, cofi_stream_t stream) {
     if (int rc = attention_check(Q, ldq, K, ldk, V, ldv, L, S, H, D_, frames)) return rc;
     if (q_colscale && q_colpart) return COFI_EINVAL;
     if (q_colpart) {
@@ -376,7 +389,27 @@ extern "C" int cofi_attention_parts(const float *Q, int ldq, const float *K, int
     if (!parts || ((uintptr_t)parts & 15) || parts_bytes < attn_layout(L, S, H, frames).bytes) return COFI_EWORKSPACE;
     AttnArgs a{Q, K, V, q_colscale, (float *)parts, ldq, ldk, ldv, L, S, H, scale * 1.4426950408889634f, q_colpart,
                q_colpart ? q_nslab / frames : 0, q_ncols, q_eps, {}};
-    return launch_parts(a, frames, cofi_s(stream));
+    return launch_parts(a, frames, x6, cofi_s(stream));
+}
+
+extern "C" int cofi_attention_parts(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, const float *q_colscale,
+                                    const float *q_colpart, int q_nslab, int q_ncols, float q_eps, int L, int S, int H, int D_, float scale,
+                                    int frames, void *parts, size_t parts_bytes, cofi_stream_t stream) {
+    return attention_parts_entry(Q, ldq, K, ldk, V, ldv, q_colscale, q_colpart, q_nslab, q_ncols, q_eps, L, S, H, D_, scale, frames, parts,
+                                 parts_bytes, false, stream);
+}
+
+extern "C" int cofi_attention_parts_bf16x6(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, const float *q_colscale,
+                                           const float *q_colpart, int q_nslab, int q_ncols, float q_eps, int L, int S, int H, int D_,
+                                           float scale, int frames, void *parts, size_t parts_bytes, cofi_stream_t stream) {
+    return attention_parts_entry(Q, ldq, K, ldk, V, ldv, q_colscale, q_colpart, q_nslab, q_ncols, q_eps, L, S, H, D_, scale, frames, parts,
+                                 parts_bytes, true, stream);
+}
+
+extern "C" int cofi_tune_attention_x6_variant(int variant) {   // A/B only: 0 / 4, 2 (one workgroup per CU), 3 (= 2, staging split pinned)
+    if (variant < 0 || variant > 4 || variant == 1) return COFI_EINVAL;
+    g_x6_wpe = variant;
+    return 0;
 }
 
 extern "C" int cofi_attention_merge(const void *parts, size_t parts_bytes, int L, int S, int H, int D_, int frames, float *O, int ldo,

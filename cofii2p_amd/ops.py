@@ -833,6 +833,17 @@ class AttnParts:
         return out
 
 
+ATTN_MODE = os.environ.get("COFI_ATTN", "auto")   # "auto" | "bf16x6" | "f32"
+
+
+def attention_arith() -> str:
+    """Arithmetic of the attention kernel: the fp32-grade bf16 split ("bf16x6", 417 TF/s roof) unless the dense contractions run on the
+    exact fp32 matrix instruction (GEMM_MODE "f32": the attention then does too, 157 TF/s roof).  COFI_ATTN=f32 / bf16x6 overrides."""
+    if ATTN_MODE in ("bf16x6", "f32"):
+        return ATTN_MODE
+    return "f32" if GEMM_MODE == "f32" else "bf16x6"
+
+
 def attention_parts(q, k, v, q_colscale=None, nhead: int = 4, frames: int = 1, q_colpart=None, q_eps: float = 1e-12) -> "AttnParts":
     """The attention kernel itself (cofi_attention_parts): -> the partial slots (AttnParts) in a per-stream workspace.
     Stack mode: q (frames*L, HD), k/v (frames*S, HD), q_colscale (frames, HD).  q_colpart (nslab, ncols, 2): the column
@@ -850,9 +861,10 @@ def attention_parts(q, k, v, q_colscale=None, nhead: int = 4, frames: int = 1, q
         raise _lib.CofiError("attention: unsupported shape (head dimension must be 32)")
     # the slot table outlives this call when it is handed to the consumer: a per-stream workspace is safe (stream ordered)
     ws = _WS_ATTN.get(nbytes, q.device)
-    rc = lib.cofi_attention_parts(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(q_colscale), _p(q_colpart),
-                                  0 if q_colpart is None else q_colpart.shape[0], 0 if q_colpart is None else q_colpart.shape[1], q_eps,
-                                  L, S, nhead, D, 1.0 / math.sqrt(D), frames, _p(ws), ws.numel(), _stream())
+    fn = lib.cofi_attention_parts_bf16x6 if attention_arith() == "bf16x6" else lib.cofi_attention_parts
+    rc = fn(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(q_colscale), _p(q_colpart),
+            0 if q_colpart is None else q_colpart.shape[0], 0 if q_colpart is None else q_colpart.shape[1], q_eps,
+            L, S, nhead, D, 1.0 / math.sqrt(D), frames, _p(ws), ws.numel(), _stream())
     _lib.check(rc, "cofi_attention_parts")
     return AttnParts(ws, L, S, nhead, D, frames)
 

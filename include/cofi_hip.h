@@ -309,6 +309,11 @@ size_t cofi_attention_workspace(int L, int S, int H, int D, int frames);
 int cofi_attention_parts(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, const float *q_colscale,
                          const float *q_colpart, int q_nslab, int q_ncols, float q_eps, int L, int S, int H, int D, float scale, int frames,
                          void *parts, size_t parts_bytes, cofi_stream_t stream);
+/* the same kernel in the fp32-grade bf16 split arithmetic of cofi_gemm_* (bf16x3 = 2: K, V, scaled Q and the softmax weights cut into
+ * three bf16 planes, six products per contraction on the bf16 matrix instruction, fp32 accumulation): same arguments, same slot table */
+int cofi_attention_parts_bf16x6(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, const float *q_colscale,
+                                const float *q_colpart, int q_nslab, int q_ncols, float q_eps, int L, int S, int H, int D, float scale,
+                                int frames, void *parts, size_t parts_bytes, cofi_stream_t stream);
 int cofi_attention_merge(const void *parts, size_t parts_bytes, int L, int S, int H, int D, int frames, float *O, int ldo,
                          cofi_stream_t stream);
 int cofi_attention_fwd(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, const float *q_colscale,

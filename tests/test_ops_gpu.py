@@ -345,27 +345,37 @@ def test_layer_norm(ops, M, C):
     close(ops.layer_norm(G(x), G(ga), G(be), res=G(r)), ref + r, 2e-5)
 
 
-def test_attention_golden(ops, mg):
+@pytest.fixture(params=["bf16x6", "f32"])
+def attn(request, ops):
+    """`ops` with the attention kernel pinned to one arithmetic: the fp32-grade bf16 split (csrc/attention_x6.inc) / the exact fp32
+    matrix instruction (csrc/attention.hip) - both are held to the same tolerances"""
+    old = ops.ATTN_MODE
+    ops.ATTN_MODE = request.param
+    yield ops
+    ops.ATTN_MODE = old
+
+
+def test_attention_golden(attn, mg):
     q, k, v = (torch.from_numpy(mg[n]).reshape(-1, 128) for n in ("att_q", "att_k", "att_v"))
-    close(ops.attention(G(q), G(k), G(v)), mg["att_out"].reshape(-1, 128), 2e-5)
+    close(attn.attention(G(q), G(k), G(v)), mg["att_out"].reshape(-1, 128), 2e-5)
 
 
 @pytest.mark.parametrize("L,S", [(1280, 1280), (1280, 128), (100, 1000), (33, 5), (2560, 640)])
-def test_attention_random(ops, L, S):
+def test_attention_random(attn, L, S):
     g = torch.Generator().manual_seed(L + S)
     q, k, v = torch.randn(L, 128, generator=g), torch.randn(S, 128, generator=g) * 2, torch.randn(S, 128, generator=g)
     cs = torch.rand(128, generator=g) + 0.5
     ref = O.full_attention((q * cs).view(L, 4, 32), k.view(S, 4, 32), v.view(S, 4, 32)).reshape(L, 128)
-    close(ops.attention(G(q), G(k), G(v), q_colscale=G(cs)), ref, 5e-5)
+    close(attn.attention(G(q), G(k), G(v), q_colscale=G(cs)), ref, 5e-5)
 
 
 @pytest.mark.parametrize("frames,L,S", [(4, 1280, 1280), (8, 1280, 1280), (16, 320, 200)])
-def test_attention_stacked_frames(ops, frames, L, S):
+def test_attention_stacked_frames(attn, frames, L, S):
     """stack mode: frame f attends only to its own keys; large grids run with 4 / 2 key splits per workgroup"""
     g = torch.Generator().manual_seed(frames * 7 + L)
     q, k, v = torch.randn(frames * L, 128, generator=g), torch.randn(frames * S, 128, generator=g) * 2, torch.randn(frames * S, 128, generator=g)
     cs = torch.rand(frames, 128, generator=g) + 0.5
-    out = ops.attention(G(q), G(k), G(v), q_colscale=G(cs), frames=frames).cpu()
+    out = attn.attention(G(q), G(k), G(v), q_colscale=G(cs), frames=frames).cpu()
     for f in (0, frames // 2, frames - 1):
         ref = O.full_attention((q[f * L:(f + 1) * L] * cs[f]).view(L, 4, 32), k[f * S:(f + 1) * S].view(S, 4, 32),
                                v[f * S:(f + 1) * S].view(S, 4, 32)).reshape(L, 128)
@@ -373,16 +383,16 @@ def test_attention_stacked_frames(ops, frames, L, S):
 
 
 @pytest.mark.parametrize("frames,L", [(1, 1280), (2, 1280), (8, 640)])
-def test_attention_q_norm_from_column_partials(ops, frames, L):
+def test_attention_q_norm_from_column_partials(attn, frames, L):
     """the token-axis norm of Q folded inside the attention kernel from the projection's column partials == the explicit
     per-frame column scale"""
     g = torch.Generator().manual_seed(frames + L)
     x, w = torch.randn(frames * L, 128, generator=g), torch.randn(384, 128, generator=g) / 11.0
-    qkv, part = ops.gemm_colstats(G(x), G(w))
+    qkv, part = attn.gemm_colstats(G(x), G(w))
     q, k, v = qkv[:, :128], qkv[:, 128:256], qkv[:, 256:]
-    cs = ops.col_inv_norm_from_colpart(part, frames * L, 128, frames=frames)
-    a = ops.attention(q, k, v, q_colscale=cs, frames=frames)
-    b = ops.attention(q, k, v, q_colpart=part, frames=frames)
+    cs = attn.col_inv_norm_from_colpart(part, frames * L, 128, frames=frames)
+    a = attn.attention(q, k, v, q_colscale=cs, frames=frames)
+    b = attn.attention(q, k, v, q_colpart=part, frames=frames)
     close(b, a.cpu(), 1e-5)
     qc = qkv.cpu()
     f = frames - 1
@@ -392,7 +402,7 @@ def test_attention_q_norm_from_column_partials(ops, frames, L):
     close(b[sl], ref, 5e-5)
 
 
-def test_attention_forced_rescale(ops):
+def test_attention_forced_rescale(attn):
     """a key block arriving late with a much larger score forces the online-softmax rescale branch"""
     L, S = 64, 256
     g = torch.Generator().manual_seed(0)
@@ -400,7 +410,36 @@ def test_attention_forced_rescale(ops):
     k[200] = q[5] * 4.0
     k[37] = q[9] * 6.0
     ref = O.full_attention(q.view(L, 4, 32), k.view(S, 4, 32), v.view(S, 4, 32)).reshape(L, 128)
-    close(ops.attention(G(q), G(k), G(v)), ref, 5e-5)
+    close(attn.attention(G(q), G(k), G(v)), ref, 5e-5)
+
+
+def test_attention_bf16x6_build_variants_bit_equal(ops):
+    """the A/B builds of the bf16x6 attention kernel (one / two workgroups per CU, staging split pinned behind the barrier) run the same
+    arithmetic in the same order: equal bits; and the split arithmetic stays within 2e-6 of the exact-fp32-instruction kernel"""
+    import ctypes
+
+    from cofii2p_amd import _lib
+
+    variant = _lib.load().cofi_tune_attention_x6_variant
+    variant.argtypes, variant.restype = [ctypes.c_int], ctypes.c_int
+    assert variant(1) != 0 and variant(7) != 0
+    g = torch.Generator().manual_seed(11)
+    frames, L, S = 3, 700, 333
+    q, k, v = G(torch.randn(frames * L, 128, generator=g)), G(torch.randn(frames * S, 128, generator=g) * 2), G(torch.randn(frames * S, 128, generator=g))
+    old = ops.ATTN_MODE
+    try:
+        ops.ATTN_MODE = "bf16x6"
+        outs = []
+        for var in (0, 2, 3):
+            assert variant(var) == 0
+            outs.append(ops.attention(q, k, v, frames=frames).clone())
+        ops.ATTN_MODE = "f32"
+        ref = ops.attention(q, k, v, frames=frames)
+    finally:
+        variant(0)
+        ops.ATTN_MODE = old
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert float((outs[0] - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
 
 
 def test_loftr_layer_golden(ops, mg):
@@ -1069,13 +1108,13 @@ def test_multi_copy(ops):
     assert len(mc.tables) == 1
 
 
-def test_attention_stress_size_sampled_rows(ops):
+def test_attention_stress_size_sampled_rows(attn):
     """BASELINE configs[4] (896x1600 image: 22 400 tokens): the L x S score matrix (8 GB per call in the reference) cannot be
     checked whole; a random sample of query rows is compared with an exact fp64 softmax of those rows"""
     L = S = 22400
     g = torch.Generator().manual_seed(77)
     q, k, v = torch.randn(L, 128, generator=g), torch.randn(S, 128, generator=g), torch.randn(S, 128, generator=g)
-    out = ops.attention(G(q), G(k), G(v)).cpu()
+    out = attn.attention(G(q), G(k), G(v)).cpu()
     rows = torch.randperm(L, generator=g)[:192]
     qs = q[rows].double().view(-1, 4, 32)
     kd, vd = k.double().view(S, 4, 32), v.double().view(S, 4, 32)
