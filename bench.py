@@ -358,7 +358,7 @@ def kernel_rooflines(model, dev, args, Bsz, frame=None, batch=None):
         ach = d["flops_per_frame"] / d["seconds_per_frame"] / 1e12
         # the bf16-split GEMM issues 3 bf16 MFMA flops per algorithmic flop: its MFMA roof for ALGORITHMIC flops is 2500/3
         # ... and the 6-term split 6: 2500 / 6
-        peak = FP32_MFMA_PEAK_TF
+        peak = attention_peak_tf() if dom == "attention_parts" else FP32_MFMA_PEAK_TF
         if dom == "gemm" and args.gemm in ("bf16x3", "bf16x6"):
             peak = BF16_MFMA_PEAK_TF / (3.0 if args.gemm == "bf16x3" else 6.0)
         # committed PMC passes exist for the two default pipelines in the fp32-grade arithmetic: stack-mode batches of 16 and batch 1
@@ -380,8 +380,10 @@ def kernel_rooflines(model, dev, args, Bsz, frame=None, batch=None):
 
     def att_row(a, what):
         ach = a["flops_per_frame"] / a["seconds_per_frame"] / 1e12
-        return {"kernel": "cofi_attention_parts", "launches": what, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": ach / FP32_MFMA_PEAK_TF, "launches_per_frame": a["launches_per_frame"],
+        from cofii2p_amd import ops as _ops
+
+        return {"kernel": "cofi_attention_parts", "launches": what, "arithmetic": _ops.attention_arith(), "bound": "mfma", "achieved": ach,
+                "peak": attention_peak_tf(), "unit": "TFLOP/s", "frac": ach / attention_peak_tf(), "launches_per_frame": a["launches_per_frame"],
                 "avg_launch_us": 1e6 * a["seconds_per_frame"] * Bsz / (a["launches_per_frame"] * Bsz)}
 
     if per.get("attention_parts"):
@@ -392,6 +394,14 @@ def kernel_rooflines(model, dev, args, Bsz, frame=None, batch=None):
     out["kernel_ms_per_frame"] = {n: round(1e3 * v["seconds_per_frame"], 4) for n, v in sorted(per.items(), key=lambda kv: -kv[1]["seconds_per_frame"])}
     out["launches_per_frame"] = {n: v["launches_per_frame"] for n, v in per.items()}
     return out
+
+
+def attention_peak_tf():
+    """Matrix-pipe roof of the attention kernel for ALGORITHMIC flops in the arithmetic it runs in (ops.attention_arith): the 6-term bf16
+    split issues six bf16 MFMA flops per algorithmic flop (2500 / 6), the exact kernel runs on the fp32 instruction (157.3)."""
+    from cofii2p_amd import ops
+
+    return BF16_MFMA_PEAK_TF / 6.0 if ops.attention_arith() == "bf16x6" else FP32_MFMA_PEAK_TF
 
 
 def pmc_traffic(kernel_family, fname="pmc_traffic.json"):
@@ -898,7 +908,8 @@ def main():
         "metric": "I2P frames/sec (160x512 img, 20480 pts)", "value": fps, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        # the arithmetic the dense contractions compute in; storage, accumulation, KPConv aggregation and attention are fp32 in all of them
+        # the arithmetic the dense contractions compute in; storage, accumulation and KPConv aggregation are fp32 in all of them, the
+        # attention kernel runs in the same 6-term split (bf16x6, bf16x3 runs) or on the exact fp32 instruction (f32 runs): "attention_arithmetic"
         "dtype": args.gemm,
         "repeats": repeats, "seconds_per_repeat": [round(x, 6) for x in dts], "distinct_frames_per_rank": len(frames),
         "frames_per_step": Bsz, "ms_per_frame": 1e3 * dt / (args.steps * Bsz),
@@ -910,9 +921,11 @@ def main():
         "per_rank_frames_per_s": None if per_rank is None else [round(args.steps * Bsz / x, 2) for x in per_rank],
         "result_gather_ms": gather_ms, "numa_node": numa_node,
         "arithmetic": "fp32 storage and accumulation everywhere; dense contractions " + arith_note,
+        "attention_arithmetic": __import__("cofii2p_amd.ops", fromlist=["ops"]).attention_arith(),
         # north star / SURVEY.md 8(d): throughput as a fraction of the attention roofline = frames/s x 13.42 GFLOP of attention per
-        # frame (4 self + 4 cross layers over both token streams: 4 * 512 * (1280 + 1280)^2) / the fp32 MFMA peak of the GPUs used (attention runs on v_mfma_f32_32x32x2_f32)
-        "attention_roofline_frac": fps * 4 * 512 * ((Opt.img_H // 8) * (Opt.img_W // 8) + args.points // 16) ** 2 / (world * FP32_MFMA_PEAK_TF * 1e12),
+        # frame (4 self + 4 cross layers over both token streams: 4 * 512 * (1280 + 1280)^2) / the matrix-pipe roof of the GPUs used in the
+        # attention kernel's arithmetic (attention_peak_tf: 416.7 TF/s for the bf16x6 kernel, 157.3 for the fp32-instruction kernel)
+        "attention_roofline_frac": fps * 4 * 512 * ((Opt.img_H // 8) * (Opt.img_W // 8) + args.points // 16) ** 2 / (world * attention_peak_tf() * 1e12),
         "config": {"workload": "%s synthetic frames (%dx%d image, %d points, KNN-128 pyramid resident in HBM), CoFiI2P.forward(mode='test') + fine "
                                "matching, %s per step per GPU, %d submissions in flight%s"
                                % ("KITTI-shape" if not args.stress else "stress (BASELINE configs[4])", Opt.img_H, Opt.img_W, args.points,

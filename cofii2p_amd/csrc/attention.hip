@@ -346,17 +346,25 @@ int attention_check(const float *Q, int ldq, const float *K, int ldk, const floa
     return 0;
 }
 
-int g_x6_wpe = 0;   // tuning hook: variant of the bf16x6 kernel (0 / 4: two workgroups per CU; 2: one; +1: staging split pinned behind the barrier)
+int g_x6_wpe = 0;   // tuning hook: build of the bf16x6 kernel (0 / 4: <= 128 registers, two workgroups per CU; 2: <= 256, one)
+
+int g_x6_dbg = 0;   // timing experiments (attention_x6.inc DBG)
 
 int launch_parts(AttnArgs a, int frames, bool x6, hipStream_t stream) {
     a.lay = attn_layout(a.L, a.S, a.H, frames);
     const dim3 grid(a.lay.nwg), block(64 * NW);
     if (x6) {
-        switch (g_x6_wpe) {
-        case 2: hipLaunchKernelGGL((attention_x6_kernel<2, false>), grid, block, 0, stream, a); break;
-        case 3: hipLaunchKernelGGL((attention_x6_kernel<2, true>), grid, block, 0, stream, a); break;
-        default: hipLaunchKernelGGL((attention_x6_kernel<4, false>), grid, block, 0, stream, a); break;
+        switch (g_x6_dbg) {   // timing experiments (wrong results)
+        case 0: break;
+#define COFI_X6_DBG(D) case D: hipLaunchKernelGGL((attention_x6_kernel<4, D>), grid, block, 0, stream, a); return cofi_launch_status();
+        COFI_X6_DBG(1) COFI_X6_DBG(2) COFI_X6_DBG(3) COFI_X6_DBG(4) COFI_X6_DBG(8) COFI_X6_DBG(9) COFI_X6_DBG(16) COFI_X6_DBG(32) COFI_X6_DBG(11) COFI_X6_DBG(15)
+#undef COFI_X6_DBG
+        default: return COFI_EINVAL;
         }
+        if (g_x6_wpe == 2)
+            hipLaunchKernelGGL((attention_x6_kernel<2>), grid, block, 0, stream, a);
+        else
+            hipLaunchKernelGGL((attention_x6_kernel<4>), grid, block, 0, stream, a);
         return cofi_launch_status();
     }
     if (a.lay.light)
@@ -406,8 +414,13 @@ extern "C" int cofi_attention_parts_bf16x6(const float *Q, int ldq, const float 
                                  parts_bytes, true, stream);
 }
 
-extern "C" int cofi_tune_attention_x6_variant(int variant) {   // A/B only: 0 / 4, 2 (one workgroup per CU), 3 (= 2, staging split pinned)
-    if (variant < 0 || variant > 4 || variant == 1) return COFI_EINVAL;
+extern "C" int cofi_tune_attention_x6_debug(int flags) {   // timing experiments only: the results are wrong
+    g_x6_dbg = flags;
+    return 0;
+}
+
+extern "C" int cofi_tune_attention_x6_variant(int variant) {   // A/B only: 0 / 4 (two workgroups per CU), 2 (one)
+    if (variant != 0 && variant != 2 && variant != 4) return COFI_EINVAL;
     g_x6_wpe = variant;
     return 0;
 }

@@ -413,8 +413,9 @@ def test_attention_forced_rescale(attn):
     close(attn.attention(G(q), G(k), G(v)), ref, 5e-5)
 
 
-def test_attention_bf16x6_build_variants_bit_equal(ops):
-    """the A/B builds of the bf16x6 attention kernel (one / two workgroups per CU, staging split pinned behind the barrier) run the same
+@pytest.mark.parametrize("frames,L,S", [(3, 700, 333), (1, 64, 2000), (1, 2560, 130), (2, 100, 4100), (1, 33, 31), (16, 1280, 1280)])
+def test_attention_bf16x6_build_variants_bit_equal(ops, frames, L, S):
+    """the A/B builds of the bf16x6 attention kernel (<= 128 registers: two workgroups per CU / <= 256: one) run the same
     arithmetic in the same order: equal bits; and the split arithmetic stays within 2e-6 of the exact-fp32-instruction kernel"""
     import ctypes
 
@@ -423,14 +424,13 @@ def test_attention_bf16x6_build_variants_bit_equal(ops):
     variant = _lib.load().cofi_tune_attention_x6_variant
     variant.argtypes, variant.restype = [ctypes.c_int], ctypes.c_int
     assert variant(1) != 0 and variant(7) != 0
-    g = torch.Generator().manual_seed(11)
-    frames, L, S = 3, 700, 333
+    g = torch.Generator().manual_seed(11 + S)
     q, k, v = G(torch.randn(frames * L, 128, generator=g)), G(torch.randn(frames * S, 128, generator=g) * 2), G(torch.randn(frames * S, 128, generator=g))
     old = ops.ATTN_MODE
     try:
         ops.ATTN_MODE = "bf16x6"
         outs = []
-        for var in (0, 2, 3):
+        for var in (0, 2):
             assert variant(var) == 0
             outs.append(ops.attention(q, k, v, frames=frames).clone())
         ops.ATTN_MODE = "f32"
@@ -438,7 +438,7 @@ def test_attention_bf16x6_build_variants_bit_equal(ops):
     finally:
         variant(0)
         ops.ATTN_MODE = old
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert all(torch.equal(outs[0], x) for x in outs[1:])
     assert float((outs[0] - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
 
 
