@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """profiles/<tag>_fetch_pmc.md + <tag>_write_pmc.md (tools/rocpd_pmc_summary.py tables) -> profiles/pmc_traffic.json.
     python tools/pmc_to_json.py FETCH.md WRITE.md <submissions | auto> [commit stamp] [attention launches per submission] [frames per submission]
-Kernel families: gemm = every gemm_*kernel + splitk epilogues (the launches behind cofi_gemm_f32* / cofi_conv2d_nhwc),
+Kernel families: gemm = every gemm_*kernel, the direct 3 x 3 convolution + splitk epilogues (the launches behind cofi_gemm_f32* / cofi_conv2d_nhwc),
 attention, kpconv_aggregate, neighbor_maxpool, group_norm_apply.
 HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in KB and on gfx950 FETCH_SIZE counts
 128-B requests at 64 B for wide coalesced reads (MI355X_MICROARCH.md §HBM)."""
@@ -9,7 +9,8 @@ import json
 import re
 import sys
 
-FAMILIES = {"gemm": ("gemm_kernel", "gemm_bf16x3_kernel", "gemm_planes_kernel", "gemm_x6_big_kernel", "splitk_epilogue"), "attention": ("attention_flat_kernel", "attention_fwd_kernel"),
+FAMILIES = {"gemm": ("gemm_kernel", "gemm_bf16x3_kernel", "gemm_planes_kernel", "gemm_x6_big_kernel", "conv3x3_direct_kernel", "splitk_epilogue"),
+            "attention": ("attention_flat_kernel", "attention_x6_kernel", "attention_fwd_kernel"),
             "kpconv_aggregate": ("kpconv_aggregate",), "neighbor_maxpool": ("neighbor_maxpool_kernel",),
             "group_norm_apply": ("group_norm_apply",), "loftr_tail": ("loftr_tail_kernel",)}
 
@@ -27,7 +28,7 @@ def main():
     fetch, write = parse(sys.argv[1], "FETCH_SIZE"), parse(sys.argv[2], "WRITE_SIZE")
     if sys.argv[3] == "auto":   # 12 attention launches per submission (4 self layers x 1 joint or 2, 4 cross x 2: transformer.py)
         per = int(sys.argv[5]) if len(sys.argv) > 5 else 12
-        frames = sum(v[0] for k, v in fetch.items() if "attention_flat_kernel" in k) // per
+        frames = sum(v[0] for k, v in fetch.items() if "attention_flat_kernel" in k or "attention_x6_kernel" in k) // per
     else:
         frames = int(sys.argv[3])
     fps = int(sys.argv[6]) if len(sys.argv) > 6 else 1   # stack mode: frames per submission
