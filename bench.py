@@ -365,6 +365,8 @@ def kernel_rooflines(model, dev, args, Bsz, frame=None, batch=None):
         pmc = None
         if args.gemm == "bf16x6" and args.points == 20480 and Opt.img_H == 160 and Bsz in (1, 16):
             pmc = pmc_traffic(dom, "pmc_traffic.json" if Bsz == 16 else "pmc_traffic_batch1.json")
+        elif args.gemm == "bf16x6" and args.points == 40960 and Opt.img_H == 896 and Bsz == 1 and dom == "gemm":
+            pmc = pmc_traffic(dom, "pmc_traffic_stress.json")   # the stress configuration (its contractions outweigh the attention kernel now)
         out["roofline"] = {"kernel": "cofi_" + dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                            # HBM bytes per launch from the committed rocprofv3 PMC passes of the default command (stamped with
                            # the commit they were collected on); None for any other configuration
