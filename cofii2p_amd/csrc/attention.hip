@@ -346,7 +346,7 @@ int attention_check(const float *Q, int ldq, const float *K, int ldk, const floa
     return 0;
 }
 
-int g_x6_wpe = 0;   // tuning hook: build of the bf16x6 kernel (0 / 4: <= 128 registers, two workgroups per CU; 2: <= 256, one)
+int g_x6_wpe = 0;   // tuning hook: build of the bf16x6 kernel (0 / 2: compiled for 2 waves per SIMD - the default; 4: for 4)
 
 int g_x6_dbg = 0;   // timing experiments (attention_x6.inc DBG)
 
@@ -356,15 +356,17 @@ int launch_parts(AttnArgs a, int frames, bool x6, hipStream_t stream) {
     if (x6) {
         switch (g_x6_dbg) {   // timing experiments (wrong results)
         case 0: break;
-#define COFI_X6_DBG(D) case D: hipLaunchKernelGGL((attention_x6_kernel<4, D>), grid, block, 0, stream, a); return cofi_launch_status();
+#define COFI_X6_DBG(D) case D: hipLaunchKernelGGL((attention_x6_kernel<2, D>), grid, block, 0, stream, a); return cofi_launch_status();
         COFI_X6_DBG(1) COFI_X6_DBG(2) COFI_X6_DBG(3) COFI_X6_DBG(4) COFI_X6_DBG(8) COFI_X6_DBG(9) COFI_X6_DBG(16) COFI_X6_DBG(32) COFI_X6_DBG(11) COFI_X6_DBG(15)
 #undef COFI_X6_DBG
         default: return COFI_EINVAL;
         }
-        if (g_x6_wpe == 2)
-            hipLaunchKernelGGL((attention_x6_kernel<2>), grid, block, 0, stream, a);
-        else
+        // both builds need 126 registers and 68 KB of LDS (two workgroups per CU); the one compiled for "2 waves per SIMD" is the
+        // better schedule (batch-16 cross launch 110 vs 116 us, joint self 201 vs 210: profiles/r05/attn_probe.txt)
+        if (g_x6_wpe == 4)
             hipLaunchKernelGGL((attention_x6_kernel<4>), grid, block, 0, stream, a);
+        else
+            hipLaunchKernelGGL((attention_x6_kernel<2>), grid, block, 0, stream, a);
         return cofi_launch_status();
     }
     if (a.lay.light)
@@ -419,7 +421,7 @@ extern "C" int cofi_tune_attention_x6_debug(int flags) {   // timing experiments
     return 0;
 }
 
-extern "C" int cofi_tune_attention_x6_variant(int variant) {   // A/B only: 0 / 4 (two workgroups per CU), 2 (one)
+extern "C" int cofi_tune_attention_x6_variant(int variant) {   // A/B only: 0 / 2 (built with launch bounds for 2 waves per SIMD), 4
     if (variant != 0 && variant != 2 && variant != 4) return COFI_EINVAL;
     g_x6_wpe = variant;
     return 0;

@@ -17,17 +17,15 @@ static __device__ __forceinline__ void cofi_split2(float a, float b, unsigned &h
 }
 // fp32 -> three bf16 planes (RNE each time): x == hi + mid + lo exactly for finite fp32 (3 x 8 significant bits).  The 6-term product
 // hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi is the fp32-grade "bf16x6" arithmetic (gemm.hip split4x3: the same rounding).
+// 22 instructions per four values.  (The subtractions two-wide - v_pk_add_f32, 18 instructions - measured SLOWER on MI355X: the
+// attention kernel 124.8 vs 113.9 us per batch-16 cross launch, the whole forward 698 -> 683 frames/s with it in the GEMM loaders.)
 static __device__ __forceinline__ void cofi_split4x3(const f32x4 v, uint2 &hi, uint2 &mid, uint2 &lo) {
-    // two-wide float arithmetic (v_pk_add_f32): 18 instructions per four values
-    const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
-    hi.x = cofi_cvt_pk_bf16(a[0], a[1]);
-    hi.y = cofi_cvt_pk_bf16(b[0], b[1]);
-    const f32x2 ha = {__uint_as_float(hi.x << 16), __uint_as_float(hi.x & 0xffff0000u)}, hb = {__uint_as_float(hi.y << 16), __uint_as_float(hi.y & 0xffff0000u)};
-    const f32x2 ra = a - ha, rb = b - hb;
-    mid.x = cofi_cvt_pk_bf16(ra[0], ra[1]);
-    mid.y = cofi_cvt_pk_bf16(rb[0], rb[1]);
-    const f32x2 ma = {__uint_as_float(mid.x << 16), __uint_as_float(mid.x & 0xffff0000u)}, mb = {__uint_as_float(mid.y << 16), __uint_as_float(mid.y & 0xffff0000u)};
-    const f32x2 sa = ra - ma, sb = rb - mb;
-    lo.x = cofi_cvt_pk_bf16(sa[0], sa[1]);
-    lo.y = cofi_cvt_pk_bf16(sb[0], sb[1]);
+    hi.x = cofi_cvt_pk_bf16(v[0], v[1]);
+    hi.y = cofi_cvt_pk_bf16(v[2], v[3]);
+    const float rx = v[0] - __uint_as_float(hi.x << 16), ry = v[1] - __uint_as_float(hi.x & 0xffff0000u);
+    const float rz = v[2] - __uint_as_float(hi.y << 16), rw = v[3] - __uint_as_float(hi.y & 0xffff0000u);
+    mid.x = cofi_cvt_pk_bf16(rx, ry);
+    mid.y = cofi_cvt_pk_bf16(rz, rw);
+    lo.x = cofi_cvt_pk_bf16(rx - __uint_as_float(mid.x << 16), ry - __uint_as_float(mid.x & 0xffff0000u));
+    lo.y = cofi_cvt_pk_bf16(rz - __uint_as_float(mid.y << 16), rw - __uint_as_float(mid.y & 0xffff0000u));
 }
