@@ -361,8 +361,8 @@ int launch_parts(AttnArgs a, int frames, bool x6, hipStream_t stream) {
 #undef COFI_X6_DBG
         default: return COFI_EINVAL;
         }
-        // both builds need 126 registers and 68 KB of LDS (two workgroups per CU); the one compiled for "2 waves per SIMD" is the
-        // better schedule (batch-16 cross launch 110 vs 116 us, joint self 201 vs 210: profiles/r05/attn_probe.txt)
+        // both builds need 126 registers and 68 KB of LDS (two workgroups per CU) and measure the same (whichever the probe times
+        // second is ~4 % faster: profiles/r05/attn_probe.txt has them in both orders)
         if (g_x6_wpe == 4)
             hipLaunchKernelGGL((attention_x6_kernel<4>), grid, block, 0, stream, a);
         else
