@@ -7,7 +7,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcofi_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
+# COFI_HIPCC_FLAGS: extra compiler flags, e.g. -DCOFI_ATTN_ABLATION (the timing-ablation builds of the bf16x6 attention kernel for
+# tools/attn_ablate.py); not part of the shipped library
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("COFI_HIPCC_FLAGS", "").split()
 
 
 def _hipcc() -> str:

@@ -346,27 +346,24 @@ int attention_check(const float *Q, int ldq, const float *K, int ldk, const floa
     return 0;
 }
 
-int g_x6_wpe = 0;   // tuning hook: build of the bf16x6 kernel (0 / 2: compiled for 2 waves per SIMD - the default; 4: for 4)
-
-int g_x6_dbg = 0;   // timing experiments (attention_x6.inc DBG)
+#ifdef COFI_ATTN_ABLATION
+int g_x6_dbg = 0;   // timing experiments (attention_x6.inc DBG; tools/attn_ablate.py): builds without one part of the kernel
+#endif
 
 int launch_parts(AttnArgs a, int frames, bool x6, hipStream_t stream) {
     a.lay = attn_layout(a.L, a.S, a.H, frames);
     const dim3 grid(a.lay.nwg), block(64 * NW);
     if (x6) {
-        switch (g_x6_dbg) {   // timing experiments (wrong results)
+#ifdef COFI_ATTN_ABLATION
+        switch (g_x6_dbg) {   // wrong results by construction
         case 0: break;
-#define COFI_X6_DBG(D) case D: hipLaunchKernelGGL((attention_x6_kernel<2, D>), grid, block, 0, stream, a); return cofi_launch_status();
+#define COFI_X6_DBG(D) case D: hipLaunchKernelGGL((attention_x6_kernel<D>), grid, block, 0, stream, a); return cofi_launch_status();
         COFI_X6_DBG(1) COFI_X6_DBG(2) COFI_X6_DBG(3) COFI_X6_DBG(4) COFI_X6_DBG(8) COFI_X6_DBG(9) COFI_X6_DBG(16) COFI_X6_DBG(32) COFI_X6_DBG(11) COFI_X6_DBG(15)
 #undef COFI_X6_DBG
         default: return COFI_EINVAL;
         }
-        // both builds need 126 registers and 68 KB of LDS (two workgroups per CU) and measure the same (whichever the probe times
-        // second is ~4 % faster: profiles/r05/attn_probe.txt has them in both orders)
-        if (g_x6_wpe == 4)
-            hipLaunchKernelGGL((attention_x6_kernel<4>), grid, block, 0, stream, a);
-        else
-            hipLaunchKernelGGL((attention_x6_kernel<2>), grid, block, 0, stream, a);
+#endif
+        hipLaunchKernelGGL((attention_x6_kernel<0>), grid, block, 0, stream, a);
         return cofi_launch_status();
     }
     if (a.lay.light)
@@ -416,16 +413,12 @@ extern "C" int cofi_attention_parts_bf16x6(const float *Q, int ldq, const float 
                                  parts_bytes, true, stream);
 }
 
+#ifdef COFI_ATTN_ABLATION
 extern "C" int cofi_tune_attention_x6_debug(int flags) {   // timing experiments only: the results are wrong
     g_x6_dbg = flags;
     return 0;
 }
-
-extern "C" int cofi_tune_attention_x6_variant(int variant) {   // A/B only: 0 / 2 (built with launch bounds for 2 waves per SIMD), 4
-    if (variant != 0 && variant != 2 && variant != 4) return COFI_EINVAL;
-    g_x6_wpe = variant;
-    return 0;
-}
+#endif
 
 extern "C" int cofi_attention_merge(const void *parts, size_t parts_bytes, int L, int S, int H, int D_, int frames, float *O, int ldo,
                                     cofi_stream_t stream) {

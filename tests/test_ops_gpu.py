@@ -414,32 +414,23 @@ def test_attention_forced_rescale(attn):
 
 
 @pytest.mark.parametrize("frames,L,S", [(3, 700, 333), (1, 64, 2000), (1, 2560, 130), (2, 100, 4100), (1, 33, 31), (16, 1280, 1280)])
-def test_attention_bf16x6_build_variants_bit_equal(ops, frames, L, S):
-    """the A/B builds of the bf16x6 attention kernel (compiled with launch bounds for 2 / for 4 waves per SIMD; both take 126 registers) run the same
-    arithmetic in the same order: equal bits; and the split arithmetic stays within 2e-6 of the exact-fp32-instruction kernel"""
-    import ctypes
-
-    from cofii2p_amd import _lib
-
-    variant = _lib.load().cofi_tune_attention_x6_variant
-    variant.argtypes, variant.restype = [ctypes.c_int], ctypes.c_int
-    assert variant(1) != 0 and variant(7) != 0
+def test_attention_bf16x6_against_the_fp32_instruction_kernel(ops, frames, L, S):
+    """the split-arithmetic attention kernel over 1 ... 5 steps per key range, a partial last key block and 16 stacked frames: bit-reproducible
+    from launch to launch, and within 5e-6 of the largest output of the exact-fp32-instruction kernel (both carry ~1e-6 of their own)"""
     g = torch.Generator().manual_seed(11 + S)
     q, k, v = G(torch.randn(frames * L, 128, generator=g)), G(torch.randn(frames * S, 128, generator=g) * 2), G(torch.randn(frames * S, 128, generator=g))
     old = ops.ATTN_MODE
     try:
         ops.ATTN_MODE = "bf16x6"
-        outs = []
-        for var in (0, 4):
-            assert variant(var) == 0
-            outs.append(ops.attention(q, k, v, frames=frames).clone())
+        a = ops.attention(q, k, v, frames=frames).clone()
+        b = ops.attention(q, k, v, frames=frames).clone()
         ops.ATTN_MODE = "f32"
         ref = ops.attention(q, k, v, frames=frames)
     finally:
-        variant(0)
         ops.ATTN_MODE = old
-    assert all(torch.equal(outs[0], x) for x in outs[1:])
-    assert float((outs[0] - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    assert torch.equal(a, b)
+    assert torch.isfinite(a).all()
+    assert float((a - ref).abs().max()) <= 5e-6 * float(ref.abs().max())
 
 
 def test_loftr_layer_golden(ops, mg):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """GPU tool: where a launch of the bf16x6 attention kernel spends its time - the kernel rebuilt WITHOUT one part at a time
 (csrc/attention_x6.inc DBG: the results of those builds are wrong, only their duration means something).
+Needs a library built with the ablation instantiations:  COFI_HIPCC_FLAGS=-DCOFI_ATTN_ABLATION python -m cofii2p_amd.build --force
     python tools/attn_ablate.py [frames L S]"""
 import ctypes
 import os
@@ -20,6 +21,8 @@ def main():
     from cofii2p_amd import _lib, ops
 
     lib = _lib.load()
+    if not hasattr(lib, "cofi_tune_attention_x6_debug"):
+        sys.exit("this libcofi_hip.so has no ablation builds: COFI_HIPCC_FLAGS=-DCOFI_ATTN_ABLATION python -m cofii2p_amd.build --force")
     dbg = lib.cofi_tune_attention_x6_debug
     dbg.argtypes, dbg.restype = [ctypes.c_int], ctypes.c_int
     frames, L, S = (int(x) for x in sys.argv[1:4]) if len(sys.argv) >= 4 else (16, 1280, 1280)

@@ -1,8 +1,7 @@
 #!/usr/bin/env python
 """GPU tool: ONE attention launch shape, repeated (profiling target for rocprofv3 passes).
-    python tools/attn_one.py --frames 16 --L 1280 --S 1280 --arith bf16x6 --variant 0 --reps 5"""
+    python tools/attn_one.py --frames 16 --L 1280 --S 1280 --arith bf16x6 --reps 5"""
 import argparse
-import ctypes
 import os
 import sys
 
@@ -16,14 +15,11 @@ def main():
     ap.add_argument("--L", type=int, default=1280)
     ap.add_argument("--S", type=int, default=1280)
     ap.add_argument("--arith", default="bf16x6", choices=["bf16x6", "f32"])
-    ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--reps", type=int, default=5)
     args = ap.parse_args()
     from cofii2p_amd import _lib, ops
 
-    lib = _lib.load()
-    lib.cofi_tune_attention_x6_variant.argtypes, lib.cofi_tune_attention_x6_variant.restype = [ctypes.c_int], ctypes.c_int
-    assert lib.cofi_tune_attention_x6_variant(args.variant) == 0
+    _lib.load()
     ops.ATTN_MODE = args.arith
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(1)

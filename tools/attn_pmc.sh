@@ -1,8 +1,8 @@
 #!/bin/bash
 # rocprofv3 PMC passes over ONE attention launch shape (GPU box, via gpurun).
-# usage: tools/attn_pmc.sh <tag> <frames> <L> <S> <bf16x6|f32> [variant]
+# usage: tools/attn_pmc.sh <tag> <frames> <L> <S> <bf16x6|f32>
 set -u
-TAG=$1; FR=$2; L=$3; S=$4; AR=$5; VAR=${6:-0}
+TAG=$1; FR=$2; L=$3; S=$4; AR=$5
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/r05/pmc_attn_$TAG.md
 mkdir -p $R/gpurun_out/r05; : > $OUT
@@ -14,7 +14,7 @@ LIST=( "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INS
 for SET in "${LIST[@]}"; do
   i=$((i+1))
   rm -rf /tmp/ap_$i
-  timeout 180 rocprofv3 --kernel-trace --pmc $SET -d /tmp/ap_$i -o x -- python $R/tools/attn_one.py --frames $FR --L $L --S $S --arith $AR --variant $VAR --reps 3 > /tmp/ap_$i.log 2>&1
+  timeout 180 rocprofv3 --kernel-trace --pmc $SET -d /tmp/ap_$i -o x -- python $R/tools/attn_one.py --frames $FR --L $L --S $S --arith $AR --reps 3 > /tmp/ap_$i.log 2>&1
   DB=$(find /tmp/ap_$i -name '*_results.db' | head -1)
   if [ -z "$DB" ]; then echo "pass $i ($SET): no db" >> $OUT; tail -3 /tmp/ap_$i.log >> $OUT; continue; fi
   echo "## pass $i: $SET" >> $OUT
