@@ -368,3 +368,25 @@ def test_graphed_train_step_refuses_a_host_side_step_counter():
     p = torch.nn.Parameter(torch.zeros(3))
     with pytest.raises(ValueError):
         GraphedTrainStep(torch.nn.Linear(1, 1), torch.optim.Adam([p], lr=1e-3), None)
+
+
+def test_attention_arithmetic_follows_the_contraction_arithmetic():
+    """ops.attention_arith(): the split-arithmetic attention kernel unless the contractions run on the exact fp32 instruction; COFI_ATTN
+    (ops.ATTN_MODE) overrides in both directions; anything else is 'auto'"""
+    from cofii2p_amd import ops
+
+    old = ops.GEMM_MODE, ops.ATTN_MODE
+    try:
+        ops.ATTN_MODE = "auto"
+        for gemm, want in (("bf16x6", "bf16x6"), ("bf16x3", "bf16x6"), ("f32", "f32")):
+            ops.GEMM_MODE = gemm
+            assert ops.attention_arith() == want
+        ops.GEMM_MODE = "bf16x6"
+        ops.ATTN_MODE = "f32"
+        assert ops.attention_arith() == "f32"
+        ops.GEMM_MODE, ops.ATTN_MODE = "f32", "bf16x6"
+        assert ops.attention_arith() == "bf16x6"
+        ops.ATTN_MODE = "something else"
+        assert ops.attention_arith() == "f32"   # falls back to the rule
+    finally:
+        ops.GEMM_MODE, ops.ATTN_MODE = old
