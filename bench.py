@@ -186,6 +186,56 @@ def record_kernel_calls(model, dev, points=20480, batch=1):
     return kt
 
 
+def graph_node_census(run):
+    """GPU dispatches of one submission, counted where the GPU sees them: `run` is captured into a hipGraph (as the product path does) and
+    the graph's nodes are counted by type through hipGraphGetNodes / hipGraphNodeGetType.  Entry-point calls (KernelTimer) under-count:
+    one cofi_* call may launch several kernels (split-K fold, statistics finalize), and torch's own copies are invisible to it."""
+    import ctypes
+
+    run()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g):
+        run()
+    raw = g.raw_cuda_graph()
+    cand = [os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"), "libamdhip64.so"]
+    hip = None
+    for c in cand:
+        try:
+            hip = ctypes.CDLL(c)
+            break
+        except OSError:
+            continue
+    if hip is None:
+        return None
+    n = ctypes.c_size_t(0)
+    if hip.hipGraphGetNodes(ctypes.c_void_p(raw), None, ctypes.byref(n)) != 0:
+        return None
+    nodes = (ctypes.c_void_p * n.value)()
+    hip.hipGraphGetNodes(ctypes.c_void_p(raw), nodes, ctypes.byref(n))
+    names = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "child_graph", 5: "empty", 6: "wait_event", 7: "event_record"}
+    census = {}
+    for nd in nodes:
+        t = ctypes.c_int(-1)
+        hip.hipGraphNodeGetType(ctypes.c_void_p(nd), ctypes.byref(t))
+        k = names.get(t.value, "type_%d" % t.value)
+        census[k] = census.get(k, 0) + 1
+    census["dispatches"] = sum(v for k, v in census.items() if k in ("kernel", "memcpy", "memset"))
+    del g
+    return census
+
+
+def submission_census(model, dev, frames_list):
+    """graph_node_census of the device part of one forward(mode='test') over `frames_list` (one frame, or a stack-mode batch)."""
+    from cofii2p_amd.network import CoFiI2P
+
+    pyr_b, img_b = CoFiI2P.stack_frames([f[0] for f in frames_list], [f[1] for f in frames_list])
+    P_b = model._pack(dev)
+    with torch.no_grad():
+        return graph_node_census(lambda: model._run_device(P_b, pyr_b["points"], pyr_b["neighbors"], pyr_b["subsampling"], pyr_b["upsampling"],
+                                                           pyr_b["feats"], img_b, "test", None, None))
+
+
 _model_ref = []
 
 
@@ -440,6 +490,7 @@ def stress_summary(dev, args):
         for _ in range(2):
             one_step(big, fr)
         torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats(dev)   # peak_mem_GB below is this configuration's own peak, not the bench process's so far
         n = 5
         t0 = time.perf_counter()
         for _ in range(n):
@@ -1065,6 +1116,16 @@ def main():
                 result.update(kernel_rooflines(model, dev, args, Bsz, batch=bpipe.batches[0]))
                 if extras:   # ... and the same rows for one frame per submission (BASELINE configs[1])
                     result["batch1_rooflines"] = kernel_rooflines(model, dev, args, 1, frame=frames[0])
+            # GPU dispatches per submission, counted in the captured hipGraph (kernel + copy + memset nodes): `launches_per_frame` above
+            # counts C-ABI entry-point calls, several of which launch more than one kernel
+            with optional_leg(result, "dispatch_census"):
+                cen = {"one_frame": submission_census(model, dev, [frames[0]])}
+                if Bsz > 1:
+                    cen["batch_of_%d" % Bsz] = submission_census(model, dev, list(frames[:Bsz]) if len(frames) >= Bsz else [frames[i % len(frames)] for i in range(Bsz)])
+                cen["note"] = "nodes of the hipGraph one forward(mode='test') + fine matching is captured into (hipGraphGetNodes), by node type"
+                result["dispatch_census"] = cen
+                if cen["one_frame"]:
+                    result["config"]["batch1_dispatches_per_frame"] = cen["one_frame"]["dispatches"]
             rf = result.get("roofline", {})
             if rf.get("bound") == "mfma" and "algorithmic_gflop_per_frame" in rf:
                 # `frac` prices one launch at a time (isolated replay); with submissions in flight the kernels share the chip, so the family's
@@ -1250,11 +1311,14 @@ def main():
                             "frames_per_s": r_, "host_ms_per_frame_in": {k_: round(1e3 * v_, 4) for k_, v_ in h_.items()}}
                     stacked_ds["note"] = ("the loader feeding the headline's stack-mode submissions of %d frames (preprocess.FrameStack; labels of a batch computed "
                                           "when its forward is collected)" % Bsz)
-                    result["config"]["with_dataside_frames_per_s"] = stacked_ds["nearest_only_upsampling"]["frames_per_s"]
+                    # the figure quoted next to `value` is the one with the REFERENCE's tables (all 128 upsampling columns, preprocess_data.py:55-99)
+                    result["config"]["with_dataside_frames_per_s"] = stacked_ds["reference_tables"]["frames_per_s"]
+                    result["config"]["with_dataside_nearest_only_frames_per_s"] = stacked_ds["nearest_only_upsampling"]["frames_per_s"]
             dtl, host = nfr / ds_rates[None][0], ds_rates[None][1]
             result["with_dataside"] = {"loader_ms_per_frame": loader_ms, "loader_frames_per_s": 1e3 / loader_ms, "frames_per_s": nfr / dtl,
                                        "ms_per_frame": 1e3 * dtl / nfr, "voxels": voxels, "raw_points": int(raw.shape[1]),
-                                       "frames_in_flight": INFL, "voxel_grids_ahead": LOOK, "draw_workers": 4,
+                                       "frames_in_flight": INFL, "voxel_grids_ahead": LOOK, "draw_workers_requested": 4,
+                                       "draw_workers": __import__("cofii2p_amd.loader", fromlist=["FrameLoader"]).FrameLoader.worker_budget(4),   # what FrameLoader actually starts (affinity mask / ranks per node)
                                        "nearest_only_upsampling_frames_per_s": ds_rates[1][0], "stack_mode_submissions": stacked_ds,
                                        "host_ms_per_frame_in": {k_: round(1e3 * v_ / nfr, 4) for k_, v_ in host.items()},
                                        "note": "kitti.py:259-393 on the device (voxel grid + resample + SE(3) + KNN pyramid + image + labels) in front of the "

@@ -11,6 +11,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcofi_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cofi_hip.h")
+TUNE_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cofi_hip_tune.h")   # tuning / test hooks: tools/ and tests/ only
 
 c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 _P, _I, _F, _Z = c_void_p, c_int, c_float, c_size_t
@@ -141,9 +142,19 @@ SIGNATURES = {
 }
 
 
-def header_symbols():
-    """Every function name declared in include/cofi_hip.h."""
-    text = open(HEADER_PATH).read()
+# include/cofi_hip_tune.h: plan overrides of the calling thread for tools/ and tests/ - not bound by load(), not used by the product
+TUNE_SIGNATURES = {
+    "cofi_tune_force_plan": (_I, [_I, _I, _I]),
+    "cofi_tune_force_planes": (_I, [_I, _I]),
+    "cofi_tune_force_big": (_I, [_I, _I]),
+    "cofi_tune_force_conv_direct": (_I, [_I]),
+    "cofi_tune_big_debug": (_I, [_I]),
+}
+
+
+def header_symbols(path=None):
+    """Every function name declared in include/cofi_hip.h (or in the header at `path`)."""
+    text = open(path or HEADER_PATH).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(cofi_[a-z0-9_]+)\s*\(", text)))
 

@@ -394,6 +394,9 @@ static int attention_parts_entry(const float *Q, int ldq, const float *K, int ld
         if (!s64 && !s32) return COFI_EINVAL;
     }
     if (!parts || ((uintptr_t)parts & 15) || parts_bytes < attn_layout(L, S, H, frames).bytes) return COFI_EWORKSPACE;
+    // the split-arithmetic kernel addresses K / V of one frame through buffer resources with 32-bit byte offsets (attention_x6.inc): a
+    // frame whose K or V block reaches 4 GB runs on the fp32-instruction kernel, whose addressing is 64-bit
+    if (x6 && ((size_t)S * ldk * sizeof(float) >= 0xffffffffull || (size_t)S * ldv * sizeof(float) >= 0xffffffffull)) x6 = false;
     AttnArgs a{Q, K, V, q_colscale, (float *)parts, ldq, ldk, ldv, L, S, H, scale * 1.4426950408889634f, q_colpart,
                q_colpart ? q_nslab / frames : 0, q_ncols, q_eps, {}};
     return launch_parts(a, frames, x6, cofi_s(stream));

@@ -60,7 +60,7 @@ struct GemmArgs {
     // frame (tiles never straddle frames: host-checked).
     NormSrc an;
     int an_rows;
-    int dbg;          // timing experiments of tools/ (cofi_tune_big_debug): never set by the product path
+    int dbg;          // cofi_tune_big_debug (include/cofi_hip_tune.h) of the calling thread; 0 on the product path.  Bit 64: the generic row-wise epilogue instead of the straight-line one (same bits)
 };
 
 // Tile coordinates of this workgroup.  The dispatcher hands workgroup L (x fastest, then y, then the K-split slice z) to XCD
@@ -1133,8 +1133,9 @@ struct TunedPlan { int M, N, K, bm, bn, ks; };
 // ... and for the bf16x6 kernel (twice the MFMAs and 1.5x the LDS traffic per K-tile move the best split): tools/tune_gemm.py --gemm bf16x6
 #include "gemm_plans_x6.inc"
 
-// tuning hook (tools/tune_gemm.py only): forces the next plans; not used by the product path
-int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;
+// Tuning / test hooks (include/cofi_hip_tune.h): plan overrides of the CALLING THREAD only - plans are chosen on the thread that enqueues a
+// launch, so a tool or a test that forces a plan cannot change the launches of any other thread; the product path never sets them.
+thread_local int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;
 
 Plan finish_plan(int K, int bm, int bn, int ks) {
     Plan p;
@@ -1227,8 +1228,8 @@ Plan make_plan(int M, int N, int K, bool fused_ln, int arith = 1) {   // arith: 
 // to minimise  rounds x (k-tiles per workgroup + fixed cost)  plus the partial-sum traffic a split adds (ks x M x N x 4 bytes written
 // and read again), in units of one K-tile of the main loop (~1.5 us).
 // tuning hook (tools only): g_force_big = 1 forces the kernel on every eligible launch (split g_force_big_ks, 0 = chosen here), -1 disables it
-int g_force_big = 0, g_force_big_ks = 0, g_big_dbg = 0;
-int g_force_direct = 0;   // tools / tests: 1 = the direct 3 x 3 kernel on every eligible convolution (no tile-count threshold), 2 = ... with 4-row tiles, -1 = never, 0 = default
+thread_local int g_force_big = 0, g_force_big_ks = 0, g_big_dbg = 0;
+thread_local int g_force_direct = 0;   // tools / tests: 1 = the direct 3 x 3 kernel on every eligible convolution (no tile-count threshold), 2 = ... with 4-row tiles, -1 = never, 0 = default
 struct TunedBig { int M, N, K, ks; };   // ks = 0: keep the small-tile kernel for this shape
 #include "gemm_plans_big.inc"
 
@@ -1280,7 +1281,7 @@ struct TunedPlanes { int M, N, K, cfg, ks; };
 
 // tuning hook (tools/tune_gemm.py only): cfg >= 0 forces that configuration and split, -2 sends pre-split operands to the
 // register-staged kernel instead (the A/B partner of the bit-identity test), -1 restores table + heuristic
-int g_force_pcfg = -1, g_force_pks = 0;
+thread_local int g_force_pcfg = -1, g_force_pks = 0;
 
 Plan finish_planes_plan(int K, int cfg, int ks) {
     Plan p;
@@ -1342,8 +1343,7 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
     g.kchunk = p.kchunk;
     dim3 grid(cofi_cdiv(g.N, p.bn), cofi_cdiv(g.M, p.bm), p.ksplit);
     g.xcd = xcd_order(g, grid);
-    static const int env_dbg = getenv("COFI_GEMM_DBG") ? atoi(getenv("COFI_GEMM_DBG")) : 0;   // timing experiments of tools/ only
-    g.dbg = g_big_dbg | env_dbg;
+    g.dbg = g_big_dbg;
     g.xcd_rcp_gy = grid.y > 1 ? (unsigned)((0x100000000ULL + grid.y - 1) / grid.y) : 0u;   // 0: gy = 1
     if (p.pcfg >= 0) {
         switch (p.pcfg) {
@@ -1626,8 +1626,8 @@ extern "C" int cofi_split_bf16_planes(const float *W, int ldw, int N, int K, voi
     return cofi_launch_status();
 }
 
-// Plan override for tools/tune_gemm.py (not declared in the public header, not used by the product path): force (bm, bn, ksplit)
-// for subsequent plans; (0,0,0) restores the table + heuristic.
+// ---- tuning / test hooks, declared in include/cofi_hip_tune.h (not part of the drop-in ABI of include/cofi_hip.h).  Every override is
+// state of the calling thread.
 extern "C" int cofi_tune_force_planes(int cfg, int ksplit) {
     if (cfg < -2 || cfg >= kNumPlanesCfg || ksplit < 0) return COFI_EINVAL;
     g_force_pcfg = cfg; g_force_pks = ksplit;
@@ -1647,7 +1647,7 @@ extern "C" int cofi_tune_force_conv_direct(int mode) {
     return 0;
 }
 
-extern "C" int cofi_tune_big_debug(int flags) {   // timing experiments only (results are WRONG with any flag set)
+extern "C" int cofi_tune_big_debug(int flags) {   // 64: the generic row-wise epilogue instead of the straight-line one (identical bits); other bits: unused
     g_big_dbg = flags;
     return 0;
 }

@@ -669,7 +669,7 @@ extern "C" int cofi_group_norm_apply_partials(const float *x, int ldx, int M, in
     fa.a = GnApplyArgs{x, nullptr, norm->gamma, norm->beta, res, nullptr, res_norm ? res_norm->gamma : nullptr, res_norm ? res_norm->beta : nullptr,
                        y, ldx, ldr, ldy, Mf, C, C / norm->groups, norm->slope, norm->groups, row_pos};
     int nb = cofi_cdiv(Mf, rpb * 4);
-    static const int cap = getenv("COFI_GN_APPLY_WGS") ? atoi(getenv("COFI_GN_APPLY_WGS")) : 2048;   // workgroups per launch (A/B switch of tools/)
+    constexpr int cap = 2048;   // workgroups per launch, grid-strided beyond (round-5 sweep of this cap: bandwidth-bound at every value)
     const int cap_f = cap / frames > 0 ? cap / frames : 1;
     if (nb > cap_f) nb = cap_f;
     if (nb < 1) nb = 1;

@@ -66,7 +66,11 @@ class FrameLoader:
         process's affinity mask (`os.sched_getaffinity`, e.g. the GPU's NUMA node after bench.pin_to_gpu_numa_node) and an equal share of
         the online cores among the LOCAL_WORLD_SIZE ranks of the node."""
         aff = len(affinity) if affinity is not None else len(os.sched_getaffinity(0))
-        lw = local_world if local_world is not None else int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
+        # LOCAL_WORLD_SIZE (torchrun / bench.py set it) = ranks on THIS node; without it: one rank per visible GPU at most - never the
+        # global WORLD_SIZE, which on a multi-node launch would divide this node's cores by the ranks of every node
+        lw = local_world if local_world is not None else int(os.environ.get("LOCAL_WORLD_SIZE", "0") or 0)
+        if lw <= 0:
+            lw = 1
         on = online if online is not None else (os.cpu_count() or aff)
         share = max(1, min(aff, on // max(1, lw)))
         return max(1, min(int(requested), share - 1))

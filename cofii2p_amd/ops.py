@@ -838,10 +838,11 @@ ATTN_MODE = os.environ.get("COFI_ATTN", "auto")   # "auto" | "bf16x6" | "f32"
 
 def attention_arith() -> str:
     """Arithmetic of the attention kernel: the fp32-grade bf16 split ("bf16x6", 417 TF/s roof) unless the dense contractions run on the
-    exact fp32 matrix instruction (GEMM_MODE "f32": the attention then does too, 157 TF/s roof).  COFI_ATTN=f32 / bf16x6 overrides."""
+    exact fp32 matrix instruction (gemm_mode() "f32" - the calling thread's `arithmetic(...)` context, else COFI_GEMM: the attention then
+    does too, 157 TF/s roof).  COFI_ATTN=f32 / bf16x6 overrides."""
     if ATTN_MODE in ("bf16x6", "f32"):
         return ATTN_MODE
-    return "f32" if GEMM_MODE == "f32" else "bf16x6"
+    return "f32" if gemm_mode() == "f32" else "bf16x6"
 
 
 def attention_parts(q, k, v, q_colscale=None, nhead: int = 4, frames: int = 1, q_colpart=None, q_eps: float = 1e-12) -> "AttnParts":

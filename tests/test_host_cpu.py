@@ -20,7 +20,15 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cofi_abi_version() == 2 and lib.cofi_target_arch() == b"gfx950"
+    assert lib.cofi_abi_version() == _lib.ABI_VERSION and lib.cofi_target_arch() == b"gfx950"
+    # the tuning / test hooks are declared too (include/cofi_hip_tune.h), and the two headers together are EVERYTHING the library exports
+    tune = _lib.header_symbols(_lib.TUNE_HEADER_PATH)
+    assert set(tune) == set(_lib.TUNE_SIGNATURES) and not set(tune) & set(declared)
+    import subprocess
+
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if ln.split()[-1].startswith("cofi_")}
+    assert exported == set(declared) | set(tune), sorted(exported ^ (set(declared) | set(tune)))
     # pure host-side queries are callable without a GPU
     assert lib.cofi_gemm_f32_workspace(1280, 512, 7680) > 0
     assert lib.cofi_gemm_f32_workspace(20480, 128, 64) == 0
@@ -388,5 +396,19 @@ def test_attention_arithmetic_follows_the_contraction_arithmetic():
         assert ops.attention_arith() == "bf16x6"
         ops.ATTN_MODE = "something else"
         assert ops.attention_arith() == "f32"   # falls back to the rule
+        # the rule reads the CALLING THREAD's arithmetic (ops.arithmetic / CoFiI2P(opt, arithmetic=...)), not the process default: a model
+        # built for exact fp32 validation must not run the split-arithmetic attention kernel, and vice versa
+        ops.ATTN_MODE = "auto"
+        ops.GEMM_MODE = "bf16x6"
+        with ops.arithmetic("f32"):
+            assert ops.gemm_mode() == "f32" and ops.attention_arith() == "f32"
+            with ops.arithmetic("bf16x6"):
+                assert ops.attention_arith() == "bf16x6"
+            assert ops.attention_arith() == "f32"
+        ops.GEMM_MODE = "f32"
+        with ops.arithmetic("bf16x6"):
+            assert ops.attention_arith() == "bf16x6"
+        with ops.arithmetic(None):
+            assert ops.attention_arith() == "f32"
     finally:
         ops.GEMM_MODE, ops.ATTN_MODE = old
