@@ -149,6 +149,7 @@ TUNE_SIGNATURES = {
     "cofi_tune_force_big": (_I, [_I, _I]),
     "cofi_tune_force_conv_direct": (_I, [_I]),
     "cofi_tune_big_debug": (_I, [_I]),
+    "cofi_tune_f16x3_resplit_events": (ctypes.c_long, [_I]),
 }
 
 

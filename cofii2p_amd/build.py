@@ -12,6 +12,12 @@ LIB = os.path.join(HERE, "libcofi_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("COFI_HIPCC_FLAGS", "").split()
 
 
+# per-file flags.  gemm.hip: the SLP pass packs adjacent scalar fp32 operations of the operand splits into v_pk_* instructions, which are slower
+# beside MFMAs (measured neutral-to-negative on the six-product kernels) and hide the v_fma_mix_f32 form of the fp16 split
+# (csrc/gemm_f16_big.inc)
+FILE_FLAGS = {"gemm.hip": ["-fno-slp-vectorize"]}
+
+
 def _hipcc() -> str:
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -41,7 +47,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        procs.append((src, subprocess.Popen([_hipcc()] + FLAGS + ["-c", src, "-o", obj])))
+        procs.append((src, subprocess.Popen([_hipcc()] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj])))
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on %s" % src)

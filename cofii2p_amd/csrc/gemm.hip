@@ -60,6 +60,8 @@ struct GemmArgs {
     // frame (tiles never straddle frames: host-checked).
     NormSrc an;
     int an_rows;
+    int f16;          // COFI_GEMM_F16X3: a launch that takes the 256 x 128 kernel runs gemm_f16_big_kernel (three fp16 products) instead of the six-product one
+    unsigned *fixflags;   // ... one word per workgroup of that launch, behind the split-K partials in the workspace: 1 = the repair launch computes this tile
     int dbg;          // cofi_tune_big_debug (include/cofi_hip_tune.h) of the calling thread; 0 on the product path.  Bit 64: the generic row-wise epilogue instead of the straight-line one (same bits)
 };
 
@@ -1085,6 +1087,7 @@ __global__ __launch_bounds__(256, WPE) void gemm_bf16x3_kernel(GemmArgs g) {
 
 #include "gemm_planes.inc"
 #include "gemm_x6_big.inc"
+#include "gemm_f16_big.inc"
 #include "conv_direct.inc"
 
 // split-K tail, same row-wise epilogue reading the partial sums.  Two tilings:
@@ -1274,6 +1277,9 @@ bool big_plan(int M, int N, int K, Plan &p) {
     return true;
 }
 
+// bytes of the f16x3 kernels' tile-flag table: one word per workgroup of a 256 x 128 launch with `ks` K-slices
+size_t f16_flag_bytes(int M, int N, int ks) { return (size_t)cofi_cdiv(M, 256) * cofi_cdiv(N, 128) * ks * sizeof(unsigned); }
+
 // ---- plans of gemm_planes_kernel (both operands pre-split): {M, N, K, configuration, split-K}, tuned on MI355X by
 // tools/tune_gemm.py --planes; anything not listed falls through to the heuristic.
 struct TunedPlanes { int M, N, K, cfg, ks; };
@@ -1364,7 +1370,21 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
         else if (cv) hipLaunchKernelGGL((gemm_x6_big_kernel<false, true, BN_>), grid, dim3(256), 0, s, g);                   \
         else hipLaunchKernelGGL((gemm_x6_big_kernel<false, false, BN_>), grid, dim3(256), 0, s, g);                          \
     } while (0)
-        COFI_LAUNCH_BIG(128);
+        if (g.f16) {
+            // the pipelined kernel, then the repair launch over the same grid (its workgroups exit at once unless the first one flagged their tile)
+#define COFI_LAUNCH_F16(ROBUST_)                                                                                             \
+    do {                                                                                                                      \
+        if (g.an.part && cv) hipLaunchKernelGGL((gemm_f16_big_kernel<true, true, ROBUST_>), grid, dim3(256), 0, s, g);       \
+        else if (g.an.part) hipLaunchKernelGGL((gemm_f16_big_kernel<true, false, ROBUST_>), grid, dim3(256), 0, s, g);       \
+        else if (cv) hipLaunchKernelGGL((gemm_f16_big_kernel<false, true, ROBUST_>), grid, dim3(256), 0, s, g);              \
+        else hipLaunchKernelGGL((gemm_f16_big_kernel<false, false, ROBUST_>), grid, dim3(256), 0, s, g);                     \
+    } while (0)
+            COFI_LAUNCH_F16(false);
+            COFI_LAUNCH_F16(true);
+#undef COFI_LAUNCH_F16
+        } else {
+            COFI_LAUNCH_BIG(128);
+        }
 #undef COFI_LAUNCH_BIG
     } else if (g.bf16x3 == 2) {
         // bf16x6: three planes per operand; K-tiles of 64 (64 x 64 tile: 54 KB of LDS) / 32 (wider tiles: 41 / 60 KB)
@@ -1464,7 +1484,8 @@ int gemm_entry(const float *A, int lda, const cofi_norm_desc_t *a_norm, const fl
     const int wsplit = (act & COFI_GEMM_W_SPLIT) ? 1 : 0;
     const int asplit = (act & COFI_GEMM_A_SPLIT) ? 1 : 0;
     const int l2n = (act & COFI_GEMM_L2NORM) ? 1 : 0;
-    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT | COFI_GEMM_A_SPLIT | COFI_GEMM_L2NORM);
+    const int f16 = (act & COFI_GEMM_F16X3) ? 1 : 0;
+    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT | COFI_GEMM_A_SPLIT | COFI_GEMM_L2NORM | COFI_GEMM_F16X3);
     if (l2n && (N > 128 || asplit)) return COFI_EUNSUPPORTED;
     if (act < 0 || act > 3 || (wsplit && (bf16x3 == 0 || (ldw & 7))) || frames <= 0) return COFI_EINVAL;
     if (asplit && bf16x3 != 1) return COFI_EINVAL;
@@ -1481,6 +1502,13 @@ int gemm_entry(const float *A, int lda, const cofi_norm_desc_t *a_norm, const fl
     g.bf16x3 = bf16x3; g.wsplit = wsplit; g.w_lo_off = (long)N * ldw; g.cv_Pout = 1; g.stat_shift = sshift;
     g.asplit = asplit; g.a_lo_off = (long)M * lda;
     g.l2n = l2n;
+    if (f16 && p.big) {   // the tile flags live behind this plan's split-K partials; a workspace without room for them: the six-product kernel
+        const size_t off = p.ksplit > 1 ? (size_t)p.ksplit * M * N * sizeof(float) : 0;
+        if (ws && ws_bytes >= off + f16_flag_bytes(M, N, p.ksplit)) {
+            g.f16 = 1;
+            g.fixflags = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + off);
+        }
+    }
     if (int rc = set_a_norm(g, a_norm, K, M / frames, frames, p)) return rc;
     return launch(g, p, cofi_s(stream));
 }
@@ -1496,7 +1524,8 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
     const int bf16x3 = (act & COFI_GEMM_BF16X6) ? 2 : ((act & COFI_GEMM_BF16X3) ? 1 : 0);
     const int wsplit = (act & COFI_GEMM_W_SPLIT) ? 1 : 0;
     const int l2n = (act & COFI_GEMM_L2NORM) ? 1 : 0;
-    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT | COFI_GEMM_L2NORM);
+    const int f16 = (act & COFI_GEMM_F16X3) ? 1 : 0;
+    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT | COFI_GEMM_L2NORM | COFI_GEMM_F16X3);
     if (act < 0 || act > 3 || (wsplit && bf16x3 == 0) || act_col0 < 0 || act_col0 > Cout) return COFI_EINVAL;
     if (l2n && Cout > 128) return COFI_EUNSUPPORTED;
     const int sshift = colpart ? stat_shift_of(stat_width, Cout) : 0;
@@ -1549,6 +1578,13 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
     g.stat_shift = sshift;
     g.act_col0 = act_col0;
     g.l2n = l2n;
+    if (f16 && p.big) {
+        const size_t off = p.ksplit > 1 ? (size_t)p.ksplit * M * Cout * sizeof(float) : 0;
+        if (ws && ws_bytes >= off + f16_flag_bytes(M, Cout, p.ksplit)) {
+            g.f16 = 1;
+            g.fixflags = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + off);
+        }
+    }
     if (int rc = set_a_norm(g, x_norm, Cin, H * W, frames, p)) return rc;   // statistics of the INPUT map: H * W rows per frame
     return launch(g, p, cofi_s(stream));
 }
@@ -1559,9 +1595,11 @@ extern "C" size_t cofi_gemm_f32_workspace(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const Plan p = make_plan(M, N, K, false), q = make_planes_plan(M, N, K), r = make_plan(M, N, K, false, 2);   // whichever kernel the operands select
     Plan b = r;
-    big_plan(M, N, K, b);
+    const bool big = big_plan(M, N, K, b);
     const int ks = std::max(std::max(p.ksplit, b.ksplit), std::max(q.ksplit, r.ksplit));
-    return ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
+    // split-K partials, then (shapes of the 256 x 128 kernels) the tile flags of COFI_GEMM_F16X3 behind the partials of THAT plan
+    const size_t partials = ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
+    return big ? std::max(partials, (b.ksplit > 1 ? (size_t)b.ksplit * M * N * sizeof(float) : 0) + f16_flag_bytes(M, N, b.ksplit)) : partials;
 }
 
 extern "C" int cofi_gemm_f32_stat_slabs(int M, int N, int K) {
@@ -1596,7 +1634,7 @@ extern "C" int cofi_gemm_f32_layernorm(const float *A, int lda, const float *W, 
     Plan p = make_plan(M, N, K, true, bf16x3);
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
     const int wsplit = (relu & COFI_GEMM_W_SPLIT) ? 1 : 0;
-    relu &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT);
+    relu &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT | COFI_GEMM_F16X3);   // the fused LayerNorm never takes the 256 x 128 kernel
     if (wsplit && (bf16x3 == 0 || (ldw & 7))) return COFI_EINVAL;
     GemmArgs g{};
     g.A = A; g.W = W; g.C = C; g.bias = bias; g.ws = (float *)ws; g.ln_gamma = gamma; g.ln_beta = beta; g.res = res;
@@ -1650,6 +1688,18 @@ extern "C" int cofi_tune_force_conv_direct(int mode) {
 extern "C" int cofi_tune_big_debug(int flags) {   // 64: the generic row-wise epilogue instead of the straight-line one (identical bits); other bits: unused
     g_big_dbg = flags;
     return 0;
+}
+
+// Diagnostic counter of gemm_f16_big_kernel: tiles re-split because they left the fp16 window of their panel's scale (all launches since the
+// last reset).  reset != 0 zeroes it after reading.  Synchronises the device.
+extern "C" long cofi_tune_f16x3_resplit_events(int reset) {
+    unsigned long long v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_f16_resplit_events), sizeof(v), 0, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned long long z = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_f16_resplit_events), &z, sizeof(z), 0, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    }
+    return (long)v;
 }
 
 extern "C" int cofi_tune_force_plan(int bm, int bn, int ksplit) {

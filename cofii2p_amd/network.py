@@ -362,7 +362,7 @@ class CoFiI2P(nn.Module):
         order = [] if order is None else list(order)
         tensors = list(points) + list(neighbors) + list(subsampling) + list(upsampling) + order + [feats, img, kpt, inl]
         # everything a captured launch sequence depends on besides the tensor signature: arithmetic, optional branches
-        key = ("stable" if inputs_stable else "copy", mode, str(img.device), slot, branch_mask, ops.gemm_mode(), self.compute_unused_image_maps,
+        key = ("stable" if inputs_stable else "copy", mode, str(img.device), slot, branch_mask, ops.gemm_mode(), ops.f16x3_big(), self.compute_unused_image_maps,
                transformer.JOINT_SELF, transformer.FUSED_CHAIN, transformer.TAIL_MAX_ROWS, kpfpn.FUSED_KPCONV, kpfpn.AGG_PLANES) + tuple(sig(t) for t in tensors)
         saved_mask, saved_slot = ops.BRANCH_MASK, ops.Workspace.slot
         ops.set_workspace_slot(slot)

@@ -20,6 +20,7 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_LEAKY01 = 0, 1, 2, 3
 GEMM_BF16X3 = 0x100
 GEMM_BF16X6 = 0x800
 GEMM_L2NORM = 0x1000   # rows L2-normalised in the epilogue (N <= 128)
+GEMM_F16X3 = 0x2000    # with GEMM_BF16X6: the large contractions (256 x 128 kernel) in the three-product fp16 split (include/cofi_hip.h)
 # arithmetic of the dense contractions: "bf16x3" (default) = 3-term bf16 split (hi*hi + hi*lo + lo*hi) on the bf16 matrix cores
 # with fp32 accumulation, ~2^-16 relative error per product; "f32" = exact fp32 MFMA (COFI_GEMM=f32)
 GEMM_MODE = os.environ.get("COFI_GEMM", "bf16x3")
@@ -40,9 +41,22 @@ def gemm_mode() -> str:
     return getattr(_TLS, "mode", None) or GEMM_MODE
 
 
+# "bf16x6" (the fp32-grade arithmetic): the LARGE contractions - the shapes of the 256 x 128 one-workgroup-per-CU kernel, which sit at the
+# chip's power wall with six bf16 products - run in the three-product fp16 split instead (COFI_GEMM_F16X3, csrc/gemm_f16_big.inc: fp16 hi +
+# lo of x * 2^e with in-kernel range tracking; same or smaller error against fp64, half the matrix work).  COFI_F16X3=0 switches it off.
+F16X3_BIG = os.environ.get("COFI_F16X3", "1") != "0"
+
+
+def f16x3_big() -> bool:
+    """True if launches of the calling thread's arithmetic may take the f16x3 kernel (part of every hipGraph cache key)."""
+    return F16X3_BIG and gemm_mode() == "bf16x6"
+
+
 def _gemm_flag() -> int:
     m = gemm_mode()
-    return GEMM_BF16X3 if m == "bf16x3" else (GEMM_BF16X6 if m == "bf16x6" else 0)
+    if m == "bf16x6":
+        return GEMM_BF16X6 | (GEMM_F16X3 if F16X3_BIG else 0)
+    return GEMM_BF16X3 if m == "bf16x3" else 0
 
 
 class arithmetic:

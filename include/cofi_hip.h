@@ -98,6 +98,14 @@ typedef struct cofi_norm_desc {
  * and activation - y = v / max(|v|, 1e-12), F.normalize(dim=1) of model/network.py:83-84, 90 - in the epilogue (a tile, or the split-K
  * reduction, spans the whole row): the stand-alone cofi_l2norm_rows pass over the output disappears. */
 #define COFI_GEMM_L2NORM 0x1000
+/* with COFI_GEMM_BF16X6: the LARGE contractions (the shapes that take the 256 x 128 one-workgroup-per-CU kernel: N >= 128, M >= 256,
+ * K % 32 == 0, fp32 W, no fused LayerNorm / L2 norm) may run in the three-product fp16 split instead of the six-product bf16 split:
+ * operand = fp16 hi + fp16 lo of x * 2^e (22-24 significant bits), products lo*hi + hi*lo + hi*hi on the fp16 matrix instruction, fp32
+ * accumulation - fp32-grade like COFI_GEMM_BF16X6 (same or smaller error against fp64) at half the matrix work.  The power-of-two
+ * scales are kept per workgroup panel INSIDE the kernel (chosen from the first K-tile, verified on every tile, the tile re-split and the
+ * accumulators rescaled - exactly - when a tile leaves the fp16 window): no caller-side range information, no extra pass, deterministic
+ * bits.  csrc/gemm_f16_big.inc.  Shapes that do not take that kernel ignore the flag (bf16x6 as before). */
+#define COFI_GEMM_F16X3 0x2000
 
 int cofi_abi_version(void);
 /* name of the code object's target, "gfx950" */

@@ -37,6 +37,11 @@ int cofi_tune_force_conv_direct(int mode);
  * Other bits are unused.  0 = default. */
 int cofi_tune_big_debug(int flags);
 
+/* Diagnostic of the f16x3 kernel (COFI_GEMM_F16X3): K-tiles re-split because they left the fp16 window of their panel's running scale,
+ * summed over all launches since the last reset (a device-side counter; the call synchronises the device).  reset != 0: zero it after
+ * reading.  -1 on error. */
+long cofi_tune_f16x3_resplit_events(int reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1248,6 +1248,7 @@ def test_big_tiles_bf16x6(ops, monkeypatch, M, N, K, frames, ks):
     result are BIT-equal to the forced 128 x 128 plan's - ragged last tiles in M and N, per-frame statistics, split-K included; and right
     against fp64."""
     monkeypatch.setattr(ops, "GEMM_MODE", "bf16x6")
+    monkeypatch.setattr(ops, "F16X3_BIG", False)   # this test is about the six-product kernel (the three-product one: test_big_tiles_f16x3)
     fp, fb = _force_hooks(ops)
     g = torch.Generator().manual_seed(M + N + K)
     a = G(torch.randn(M, K, generator=g))
@@ -1291,6 +1292,7 @@ def test_big_tiles_convolution_bf16x6(ops, monkeypatch, pad, cmid):
     from cofii2p_amd.image import _nhwc_weight
 
     monkeypatch.setattr(ops, "GEMM_MODE", "bf16x6")
+    monkeypatch.setattr(ops, "F16X3_BIG", False)
     fp, fb = _force_hooks(ops)
     frames, Cin, Cmid, Cout, H, W = 2, 64, cmid, 256, 40 + 2 * (1 - pad), 128 + 2 * (1 - pad)
     g = torch.Generator().manual_seed(12)
@@ -1384,3 +1386,218 @@ def test_direct_3x3_convolution_bf16x6(ops, monkeypatch, H, W, Cin, frames, res_
     ref = torch.nn.functional.conv2d(x.cpu().reshape(frames, H, W, Cin).permute(0, 3, 1, 2).double(), wa.w.cpu().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2).double(), padding=1)
     refm = ref.permute(0, 2, 3, 1).reshape(-1, Cout)
     assert float((direct[0].double().cpu() - refm).abs().max()) < 2e-6 * max(1.0, float(refm.abs().max())) * 4
+
+
+# ------------------------------------------------------------------------------------------ f16x3: the three-product fp16 split of the large contractions
+def _f16_events(ops, reset=True):
+    import ctypes
+
+    fn = ops._lib.load().cofi_tune_f16x3_resplit_events
+    fn.argtypes, fn.restype = [ctypes.c_int], ctypes.c_long
+    return fn(1 if reset else 0)
+
+
+def _scaled_err(out, ref, scale):
+    d = (out.double().cpu() - ref).abs() / scale
+    return float(d.max()), float(d.pow(2).mean().sqrt())
+
+
+# every contraction shape of the KITTI forward that takes the 256 x 128 kernel (rows reduced to a few tiles where the batch-16 row count is
+# only repetition), K = 7680 included, plus ragged tiles
+F16_GATE_SHAPES = [(2048, 512, 7680), (4096, 1024, 3072), (4096, 256, 3840), (8192, 512, 1536), (8192, 128, 1920), (2048, 2048, 512), (2048, 1024, 2048),
+                   (2048, 2048, 1024), (4096, 1024, 256 + 256), (2048, 512, 2048), (2048, 256, 3840), (2048, 512, 1024), (4096 + 77, 256, 1024), (333, 130, 96)]
+
+
+@pytest.mark.parametrize("M,N,K", F16_GATE_SHAPES)
+def test_gemm_f16x3_is_fp32_grade(ops, monkeypatch, M, N, K):
+    """THE GATE of the three-product fp16 split (COFI_GEMM_F16X3, csrc/gemm_f16_big.inc): on every shape of the forward that takes the
+    256 x 128 kernel, against fp64, its error is at most 2 x the exact-fp32 MFMA kernel's (the bound test_gemm_bf16x6_is_fp32_grade holds
+    the six-product split to) - largest scaled deviation and rms -, on operands with a heavy-tailed magnitude distribution as well as on
+    normal ones; the pipelined kernel never had to hand a tile to the repair launch; two runs give identical bits."""
+    fp, fb = _force_hooks(ops)
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    for heavy in (False, True):
+        a = torch.randn(M, K, generator=g) * 3
+        if heavy:   # magnitudes over ~2^10: the per-panel scale has to place them
+            a = a * torch.exp(1.5 * torch.randn(M, K, generator=g))
+        w = torch.randn(N, K, generator=g) / K ** 0.5
+        bias = torch.randn(N, generator=g)
+        ref = a.double() @ w.double().t() + bias.double()
+        scale = a.double().abs() @ w.double().abs().t()
+        err = {}
+        try:
+            fb(1, 0)
+            for mode, f16 in (("f32", False), ("bf16x6", False), ("bf16x6", True)):
+                monkeypatch.setattr(ops, "GEMM_MODE", mode)
+                monkeypatch.setattr(ops, "F16X3_BIG", f16)
+                _f16_events(ops)
+                out = ops.gemm(G(a), G(w), bias=G(bias))
+                key = "f16x3" if f16 else mode
+                err[key] = _scaled_err(out, ref, scale)
+                if f16:
+                    assert _f16_events(ops) == 0, "the pipelined kernel handed tiles to the repair launch on ordinary data"
+                    assert torch.equal(out, ops.gemm(G(a), G(w), bias=G(bias)))
+                    assert not torch.equal(out, x6_out)   # ... and it is the three-product kernel that ran
+                elif mode == "bf16x6":
+                    x6_out = out
+        finally:
+            fb(0, 0)
+        assert err["f16x3"][0] < max(2.0 * err["f32"][0], 2e-7) and err["f16x3"][1] < 1.5 * err["f32"][1], (heavy, err)
+        assert err["f16x3"][1] < 1.5 * err["bf16x6"][1] + 1e-9, (heavy, err)
+
+
+@pytest.mark.parametrize("M,N,K,frames,ks", [(4096, 256, 512, 1, 1), (4096 + 77, 256, 1024, 1, 1), (8192, 192, 512, 2, 1), (2048, 512, 2560, 2, 2),
+                                            (1024, 128, 7680, 1, 3), (333, 130, 96, 1, 1), (20480, 512, 1536, 4, 1),
+                                            (512, 128, 32, 1, 1), (768, 256, 64, 2, 1), (256, 128, 128, 1, 1)])
+def test_big_tiles_f16x3(ops, monkeypatch, M, N, K, frames, ks):
+    """The f16x3 256 x 128 kernel with every epilogue / loader form of the six-product one (test_big_tiles_bf16x6): output, column statistics
+    and the normalising loader's result agree with the bf16x6 kernel's to fp32 rounding (both are fp32-grade; the K order is the same, the
+    products differ), ragged last tiles, per-frame statistics, split-K; and right against fp64."""
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x6")
+    fp, fb = _force_hooks(ops)
+    g = torch.Generator().manual_seed(M + N + K)
+    a = G(torch.randn(M, K, generator=g))
+    w = G(torch.randn(N, K, generator=g) / K ** 0.5)
+    bias = G(torch.randn(N, generator=g))
+    N2 = 256
+    w2 = ops.presplit(G(torch.randn(N2, N, generator=g) / N ** 0.5))
+    gam, bet = G(torch.randn(N, generator=g)), G(torch.randn(N, generator=g))
+    groups = 32 if N % 32 == 0 else 2
+    per_frame = M % frames == 0 and (M // frames) % 256 == 0
+    fr = frames if per_frame else 1
+
+    def run():
+        y, part = ops.gemm_colstats(a, w, bias=bias, frames=fr)
+        st = ops.ColStats(part, M, groups, fr)
+        z = ops.gemm(ops.Normed(y, st, gam, bet, 0.1), w2, frames=fr) if (st.fusable() and N % 32 == 0) else None
+        return y.clone(), part.clone(), None if z is None else z.clone()
+
+    try:
+        assert fb(1, ks) == 0
+        monkeypatch.setattr(ops, "F16X3_BIG", True)
+        _f16_events(ops)
+        f16 = run()
+        assert _f16_events(ops) == 0
+        monkeypatch.setattr(ops, "F16X3_BIG", False)
+        x6 = run()
+    finally:
+        fb(0, 0)
+    ref = a.double().cpu() @ w.double().cpu().t() + bias.double().cpu()
+    scale = a.double().cpu().abs() @ w.double().cpu().abs().t() + bias.double().cpu().abs()
+    assert float(((f16[0].double().cpu() - ref).abs() / scale).max()) < 2e-6
+    assert not torch.equal(f16[0], x6[0])
+    close(f16[1], x6[1], 2e-5 * max(1.0, float(x6[1].abs().max())))
+    if f16[2] is not None:
+        close(f16[2], x6[2], 2e-4)
+
+
+def test_f16x3_range_tracking(ops, monkeypatch):
+    """The range side of the fp16 split.  The scale of a workgroup's panel comes from its first K-tile, so:
+    (a) operands far outside fp16's own range - |x| up to 1e9, or all below 1e-8 - are placed by it: no repair, fp32-grade;
+    (b) a K-tile that leaves the window later - an entry 1e4 x larger than anything before (it would overflow to infinity), or tiles 1e5 x
+        smaller than the first (their residuals would be flushed) - sends exactly the affected workgroups to the repair launch, whose
+        results are fp32-grade again and the same from run to run;
+    (c) an all-zero first tile, zero rows;  (d) non-finite inputs come out non-finite in their rows only."""
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x6")
+    monkeypatch.setattr(ops, "F16X3_BIG", True)
+    fp, fb = _force_hooks(ops)
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 1024, 256, 1024   # 4 x 2 tiles of 256 x 128
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+
+    def check(a, w_, expect_events, tol=2e-6):
+        ref = a.double() @ w_.double().t()
+        scale = a.double().abs() @ w_.double().abs().t() + 1e-300
+        _f16_events(ops)
+        out = ops.gemm(G(a), G(w_))
+        ev = _f16_events(ops)
+        assert (ev > 0) == expect_events if isinstance(expect_events, bool) else ev == expect_events, ev
+        fin = torch.isfinite(ref)
+        e = ((out.double().cpu() - ref).abs() / scale)[fin]
+        assert float(e.max()) < tol, float(e.max())
+        assert torch.equal(out, ops.gemm(G(a), G(w_)))
+        return out, ev
+
+    try:
+        fb(1, 1)
+        a0 = torch.randn(M, K, generator=g)
+        check(a0, w, False)
+        # (a) magnitudes no fp16 could hold, placed by the first tile
+        check(a0 * 1e9, w, False)
+        check(a0 * 1e-9, w * 1e-6, False)
+        # (b) one entry 1e4 x the rest in K-tile 20 of row panel 1: its two workgroups (two column tiles) are repaired, the others are not
+        a1 = a0.clone()
+        a1[300, 20 * 32 + 5] = 3e4
+        check(a1, w, 2)
+        # ... tiles far BELOW the window: columns 512.. of row panel 2 are 1e-6 x the first tiles
+        a2 = a0.clone()
+        a2[512:768, 512:] *= 1e-6
+        check(a2, w, 2)
+        # ... the same on the W side: one column panel
+        w1 = w.clone()
+        w1[130, 700] = 500.0
+        check(a0, w1, 4)
+        # a panel whose rows differ by 2^20 in magnitude: the small rows keep an fp32-grade RELATIVE error down to 2^-12 of the panel maximum
+        a3 = a0.clone()
+        a3[0:64] *= 2.0 ** -12
+        check(a3, w, False, tol=4e-6)
+        # (c) zeros
+        a4 = a0.clone()
+        a4[:, :32] = 0
+        a4[100:110] = 0
+        check(a4, w, False)
+        # (d) non-finite inputs stay in their rows
+        a5 = a0.clone()
+        a5[5, 40] = float("inf")
+        a5[700, 900] = float("nan")
+        out = ops.gemm(G(a5), G(w)).cpu()
+        bad = ~torch.isfinite(out).all(1)
+        assert bad[5] and bad[700] and int(bad.sum()) == 2
+        good = ~bad
+        ref = a5.double() @ w.double().t()
+        scale = a5.double().abs() @ w.double().abs().t()
+        assert float(((out.double() - ref).abs() / scale)[good].max()) < 2e-6
+    finally:
+        fb(0, 0)
+
+
+@pytest.mark.parametrize("pad,cmid", [(1, 128), (0, 128)])
+def test_big_tiles_convolution_f16x3(ops, monkeypatch, pad, cmid):
+    """3 x 3 / stride 1 convolutions on the f16x3 256 x 128 kernel, pending InstanceNorm + ReLU of the producer applied by the loader
+    included, stack mode: agrees with the six-product kernel to fp32 rounding and with torch's convolution."""
+    from cofii2p_amd.image import _nhwc_weight
+
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x6")
+    fp, fb = _force_hooks(ops)
+    frames, Cin, Cmid, Cout, H, W = 2, 64, cmid, 256, 40 + 2 * (1 - pad), 128 + 2 * (1 - pad)
+    g = torch.Generator().manual_seed(12)
+    x = G(torch.randn(frames * H * W, Cin, generator=g))
+    wa = ops.presplit(G(_nhwc_weight(torch.randn(Cmid, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)))
+    wb = ops.presplit(G(_nhwc_weight(torch.randn(Cout, Cmid, 3, 3, generator=g) / (Cmid * 9) ** 0.5)))
+
+    def run():
+        y1, p1, Ho, Wo = ops.conv2d_nhwc(x, H, W, wa, 3, 1, pad, colstats=True, frames=frames)
+        if pad == 1:
+            nm = ops.Normed(y1, ops.ColStats(p1, y1.shape[0], Cmid, frames), slope=0.0)   # InstanceNorm + ReLU pending
+            y2, p2, _, _ = ops.conv2d_nhwc(nm, Ho, Wo, wb, 3, 1, 1, colstats=True, frames=frames)
+            return y1.clone(), p1.clone(), y2.clone(), p2.clone()
+        return y1.clone(), p1.clone()
+
+    try:
+        assert fb(1, 1) == 0
+        monkeypatch.setattr(ops, "F16X3_BIG", True)
+        _f16_events(ops)
+        r16 = run()
+        assert _f16_events(ops) == 0
+        monkeypatch.setattr(ops, "F16X3_BIG", False)
+        r6 = run()
+    finally:
+        fb(0, 0)
+    assert not torch.equal(r16[0], r6[0])
+    close(r16[0], r6[0], 2e-5)
+    close(r16[1], r6[1], 2e-5 * max(1.0, float(r6[1].abs().max())))
+    if pad == 1:
+        close(r16[2], r6[2], 3e-4)
+    y16 = r16[0]
+    ref = torch.nn.functional.conv2d(x.cpu().reshape(frames, H, W, Cin).permute(0, 3, 1, 2), wa.w.cpu().reshape(Cmid, 3, 3, Cin).permute(0, 3, 1, 2), padding=pad)
+    close(y16, ref.permute(0, 2, 3, 1).reshape(-1, Cmid), 2e-5)
