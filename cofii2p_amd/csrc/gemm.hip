@@ -1372,15 +1372,20 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
     } while (0)
         if (g.f16) {
             // the pipelined kernel, then the repair launch over the same grid (its workgroups exit at once unless the first one flagged their tile)
-#define COFI_LAUNCH_F16(ROBUST_)                                                                                             \
-    do {                                                                                                                      \
-        if (g.an.part && cv) hipLaunchKernelGGL((gemm_f16_big_kernel<true, true, ROBUST_>), grid, dim3(256), 0, s, g);       \
-        else if (g.an.part) hipLaunchKernelGGL((gemm_f16_big_kernel<true, false, ROBUST_>), grid, dim3(256), 0, s, g);       \
-        else if (cv) hipLaunchKernelGGL((gemm_f16_big_kernel<false, true, ROBUST_>), grid, dim3(256), 0, s, g);              \
-        else hipLaunchKernelGGL((gemm_f16_big_kernel<false, false, ROBUST_>), grid, dim3(256), 0, s, g);                     \
+#define COFI_LAUNCH_F16(ROBUST_, NW_)                                                                                                  \
+    do {                                                                                                                                \
+        if (g.an.part && cv) hipLaunchKernelGGL((gemm_f16_big_kernel<true, true, ROBUST_, NW_>), grid, dim3(64 * NW_), 0, s, g);       \
+        else if (g.an.part) hipLaunchKernelGGL((gemm_f16_big_kernel<true, false, ROBUST_, NW_>), grid, dim3(64 * NW_), 0, s, g);       \
+        else if (cv) hipLaunchKernelGGL((gemm_f16_big_kernel<false, true, ROBUST_, NW_>), grid, dim3(64 * NW_), 0, s, g);              \
+        else hipLaunchKernelGGL((gemm_f16_big_kernel<false, false, ROBUST_, NW_>), grid, dim3(64 * NW_), 0, s, g);                     \
     } while (0)
-            COFI_LAUNCH_F16(false);
-            COFI_LAUNCH_F16(true);
+            if (g.dbg & 256) {   // cofi_tune_big_debug bit 256 (A/B): the four-wave geometry
+                COFI_LAUNCH_F16(false, 4);
+                COFI_LAUNCH_F16(true, 4);
+            } else {
+                COFI_LAUNCH_F16(false, 8);
+                COFI_LAUNCH_F16(true, 8);
+            }
 #undef COFI_LAUNCH_F16
         } else {
             COFI_LAUNCH_BIG(128);
@@ -1685,7 +1690,7 @@ extern "C" int cofi_tune_force_conv_direct(int mode) {
     return 0;
 }
 
-extern "C" int cofi_tune_big_debug(int flags) {   // 64: the generic row-wise epilogue instead of the straight-line one (identical bits); other bits: unused
+extern "C" int cofi_tune_big_debug(int flags) {   // 64: the generic row-wise epilogue (identical bits); 256: the four-wave f16x3 geometry (identical bits); other bits: unused
     g_big_dbg = flags;
     return 0;
 }

@@ -34,6 +34,7 @@ int cofi_tune_force_big(int mode, int ksplit);
 int cofi_tune_force_conv_direct(int mode);
 
 /* Bit 64: the generic row-wise epilogue instead of the straight-line one (identical bits, slower: the A/B of DESIGN 14.3).
+ * Bit 256: the f16x3 kernel in its four-wave geometry (one wave per SIMD) instead of the eight-wave one (identical bits).
  * Other bits are unused.  0 = default. */
 int cofi_tune_big_debug(int flags);
 

@@ -1405,7 +1405,7 @@ def _scaled_err(out, ref, scale):
 # every contraction shape of the KITTI forward that takes the 256 x 128 kernel (rows reduced to a few tiles where the batch-16 row count is
 # only repetition), K = 7680 included, plus ragged tiles
 F16_GATE_SHAPES = [(2048, 512, 7680), (4096, 1024, 3072), (4096, 256, 3840), (8192, 512, 1536), (8192, 128, 1920), (2048, 2048, 512), (2048, 1024, 2048),
-                   (2048, 2048, 1024), (4096, 1024, 256 + 256), (2048, 512, 2048), (2048, 256, 3840), (2048, 512, 1024), (4096 + 77, 256, 1024), (333, 130, 96)]
+                   (2048, 2048, 1024), (4096, 1024, 256 + 256), (2048, 512, 2048), (2048, 256, 3840), (2048, 512, 1024), (4096 + 77, 256, 1024), (777, 130, 512)]
 
 
 @pytest.mark.parametrize("M,N,K", F16_GATE_SHAPES)
@@ -1435,9 +1435,12 @@ def test_gemm_f16x3_is_fp32_grade(ops, monkeypatch, M, N, K):
                 key = "f16x3" if f16 else mode
                 err[key] = _scaled_err(out, ref, scale)
                 if f16:
-                    assert _f16_events(ops) == 0, "the pipelined kernel handed tiles to the repair launch on ordinary data"
-                    assert torch.equal(out, ops.gemm(G(a), G(w), bias=G(bias)))
-                    assert not torch.equal(out, x6_out)   # ... and it is the three-product kernel that ran
+                    ev = _f16_events(ops)
+                    # normal operands never leave the window; the heavy-tailed ones (single entries 2^5 above anything the scouts saw) may
+                    # send a few workgroups to the repair launch - their results are held to the same bound below
+                    assert ev == 0 or heavy, ("the pipelined kernel handed tiles to the repair launch on ordinary data", ev)
+                    assert torch.equal(out, ops.gemm(G(a), G(w), bias=G(bias))), heavy
+                    assert not torch.equal(out, x6_out), (heavy, ev)   # ... and it is the three-product kernel that ran
                 elif mode == "bf16x6":
                     x6_out = out
         finally:

@@ -24,6 +24,8 @@ def main():
     lib = _lib.load()
     ev = lib.cofi_tune_f16x3_resplit_events
     ev.argtypes, ev.restype = [ctypes.c_int], ctypes.c_long
+    lib.cofi_tune_big_debug.argtypes, lib.cofi_tune_big_debug.restype = [ctypes.c_int], ctypes.c_int
+    lib.cofi_tune_big_debug(int(os.environ.get("PROBE_DBG", "0")))   # 256: the four-wave geometry of the f16x3 kernel
     dev = torch.device("cuda", 0)
     model = CoFiI2P(bench.Opt()).to(dev)
     frames = bench.make_inputs(dev, [0, 1], 20480)
