@@ -35,12 +35,12 @@ class TailDesc(ctypes.Structure):
                 ("n1_gamma", c_void_p), ("n1_beta", c_void_p), ("n2_gamma", c_void_p), ("n2_beta", c_void_p), ("eps", c_float),
                 ("out", c_void_p), ("ldo", c_int),
                 ("proj_n", c_int * 2), ("proj_w", c_void_p * 2), ("proj_y", c_void_p * 2), ("proj_ldy", c_int * 2), ("proj_part", c_void_p * 2),
-                ("out_l2", c_void_p), ("ld_l2", c_int), ("out_l2t", c_void_p), ("ld_l2t", c_int)]
+                ("out_l2", c_void_p), ("ld_l2", c_int), ("out_l2t", c_void_p), ("ld_l2t", c_int), ("w_frag", c_int)]
 
 
 _T = ctypes.POINTER(TailDesc)
 
-ABI_VERSION = 2   # COFI_ABI_VERSION of include/cofi_hip.h this table mirrors
+ABI_VERSION = 3   # COFI_ABI_VERSION of include/cofi_hip.h this table mirrors
 
 # name -> (restype, argtypes); mirrors include/cofi_hip.h declaration by declaration
 SIGNATURES = {
@@ -84,6 +84,9 @@ SIGNATURES = {
     "cofi_attention_workspace": (_Z, [_I, _I, _I, _I, _I]),
     "cofi_attention_parts": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _F, _I, _I, _I, _I, _F, _I, _P, _Z, _P]),
     "cofi_attention_parts_bf16x6": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _F, _I, _I, _I, _I, _F, _I, _P, _Z, _P]),
+    "cofi_attention_kv_planes_bytes": (_Z, [_I, _I, _I, _I]),
+    "cofi_attention_kv_planes": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "cofi_attention_parts_planes": (_I, [_P, _I, _P, _Z, _P, _P, _I, _I, _F, _I, _I, _I, _I, _F, _I, _P, _Z, _P]),
     "cofi_attention_merge": (_I, [_P, _Z, _I, _I, _I, _I, _I, _P, _I, _P]),
     "cofi_attention_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P, _Z, _I, _P]),
     "cofi_attention_fwd_colpart": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _F, _P, _I, _I, _I, _I, _I, _F, _P, _Z, _I, _P]),

@@ -37,6 +37,23 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _deps(path, seen=None):
+    """`path` and every file it includes with #include "..." (csrc/ and include/), transitively."""
+    import re
+
+    seen = set() if seen is None else seen
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    with open(path) as fh:
+        for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', fh.read(), flags=re.M):
+            for d in (os.path.dirname(path), CSRC, os.path.join(HERE, "..", "include")):
+                if os.path.exists(os.path.join(d, name)):
+                    _deps(os.path.normpath(os.path.join(d, name)), seen)
+                    break
+    return seen
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
@@ -44,10 +61,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(objdir, exist_ok=True)
     procs = []
     objs = []
+    stamp = " ".join(FLAGS)
+    stamp_file = os.path.join(objdir, "flags.txt")
+    same_flags = os.path.exists(stamp_file) and open(stamp_file).read() == stamp
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
+        # an object newer than its source and everything the source includes is kept (same flags, not --force)
+        if not force and same_flags and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in _deps(src)):
+            continue
         procs.append((src, subprocess.Popen([_hipcc()] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj])))
+    with open(stamp_file, "w") as fh:
+        fh.write(stamp)
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on %s" % src)

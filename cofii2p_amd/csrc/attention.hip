@@ -51,6 +51,7 @@ struct AttnArgs {
     int q_nslab, q_ncols;
     float q_eps;
     AttnLayout lay;
+    const unsigned char *kvimg;   // bf16x6 kernel only: K / V pre-split by cofi_attention_kv_planes (then K == V == nullptr); attention_x6.inc
 };
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -357,13 +358,14 @@ int launch_parts(AttnArgs a, int frames, bool x6, hipStream_t stream) {
 #ifdef COFI_ATTN_ABLATION
         switch (g_x6_dbg) {   // wrong results by construction
         case 0: break;
-#define COFI_X6_DBG(D) case D: hipLaunchKernelGGL((attention_x6_kernel<D>), grid, block, 0, stream, a); return cofi_launch_status();
+#define COFI_X6_DBG(D) case D: hipLaunchKernelGGL((attention_x6_kernel<D, false>), grid, block, 0, stream, a); return cofi_launch_status();
         COFI_X6_DBG(1) COFI_X6_DBG(2) COFI_X6_DBG(3) COFI_X6_DBG(4) COFI_X6_DBG(8) COFI_X6_DBG(9) COFI_X6_DBG(16) COFI_X6_DBG(32) COFI_X6_DBG(11) COFI_X6_DBG(15)
 #undef COFI_X6_DBG
         default: return COFI_EINVAL;
         }
 #endif
-        hipLaunchKernelGGL((attention_x6_kernel<0>), grid, block, 0, stream, a);
+        if (a.kvimg) hipLaunchKernelGGL((attention_x6_kernel<0, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((attention_x6_kernel<0, false>), grid, block, 0, stream, a);
         return cofi_launch_status();
     }
     if (a.lay.light)
@@ -398,7 +400,7 @@ static int attention_parts_entry(const float *Q, int ldq, const float *K, int ld
     // frame whose K or V block reaches 4 GB runs on the fp32-instruction kernel, whose addressing is 64-bit
     if (x6 && ((size_t)S * ldk * sizeof(float) >= 0xffffffffull || (size_t)S * ldv * sizeof(float) >= 0xffffffffull)) x6 = false;
     AttnArgs a{Q, K, V, q_colscale, (float *)parts, ldq, ldk, ldv, L, S, H, scale * 1.4426950408889634f, q_colpart,
-               q_colpart ? q_nslab / frames : 0, q_ncols, q_eps, {}};
+               q_colpart ? q_nslab / frames : 0, q_ncols, q_eps, {}, nullptr};
     return launch_parts(a, frames, x6, cofi_s(stream));
 }
 
@@ -414,6 +416,43 @@ extern "C" int cofi_attention_parts_bf16x6(const float *Q, int ldq, const float 
                                            float scale, int frames, void *parts, size_t parts_bytes, cofi_stream_t stream) {
     return attention_parts_entry(Q, ldq, K, ldk, V, ldv, q_colscale, q_colpart, q_nslab, q_ncols, q_eps, L, S, H, D_, scale, frames, parts,
                                  parts_bytes, true, stream);
+}
+
+extern "C" size_t cofi_attention_kv_planes_bytes(int S, int H, int D_, int frames) {
+    if (S <= 0 || H <= 0 || D_ != D || frames <= 0) return 0;
+    return (size_t)frames * H * cofi_cdiv(S, 32) * x6::IMG_BLOCK;
+}
+
+extern "C" int cofi_attention_kv_planes(const float *K, int ldk, const float *V, int ldv, int S, int H, int D_, int frames, void *planes, size_t planes_bytes,
+                                        cofi_stream_t stream) {
+    if (!K || !V || S <= 0 || H <= 0 || frames <= 0) return COFI_EINVAL;
+    if (D_ != D) return COFI_EUNSUPPORTED;
+    if ((ldk & 3) || ldk < H * D || ldv < H * D || ((uintptr_t)K & 15)) return COFI_EINVAL;
+    if (!planes || ((uintptr_t)planes & 15) || planes_bytes < cofi_attention_kv_planes_bytes(S, H, D_, frames)) return COFI_EWORKSPACE;
+    const int P = cofi_cdiv(S, 32);
+    if (H > 65535 || frames > 65535) return COFI_EUNSUPPORTED;
+    hipLaunchKernelGGL(attention_kv_planes_kernel, dim3(P, H, frames), dim3(256), 0, cofi_s(stream), K, ldk, V, ldv, S, H, (unsigned char *)planes, P);
+    return cofi_launch_status();
+}
+
+extern "C" int cofi_attention_parts_planes(const float *Q, int ldq, const void *planes, size_t planes_bytes, const float *q_colscale, const float *q_colpart,
+                                           int q_nslab, int q_ncols, float q_eps, int L, int S, int H, int D_, float scale, int frames, void *parts,
+                                           size_t parts_bytes, cofi_stream_t stream) {
+    if (!Q || !planes || L <= 0 || S <= 0 || H <= 0 || frames <= 0) return COFI_EINVAL;
+    if (D_ != D) return COFI_EUNSUPPORTED;
+    if ((ldq & 3) || ldq < H * D || ((uintptr_t)Q & 15) || ((uintptr_t)planes & 15)) return COFI_EINVAL;
+    if (planes_bytes < cofi_attention_kv_planes_bytes(S, H, D_, frames)) return COFI_EWORKSPACE;
+    if (q_colscale && q_colpart) return COFI_EINVAL;
+    if (q_colpart) {
+        if (q_nslab <= 0 || (q_nslab % frames) || q_ncols < H * D) return COFI_EINVAL;
+        const bool s64 = q_nslab / frames == cofi_cdiv(L, 64) && (frames == 1 || L % 64 == 0);
+        const bool s32 = q_nslab / frames == cofi_cdiv(L, 32) && (frames == 1 || L % 32 == 0);
+        if (!s64 && !s32) return COFI_EINVAL;
+    }
+    if (!parts || ((uintptr_t)parts & 15) || parts_bytes < attn_layout(L, S, H, frames).bytes) return COFI_EWORKSPACE;
+    AttnArgs a{Q, nullptr, nullptr, q_colscale, (float *)parts, ldq, 0, 0, L, S, H, scale * 1.4426950408889634f, q_colpart,
+               q_colpart ? q_nslab / frames : 0, q_ncols, q_eps, {}, (const unsigned char *)planes};
+    return launch_parts(a, frames, true, cofi_s(stream));
 }
 
 #ifdef COFI_ATTN_ABLATION

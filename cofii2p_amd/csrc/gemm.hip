@@ -1236,7 +1236,7 @@ thread_local int g_force_direct = 0;   // tools / tests: 1 = the direct 3 x 3 ke
 struct TunedBig { int M, N, K, ks; };   // ks = 0: keep the small-tile kernel for this shape
 #include "gemm_plans_big.inc"
 
-bool big_plan(int M, int N, int K, Plan &p) {
+bool big_plan(int M, int N, int K, Plan &p, bool f16 = false) {   // f16: the launch will run gemm_f16_big_kernel (COFI_GEMM_F16X3)
     static const int mode = getenv("COFI_GEMM_BIG") ? atoi(getenv("COFI_GEMM_BIG")) : 1;   // A/B switch: 0 = never
     if (g_force_big < 0 || (mode == 0 && g_force_big == 0) || g_force_bm) return false;
     // N <= 64: the 256 x 64 instantiation of the kernel (four waves of 64 x 64) exists in the template and is bit-equal, but LOSES to the
@@ -1250,10 +1250,17 @@ bool big_plan(int M, int N, int K, Plan &p) {
     if (g_force_big > 0 && g_force_big_ks > 0) ks = g_force_big_ks;
     if (!ks && g_force_big == 0) {
         bool listed = false;
-        for (const TunedBig &t : kTunedBig)
-            if (t.M == M && t.N == N && t.K == K) { ks = t.ks; listed = true; break; }
+        static const int f16_table = getenv("COFI_GEMM_F16_TABLE") ? atoi(getenv("COFI_GEMM_F16_TABLE")) : 1;   // A/B switch: 0 = the six-product kernel's table and thresholds
+        if (!f16_table) f16 = false;
+        if (f16)
+            for (const TunedBig &t : kTunedBigF16)
+                if (t.M == M && t.N == N && t.K == K) { ks = t.ks; listed = true; break; }
+        if (!listed)
+            for (const TunedBig &t : kTunedBig)
+                if (t.M == M && t.N == N && t.K == K) { ks = t.ks; listed = true; break; }
         if (listed && ks == 0) return false;
-        if (!listed && (tiles < 160 || K < 512)) return false;   // short loops / small grids: two or three small workgroups per CU overlap their prologues and epilogues
+        if (!listed && (tiles < 160 || K < (f16 ? 256 : 512))) return false;   // short loops / small grids: two or three small workgroups per CU overlap their prologues and epilogues
+        if (!listed && K < 512) ks = 1;
     }
     if (!ks) {
         double best = 1e30;
@@ -1498,7 +1505,7 @@ int gemm_entry(const float *A, int lda, const cofi_norm_desc_t *a_norm, const fl
     const int sshift = colpart ? stat_shift_of(stat_width, N) : 0;
     if (sshift < 0) return COFI_EINVAL;
     Plan p = (asplit && g_force_pcfg != -2) ? make_planes_plan(M, N, K) : make_plan(M, N, K, l2n != 0, bf16x3);
-    if (bf16x3 == 2 && !wsplit && !asplit && !l2n && !(a_norm && frames > 1 && (M / frames) % 256)) big_plan(M, N, K, p);   // the 256 x 128 kernel for the large shapes
+    if (bf16x3 == 2 && !wsplit && !asplit && !l2n && !(a_norm && frames > 1 && (M / frames) % 256)) big_plan(M, N, K, p, f16 != 0);   // the 256 x 128 kernel for the large shapes
     if (a_norm && frames > 1 && p.pcfg < 0 && p.bm == 128 && p.bn == 64 && (M / frames) % 128) p.bm = 64;   // a normalising tile stays inside one frame
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * N * sizeof(float))) return COFI_EWORKSPACE;
     GemmArgs g{};
@@ -1572,7 +1579,7 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
     // the 256 x 128 kernel: 3 x 3 / stride 1 / pad <= 1 convolutions whose K-tiles of 32 lie inside one tap, 32-bit byte offsets into the input
     if (bf16x3 == 2 && !wsplit && !l2n && ks == 3 && stride == 1 && pad <= 1 && (Cin % 32) == 0 &&
         (size_t)frames * H * W * ldx * sizeof(float) < 0xffffffffull && !(x_norm && frames > 1 && (Ho * Wo) % 256))
-        big_plan(M, Cout, K, p);
+        big_plan(M, Cout, K, p, f16 != 0);
     if (x_norm && frames > 1 && p.bm == 128 && p.bn == 64 && (Ho * Wo) % 128) p.bm = 64;   // a normalising tile stays inside one frame
     if (p.ksplit > 1 && (!ws || ws_bytes < (size_t)p.ksplit * M * Cout * sizeof(float))) return COFI_EWORKSPACE;
     GemmArgs g{};
@@ -1599,12 +1606,13 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
 extern "C" size_t cofi_gemm_f32_workspace(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const Plan p = make_plan(M, N, K, false), q = make_planes_plan(M, N, K), r = make_plan(M, N, K, false, 2);   // whichever kernel the operands select
-    Plan b = r;
-    const bool big = big_plan(M, N, K, b);
-    const int ks = std::max(std::max(p.ksplit, b.ksplit), std::max(q.ksplit, r.ksplit));
-    // split-K partials, then (shapes of the 256 x 128 kernels) the tile flags of COFI_GEMM_F16X3 behind the partials of THAT plan
+    Plan b = r, bf = r;
+    big_plan(M, N, K, b);                            // the six-product 256 x 128 kernel's plan ...
+    const bool bigf = big_plan(M, N, K, bf, true);   // ... and the f16x3 kernel's (its own table of shapes and splits)
+    const int ks = std::max(std::max(p.ksplit, b.ksplit), std::max(std::max(q.ksplit, r.ksplit), bf.ksplit));
+    // split-K partials, then (shapes of the f16x3 kernel) its tile flags behind the partials of THAT plan
     const size_t partials = ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
-    return big ? std::max(partials, (b.ksplit > 1 ? (size_t)b.ksplit * M * N * sizeof(float) : 0) + f16_flag_bytes(M, N, b.ksplit)) : partials;
+    return bigf ? std::max(partials, (bf.ksplit > 1 ? (size_t)bf.ksplit * M * N * sizeof(float) : 0) + f16_flag_bytes(M, N, bf.ksplit)) : partials;
 }
 
 extern "C" int cofi_gemm_f32_stat_slabs(int M, int N, int K) {

@@ -97,7 +97,8 @@ __device__ __forceinline__ void split_store1(float v, unsigned char *p, int pstr
 // are in flight ahead of the one being multiplied.  The workgroup is alone on its CU (40-80 workgroups per launch) and a
 // chunk is only ~0.2 us of MFMA work, so the stage is a chain of L2 round trips: PF = all chunks (one round trip per stage)
 // where the registers allow it - one wave per SIMD may use the whole 512-entry register file.
-template <int NPL, int NT, int KSTEPS, int PF, int CH>
+// FRAG: the weight planes are stored in fragment order (cofi_loftr_tail_desc_t::w_frag): block (row block T, k-step s) = the wave's 64 x 16 B.
+template <int NPL, int NT, int KSTEPS, int PF, int CH, bool FRAG>
 __device__ __forceinline__ void gemm_stage(f32x16 (&acc)[NT], const unsigned char *a_pl, int a_pstride, int a_stride,
                                            const unsigned short *const *w, int K, int nbase, int li, int lh) {
     constexpr int NCH = KSTEPS / CH;
@@ -106,10 +107,10 @@ __device__ __forceinline__ void gemm_stage(f32x16 (&acc)[NT], const unsigned cha
     auto loadw = [&](int c, int slot) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const size_t roff = (size_t)(nbase + 32 * t + li) * K + 8 * lh;
+            const size_t roff = FRAG ? ((size_t)((nbase >> 5) + t) * KSTEPS * 64 + (li + 32 * lh)) * 8 : (size_t)(nbase + 32 * t + li) * K + 8 * lh;
 #pragma unroll
             for (int s = 0; s < CH; ++s) {
-                const int k0 = 16 * (c * CH + s);
+                const int k0 = (FRAG ? 512 : 16) * (c * CH + s);
 #pragma unroll
                 for (int p = 0; p < NPL; ++p) b[slot][p][t][s].u = *reinterpret_cast<const uint4 *>(w[p] + roff + k0);
             }
@@ -157,14 +158,14 @@ __device__ __forceinline__ void gemm_stage(f32x16 (&acc)[NT], const unsigned cha
 // y = out_tile @ Wp^T for one projection segment of N = 128 NT columns: wave w owns columns [32 NT w, 32 NT (w + 1)); the accumulator
 // tiles go straight to memory (a store instruction of a 32 x 32 D tile writes two 128-byte row segments) and each column's {sum, sum
 // of squares} over the workgroup's rows - one 32-row slab - to the partials table.
-template <int NPL, int NT>
+template <int NPL, int NT, bool FRAG>
 __device__ __forceinline__ void proj_stage(const ProjSeg &ps, const unsigned char *a_pl, int a_pstride, int r0, int L, int wave, int li, int lh) {
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    gemm_stage<NPL, NT, 8, 1, NPL == 3 ? 2 : 4>(acc, a_pl, a_pstride, S128, ps.w, C, wave * 32 * NT, li, lh);
+    gemm_stage<NPL, NT, 8, 1, NPL == 3 ? 2 : 4, FRAG>(acc, a_pl, a_pstride, S128, ps.w, C, wave * 32 * NT, li, lh);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int col = wave * 32 * NT + 32 * t + li;
@@ -190,7 +191,7 @@ __device__ __forceinline__ void proj_stage(const ProjSeg &ps, const unsigned cha
     }
 }
 
-template <int NPL>
+template <int NPL, bool FRAG>
 __global__ __launch_bounds__(256) void loftr_tail_kernel(TailArgs a) {
     // LDS carve (bytes): msg planes NPL*R*S128 | cat planes NPL*R*S256 | h planes NPL*R*S256 | fp32 staging R*FLD*4
     constexpr int P128 = R * S128, P256 = R * S256;   // bytes per plane
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailArgs a) {
         f32x16 acc[1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-        gemm_stage<NPL, 1, 8, 2, 4>(acc, msg_pl, P128, S128, a.wm, C, wave * 32, li, lh);
+        gemm_stage<NPL, 1, 8, 2, 4, FRAG>(acc, msg_pl, P128, S128, a.wm, C, wave * 32, li, lh);
         acc_to_stage(acc[0], wave * 32);
     }
     __syncthreads();
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailArgs a) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        gemm_stage<NPL, 2, 16, 2, NPL == 3 ? 2 : 4>(acc, cat_pl, P256, S256, a.w0, 2 * C, wave * 64, li, lh);
+        gemm_stage<NPL, 2, 16, 2, NPL == 3 ? 2 : 4, FRAG>(acc, cat_pl, P256, S256, a.w0, 2 * C, wave * 64, li, lh);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailArgs a) {
         f32x16 acc[1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-        gemm_stage<NPL, 1, 16, NPL == 3 ? 2 : 4, 4>(acc, h_pl, P256, S256, a.w2, 2 * C, wave * 32, li, lh);
+        gemm_stage<NPL, 1, 16, NPL == 3 ? 2 : 4, 4, FRAG>(acc, h_pl, P256, S256, a.w2, 2 * C, wave * 32, li, lh);
         acc_to_stage(acc[0], wave * 32);
     }
     __syncthreads();
@@ -334,18 +335,21 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailArgs a) {
 #pragma unroll
     for (int sgi = 0; sgi < 2; ++sgi) {
         const ProjSeg &ps = a.proj[sgi];
-        if (ps.N == 128) proj_stage<NPL, 1>(ps, msg_pl, P128, r0, a.L, wave, li, lh);
-        else if (ps.N == 256) proj_stage<NPL, 2>(ps, msg_pl, P128, r0, a.L, wave, li, lh);
-        else if (ps.N == 384) proj_stage<NPL, 3>(ps, msg_pl, P128, r0, a.L, wave, li, lh);
+        if (ps.N == 128) proj_stage<NPL, 1, FRAG>(ps, msg_pl, P128, r0, a.L, wave, li, lh);
+        else if (ps.N == 256) proj_stage<NPL, 2, FRAG>(ps, msg_pl, P128, r0, a.L, wave, li, lh);
+        else if (ps.N == 384) proj_stage<NPL, 3, FRAG>(ps, msg_pl, P128, r0, a.L, wave, li, lh);
     }
 }
 
-int launch_tail(const TailArgs &a, int planes, hipStream_t s) {
+int launch_tail(const TailArgs &a, int planes, hipStream_t s, bool frag = false) {
     const int nwg = cofi_cdiv(a.L, R);
-    if (planes == 3)
-        hipLaunchKernelGGL(loftr_tail_kernel<3>, dim3(nwg), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL(loftr_tail_kernel<2>, dim3(nwg), dim3(256), 0, s, a);
+    if (planes == 3) {
+        if (frag) hipLaunchKernelGGL((loftr_tail_kernel<3, true>), dim3(nwg), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((loftr_tail_kernel<3, false>), dim3(nwg), dim3(256), 0, s, a);
+    } else {
+        if (frag) hipLaunchKernelGGL((loftr_tail_kernel<2, true>), dim3(nwg), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((loftr_tail_kernel<2, false>), dim3(nwg), dim3(256), 0, s, a);
+    }
     return cofi_launch_status();
 }
 
@@ -355,7 +359,7 @@ bool mis16(const void *p) { return ((uintptr_t)p & 15) != 0; }
 
 extern "C" int cofi_loftr_tail(const cofi_loftr_tail_desc_t *d, cofi_stream_t stream) {
     if (!d || !d->x || !d->wm || !d->w0 || !d->w2 || !d->n1_gamma || !d->n1_beta || !d->n2_gamma || !d->n2_beta || !d->out) return COFI_EINVAL;
-    if (d->planes != 2 && d->planes != 3) return COFI_EUNSUPPORTED;
+    if ((d->planes != 2 && d->planes != 3) || (d->w_frag != 0 && d->w_frag != 1)) return COFI_EUNSUPPORTED;
     if ((d->msg != nullptr) == (d->parts != nullptr)) return COFI_EINVAL;   // exactly one form of the message operand
     if ((d->ldx & 3) || d->ldx < C || d->ldo < C || mis16(d->x) || mis16(d->wm) || mis16(d->w0) || mis16(d->w2)) return COFI_EINVAL;
     TailArgs a{};
@@ -391,7 +395,7 @@ extern "C" int cofi_loftr_tail(const cofi_loftr_tail_desc_t *d, cofi_stream_t st
     }
     if ((d->out_l2 && d->ld_l2 < C) || (d->out_l2t && d->ld_l2t < a.L)) return COFI_EINVAL;
     a.l2 = d->out_l2; a.ld_l2 = d->ld_l2; a.l2t = d->out_l2t; a.ld_l2t = d->ld_l2t;
-    return launch_tail(a, d->planes, cofi_s(stream));
+    return launch_tail(a, d->planes, cofi_s(stream), d->w_frag != 0);
 }
 
 extern "C" int cofi_loftr_tail_bf16x3(const float *msg, int ldm, const float *x, int ldx, const uint16_t *wm_hi, const uint16_t *wm_lo,

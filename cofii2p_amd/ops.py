@@ -827,6 +827,11 @@ def extract_patches_nhwc(fmap, H2: int, W2: int, xy, cnt, cap: int, center_scale
 
 # ------------------------------------------------------------------------------------------ attention
 _WS_ATTN = Workspace()
+_WS_ATTN_KV = Workspace()
+# bf16x6 attention: K / V are cut into their bf16 planes ONCE per call (cofi_attention_kv_planes, one extra launch) from this many key rows
+# per call (frames * S) - otherwise by every workgroup of the attention kernel again (L / 64 times per frame and head).  The extra launch costs
+# more than it saves on one KITTI frame (1280 keys); stack-mode batches and the stress configuration take it.  COFI_ATTN_PRESPLIT_ROWS=0: never.
+ATTN_PRESPLIT_ROWS = int(os.environ.get("COFI_ATTN_PRESPLIT_ROWS", "4096"))
 
 
 class AttnParts:
@@ -876,6 +881,15 @@ def attention_parts(q, k, v, q_colscale=None, nhead: int = 4, frames: int = 1, q
         raise _lib.CofiError("attention: unsupported shape (head dimension must be 32)")
     # the slot table outlives this call when it is handed to the consumer: a per-stream workspace is safe (stream ordered)
     ws = _WS_ATTN.get(nbytes, q.device)
+    if attention_arith() == "bf16x6" and 0 < ATTN_PRESPLIT_ROWS <= frames * S:
+        pb = lib.cofi_attention_kv_planes_bytes(S, nhead, D, frames)
+        img = _WS_ATTN_KV.get(pb, q.device)
+        _lib.check(lib.cofi_attention_kv_planes(_p(k), _ld(k), _p(v), _ld(v), S, nhead, D, frames, _p(img), img.numel(), _stream()), "cofi_attention_kv_planes")
+        rc = lib.cofi_attention_parts_planes(_p(q), _ld(q), _p(img), img.numel(), _p(q_colscale), _p(q_colpart),
+                                             0 if q_colpart is None else q_colpart.shape[0], 0 if q_colpart is None else q_colpart.shape[1], q_eps,
+                                             L, S, nhead, D, 1.0 / math.sqrt(D), frames, _p(ws), ws.numel(), _stream())
+        _lib.check(rc, "cofi_attention_parts_planes")
+        return AttnParts(ws, L, S, nhead, D, frames)
     fn = lib.cofi_attention_parts_bf16x6 if attention_arith() == "bf16x6" else lib.cofi_attention_parts
     rc = fn(_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(q_colscale), _p(q_colpart),
             0 if q_colpart is None else q_colpart.shape[0], 0 if q_colpart is None else q_colpart.shape[1], q_eps,
@@ -911,6 +925,26 @@ def split_planes(w: torch.Tensor, n: int) -> torch.Tensor:
     return torch.stack(out).contiguous()
 
 
+def fragment_order(planes: torch.Tensor) -> torch.Tensor:
+    """(n, N, K) bf16 planes -> the same values in MFMA-FRAGMENT ORDER (cofi_loftr_tail_desc_t::w_frag, include/cofi_hip.h): per plane, row
+    block T = n / 32 and k-step s = k / 16 the 64 lanes x 8 bf16 of a wave's B operand, contiguous (1 KB).  Shape kept (n, N, K) - only the
+    order in memory changes."""
+    n, N, K = planes.shape
+    if N % 32 or K % 16:
+        raise _lib.CofiError("fragment_order: N must be a multiple of 32 and K of 16")
+    return planes.view(n, N // 32, 32, K // 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous().view(n, N, K)
+
+
+# the fused layer tail reads its weight planes in fragment order (one contiguous 1 KB segment per wave load instead of 32 row pieces of 32 B);
+# COFI_TAIL_FRAG=0: the row-major planes (A/B; identical bits)
+TAIL_FRAG = os.environ.get("COFI_TAIL_FRAG", "1") != "0"
+
+
+def tail_suffix() -> str:
+    """Key suffix of the tail's weight planes in a packed layer (transformer.pack_layer): ".pN" row-major, ".fN" fragment order."""
+    return (".f%d" if TAIL_FRAG else ".p%d") % tail_planes()
+
+
 def tail_planes() -> int:
     """bf16 planes per operand of the fused layer tail for the current arithmetic; 0 = not served (exact fp32)."""
     return {"bf16x3": 2, "bf16x6": 3}.get(gemm_mode(), 0)
@@ -926,8 +960,9 @@ def loftr_tail(msg, x, w, out, eps: float = 1e-5, proj=(), out_l2=None, out_l2t=
     npl = tail_planes()
     if npl == 0:
         raise _lib.CofiError("loftr_tail serves the bf16x3 / bf16x6 arithmetics")
-    sfx = ".p%d" % npl
+    sfx = tail_suffix()
     d = _lib.TailDesc()
+    d.w_frag = 1 if TAIL_FRAG else 0   # (the projection planes in `proj` must come from the same suffix)
     keep = []   # tensors whose addresses the descriptor holds (alive until the launch is enqueued)
     if isinstance(msg, AttnParts):
         d.parts, d.parts_bytes, d.L, d.S, d.H, d.frames = msg.buf.data_ptr(), msg.buf.numel(), msg.L, msg.S, msg.H, msg.frames

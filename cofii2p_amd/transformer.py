@@ -25,7 +25,8 @@ def pack_layer(sd: Dict[str, torch.Tensor], p: str) -> Dict[str, torch.Tensor]:
     """Fused projection weights of one LoFTREncoderLayer: [Wq;Wk;Wv] (3C,C) for self layers,
     [Wk;Wv] for cross layers; everything else is used in place (nn.Linear layout == GEMM layout).  The weights the fused layer tail
     reads (merge, MLP, and the stacked projections a PREVIOUS layer's tail computes for this one) also as bf16 planes:
-    ".p2" = (2, N, K) hi / lo (3-term split), ".p3" = (3, N, K) hi / mid / lo (6-term split)."""
+    ".p2" = (2, N, K) hi / lo (3-term split), ".p3" = (3, N, K) hi / mid / lo (6-term split); ".f2" / ".f3" = the same planes in
+    MFMA-fragment order (ops.fragment_order), the form the tail kernel streams."""
     wq, wk, wv = sd[p + "q_proj.weight"], sd[p + "k_proj.weight"], sd[p + "v_proj.weight"]
     out = {
         "q_proj.weight": wq.contiguous(),
@@ -40,6 +41,7 @@ def pack_layer(sd: Dict[str, torch.Tensor], p: str) -> Dict[str, torch.Tensor]:
     for name in ("merge", "mlp.0", "mlp.2", "qkv", "kv"):
         for n in (2, 3):
             out["%s.p%d" % (name, n)] = ops.split_planes(out[name + ".weight"], n)
+            out["%s.f%d" % (name, n)] = ops.fragment_order(out["%s.p%d" % (name, n)])   # ... and in fragment order (ops.TAIL_FRAG)
     return out
 
 
@@ -128,7 +130,7 @@ def _run_chain(layers, kinds, ts: "TokenStreams", nhead: int, frames: int, l2=No
     front of layer 0, then per self layer attention + tail, per cross layer (attention + tail) x 2 - every tail computes, from its
     32-row tile of `out` still in LDS, the q / k / v the following attention calls read (and the column partials of q for the token-axis
     norm).  l2 = (img_l2, pc_l2, img_l2t, pc_l2t): F.normalize(dim=1) of the last layer's outputs written by its tails (entries may be None)."""
-    C, sfx = ts.C, ".p%d" % ops.tail_planes()
+    C, sfx = ts.C, ops.tail_suffix()
     T = ts.img[0].shape[0]            # rows per stream (frames * tokens)
     dev = ts.both[0].device
     qkv = [torch.empty((2 * T, 3 * C), dtype=torch.float32, device=dev) for _ in range(2)]

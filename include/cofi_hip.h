@@ -37,7 +37,7 @@ extern "C" {
 
 /* 2: cofi_split_bf16_planes (nplanes), cofi_transpose (frames) and cofi_select_matches (frames) gained positional arguments (round 4);
  * a caller built against version 1 must not bind this library */
-#define COFI_ABI_VERSION 2
+#define COFI_ABI_VERSION 3
 
 #define COFI_EINVAL (-1)      /* bad shape / alignment / null pointer */
 #define COFI_EWORKSPACE (-2)  /* workspace too small */
@@ -322,6 +322,18 @@ int cofi_attention_parts(const float *Q, int ldq, const float *K, int ldk, const
 int cofi_attention_parts_bf16x6(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, const float *q_colscale,
                                 const float *q_colpart, int q_nslab, int q_ncols, float q_eps, int L, int S, int H, int D, float scale,
                                 int frames, void *parts, size_t parts_bytes, cofi_stream_t stream);
+/* The bf16x6 kernel with K / V split ONCE (round 6): cofi_attention_kv_planes cuts K and V (frames * S rows, H heads of 32 channels) into the
+ * three bf16 planes of the split arithmetic, laid out per (frame, head, 32-key block) exactly as the attention kernel's LDS tiles
+ * (K rows = keys; V transposed, keys in MFMA accumulator order; 12 288 bytes per block; rows past S are zero) - `planes`,
+ * cofi_attention_kv_planes_bytes(S, H, D, frames) bytes, 16-byte aligned.  cofi_attention_parts_planes is cofi_attention_parts_bf16x6 reading
+ * that image instead of K / V: same products in the same order, identical bits.  Without it every one of the L / 64 workgroups of a
+ * (frame, head) repeats the split of the whole K / V. */
+size_t cofi_attention_kv_planes_bytes(int S, int H, int D, int frames);
+int cofi_attention_kv_planes(const float *K, int ldk, const float *V, int ldv, int S, int H, int D, int frames, void *planes, size_t planes_bytes,
+                             cofi_stream_t stream);
+int cofi_attention_parts_planes(const float *Q, int ldq, const void *planes, size_t planes_bytes, const float *q_colscale, const float *q_colpart,
+                                int q_nslab, int q_ncols, float q_eps, int L, int S, int H, int D, float scale, int frames, void *parts,
+                                size_t parts_bytes, cofi_stream_t stream);
 int cofi_attention_merge(const void *parts, size_t parts_bytes, int L, int S, int H, int D, int frames, float *O, int ldo,
                          cofi_stream_t stream);
 int cofi_attention_fwd(const float *Q, int ldq, const float *K, int ldk, const float *V, int ldv, const float *q_colscale,
@@ -376,6 +388,10 @@ typedef struct cofi_loftr_tail_desc {
     float *proj_part[2];
     float *out_l2; int ld_l2;
     float *out_l2t; int ld_l2t;
+    int w_frag;   /* 0: every weight plane is (N, K) row-major.  1: every plane is stored in MFMA-FRAGMENT ORDER - for row block T = n / 32 and
+                   * k-step s = k / 16 the 64 x 8 bf16 a wave's B operand holds, lane-major:
+                   *     plane[((T * (K / 16) + s) * 64 + lane) * 8 + i] = W[32 T + (lane & 31)][16 s + 8 (lane >> 5) + i]
+                   * so that a wave's weight load is one contiguous 1 KB segment (row-major: 32 pieces of 32 B in 32 different lines). */
 } cofi_loftr_tail_desc_t;
 int cofi_loftr_tail(const cofi_loftr_tail_desc_t *desc, cofi_stream_t stream);
 

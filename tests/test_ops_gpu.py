@@ -345,14 +345,32 @@ def test_layer_norm(ops, M, C):
     close(ops.layer_norm(G(x), G(ga), G(be), res=G(r)), ref + r, 2e-5)
 
 
-@pytest.fixture(params=["bf16x6", "f32"])
+@pytest.fixture(params=["bf16x6", "bf16x6-presplit", "f32"])
 def attn(request, ops):
-    """`ops` with the attention kernel pinned to one arithmetic: the fp32-grade bf16 split (csrc/attention_x6.inc) / the exact fp32
-    matrix instruction (csrc/attention.hip) - both are held to the same tolerances"""
-    old = ops.ATTN_MODE
-    ops.ATTN_MODE = request.param
+    """`ops` with the attention kernel pinned to one arithmetic: the fp32-grade bf16 split (csrc/attention_x6.inc; K / V split by every
+    workgroup, or ONCE by cofi_attention_kv_planes - "presplit") / the exact fp32 matrix instruction (csrc/attention.hip) - all held to
+    the same tolerances"""
+    old, old_rows = ops.ATTN_MODE, ops.ATTN_PRESPLIT_ROWS
+    ops.ATTN_MODE = request.param.split("-")[0]
+    ops.ATTN_PRESPLIT_ROWS = 1 if request.param.endswith("presplit") else 0
     yield ops
-    ops.ATTN_MODE = old
+    ops.ATTN_MODE, ops.ATTN_PRESPLIT_ROWS = old, old_rows
+
+
+@pytest.mark.parametrize("frames,L,S", [(1, 1280, 1280), (3, 700, 333), (1, 64, 2000), (2, 100, 4100), (1, 33, 31), (16, 1280, 1280), (1, 96, 5)])
+def test_attention_presplit_is_bit_equal(ops, monkeypatch, frames, L, S):
+    """cofi_attention_kv_planes + cofi_attention_parts_planes == cofi_attention_parts_bf16x6 bit for bit (same planes, same products, same order):
+    full and partial key blocks, key ranges that end inside a step, K / V as strided views of one projection output"""
+    monkeypatch.setattr(ops, "ATTN_MODE", "bf16x6")
+    g = torch.Generator().manual_seed(3 * S + L)
+    q = G(torch.randn(frames * L, 128, generator=g))
+    kv = G(torch.randn(frames * S, 256, generator=g) * 1.5)
+    cs = G(torch.rand(frames, 128, generator=g) + 0.5)
+    outs = []
+    for rows in (0, 1):
+        monkeypatch.setattr(ops, "ATTN_PRESPLIT_ROWS", rows)
+        outs.append(ops.attention(q, kv[:, :128], kv[:, 128:], q_colscale=cs, frames=frames).clone())
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_attention_golden(attn, mg):
@@ -992,14 +1010,16 @@ def test_loftr_layer_fused_tail(ops, mg, monkeypatch, mode, tol):
     close(loftr_layer(w, G(x), G(src)), O.loftr_layer({"l." + k: v for k, v in sd.items()}, "l.", x, src), tol)
 
 
+@pytest.mark.parametrize("frag", [True, False])
 @pytest.mark.parametrize("mode,tol", [("bf16x3", 2e-4), ("bf16x6", 2e-5)])
-def test_loftr_tail_fused_successors(ops, monkeypatch, mode, tol):
+def test_loftr_tail_fused_successors(ops, monkeypatch, mode, tol, frag):
     """cofi_loftr_tail with its optional successors: two projection segments of `out` (+ the 32-row column partials the attention
     kernel folds into the token-axis Q norm) and F.normalize(out, dim=1) token- and channel-major, against the same launch without
     them + fp64 torch; rows = 200: a partial last tile"""
     from cofii2p_amd.transformer import pack_layer
 
     monkeypatch.setattr(ops, "GEMM_MODE", mode)
+    monkeypatch.setattr(ops, "TAIL_FRAG", frag)   # weight planes in fragment order (default) / row-major: identical bits
     g = torch.Generator().manual_seed(21)
     rn = lambda *s: torch.randn(*s, generator=g)
     sd = {"q_proj.weight": rn(128, 128) / 11, "k_proj.weight": rn(128, 128) / 11, "v_proj.weight": rn(128, 128) / 11, "merge.weight": rn(128, 128) / 11,
@@ -1009,7 +1029,10 @@ def test_loftr_tail_fused_successors(ops, monkeypatch, mode, tol):
     for rows in (200, 256):
         msg, x = G(rn(rows, 128)), G(rn(rows, 128))
         base = ops.loftr_tail(msg, x, w, torch.empty_like(x))
-        sfx = ".p%d" % ops.tail_planes()
+        with monkeypatch.context() as mp:
+            mp.setattr(ops, "TAIL_FRAG", not frag)
+            assert torch.equal(base, ops.loftr_tail(msg, x, w, torch.empty_like(x)))   # the other weight layout: same bits
+        sfx = ops.tail_suffix()
         y0, y1 = torch.empty((rows, 256), device=DEV), torch.empty((rows, 400), device=DEV)[:, 8:392]   # a strided destination
         part = torch.empty(((rows + 31) // 32, 384, 2), device=DEV) if rows % 32 == 0 else None
         l2, l2t = torch.empty((rows, 128), device=DEV), torch.empty((128, rows), device=DEV)
