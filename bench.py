@@ -118,12 +118,12 @@ def train_step_summary(dev, frame, steps=8, warmup=3, arith="bf16x6", eager=True
 
         kt.record_fn(one)
         per = kt.measure(reps=3)
-        gsum = {"seconds_per_frame": 0.0, "flops_per_frame": 0.0, "launches_per_frame": 0}
+        gsum = {"seconds_per_frame": 0.0, "flops_per_frame": 0.0, "launches_per_frame": 0, "f16x3_flops_per_frame": 0.0}
         for n in ("gemm", "gemm_colstats", "gemm_layernorm", "conv2d_nhwc"):
             if n in per:
                 for k in gsum:
                     gsum[k] += per[n][k]
-        peak_tf = BF16_MFMA_PEAK_TF / (6.0 if arith == "bf16x6" else 3.0) if arith in ("bf16x6", "bf16x3") else FP32_MFMA_PEAK_TF
+        peak_tf, _share = gemm_mix_peak(gsum, arith)   # (the large backward contractions take the f16x3 kernel too)
         breakdown = {"kernel_ms_per_step": {n: round(1e3 * v["seconds_per_frame"], 3) for n, v in sorted(per.items(), key=lambda kv: -kv[1]["seconds_per_frame"])},
                      "recorded_entry_point_calls_per_step": int(sum(v["launches_per_frame"] for v in per.values())),
                      "roofline": {"kernel": "cofi_gemm (forward + backward contractions)", "bound": "mfma", "unit": "TFLOP/s", "peak": peak_tf,
@@ -331,12 +331,21 @@ class KernelTimer:
         torch.cuda.synchronize()
 
     def measure(self, reps=5):
+        import ctypes
+
+        from cofii2p_amd import _lib
+
+        census = _lib.load().cofi_tune_f16x3_launch_flops   # include/cofi_hip_tune.h: which of this thread's contractions took the f16x3 kernel
+        census.argtypes, census.restype = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)], ctypes.c_long
         out = {}
         for name, calls in self.calls.items():
             def run():
                 for fn, a, k, _ in calls:
                     fn(*a, **k)
+            census(1, None)
             run()
+            f16_flops = ctypes.c_double(0.0)
+            f16_n = census(1, ctypes.byref(f16_flops))
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -351,7 +360,7 @@ class KernelTimer:
             torch.cuda.synchronize()
             sec = s.elapsed_time(e) * 1e-3 / reps
             out[name] = {"seconds_per_frame": sec, "flops_per_frame": sum(c[3][0] for c in calls), "bytes_per_frame": sum(c[3][1] for c in calls),
-                         "launches_per_frame": len(calls)}
+                         "launches_per_frame": len(calls), "f16x3_flops_per_frame": f16_flops.value, "f16x3_launches": f16_n}
             del g
         return out
 
@@ -377,12 +386,12 @@ def kernel_rooflines(model, dev, args, Bsz, frame=None, batch=None):
     per = kt.measure()
     del kt
     for v in per.values():  # per FRAME figures (launch counts stay per submission)
-        for kk in ("seconds_per_frame", "flops_per_frame", "bytes_per_frame"):
+        for kk in ("seconds_per_frame", "flops_per_frame", "bytes_per_frame", "f16x3_flops_per_frame"):
             v[kk] /= Bsz
         v["launches_per_frame"] = v["launches_per_frame"] / Bsz
     across = per.pop("attention_cross", None)
     # the GEMM / implicit-GEMM convolution entry points launch the same MFMA kernel (different loaders / epilogues): one roofline row
-    gsum = {"seconds_per_frame": 0.0, "flops_per_frame": 0.0, "bytes_per_frame": 0.0, "launches_per_frame": 0}
+    gsum = {"seconds_per_frame": 0.0, "flops_per_frame": 0.0, "bytes_per_frame": 0.0, "launches_per_frame": 0, "f16x3_flops_per_frame": 0.0, "f16x3_launches": 0}
     for n in ("gemm", "gemm_colstats", "gemm_layernorm", "conv2d_nhwc"):
         if n in per:
             for k in gsum:
@@ -395,10 +404,11 @@ def kernel_rooflines(model, dev, args, Bsz, frame=None, batch=None):
         # the contraction family next to a dominant attention kernel (the stress configuration): its own row, counter traffic from the
         # committed PMC passes of that configuration when they exist
         gd = per["gemm"]
-        gpeak = BF16_MFMA_PEAK_TF / (3.0 if args.gemm == "bf16x3" else 6.0) if args.gemm in ("bf16x3", "bf16x6") else FP32_MFMA_PEAK_TF
+        gpeak, gshare = gemm_mix_peak(gd, args.gemm)
         gach = gd["flops_per_frame"] / gd["seconds_per_frame"] / 1e12
         gp = pmc_traffic("gemm", "pmc_traffic_stress.json") if (args.gemm == "bf16x6" and args.points == 40960 and Opt.img_H == 896 and Bsz == 1) else None
         out["roofline_gemm"] = {"kernel": "cofi_gemm", "bound": "mfma", "achieved": gach, "peak": gpeak, "unit": "TFLOP/s", "frac": gach / gpeak,
+                                "f16x3_flop_share": gshare, "f16x3_launches_per_submission": gd.get("f16x3_launches", 0),
                                 "traffic": None if gp is None else gp.get("traffic_bytes_per_launch"),
                                 "traffic_collected_on": None if gp is None else gp.get("collected_on"),
                                 "algorithmic_bytes_per_launch": gd["bytes_per_frame"] / gd["launches_per_frame"],
@@ -409,8 +419,9 @@ def kernel_rooflines(model, dev, args, Bsz, frame=None, batch=None):
         # the bf16-split GEMM issues 3 bf16 MFMA flops per algorithmic flop: its MFMA roof for ALGORITHMIC flops is 2500/3
         # ... and the 6-term split 6: 2500 / 6
         peak = attention_peak_tf() if dom == "attention_parts" else FP32_MFMA_PEAK_TF
+        mix_share = None
         if dom == "gemm" and args.gemm in ("bf16x3", "bf16x6"):
-            peak = BF16_MFMA_PEAK_TF / (3.0 if args.gemm == "bf16x3" else 6.0)
+            peak, mix_share = gemm_mix_peak(d, args.gemm)
         # committed PMC passes exist for the two default pipelines in the fp32-grade arithmetic: stack-mode batches of 16 and batch 1
         pmc = None
         if args.gemm == "bf16x6" and args.points == 20480 and Opt.img_H == 160 and Bsz in (1, 16):
@@ -425,6 +436,10 @@ def kernel_rooflines(model, dev, args, Bsz, frame=None, batch=None):
                            "algorithmic_bytes_per_launch": d["bytes_per_frame"] / d["launches_per_frame"],
                            "launches_per_frame": d["launches_per_frame"], "avg_launch_us": 1e6 * d["seconds_per_frame"] / d["launches_per_frame"],
                            "algorithmic_gflop_per_frame": d["flops_per_frame"] / 1e9}
+        if mix_share is not None:
+            out["roofline"].update({"f16x3_flop_share": mix_share, "f16x3_launches_per_submission": d.get("f16x3_launches", 0),
+                                    "peak_note": "roof of the launch MIX for algorithmic flops: 2500 / 6 TF/s for the six-product bf16 kernels, 2500 / 3 for the "
+                                                 "launches on the three-product fp16 kernel (f16x3_flop_share of the flops); total flops / sum of each part's time at its roof"})
     else:
         ach = d["bytes_per_frame"] / d["seconds_per_frame"] / 1e9
         out["roofline"] = {"kernel": "cofi_" + dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -446,6 +461,21 @@ def kernel_rooflines(model, dev, args, Bsz, frame=None, batch=None):
     out["kernel_ms_per_frame"] = {n: round(1e3 * v["seconds_per_frame"], 4) for n, v in sorted(per.items(), key=lambda kv: -kv[1]["seconds_per_frame"])}
     out["launches_per_frame"] = {n: v["launches_per_frame"] for n, v in per.items()}
     return out
+
+
+def gemm_mix_peak(gd, gemm_mode):
+    """Matrix roof of a contraction launch list for ALGORITHMIC flops.  bf16x3: 2500 / 3; bf16x6: 2500 / 6 for the launches of the six-product
+    kernels and 2500 / 3 for those that took the three-product fp16 kernel (COFI_GEMM_F16X3: fp16 and bf16 MFMA share the 2500 TF/s dense
+    peak) - the roof of the MIX is total flops over the sum of each part's time at its own roof.  -> (peak TF/s, share of the flops on f16x3)"""
+    if gemm_mode == "f32":
+        return FP32_MFMA_PEAK_TF, 0.0
+    if gemm_mode == "bf16x3":
+        return BF16_MFMA_PEAK_TF / 3.0, 0.0
+    tot, f16 = gd["flops_per_frame"], min(gd.get("f16x3_flops_per_frame", 0.0), gd["flops_per_frame"])
+    if tot <= 0:
+        return BF16_MFMA_PEAK_TF / 6.0, 0.0
+    t = f16 / (BF16_MFMA_PEAK_TF / 3.0) + (tot - f16) / (BF16_MFMA_PEAK_TF / 6.0)
+    return tot / t, f16 / tot
 
 
 def attention_peak_tf():

@@ -61,6 +61,8 @@ SIGNATURES = {
     "cofi_kpconv_aggregate": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _F, _P, _P, _I, _I, _P, _I, _P, _P]),
     "cofi_neighbor_maxpool": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P]),
     "cofi_gather_rows": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P]),
+    "cofi_gemm_f16x3_eligible": (_I, [_I, _I, _I, _I, _I]),
+    "cofi_conv2d_f16x3_eligible": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "cofi_gemm_f32_workspace": (_Z, [_I, _I, _I]),
     "cofi_gemm_f32": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _Z, _P]),
     "cofi_split_bf16_planes": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
@@ -153,6 +155,7 @@ TUNE_SIGNATURES = {
     "cofi_tune_force_conv_direct": (_I, [_I]),
     "cofi_tune_big_debug": (_I, [_I]),
     "cofi_tune_f16x3_resplit_events": (ctypes.c_long, [_I]),
+    "cofi_tune_f16x3_launch_flops": (ctypes.c_long, [_I, _P]),
 }
 
 

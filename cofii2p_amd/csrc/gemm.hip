@@ -61,6 +61,7 @@ struct GemmArgs {
     NormSrc an;
     int an_rows;
     int f16;          // COFI_GEMM_F16X3: a launch that takes the 256 x 128 kernel runs gemm_f16_big_kernel (three fp16 products) instead of the six-product one
+    const float *wscale;  // COFI_GEMM_W_F16PRE: the panel scales of the pre-split W (one per 128 rows), stored behind the (N, ldw) matrix; nullptr: W is fp32
     unsigned *fixflags;   // ... one word per workgroup of that launch, behind the split-K partials in the workspace: 1 = the repair launch computes this tile
     int dbg;          // cofi_tune_big_debug (include/cofi_hip_tune.h) of the calling thread; 0 on the product path.  Bit 64: the generic row-wise epilogue instead of the straight-line one (same bits)
 };
@@ -1232,6 +1233,8 @@ Plan make_plan(int M, int N, int K, bool fused_ln, int arith = 1) {   // arith: 
 // and read again), in units of one K-tile of the main loop (~1.5 us).
 // tuning hook (tools only): g_force_big = 1 forces the kernel on every eligible launch (split g_force_big_ks, 0 = chosen here), -1 disables it
 thread_local int g_force_big = 0, g_force_big_ks = 0, g_big_dbg = 0;
+thread_local long g_f16_launches = 0;     // launches of the calling thread that took gemm_f16_big_kernel, and their 2 M N K (cofi_tune_f16x3_launch_flops)
+thread_local double g_f16_flops = 0.0;
 thread_local int g_force_direct = 0;   // tools / tests: 1 = the direct 3 x 3 kernel on every eligible convolution (no tile-count threshold), 2 = ... with 4-row tiles, -1 = never, 0 = default
 struct TunedBig { int M, N, K, ks; };   // ks = 0: keep the small-tile kernel for this shape
 #include "gemm_plans_big.inc"
@@ -1378,20 +1381,25 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
         else hipLaunchKernelGGL((gemm_x6_big_kernel<false, false, BN_>), grid, dim3(256), 0, s, g);                          \
     } while (0)
         if (g.f16) {
+            ++g_f16_launches;
+            g_f16_flops += 2.0 * g.M * g.N * g.K;
             // the pipelined kernel, then the repair launch over the same grid (its workgroups exit at once unless the first one flagged their tile)
-#define COFI_LAUNCH_F16(ROBUST_, NW_)                                                                                                  \
-    do {                                                                                                                                \
-        if (g.an.part && cv) hipLaunchKernelGGL((gemm_f16_big_kernel<true, true, ROBUST_, NW_>), grid, dim3(64 * NW_), 0, s, g);       \
-        else if (g.an.part) hipLaunchKernelGGL((gemm_f16_big_kernel<true, false, ROBUST_, NW_>), grid, dim3(64 * NW_), 0, s, g);       \
-        else if (cv) hipLaunchKernelGGL((gemm_f16_big_kernel<false, true, ROBUST_, NW_>), grid, dim3(64 * NW_), 0, s, g);              \
-        else hipLaunchKernelGGL((gemm_f16_big_kernel<false, false, ROBUST_, NW_>), grid, dim3(64 * NW_), 0, s, g);                     \
+#define COFI_LAUNCH_F16(ROBUST_, NW_, WPRE_)                                                                                                  \
+    do {                                                                                                                                       \
+        if (g.an.part && cv) hipLaunchKernelGGL((gemm_f16_big_kernel<true, true, ROBUST_, NW_, WPRE_>), grid, dim3(64 * NW_), 0, s, g);       \
+        else if (g.an.part) hipLaunchKernelGGL((gemm_f16_big_kernel<true, false, ROBUST_, NW_, WPRE_>), grid, dim3(64 * NW_), 0, s, g);       \
+        else if (cv) hipLaunchKernelGGL((gemm_f16_big_kernel<false, true, ROBUST_, NW_, WPRE_>), grid, dim3(64 * NW_), 0, s, g);              \
+        else hipLaunchKernelGGL((gemm_f16_big_kernel<false, false, ROBUST_, NW_, WPRE_>), grid, dim3(64 * NW_), 0, s, g);                     \
     } while (0)
-            if (g.dbg & 256) {   // cofi_tune_big_debug bit 256 (A/B): the four-wave geometry
-                COFI_LAUNCH_F16(false, 4);
-                COFI_LAUNCH_F16(true, 4);
+            if (g.wscale) {      // pre-split W (eight-wave geometry only)
+                COFI_LAUNCH_F16(false, 8, true);
+                COFI_LAUNCH_F16(true, 8, true);
+            } else if (g.dbg & 256) {   // cofi_tune_big_debug bit 256 (A/B): the four-wave geometry
+                COFI_LAUNCH_F16(false, 4, false);
+                COFI_LAUNCH_F16(true, 4, false);
             } else {
-                COFI_LAUNCH_F16(false, 8);
-                COFI_LAUNCH_F16(true, 8);
+                COFI_LAUNCH_F16(false, 8, false);
+                COFI_LAUNCH_F16(true, 8, false);
             }
 #undef COFI_LAUNCH_F16
         } else {
@@ -1497,7 +1505,9 @@ int gemm_entry(const float *A, int lda, const cofi_norm_desc_t *a_norm, const fl
     const int asplit = (act & COFI_GEMM_A_SPLIT) ? 1 : 0;
     const int l2n = (act & COFI_GEMM_L2NORM) ? 1 : 0;
     const int f16 = (act & COFI_GEMM_F16X3) ? 1 : 0;
-    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT | COFI_GEMM_A_SPLIT | COFI_GEMM_L2NORM | COFI_GEMM_F16X3);
+    const int wf16 = (act & COFI_GEMM_W_F16PRE) ? 1 : 0;
+    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT | COFI_GEMM_A_SPLIT | COFI_GEMM_L2NORM | COFI_GEMM_F16X3 | COFI_GEMM_W_F16PRE);
+    if (wf16 && (!f16 || wsplit)) return COFI_EINVAL;
     if (l2n && (N > 128 || asplit)) return COFI_EUNSUPPORTED;
     if (act < 0 || act > 3 || (wsplit && (bf16x3 == 0 || (ldw & 7))) || frames <= 0) return COFI_EINVAL;
     if (asplit && bf16x3 != 1) return COFI_EINVAL;
@@ -1521,6 +1531,10 @@ int gemm_entry(const float *A, int lda, const cofi_norm_desc_t *a_norm, const fl
             g.fixflags = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + off);
         }
     }
+    if (wf16) {   // a pre-split W is readable by gemm_f16_big_kernel only: the caller asks cofi_gemm_f16x3_eligible first
+        if (!g.f16) return COFI_EUNSUPPORTED;
+        g.wscale = W + (size_t)N * ldw;
+    }
     if (int rc = set_a_norm(g, a_norm, K, M / frames, frames, p)) return rc;
     return launch(g, p, cofi_s(stream));
 }
@@ -1537,7 +1551,9 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
     const int wsplit = (act & COFI_GEMM_W_SPLIT) ? 1 : 0;
     const int l2n = (act & COFI_GEMM_L2NORM) ? 1 : 0;
     const int f16 = (act & COFI_GEMM_F16X3) ? 1 : 0;
-    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT | COFI_GEMM_L2NORM | COFI_GEMM_F16X3);
+    const int wf16 = (act & COFI_GEMM_W_F16PRE) ? 1 : 0;
+    act &= ~(COFI_GEMM_BF16X3 | COFI_GEMM_BF16X6 | COFI_GEMM_W_SPLIT | COFI_GEMM_L2NORM | COFI_GEMM_F16X3 | COFI_GEMM_W_F16PRE);
+    if (wf16 && (!f16 || wsplit)) return COFI_EINVAL;
     if (act < 0 || act > 3 || (wsplit && bf16x3 == 0) || act_col0 < 0 || act_col0 > Cout) return COFI_EINVAL;
     if (l2n && Cout > 128) return COFI_EUNSUPPORTED;
     const int sshift = colpart ? stat_shift_of(stat_width, Cout) : 0;
@@ -1553,7 +1569,7 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
         const bool ok = bf16x3 == 2 && !wsplit && !l2n && ks == 3 && stride == 1 && pad == 1 && Cout == 64 && (Cin % 16) == 0 && Cin <= 512 && (W % 64) == 0 &&
                         (H % 4) == 0 && (!x_norm || x_norm->scale_shift) && (size_t)frames * H * W * ldx * sizeof(float) < 0xffffffffull &&
                         (size_t)Cout * K * sizeof(float) < 0xffffffffull;
-        if (ok && mode >= 0 && (mode > 0 || tiles >= 256) && !g_force_bm) {
+        if (ok && !wf16 && mode >= 0 && (mode > 0 || tiles >= 256) && !g_force_bm) {
             GemmArgs g{};
             g.A = x; g.W = Wt; g.C = y; g.bias = bias; g.colpart = colpart; g.res = res;
             g.lda = ldx; g.ldw = K; g.ldc = ldy; g.ldr = ldr; g.M = M; g.N = Cout; g.K = K; g.act = act; g.ksplit = 1;
@@ -1597,11 +1613,34 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
             g.fixflags = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + off);
         }
     }
+    if (wf16) {
+        if (!g.f16) return COFI_EUNSUPPORTED;
+        g.wscale = Wt + (size_t)Cout * ldw;
+    }
     if (int rc = set_a_norm(g, x_norm, Cin, H * W, frames, p)) return rc;   // statistics of the INPUT map: H * W rows per frame
     return launch(g, p, cofi_s(stream));
 }
 
 }  // namespace
+
+// Would a COFI_GEMM_BF16X6 | COFI_GEMM_F16X3 launch of this shape run on gemm_f16_big_kernel (with a workspace of cofi_gemm_f32_workspace bytes)?
+// The conditions of gemm_entry / conv_entry, restated: a caller holding a pre-split W (COFI_GEMM_W_F16PRE) asks before it passes it.
+extern "C" int cofi_gemm_f16x3_eligible(int M, int N, int K, int pending_norm, int frames) {
+    if (M <= 0 || N <= 0 || K <= 0 || frames <= 0) return 0;
+    if (pending_norm && frames > 1 && (M / frames) % 256) return 0;
+    Plan p = make_plan(M, N, K, false, 2);
+    return big_plan(M, N, K, p, true) ? 1 : 0;
+}
+
+extern "C" int cofi_conv2d_f16x3_eligible(int H, int W, int Cin, int Cout, int ks, int stride, int pad, int ldx, int pending_norm, int frames) {
+    if (H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || stride <= 0 || pad < 0 || frames <= 0 || (ks != 1 && ks != 3)) return 0;
+    const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
+    const int M = Ho * Wo * frames, K = ks * ks * Cin;
+    if (!(ks == 3 && stride == 1 && pad <= 1 && (Cin % 32) == 0 && (size_t)frames * H * W * ldx * sizeof(float) < 0xffffffffull)) return 0;
+    if (pending_norm && frames > 1 && (Ho * Wo) % 256) return 0;
+    Plan p = make_plan(M, Cout, K, false, 2);
+    return big_plan(M, Cout, K, p, true) ? 1 : 0;
+}
 
 extern "C" size_t cofi_gemm_f32_workspace(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -1713,6 +1752,15 @@ extern "C" long cofi_tune_f16x3_resplit_events(int reset) {
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_f16_resplit_events), &z, sizeof(z), 0, hipMemcpyHostToDevice) != hipSuccess) return -1;
     }
     return (long)v;
+}
+
+// Host-side census (bench.py's roofline of a launch list that mixes the two arithmetics): contractions the CALLING THREAD enqueued on
+// gemm_f16_big_kernel since the last reset -> their count, *flops = the sum of their 2 M N K.
+extern "C" long cofi_tune_f16x3_launch_flops(int reset, double *flops) {
+    const long n = g_f16_launches;
+    if (flops) *flops = g_f16_flops;
+    if (reset) { g_f16_launches = 0; g_f16_flops = 0.0; }
+    return n;
 }
 
 extern "C" int cofi_tune_force_plan(int bm, int bn, int ksplit) {

@@ -20,6 +20,7 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_LEAKY01 = 0, 1, 2, 3
 GEMM_BF16X3 = 0x100
 GEMM_BF16X6 = 0x800
 GEMM_L2NORM = 0x1000   # rows L2-normalised in the epilogue (N <= 128)
+GEMM_W_F16PRE = 0x4000   # with GEMM_F16X3, launches of its kernel only: W pre-split into fp16 hi / lo with panel scales (pack_f16x3_weight; include/cofi_hip.h)
 GEMM_F16X3 = 0x2000    # with GEMM_BF16X6: the large contractions (256 x 128 kernel) in the three-product fp16 split (include/cofi_hip.h)
 # arithmetic of the dense contractions: "bf16x3" (default) = 3-term bf16 split (hi*hi + hi*lo + lo*hi) on the bf16 matrix cores
 # with fp32 accumulation, ~2^-16 relative error per product; "f32" = exact fp32 MFMA (COFI_GEMM=f32)
@@ -45,6 +46,33 @@ def gemm_mode() -> str:
 # chip's power wall with six bf16 products - run in the three-product fp16 split instead (COFI_GEMM_F16X3, csrc/gemm_f16_big.inc: fp16 hi +
 # lo of x * 2^e with in-kernel range tracking; same or smaller error against fp64, half the matrix work).  COFI_F16X3=0 switches it off.
 F16X3_BIG = os.environ.get("COFI_F16X3", "1") != "0"
+
+
+# ... and those launches read the STATIC operand (SplitW weights) pre-split: the kernel copies W's two fp16 planes instead of splitting the
+# 128 x 32 W tile again in every workgroup (a third of the split work of its K-tile).  COFI_F16X3_WPRE=0: W is split on the fly (A/B).
+F16X3_WPRE = os.environ.get("COFI_F16X3_WPRE", "1") != "0"
+
+
+def pack_f16x3_weight(w: torch.Tensor) -> torch.Tensor:
+    """fp32 (N, K) weight, K % 4 == 0 -> the COFI_GEMM_W_F16PRE operand (include/cofi_hip.h): a flat fp32-typed buffer of N * K + ceil(N / 128)
+    words - the matrix with every aligned group of four values replaced by {hi0..hi3, lo0..lo3} fp16 of w * s (hi = f16(w s) round to nearest
+    even, lo = f16(w s - hi)), s = the power of two of the row's 128-row panel that puts the panel's largest |w| into [2^11, 2^12) (the choice
+    of f16_scale_for in csrc/gemm_f16_big.inc), followed by the panel scales."""
+    N, K = w.shape
+    if K % 4:
+        raise _lib.CofiError("pack_f16x3_weight: K must be a multiple of 4")
+    npan = (N + 127) // 128
+    wp = torch.zeros((npan * 128, K), dtype=torch.float32, device=w.device)
+    wp[:N] = w
+    m = wp.view(npan, 128 * K).abs().amax(1)
+    e = (m.view(torch.int32) >> 23) & 0xff                       # biased exponent of the panel maximum
+    se = (127 + 11 - (e - 127)).clamp(27, 227)
+    scale = torch.where((e == 0) | (e == 255), torch.ones_like(m), (se << 23).view(torch.float32))
+    x = wp * scale.repeat_interleave(128)[:, None]               # exact: a power of two
+    hi = x.to(torch.float16)
+    lo = (x - hi.to(torch.float32)).to(torch.float16)
+    packed = torch.cat([hi.view(npan * 128, K // 4, 4), lo.view(npan * 128, K // 4, 4)], dim=2).contiguous().view(npan * 128, 2 * K).view(torch.float32)
+    return torch.cat([packed[:N].reshape(-1), scale]).contiguous()
 
 
 def f16x3_big() -> bool:
@@ -111,6 +139,15 @@ class SplitW:
         self.planes = torch.empty((2, N, self.ldp), dtype=torch.int16, device=w.device)
         _lib.check(lib.cofi_split_bf16_planes(_p(w), _ld(w), N, K, _p(self.planes), self.ldp, 2, _stream()), "cofi_split_bf16_planes")
         self._planes3 = None
+        self._f16pre = None
+
+    @property
+    def f16pre(self):
+        """the weight as the f16x3 kernel's pre-split operand (pack_f16x3_weight), built on first use (outside graph capture: the packed
+        model is warmed eagerly once before any capture)"""
+        if self._f16pre is None:
+            self._f16pre = pack_f16x3_weight(self.w if self.w.is_contiguous() else self.w.contiguous())
+        return self._f16pre
 
     @property
     def planes3(self):
@@ -132,13 +169,16 @@ def presplit(w):
     return w if isinstance(w, SplitW) else SplitW(w)
 
 
-def _wargs(w):
-    """(pointer, leading dimension, extra flag) of a weight operand for the current GEMM mode."""
+def _wargs(w, f16_eligible=None):
+    """(pointer, leading dimension, extra flag) of a weight operand for the current GEMM mode.  f16_eligible: callable -> bool, asked only for
+    a SplitW in the f16x3 configuration: does this launch run on the f16x3 kernel (cofi_gemm_f16x3_eligible / cofi_conv2d_f16x3_eligible)?"""
     if isinstance(w, SplitW):
         if gemm_mode() == "bf16x3":
             return _p(w.planes), w.ldp, GEMM_W_SPLIT
         if gemm_mode() == "bf16x6" and X6_W_SPLIT:
             return _p(w.planes3), w.ldp, GEMM_W_SPLIT
+        if f16_eligible is not None and F16X3_WPRE and f16x3_big() and w.shape[1] % 4 == 0 and f16_eligible():
+            return _p(w.f16pre), w.shape[1], GEMM_W_F16PRE
         w = w.w
     return _p(w), _ld(w), 0
 
@@ -394,7 +434,7 @@ def _gemm_impl(a, w, out, bias, rowdiv, act, stat_width, frames, l2norm=False):
     if M == 0:   # zero rows: nothing to launch (torch hands out a null pointer for an empty tensor, which the C ABI rejects)
         return out, colpart
     ws = _WS_GEMM.get(lib.cofi_gemm_f32_workspace(M, N, K), a.device)
-    wp, wld, wflag = _wargs(w)
+    wp, wld, wflag = _wargs(w, None if (l2norm or aflag) else (lambda: lib.cofi_gemm_f16x3_eligible(M, N, K, int(nd is not None), frames) == 1))
     if l2norm and N > 128:
         raise _lib.CofiError("gemm: the L2-normalising epilogue serves N <= 128")
     rc = lib.cofi_gemm_f32_fused(a_ptr, a_ld, None if nd is None else ctypes.byref(nd), wp, wld, _p(out), _ld(out), M, N, K, _p(bias),
@@ -772,7 +812,8 @@ def conv2d_nhwc(x, H: int, W: int, w, ks: int, stride: int = 1, pad: int = 1, bi
     if colstats:
         part = torch.empty((lib.cofi_gemm_f32_stat_slabs(M, Cout, K), Cout // stat_width, 2), dtype=torch.float32, device=x.device)
     ws = _WS_GEMM.get(lib.cofi_gemm_f32_workspace(M, Cout, K), x.device)
-    wp, _wld, wflag = _wargs(w)   # convolution weights are dense (Cout, K) / planes (2, Cout, roundup8(K))
+    # convolution weights are dense (Cout, K) / planes (2, Cout, roundup8(K)) / the f16x3 kernel's pre-split form
+    wp, _wld, wflag = _wargs(w, None if l2norm else (lambda: lib.cofi_conv2d_f16x3_eligible(H, W, Cin, Cout, ks, stride, pad, _ld(x), int(nd is not None), frames) == 1))
     rc = lib.cofi_conv2d_nhwc_fused(_p(x), _ld(x), None if nd is None else ctypes.byref(nd), H, W, Cin, wp, Cout, ks, stride, pad, _p(bias),
                                     _p(res), 0 if res is None else _ld(res), act | _gemm_flag() | wflag | (GEMM_L2NORM if l2norm else 0), act_col0, _p(out), _ld(out), _p(part), stat_width,
                                     _p(ws), 0 if ws is None else ws.numel(), frames, _stream())
@@ -828,10 +869,12 @@ def extract_patches_nhwc(fmap, H2: int, W2: int, xy, cnt, cap: int, center_scale
 # ------------------------------------------------------------------------------------------ attention
 _WS_ATTN = Workspace()
 _WS_ATTN_KV = Workspace()
-# bf16x6 attention: K / V are cut into their bf16 planes ONCE per call (cofi_attention_kv_planes, one extra launch) from this many key rows
-# per call (frames * S) - otherwise by every workgroup of the attention kernel again (L / 64 times per frame and head).  The extra launch costs
-# more than it saves on one KITTI frame (1280 keys); stack-mode batches and the stress configuration take it.  COFI_ATTN_PRESPLIT_ROWS=0: never.
-ATTN_PRESPLIT_ROWS = int(os.environ.get("COFI_ATTN_PRESPLIT_ROWS", "4096"))
+# bf16x6 attention: K / V are cut into their bf16 planes ONCE per call (cofi_attention_kv_planes, one extra launch) when a frame has at least
+# this many QUERY rows - every 64 of them are a workgroup that otherwise repeats the split of the frame's whole K / V.  Measured on MI355X
+# (tools/attn_presplit_probe.py, profiles/r06/attn_presplit_probe.txt; us per call, split in every workgroup -> split launch + kernel):
+# L = 1280 (KITTI; 16 frames) 113.8 -> 11.5 + 100.2, a tie, and a loss on one frame (12.7 -> 3.5 + 12.2); L = 2560 224 -> 12 + 189;
+# L = 22400 (stress) 243 -> 4 + 199 and 1580 -> 12 + 1462.  Hence the threshold.  COFI_ATTN_PRESPLIT_ROWS=0: never, 1: always.
+ATTN_PRESPLIT_ROWS = int(os.environ.get("COFI_ATTN_PRESPLIT_ROWS", "2048"))
 
 
 class AttnParts:
@@ -881,7 +924,7 @@ def attention_parts(q, k, v, q_colscale=None, nhead: int = 4, frames: int = 1, q
         raise _lib.CofiError("attention: unsupported shape (head dimension must be 32)")
     # the slot table outlives this call when it is handed to the consumer: a per-stream workspace is safe (stream ordered)
     ws = _WS_ATTN.get(nbytes, q.device)
-    if attention_arith() == "bf16x6" and 0 < ATTN_PRESPLIT_ROWS <= frames * S:
+    if attention_arith() == "bf16x6" and 0 < ATTN_PRESPLIT_ROWS <= L:
         pb = lib.cofi_attention_kv_planes_bytes(S, nhead, D, frames)
         img = _WS_ATTN_KV.get(pb, q.device)
         _lib.check(lib.cofi_attention_kv_planes(_p(k), _ld(k), _p(v), _ld(v), S, nhead, D, frames, _p(img), img.numel(), _stream()), "cofi_attention_kv_planes")

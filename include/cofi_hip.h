@@ -106,6 +106,13 @@ typedef struct cofi_norm_desc {
  * accumulators rescaled - exactly - when a tile leaves the fp16 window): no caller-side range information, no extra pass, deterministic
  * bits.  csrc/gemm_f16_big.inc.  Shapes that do not take that kernel ignore the flag (bf16x6 as before). */
 #define COFI_GEMM_F16X3 0x2000
+/* with COFI_GEMM_F16X3, for launches that take its kernel (ask cofi_gemm_f16x3_eligible / cofi_conv2d_f16x3_eligible first; any other launch
+ * returns COFI_EUNSUPPORTED): W is a STATIC operand split once - an (N, ldw) buffer of the fp32 matrix's shape in which every aligned group of
+ * four values w[n][4 g .. 4 g + 3] is replaced by eight fp16 {hi0 hi1 hi2 hi3 lo0 lo1 lo2 lo3}, hi = f16(w s), lo = f16(w s - hi), s = the power
+ * of two of the row's 128-row panel that puts the panel's largest |w| into [2^11, 2^12) (1 for an all-zero panel); the ceil(N / 128) panel
+ * scales follow the matrix as fp32 at W[N * ldw ...].  The kernel then copies W's planes instead of splitting them in each of its M / 256
+ * workgroups (cofii2p_amd.ops.pack_f16x3_weight builds the buffer). */
+#define COFI_GEMM_W_F16PRE 0x4000
 
 int cofi_abi_version(void);
 /* name of the code object's target, "gfx950" */
@@ -209,6 +216,10 @@ int cofi_gather_rows(const float *x, int ldx, int N, int C, const int32_t *idx, 
  * bias / rowdiv may be NULL.  Deep-K problems are split over K into `ws` and reduced in a fixed
  * order (deterministic, no float atomics) by a fold launch.  Launches that run CONCURRENTLY (different streams) need different workspaces.
  */
+/* 1 if a COFI_GEMM_BF16X6 | COFI_GEMM_F16X3 launch of this shape (fp32 operands, no fused LayerNorm / L2 norm; pending_norm: A carries a
+ * pending normalisation, `frames` stacked frames) runs on the f16x3 kernel - i.e. may be given a COFI_GEMM_W_F16PRE weight. */
+int cofi_gemm_f16x3_eligible(int M, int N, int K, int pending_norm, int frames);
+int cofi_conv2d_f16x3_eligible(int H, int W, int Cin, int Cout, int ks, int stride, int pad, int ldx, int pending_norm, int frames);
 size_t cofi_gemm_f32_workspace(int M, int N, int K);
 int cofi_gemm_f32(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K, const float *bias,
                   const float *rowdiv, int act, void *ws, size_t ws_bytes, cofi_stream_t stream);

@@ -43,6 +43,11 @@ int cofi_tune_big_debug(int flags);
  * reading.  -1 on error. */
 long cofi_tune_f16x3_resplit_events(int reset);
 
+/* Host-side census: contractions the calling thread enqueued (or captured) on the f16x3 kernel since the last reset -> their count;
+ * *flops (optional) = the sum of their 2 M N K.  bench.py prices a launch list that mixes the six-product and the three-product kernel
+ * against the mix of their two matrix roofs with it.  reset != 0: zero both after reading. */
+long cofi_tune_f16x3_launch_flops(int reset, double *flops);
+
 #ifdef __cplusplus
 }
 #endif

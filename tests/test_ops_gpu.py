@@ -1450,14 +1450,19 @@ def test_gemm_f16x3_is_fp32_grade(ops, monkeypatch, M, N, K):
         err = {}
         try:
             fb(1, 0)
-            for mode, f16 in (("f32", False), ("bf16x6", False), ("bf16x6", True)):
+            for mode, f16, pre in (("f32", False, False), ("bf16x6", False, False), ("bf16x6", True, False), ("bf16x6", True, True)):
                 monkeypatch.setattr(ops, "GEMM_MODE", mode)
                 monkeypatch.setattr(ops, "F16X3_BIG", f16)
                 _f16_events(ops)
-                out = ops.gemm(G(a), G(w), bias=G(bias))
-                key = "f16x3" if f16 else mode
+                # pre: the weight as a static operand (SplitW) - the kernel reads W's fp16 planes pre-split with panel scales (COFI_GEMM_W_F16PRE)
+                wd = ops.presplit(G(w)) if pre else G(w)
+                out = ops.gemm(G(a), wd, bias=G(bias))
+                key = ("f16x3pre" if pre else "f16x3") if f16 else mode
                 err[key] = _scaled_err(out, ref, scale)
-                if f16:
+                if pre:
+                    assert wd._f16pre is not None, "the launch did not take the pre-split weight"
+                    assert torch.equal(out, ops.gemm(G(a), wd, bias=G(bias)))
+                elif f16:
                     ev = _f16_events(ops)
                     # normal operands never leave the window; the heavy-tailed ones (single entries 2^5 above anything the scouts saw) may
                     # send a few workgroups to the repair launch - their results are held to the same bound below
@@ -1468,8 +1473,9 @@ def test_gemm_f16x3_is_fp32_grade(ops, monkeypatch, M, N, K):
                     x6_out = out
         finally:
             fb(0, 0)
-        assert err["f16x3"][0] < max(2.0 * err["f32"][0], 2e-7) and err["f16x3"][1] < 1.5 * err["f32"][1], (heavy, err)
-        assert err["f16x3"][1] < 1.5 * err["bf16x6"][1] + 1e-9, (heavy, err)
+        for key in ("f16x3", "f16x3pre"):
+            assert err[key][0] < max(2.0 * err["f32"][0], 2e-7) and err[key][1] < 1.5 * err["f32"][1], (key, heavy, err)
+            assert err[key][1] < 1.5 * err["bf16x6"][1] + 1e-9, (key, heavy, err)
 
 
 @pytest.mark.parametrize("M,N,K,frames,ks", [(4096, 256, 512, 1, 1), (4096 + 77, 256, 1024, 1, 1), (8192, 192, 512, 2, 1), (2048, 512, 2560, 2, 2),

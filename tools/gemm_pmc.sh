@@ -4,12 +4,12 @@
 set -u
 TAG=$1; SHAPE=$2; KERN=$3; KS=$4; SUB=${5:-gemm_}
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r05/pmc_$TAG.md
-mkdir -p $R/gpurun_out/r05; : > $OUT
+OUT=$R/gpurun_out/${PMC_DIR:-r05}/pmc_$TAG.md
+mkdir -p $R/gpurun_out/${PMC_DIR:-r05}; : > $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
 LIST=( "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM" \
-       "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_MFMA_MOPS_BF16" \
+       "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16" \
        "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" )
 for SET in "${LIST[@]}"; do
   i=$((i+1))
