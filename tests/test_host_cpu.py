@@ -412,3 +412,43 @@ def test_attention_arithmetic_follows_the_contraction_arithmetic():
             assert ops.attention_arith() == "f32"
     finally:
         ops.GEMM_MODE, ops.ATTN_MODE = old
+
+
+def test_pack_f16x3_weight_layout_and_scales():
+    """ops.pack_f16x3_weight (the COFI_GEMM_W_F16PRE operand, include/cofi_hip.h): groups of four values become {hi0..3, lo0..3} fp16 of w * s in
+    place, one power-of-two scale per 128-row panel behind the matrix that puts the panel's largest |w| into [2^11, 2^12); hi + lo restores
+    w to 2^-22 of the panel maximum; an all-zero panel keeps scale 1"""
+    import torch
+
+    from cofii2p_amd import ops
+
+    g = torch.Generator().manual_seed(4)
+    N, K = 300, 96
+    w = torch.randn(N, K, generator=g) * torch.tensor([0.01] * 128 + [7.0] * 128 + [0.0] * 44)[:, None]
+    buf = ops.pack_f16x3_weight(w)
+    assert buf.dtype == torch.float32 and buf.numel() == N * K + 3
+    scale = buf[N * K:]
+    assert float(scale[2]) == 1.0
+    h = buf[:N * K].view(N, K).view(torch.float16).view(N, K // 4, 8)
+    hi, lo = h[:, :, :4].reshape(N, K).float(), h[:, :, 4:].reshape(N, K).float()
+    for p in range(2):
+        rows = slice(128 * p, 128 * (p + 1))
+        s = float(scale[p])
+        assert s == 2.0 ** round(float(torch.log2(scale[p])))                       # a power of two
+        assert 2048.0 <= float(hi[rows].abs().max()) < 4096.0 + 2.0                 # (the maximum may round up to 2^12)
+        assert torch.equal(hi[rows], (w[rows] * s).to(torch.float16).float())        # hi = f16(w s), RNE
+        assert float(((hi[rows] + lo[rows]) / s - w[rows]).abs().max()) <= 2.0 ** -22 * float(w[rows].abs().max())
+    assert float(hi[256:].abs().max()) == 0.0 and float(lo[256:].abs().max()) == 0.0
+
+
+def test_fragment_order_is_the_mfma_b_operand_order():
+    """ops.fragment_order (cofi_loftr_tail_desc_t::w_frag): plane[((T * (K / 16) + s) * 64 + lane) * 8 + i] = W[32 T + (lane & 31)][16 s + 8 (lane >> 5) + i]"""
+    import torch
+
+    from cofii2p_amd import ops
+
+    N, K = 64, 48
+    w = torch.arange(2 * N * K, dtype=torch.int16).view(2, N, K)
+    f = ops.fragment_order(w).reshape(2, -1)
+    for (p, T, s, lane, i) in [(0, 0, 0, 0, 0), (1, 1, 2, 37, 5), (0, 1, 1, 63, 7), (1, 0, 2, 31, 3)]:
+        assert int(f[p, ((T * (K // 16) + s) * 64 + lane) * 8 + i]) == int(w[p, 32 * T + (lane & 31), 16 * s + 8 * (lane >> 5) + i])
