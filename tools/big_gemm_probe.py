@@ -36,8 +36,11 @@ def main():
     force_big = lib.cofi_tune_force_big
     force_big.argtypes, force_big.restype = [ctypes.c_int] * 2, ctypes.c_int
     dev = torch.device("cuda", 0)
+    npts = 20480
+    if os.environ.get("PROBE_STRESS", "0") == "1":   # BASELINE configs[4]: 896 x 1600 image, 40960 points
+        bench.Opt.img_H, bench.Opt.img_W, npts = 896, 1600, 40960
     model = CoFiI2P(bench.Opt()).to(dev)
-    frames = bench.make_inputs(dev, [0, 1], 20480)
+    frames = bench.make_inputs(dev, [0, 1], npts)
     bench.one_step(model, frames[0])
     bsz = int(os.environ.get("PROBE_BATCH", "16"))
     ks_list = [int(x) for x in os.environ.get("PROBE_KS", "0,1,2,3,4").split(",")]
@@ -52,7 +55,7 @@ def main():
     for name in ("gemm", "gemm_colstats", "conv2d_nhwc"):
         for fn, a, k, (fl, by) in kt.calls.get(name, []):
             sh = shape_of(name, a, k)   # (M, N, K)
-            if int(os.environ.get("PROBE_MINN", "128")) <= sh[1] <= int(os.environ.get("PROBE_MAXN", "100000")) and sh[2] >= mink and sh[2] % 32 == 0 and sh[0] >= 4096:
+            if int(os.environ.get("PROBE_MINN", "128")) <= sh[1] <= int(os.environ.get("PROBE_MAXN", "100000")) and sh[2] >= mink and sh[2] % 32 == 0 and sh[0] >= int(os.environ.get("PROBE_MINM", "4096")):
                 seen.setdefault((name,) + tuple(sh), [fn, a, k, 0, fl])[3] += 1
     tot = {}
     print("%-44s %3s %9s | %s" % ("shape", "x", "small us", "  ".join("big ks=%d" % k for k in ks_list)))
