@@ -1633,3 +1633,29 @@ def test_big_tiles_convolution_f16x3(ops, monkeypatch, pad, cmid):
     y16 = r16[0]
     ref = torch.nn.functional.conv2d(x.cpu().reshape(frames, H, W, Cin).permute(0, 3, 1, 2), wa.w.cpu().reshape(Cmid, 3, 3, Cin).permute(0, 3, 1, 2), padding=pad)
     close(y16, ref.permute(0, 2, 3, 1).reshape(-1, Cmid), 2e-5)
+
+
+def test_f16x3_presplit_weight_is_refused_where_the_kernel_does_not_run(ops, monkeypatch):
+    """COFI_GEMM_W_F16PRE is readable by gemm_f16_big_kernel only: cofi_gemm_f16x3_eligible says which launches run on it, ops passes the
+    pre-split form exactly there, and the C ABI REFUSES it (COFI_EUNSUPPORTED, nothing launched) on any other launch instead of
+    multiplying fp16 pairs as if they were fp32"""
+    import ctypes
+
+    monkeypatch.setattr(ops, "GEMM_MODE", "bf16x6")
+    monkeypatch.setattr(ops, "F16X3_BIG", True)
+    lib = ops._lib.load()
+    g = torch.Generator().manual_seed(2)
+    for (M, N, K), want in (((40960, 256, 1024), 1), ((512, 64, 256), 0), ((40960, 256, 100), 0), ((1280, 128, 128), 0)):
+        assert lib.cofi_gemm_f16x3_eligible(M, N, K, 0, 1) == want, (M, N, K)
+        a = G(torch.randn(M, K, generator=g))
+        w = ops.presplit(G(torch.randn(N, K, generator=g) / K ** 0.5))
+        out = ops.gemm(a, w)
+        assert (w._f16pre is not None) == bool(want), (M, N, K)            # ops hands over the pre-split form only where it is eligible
+        close(out, (a.cpu().double() @ w.w.cpu().double().t()).float(), 2e-5 * K ** 0.5)
+        if not want and K % 4 == 0:
+            c = torch.empty((M, N), device=DEV)
+            ws = ops._WS_GEMM.get(lib.cofi_gemm_f32_workspace(M, N, K), a.device)
+            flags = ops.GEMM_BF16X6 | ops.GEMM_F16X3 | ops.GEMM_W_F16PRE
+            rc = lib.cofi_gemm_f32_fused(ops._p(a), K, None, ops._p(w.f16pre), K, ops._p(c), N, M, N, K, None, None, flags, None, 1, ops._p(ws),
+                                         0 if ws is None else ws.numel(), 1, ops._stream())
+            assert rc == -3, rc   # COFI_EUNSUPPORTED
