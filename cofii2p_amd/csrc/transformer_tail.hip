@@ -31,6 +31,18 @@ constexpr int R = 32;             // token rows per workgroup
 constexpr int S128 = 128 * 2 + 16;  // LDS row stride (bytes) of a 128-deep bf16 plane: 68 dwords
 constexpr int S256 = 256 * 2 + 16;  // ... of a 256-deep plane: 132 dwords (both = 4 mod 64: conflict-free b128 reads)
 constexpr int FLD = C + 4;          // fp32 staging tile leading dimension
+// chunks of weight fragments in flight ahead of the one being multiplied, bf16x6 (three planes): stage 2 / stage 3 / projections.  Deeper
+// (3 / 3 / 2: 256 + 76 registers, no spills; 5 / 3 / 3 spills) measured the same batch-1 pipeline rate on one box - 533.5 / 532.7 vs 533.4 /
+// 532.5 frames/s, profiles/r06/ab_tail_pf.txt - so the shallower, smaller form stays.
+#ifndef TAIL_PF_S2
+#define TAIL_PF_S2 2
+#endif
+#ifndef TAIL_PF_S3
+#define TAIL_PF_S3 2
+#endif
+#ifndef TAIL_PF_PROJ
+#define TAIL_PF_PROJ 1
+#endif
 
 struct ProjSeg {
     const unsigned short *w[3];   // planes of the (N, 128) stacked projection weight
@@ -165,7 +177,7 @@ __device__ __forceinline__ void proj_stage(const ProjSeg &ps, const unsigned cha
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    gemm_stage<NPL, NT, 8, 1, NPL == 3 ? 2 : 4, FRAG>(acc, a_pl, a_pstride, S128, ps.w, C, wave * 32 * NT, li, lh);
+    gemm_stage<NPL, NT, 8, NPL == 3 ? TAIL_PF_PROJ : 1, NPL == 3 ? 2 : 4, FRAG>(acc, a_pl, a_pstride, S128, ps.w, C, wave * 32 * NT, li, lh);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int col = wave * 32 * NT + 32 * t + li;
@@ -265,7 +277,7 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailArgs a) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        gemm_stage<NPL, 2, 16, 2, NPL == 3 ? 2 : 4, FRAG>(acc, cat_pl, P256, S256, a.w0, 2 * C, wave * 64, li, lh);
+        gemm_stage<NPL, 2, 16, NPL == 3 ? TAIL_PF_S2 : 2, NPL == 3 ? 2 : 4, FRAG>(acc, cat_pl, P256, S256, a.w0, 2 * C, wave * 64, li, lh);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailArgs a) {
         f32x16 acc[1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-        gemm_stage<NPL, 1, 16, NPL == 3 ? 2 : 4, 4, FRAG>(acc, h_pl, P256, S256, a.w2, 2 * C, wave * 32, li, lh);
+        gemm_stage<NPL, 1, 16, NPL == 3 ? TAIL_PF_S3 : 4, 4, FRAG>(acc, h_pl, P256, S256, a.w2, 2 * C, wave * 32, li, lh);
         acc_to_stage(acc[0], wave * 32);
     }
     __syncthreads();
