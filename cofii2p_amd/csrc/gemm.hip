@@ -1271,7 +1271,8 @@ bool big_plan(int M, int N, int K, Plan &p, bool f16 = false) {   // f16: the la
             const int chunk = cofi_cdiv(cofi_cdiv(ktiles, c), 4) * 4;   // k-chunks in multiples of 128, as the other kernels
             const int eff = cofi_cdiv(ktiles, chunk);
             if (eff != c || chunk < 8) continue;
-            const double rounds = (double)cofi_cdiv(tiles * c, 256);
+            // f16x3 (pre-split W): 128 x 128 tiles, two workgroups per CU; else one 256 x 128 workgroup per CU
+            const double rounds = f16 ? (double)cofi_cdiv((long)cofi_cdiv(M, 128) * cofi_cdiv(N, bn) * c, 512) : (double)cofi_cdiv(tiles * c, 256);
             const double partial = c > 1 ? 2.0 * c * (double)M * N * 4.0 / 4.0e12 / 1.5e-6 : 0.0;   // in K-tile units
             const double cost = rounds * (chunk + 6.0) + partial + (c > 1 ? 4.0 : 0.0);
             if (cost < best) { best = cost; ks = c; }
@@ -1287,8 +1288,17 @@ bool big_plan(int M, int N, int K, Plan &p, bool f16 = false) {   // f16: the la
     return true;
 }
 
+// f16x3 kernel with pre-split W: 128 x 128 tiles, two workgroups per CU, instead of one 256 x 128 workgroup (gemm_f16_big.inc).
+// Measured on the large contractions of a batch-16 forward (tools/f16_probe.py, profiles/r06/f16_probe_bm256.txt / _bm128.txt, same K splits):
+// 8.81 -> 8.28 ms per submission, 27 of 29 shapes faster.  COFI_GEMM_F16_BM256=1 / cofi_tune_big_debug bit 512 (A/B): the 256-row form.
+bool f16_two_per_cu(int M, int N, int K, const Plan &p) {
+    (void)M; (void)N; (void)K; (void)p;
+    static const int bm256 = getenv("COFI_GEMM_F16_BM256") ? atoi(getenv("COFI_GEMM_F16_BM256")) : 0;
+    return !bm256 && (g_big_dbg & 512) == 0;
+}
+
 // bytes of the f16x3 kernels' tile-flag table: one word per workgroup of a 256 x 128 launch with `ks` K-slices
-size_t f16_flag_bytes(int M, int N, int ks) { return (size_t)cofi_cdiv(M, 256) * cofi_cdiv(N, 128) * ks * sizeof(unsigned); }
+size_t f16_flag_bytes(int M, int N, int ks, int bm = 128) { return (size_t)cofi_cdiv(M, bm) * cofi_cdiv(N, 128) * ks * sizeof(unsigned); }   // (sized for the 128-row tiles: covers both forms)
 
 // ---- plans of gemm_planes_kernel (both operands pre-split): {M, N, K, configuration, split-K}, tuned on MI355X by
 // tools/tune_gemm.py --planes; anything not listed falls through to the heuristic.
@@ -1384,14 +1394,18 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
             ++g_f16_launches;
             g_f16_flops += 2.0 * g.M * g.N * g.K;
             // the pipelined kernel, then the repair launch over the same grid (its workgroups exit at once unless the first one flagged their tile)
-#define COFI_LAUNCH_F16(ROBUST_, NW_, WPRE_)                                                                                                  \
-    do {                                                                                                                                       \
-        if (g.an.part && cv) hipLaunchKernelGGL((gemm_f16_big_kernel<true, true, ROBUST_, NW_, WPRE_>), grid, dim3(64 * NW_), 0, s, g);       \
-        else if (g.an.part) hipLaunchKernelGGL((gemm_f16_big_kernel<true, false, ROBUST_, NW_, WPRE_>), grid, dim3(64 * NW_), 0, s, g);       \
-        else if (cv) hipLaunchKernelGGL((gemm_f16_big_kernel<false, true, ROBUST_, NW_, WPRE_>), grid, dim3(64 * NW_), 0, s, g);              \
-        else hipLaunchKernelGGL((gemm_f16_big_kernel<false, false, ROBUST_, NW_, WPRE_>), grid, dim3(64 * NW_), 0, s, g);                     \
+#define COFI_LAUNCH_F16B(ROBUST_, NW_, WPRE_, BM_)                                                                                                  \
+    do {                                                                                                                                            \
+        if (g.an.part && cv) hipLaunchKernelGGL((gemm_f16_big_kernel<true, true, ROBUST_, NW_, WPRE_, BM_>), grid, dim3(64 * NW_), 0, s, g);       \
+        else if (g.an.part) hipLaunchKernelGGL((gemm_f16_big_kernel<true, false, ROBUST_, NW_, WPRE_, BM_>), grid, dim3(64 * NW_), 0, s, g);       \
+        else if (cv) hipLaunchKernelGGL((gemm_f16_big_kernel<false, true, ROBUST_, NW_, WPRE_, BM_>), grid, dim3(64 * NW_), 0, s, g);              \
+        else hipLaunchKernelGGL((gemm_f16_big_kernel<false, false, ROBUST_, NW_, WPRE_, BM_>), grid, dim3(64 * NW_), 0, s, g);                     \
     } while (0)
-            if (g.wscale) {      // pre-split W (eight-wave geometry only)
+#define COFI_LAUNCH_F16(ROBUST_, NW_, WPRE_) COFI_LAUNCH_F16B(ROBUST_, NW_, WPRE_, 256)
+            if (g.wscale && p.bm == 128) {   // pre-split W, 128 x 128 tiles: two workgroups per CU
+                COFI_LAUNCH_F16B(false, 4, true, 128);
+                COFI_LAUNCH_F16B(true, 4, true, 128);
+            } else if (g.wscale) {      // pre-split W (eight-wave geometry only)
                 COFI_LAUNCH_F16(false, 8, true);
                 COFI_LAUNCH_F16(true, 8, true);
             } else if (g.dbg & 256) {   // cofi_tune_big_debug bit 256 (A/B): the four-wave geometry
@@ -1402,6 +1416,7 @@ int launch(const GemmArgs &g0, const Plan &p, hipStream_t s) {
                 COFI_LAUNCH_F16(true, 8, false);
             }
 #undef COFI_LAUNCH_F16
+#undef COFI_LAUNCH_F16B
         } else {
             COFI_LAUNCH_BIG(128);
         }
@@ -1524,6 +1539,7 @@ int gemm_entry(const float *A, int lda, const cofi_norm_desc_t *a_norm, const fl
     g.bf16x3 = bf16x3; g.wsplit = wsplit; g.w_lo_off = (long)N * ldw; g.cv_Pout = 1; g.stat_shift = sshift;
     g.asplit = asplit; g.a_lo_off = (long)M * lda;
     g.l2n = l2n;
+    if (f16 && p.big && wf16 && f16_two_per_cu(M, N, K, p)) p.bm = 128;
     if (f16 && p.big) {   // the tile flags live behind this plan's split-K partials; a workspace without room for them: the six-product kernel
         const size_t off = p.ksplit > 1 ? (size_t)p.ksplit * M * N * sizeof(float) : 0;
         if (ws && ws_bytes >= off + f16_flag_bytes(M, N, p.ksplit)) {
@@ -1606,6 +1622,7 @@ int conv_entry(const float *x, int ldx, const cofi_norm_desc_t *x_norm, int H, i
     g.stat_shift = sshift;
     g.act_col0 = act_col0;
     g.l2n = l2n;
+    if (f16 && p.big && wf16 && f16_two_per_cu(M, Cout, K, p)) p.bm = 128;
     if (f16 && p.big) {
         const size_t off = p.ksplit > 1 ? (size_t)p.ksplit * M * Cout * sizeof(float) : 0;
         if (ws && ws_bytes >= off + f16_flag_bytes(M, Cout, p.ksplit)) {

@@ -35,6 +35,7 @@ int cofi_tune_force_conv_direct(int mode);
 
 /* Bit 64: the generic row-wise epilogue instead of the straight-line one (identical bits, slower: the A/B of DESIGN 14.3).
  * Bit 256: the f16x3 kernel in its four-wave geometry (one wave per SIMD) instead of the eight-wave one (identical bits).
+ * Bit 512: the f16x3 kernel with pre-split weights in its 256-row one-workgroup-per-CU form instead of 128 x 128 tiles, two per CU.
  * Other bits are unused.  0 = default. */
 int cofi_tune_big_debug(int flags);
 
