@@ -58,6 +58,7 @@ def pack_f16x3_weight(w: torch.Tensor) -> torch.Tensor:
     words - the matrix with every aligned group of four values replaced by {hi0..hi3, lo0..lo3} fp16 of w * s (hi = f16(w s) round to nearest
     even, lo = f16(w s - hi)), s = the power of two of the row's 128-row panel that puts the panel's largest |w| into [2^11, 2^12) (the choice
     of f16_scale_for in csrc/gemm_f16_big.inc), followed by the panel scales."""
+    w = w.detach()   # (a Parameter of a caller that runs the forward outside torch.no_grad(): the packed form is data, not a graph node)
     N, K = w.shape
     if K % 4:
         raise _lib.CofiError("pack_f16x3_weight: K must be a multiple of 4")

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--colstats", action="store_true")
     ap.add_argument("--time", action="store_true")
+    ap.add_argument("--presplit", action="store_true", help="W as a static operand (ops.SplitW): the f16x3 kernel reads it pre-split (COFI_GEMM_W_F16PRE)")
     ap.add_argument("--dbg", type=int, default=0, help="cofi_tune_big_debug flags (timing experiments: results are wrong)")
     args = ap.parse_args()
     from cofii2p_amd import _lib, ops
@@ -42,6 +43,8 @@ def main():
         fb(-1, 0)
         if args.bm:
             fp(args.bm, args.bn, args.ks)
+    if args.presplit:
+        w = ops.presplit(w)
     fn = (lambda: ops.gemm_colstats(a, w)) if args.colstats else (lambda: ops.gemm(a, w))
     fn()
     torch.cuda.synchronize()
