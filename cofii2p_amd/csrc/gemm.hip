@@ -1265,6 +1265,13 @@ bool big_plan(int M, int N, int K, Plan &p, bool f16 = false) {   // f16: the la
         if (!listed && (tiles < 160 || K < (f16 ? 256 : 512))) return false;   // short loops / small grids: two or three small workgroups per CU overlap their prologues and epilogues
         if (!listed && K < 512) ks = 1;
     }
+    // The f16x3 kernel never splits K from this many 128 x 128 tiles up (COFI_GEMM_F16_KS1_TILES, 0 = off: the table's / cost model's splits
+    // everywhere).  A split pays for a launch that runs ALONE on the chip - it fills idle CUs - and that is how the table was measured; beside
+    // the other submissions of a pipeline its partial sums are only extra traffic and a fold launch.  Same box, frames/s with the splits /
+    // capped at 80 / never split: batch 16 827 / 837 / 842 (another box 825 at 80, 824 never), batch 1 511 / 515 / 506, stress (one frame,
+    // nothing else in flight) 59.5 / - / 58.4 with 59.4 at 160: small grids still need their splits (profiles/r06/ab_ks1*.txt).
+    static const long ks1_tiles = getenv("COFI_GEMM_F16_KS1_TILES") ? atol(getenv("COFI_GEMM_F16_KS1_TILES")) : 80;
+    if (f16 && ks1_tiles > 0 && g_force_big == 0 && (long)cofi_cdiv(M, 128) * cofi_cdiv(N, 128) >= ks1_tiles) ks = 1;
     if (!ks) {
         double best = 1e30;
         for (int c = 1; c <= 8; ++c) {
